@@ -1,0 +1,93 @@
+"""ctypes binding of librssf.so (the C ABI declared in include/rssf.h).
+
+Fails loudly if the shared library is missing: there is deliberately no fallback path.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: it brings in the HIP runtime librssf links against)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librssf.so")
+
+RSSF_F32, RSSF_BF16 = 0, 1
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class WinAttnFwdParams(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "x", "y", "stats_x", "stats_y", "omega", "ln_gamma", "ln_beta",
+        "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "out")] + [
+        (n, c_int) for n in ("B", "H", "W", "C", "heads", "window", "dtype")]
+
+
+class WinAttnBwdParams(ctypes.Structure):
+    _fields_ = [("f", WinAttnFwdParams)] + [(n, c_void_p) for n in (
+        "dout", "dxhat", "dyhat", "domega", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv", "dwo", "dbo")]
+
+
+# name -> (restype, argtypes); every symbol include/rssf.h declares must appear here (tests check it)
+SIGNATURES = {
+    "rssf_version": (ctypes.c_char_p, []),
+    "rssf_arch": (ctypes.c_char_p, []),
+    "rssf_last_error": (ctypes.c_char_p, []),
+    "rssf_layernorm_fwd": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_float, c_int, c_void_p]),
+    "rssf_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_void_p]),
+    "rssf_gate_pool_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "rssf_gate_weights_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "rssf_gate_weights_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),
+    "rssf_gate_pool_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "rssf_winattn_fwd": (c_int, [ctypes.POINTER(WinAttnFwdParams), c_void_p]),
+    "rssf_winattn_bwd": (c_int, [ctypes.POINTER(WinAttnBwdParams), c_void_p]),
+    "rssf_debug_mma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librssf.so once; raise (never fall back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"librssf.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  representationlearning_amd has no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rssf_arch() != b"gfx950":
+        raise RuntimeError("librssf.so was not built for gfx950")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rssf_status {rc}): {load().rssf_last_error().decode()}")
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return RSSF_F32
+    if t.dtype == torch.bfloat16:
+        return RSSF_BF16
+    raise TypeError(f"librssf supports float32/bfloat16 activations, got {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("librssf ops run on the MI355X only (got a CPU tensor); there is no CPU fallback")

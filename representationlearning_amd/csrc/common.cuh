@@ -1,0 +1,145 @@
+// Shared device helpers for the RSSFormer HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include "../../include/rssf.h"
+
+#define RSSF_WAVE 64
+
+namespace rssf {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+// ---- bf16 <-> f32 (bf16 carried as raw uint16) -------------------------------------------------
+struct bf16_t { uint16_t v; };
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float cvt(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(p->v); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f2bf(v); }
+};
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return Elem<T>::ld(p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { Elem<T>::st(p, v); }
+
+// Vector access: VEC elements (16 bytes for bf16 x8, 16 bytes for f32 x4)
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  float4 raw;
+  __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = raw; }
+  __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
+  __device__ __forceinline__ void set(int i, float v) { (&raw.x)[i] = v; }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  uint4 raw;
+  __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  __device__ __forceinline__ float get(int i) const {
+    uint32_t w = (&raw.x)[i >> 1];
+    return (i & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+  }
+  __device__ __forceinline__ void set(int i, float v) {
+    uint32_t& w = (&raw.x)[i >> 1];
+    uint32_t h = f2bf(v);
+    w = (i & 1) ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
+  }
+};
+
+// ---- wave reductions ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---- MFMA 16x16 tile helpers -----------------------------------------------------------------------
+// One wave computes D(16x16) += A(16xK) * B(Kx16).  Operands are addressed "k-contiguous":
+//   A element (m,k) at A[m*lda + k],  B element (k,n) at B[n*ldb + k]   (i.e. B is stored as B^T rows).
+// C/D layout (all 16x16 shapes, gfx950): lane l holds D[row = (l>>4)*4 + r][col = l&15], r = 0..3.
+// A/B fragment layout: lane l supplies row/col (l&15) and k-slots (l>>4)*KPL .. +KPL of each K-step.
+template <typename T> struct Mma;
+template <> struct Mma<float> {                 // v_mfma_f32_16x16x4_f32 : exact f32, K-step 4, KPL 1
+  static constexpr int KSTEP = 4, KPL = 1;
+  typedef float frag;
+  static __device__ __forceinline__ frag load(const float* p) { return *p; }
+  static __device__ __forceinline__ frag zero() { return 0.f; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16_t> {                // v_mfma_f32_16x16x16_bf16 : K-step 16, KPL 4
+  static constexpr int KSTEP = 16, KPL = 4;
+  typedef s16x4 frag;
+  static __device__ __forceinline__ frag load(const bf16_t* p) { return *reinterpret_cast<const s16x4*>(p); }
+  static __device__ __forceinline__ frag zero() { return s16x4{0, 0, 0, 0}; }
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  }
+};
+
+// D += A[rowA0.., :K] * B[rowB0.., :K]^T ; K multiple of KSTEP; A,B in LDS (or global), k-contiguous.
+template <typename T>
+__device__ __forceinline__ f32x4 mma_tile(const T* A, int lda, const T* B, int ldb, int K, f32x4 acc) {
+  const int lane = threadIdx.x & 63;
+  const T* pa = A + (lane & 15) * lda + (lane >> 4) * Mma<T>::KPL;
+  const T* pb = B + (lane & 15) * ldb + (lane >> 4) * Mma<T>::KPL;
+  for (int k = 0; k < K; k += Mma<T>::KSTEP) acc = Mma<T>::mma(Mma<T>::load(pa + k), Mma<T>::load(pb + k), acc);
+  return acc;
+}
+
+// Pack 4 accumulator values (k-slots (l>>4)*4 + r of a 16-wide K tile) into a B/A fragment for the NEXT
+// mma whose K axis is this tile's row axis (register chaining, no LDS).  bf16: one frag; f32: 4 frags.
+__device__ __forceinline__ s16x4 pack_bf16x4(f32x4 v) {
+  s16x4 r;
+  r[0] = (short)f2bf(v[0]); r[1] = (short)f2bf(v[1]); r[2] = (short)f2bf(v[2]); r[3] = (short)f2bf(v[3]);
+  return r;
+}
+
+}  // namespace rssf
+
+// ---- host-side error plumbing ------------------------------------------------------------------------
+namespace rssf {
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+}
+#define RSSF_REQUIRE(cond, ...)                          \
+  do {                                                   \
+    if (!(cond)) {                                       \
+      rssf::set_error(__VA_ARGS__);                      \
+      return RSSF_ERR_BAD_ARG;                           \
+    }                                                    \
+  } while (0)

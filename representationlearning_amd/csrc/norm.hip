@@ -1,0 +1,229 @@
+// LayerNorm over the channel axis of channels-last tokens [rows, C] (eps 1e-6).
+// Reference: modules/MTFM.py:64,80-81 (nn.LayerNorm(C, eps=1e-6)), applied at :107 (norm1 on both
+// streams) and :109 (norm2).  HBM-bound: one read (+ one write); 16-byte lane accesses, G lanes per row.
+#include "common.cuh"
+using namespace rssf;
+
+namespace {
+
+// ---- forward ------------------------------------------------------------------------------------------
+// G lanes cooperate on one row (G*VEC == C); fallback G==0: one thread per row, scalar loop.
+template <typename T, int G>
+__global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, T* __restrict__ y,
+                                                  float* __restrict__ stats, int64_t rows, int C, float eps) {
+  constexpr int VEC = Vec<T>::N;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid / G;
+  const int sub = (int)(gid % G);
+  const bool ok = row < rows;
+  Vec<T> v;
+  float s = 0.f;
+  if (ok) {
+    v.load(x + row * C + sub * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += v.get(i);
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / C;
+  float q = 0.f;
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { float d = v.get(i) - mean; q += d * d; }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / C + eps);
+  if (!ok) return;
+  if (stats && sub == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  if (y) {
+    Vec<T> o;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int c = sub * VEC + i;
+      o.set(i, (v.get(i) - mean) * rstd * gamma[c] + beta[c]);
+    }
+    o.store(y + row * C + sub * VEC);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_fwd_scalar(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ stats, int64_t rows, int C, float eps) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const T* xr = x + row * C;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += ldf(xr + c);
+  const float mean = s / C;
+  float q = 0.f;
+  for (int c = 0; c < C; ++c) { float d = ldf(xr + c) - mean; q += d * d; }
+  const float rstd = rsqrtf(q / C + eps);
+  if (stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  if (y) for (int c = 0; c < C; ++c) stf(y + row * C + c, (ldf(xr + c) - mean) * rstd * gamma[c] + beta[c]);
+}
+
+// ---- backward -------------------------------------------------------------------------------------------
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g*xhat)),  g = dy*gamma ;  dgamma += sum_rows dy*xhat ; dbeta += sum dy
+// G lanes per row (VEC channels each, register-resident); each lane keeps its own dgamma/dbeta partials over a
+// grid-stride loop of rows, flushed once through LDS -> one global atomicAdd per channel per block.
+template <typename T, int G>
+__global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dy, const T* __restrict__ x,
+                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                  const T* __restrict__ dx_add, T* __restrict__ dx,
+                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                  int64_t rows, int C) {
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sg = reinterpret_cast<float*>(smem_raw);
+  float* sb = sg + C;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sg[i] = 0.f;
+  __syncthreads();
+  const int sub = threadIdx.x % G;
+  float gam[VEC], ag[VEC], ab[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { gam[i] = gamma[sub * VEC + i]; ag[i] = 0.f; ab[i] = 0.f; }
+  const int64_t rows_per_pass = (int64_t)gridDim.x * (blockDim.x / G);
+  const int64_t niter = (rows + rows_per_pass - 1) / rows_per_pass;
+  for (int64_t it = 0; it < niter; ++it) {
+    const int64_t row = it * rows_per_pass + (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
+    const bool ok = row < rows;
+    Vec<T> vx, vd;
+    float mean = 0.f, rstd = 0.f, s1 = 0.f, s2 = 0.f, xh[VEC], g[VEC];
+    if (ok) {
+      vx.load(x + row * C + sub * VEC);
+      vd.load(dy + row * C + sub * VEC);
+      mean = stats[row * 2]; rstd = stats[row * 2 + 1];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        xh[i] = (vx.get(i) - mean) * rstd;
+        const float d = vd.get(i);
+        g[i] = d * gam[i];
+        s1 += g[i]; s2 += g[i] * xh[i];
+        ag[i] += d * xh[i]; ab[i] += d;
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (ok) {
+      s1 /= C; s2 /= C;
+      Vec<T> o, va;
+      if (dx_add) va.load(dx_add + row * C + sub * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float v = rstd * (g[i] - s1 - xh[i] * s2);
+        if (dx_add) v += va.get(i);
+        o.set(i, v);
+      }
+      o.store(dx + row * C + sub * VEC);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { atomicAdd(&sg[sub * VEC + i], ag[i]); atomicAdd(&sb[sub * VEC + i], ab[i]); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += blockDim.x) { atomicAdd(&dgamma[i], sg[i]); atomicAdd(&dbeta[i], sb[i]); }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_bwd_scalar(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const T* __restrict__ dx_add, T* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int64_t rows, int C) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sg = reinterpret_cast<float*>(smem_raw);   // [C] dgamma, [C] dbeta
+  float* sb = sg + C;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sg[i] = 0.f;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += stride) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const T* xr = x + row * C;
+    const T* gr = dy + row * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float xh = (ldf(xr + c) - mean) * rstd;
+      const float d = ldf(gr + c);
+      const float g = d * gamma[c];
+      s1 += g; s2 += g * xh;
+      atomicAdd(&sg[c], d * xh);
+      atomicAdd(&sb[c], d);
+    }
+    s1 /= C; s2 /= C;
+    for (int c = 0; c < C; ++c) {
+      const float xh = (ldf(xr + c) - mean) * rstd;
+      float v = rstd * (ldf(gr + c) * gamma[c] - s1 - xh * s2);
+      if (dx_add) v += ldf(dx_add + row * C + c);
+      stf(dx + row * C + c, v);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    atomicAdd(&dgamma[i], sg[i]);
+    atomicAdd(&dbeta[i], sb[i]);
+  }
+}
+
+template <typename T>
+int ln_bwd_launch(const void* dy, const void* x, const float* stats, const float* gamma, const void* dx_add, void* dx,
+                  float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t st) {
+  constexpr int VEC = Vec<T>::N;
+  const int G = (C % VEC == 0) ? C / VEC : 0;
+  const size_t sh = 2 * C * sizeof(float);
+  const T* a = (const T*)dy; const T* b = (const T*)x; const T* c = (const T*)dx_add; T* d = (T*)dx;
+  auto grid = [&](int g) { int64_t n = (rows * g + 255) / 256; return dim3((unsigned)(n > 1024 ? 1024 : n)); };
+  switch (G) {
+    case 1: ln_bwd_vec<T, 1><<<grid(1), 256, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
+    case 2: ln_bwd_vec<T, 2><<<grid(2), 256, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
+    case 4: ln_bwd_vec<T, 4><<<grid(4), 256, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
+    case 8: ln_bwd_vec<T, 8><<<grid(8), 256, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
+    case 16: ln_bwd_vec<T, 16><<<grid(16), 256, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
+    default: ln_bwd_scalar<T><<<grid(1), 256, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
+  }
+  return check_launch("layernorm_bwd");
+}
+
+template <typename T>
+int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* stats, int64_t rows, int C,
+                  float eps, hipStream_t st) {
+  constexpr int VEC = Vec<T>::N;
+  const T* xp = (const T*)x; T* yp = (T*)y;
+  const int G = (C % VEC == 0) ? C / VEC : 0;
+  auto grid = [&](int g) { return dim3((unsigned)((rows * g + 255) / 256)); };
+  switch (G) {
+    case 1: ln_fwd_vec<T, 1><<<grid(1), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
+    case 2: ln_fwd_vec<T, 2><<<grid(2), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
+    case 4: ln_fwd_vec<T, 4><<<grid(4), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
+    case 8: ln_fwd_vec<T, 8><<<grid(8), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
+    case 16: ln_fwd_vec<T, 16><<<grid(16), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
+    default: ln_fwd_scalar<T><<<grid(1), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
+  }
+  return check_launch("layernorm_fwd");
+}
+}  // namespace
+
+extern "C" int rssf_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                  int64_t rows, int C, float eps, int dtype, void* stream) {
+  RSSF_REQUIRE(x && rows > 0 && C > 0 && C <= 1024, "layernorm_fwd: bad shape rows=%lld C=%d", (long long)rows, C);
+  RSSF_REQUIRE(y == nullptr || (gamma && beta), "layernorm_fwd: gamma/beta required when y is requested");
+  RSSF_REQUIRE(y || stats, "layernorm_fwd: nothing to compute");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return ln_fwd_launch<float>(x, gamma, beta, y, stats, rows, C, eps, st);
+  if (dtype == RSSF_BF16) return ln_fwd_launch<bf16_t>(x, gamma, beta, y, stats, rows, C, eps, st);
+  set_error("layernorm_fwd: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}
+
+extern "C" int rssf_layernorm_bwd(const void* dy, const void* x, const float* stats, const float* gamma,
+                                  const void* dx_add, void* dx, float* dgamma, float* dbeta, int64_t rows, int C,
+                                  int dtype, void* stream) {
+  RSSF_REQUIRE(dy && x && stats && gamma && dx && dgamma && dbeta && rows > 0 && C > 0 && C <= 1024,
+               "layernorm_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return ln_bwd_launch<float>(dy, x, stats, gamma, dx_add, dx, dgamma, dbeta, rows, C, st);
+  if (dtype == RSSF_BF16) return ln_bwd_launch<bf16_t>(dy, x, stats, gamma, dx_add, dx, dgamma, dbeta, rows, C, st);
+  set_error("layernorm_bwd: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}

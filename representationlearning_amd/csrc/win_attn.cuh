@@ -1,0 +1,173 @@
+// Shared pieces of the fused 7x7-window cross-attention kernels (forward and backward).
+#pragma once
+#include "common.cuh"
+
+namespace rssf {
+namespace wa {
+
+constexpr int LP = 64;      // window tokens padded to 4 MFMA tiles (49 live)
+constexpr int NT = LP / 16;
+constexpr int MAX_MT = 4;   // virtual channel tiles: heads * ceil16(d) / 16  (Base 2, Tiny 2, Large 4)
+
+template <typename T> struct Pad;           // LDS row padding (elements) that keeps fragment reads conflict-free
+template <> struct Pad<bf16_t> { static constexpr int X = 8; };
+template <> struct Pad<float> { static constexpr int X = 4; };
+
+// compile-time tiling of one (C, heads) configuration
+template <int C_, int HEADS_> struct Dims {
+  static constexpr int C = C_, HEADS = HEADS_;
+  static constexpr int D = C / HEADS;
+  static constexpr int DP = (D + 15) / 16 * 16;      // head dim padded to MFMA tiles
+  static constexpr int CP = (C + 15) / 16 * 16;      // input channels padded (K of the projections)
+  static constexpr int CV = HEADS * DP;              // "virtual" channels: per-head padded layout
+  static constexpr int MT = CV / 16, CT = CP / 16, TPH = DP / 16;
+  static_assert(C % HEADS == 0, "embed_dim must be divisible by num_heads");
+};
+
+struct Geom {           // runtime geometry (image / window grid)
+  int B, H, W, win, L, QH, QW, padT, padL, nWin, N;
+};
+
+inline Geom make_geom(int B, int H, int W, int win) {
+  Geom g;
+  g.B = B; g.H = H; g.W = W; g.win = win; g.L = win * win;
+  const int ph = (win - H % win) % win, pw = (win - W % win) % win;
+  g.QH = (H + ph) / win; g.QW = (W + pw) / win;
+  g.padT = ph / 2; g.padL = pw / 2;          // center pad: floor(P/2) before (multihead_isa_attention.py:375-381)
+  g.nWin = B * g.QH * g.QW;
+  g.N = H * W;
+  return g;
+}
+
+// wave-local LDS ordering: LDS ops of one wave complete in order; this only stops the compiler from moving
+// cross-lane-dependent LDS accesses across the point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// real channel of virtual channel m (= h*dp + dc), or -1 for a padding row
+template <typename DM>
+__device__ __forceinline__ int real_ch(int m) {
+  const int h = m / DM::DP, dc = m % DM::DP;
+  return (dc < DM::D && h < DM::HEADS) ? h * DM::D + dc : -1;
+}
+
+// token index (within the image) of window slot t, or -1 if the slot lies in the zero padding / beyond 49
+__device__ __forceinline__ int slot_token(const Geom& g, int qh, int qw, int t) {
+  if (t >= g.L) return -1;
+  const int u = qh * g.win + t / g.win - g.padT;
+  const int v = qw * g.win + t % g.win - g.padL;
+  return (u >= 0 && u < g.H && v >= 0 && v < g.W) ? u * g.W + v : -1;
+}
+
+// fragment from 4 accumulator values (k-slots (l>>4)*4 + r): chaining C-layout registers into the next MFMA
+template <typename T> struct Chain;
+template <> struct Chain<bf16_t> {
+  static constexpr int STEPS = 1;
+  static __device__ __forceinline__ s16x4 frag(const f32x4& v, int) { return pack_bf16x4(v); }
+};
+template <> struct Chain<float> {
+  static constexpr int STEPS = 4;
+  static __device__ __forceinline__ float frag(const f32x4& v, int r) { return v[r]; }
+};
+
+// D += X * Y where both operands come from C-layout register tiles whose row axis (4g+r) is the K axis.
+template <typename T>
+__device__ __forceinline__ f32x4 mma_chain(const f32x4& a, const f32x4& b, f32x4 acc) {
+#pragma unroll
+  for (int s = 0; s < Chain<T>::STEPS; ++s) acc = Mma<T>::mma(Chain<T>::frag(a, s), Chain<T>::frag(b, s), acc);
+  return acc;
+}
+
+// A operand from LDS (k-contiguous rows), B operand chained from a C-layout register tile covering 16 k-slots
+// starting at k0 (slot order within the tile: 4g + r).
+template <typename T>
+__device__ __forceinline__ f32x4 mma_lds_chain(const T* A, int lda, int k0, const f32x4& b, f32x4 acc);
+template <>
+__device__ __forceinline__ f32x4 mma_lds_chain<bf16_t>(const bf16_t* A, int lda, int k0, const f32x4& b, f32x4 acc) {
+  const int lane = threadIdx.x & 63;
+  const bf16_t* pa = A + (lane & 15) * lda + k0 + (lane >> 4) * 4;
+  return Mma<bf16_t>::mma(Mma<bf16_t>::load(pa), pack_bf16x4(b), acc);
+}
+template <>
+__device__ __forceinline__ f32x4 mma_lds_chain<float>(const float* A, int lda, int k0, const f32x4& b, f32x4 acc) {
+  const int lane = threadIdx.x & 63;
+  const float* pa = A + (lane & 15) * lda + k0 + (lane >> 4) * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc = Mma<float>::mma(pa[r], b[r], acc);
+  return acc;
+}
+// B operand from LDS, A operand chained from registers.
+template <typename T>
+__device__ __forceinline__ f32x4 mma_chain_lds(const f32x4& a, const T* Bm, int ldb, int k0, f32x4 acc);
+template <>
+__device__ __forceinline__ f32x4 mma_chain_lds<bf16_t>(const f32x4& a, const bf16_t* Bm, int ldb, int k0, f32x4 acc) {
+  const int lane = threadIdx.x & 63;
+  const bf16_t* pb = Bm + (lane & 15) * ldb + k0 + (lane >> 4) * 4;
+  return Mma<bf16_t>::mma(pack_bf16x4(a), Mma<bf16_t>::load(pb), acc);
+}
+template <>
+__device__ __forceinline__ f32x4 mma_chain_lds<float>(const f32x4& a, const float* Bm, int ldb, int k0, f32x4 acc) {
+  const int lane = threadIdx.x & 63;
+  const float* pb = Bm + (lane & 15) * ldb + k0 + (lane >> 4) * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc = Mma<float>::mma(a[r], pb[r], acc);
+  return acc;
+}
+
+// Load the two 49xC tiles of one window, apply LayerNorm (precomputed {mean,rstd}) and the gate weight
+// omega[(n*C+c) mod N] (the reference's view-scramble), write them to LDS as T with
+// zero rows for padded / dead slots and zero columns C..Cp.  16-byte lane accesses when C % VEC == 0.
+template <typename T, typename DM>
+__device__ __forceinline__ void load_gated_tiles(const rssf_winattn_fwd_params& p, const Geom& g, const float* sLn,
+                                                 const T* X, const T* Y, const float* om0, int64_t img, int qh, int qw,
+                                                 T* xs, T* ys, int ldx, int lane) {
+  constexpr int V = Vec<T>::N;
+  if constexpr (DM::C % V == 0) {
+    constexpr int cpr = DM::CP / V;
+    for (int e = lane; e < LP * cpr; e += 64) {
+      const int t = e / cpr, c0 = (e % cpr) * V;
+      const int n = slot_token(g, qh, qw, t);
+      Vec<T> ox, oy;
+      ox.raw = {0, 0, 0, 0}; oy.raw = {0, 0, 0, 0};
+      if (n >= 0 && c0 < DM::C) {
+        const int64_t f = (int64_t)n * DM::C + c0;
+        Vec<T> vx, vy;
+        vx.load(X + img * DM::C + f);
+        vy.load(Y + img * DM::C + f);
+        const float2 sx = *reinterpret_cast<const float2*>(p.stats_x + (img + n) * 2);
+        const float2 sy = *reinterpret_cast<const float2*>(p.stats_y + (img + n) * 2);
+        int pp = (int)(f % g.N);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float ga = sLn[c0 + i], be = sLn[DM::CP + c0 + i];
+          ox.set(i, ((vx.get(i) - sx.x) * sx.y * ga + be) * om0[pp]);
+          oy.set(i, ((vy.get(i) - sy.x) * sy.y * ga + be) * om0[g.N + pp]);
+          if (++pp == g.N) pp = 0;
+        }
+      }
+      ox.store(xs + t * ldx + c0);
+      oy.store(ys + t * ldx + c0);
+    }
+  } else {
+    for (int e = lane; e < LP * DM::CP; e += 64) {
+      const int t = e / DM::CP, c = e % DM::CP;
+      const int n = slot_token(g, qh, qw, t);
+      float vx = 0.f, vy = 0.f;
+      if (n >= 0 && c < DM::C) {
+        const int64_t f = (int64_t)n * DM::C + c;
+        const int pp = (int)(f % g.N);
+        const float* sx = p.stats_x + (img + n) * 2;
+        const float* sy = p.stats_y + (img + n) * 2;
+        vx = ((ldf(X + img * DM::C + f) - sx[0]) * sx[1] * sLn[c] + sLn[DM::CP + c]) * om0[pp];
+        vy = ((ldf(Y + img * DM::C + f) - sy[0]) * sy[1] * sLn[c] + sLn[DM::CP + c]) * om0[g.N + pp];
+      }
+      stf(xs + t * ldx + c, vx);
+      stf(ys + t * ldx + c, vy);
+    }
+  }
+}
+
+}  // namespace wa
+}  // namespace rssf

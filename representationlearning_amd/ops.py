@@ -1,0 +1,139 @@
+"""Thin Python wrappers over the librssf C ABI (one function per entry point, no arithmetic here).
+
+All activations are channels-last token tensors [B, N, C] (== NHWC) in fp32 or bf16 on the GPU;
+parameters / statistics / parameter gradients are fp32.  Autograd glue lives in `autograd.py`.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+LN_EPS = 1e-6
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), "parameters/statistics must be contiguous fp32"
+    return t
+
+
+def _tok(t):
+    if not t.is_contiguous():
+        raise RuntimeError("librssf expects contiguous channels-last tokens [B,N,C]")
+    return t
+
+
+def layernorm_fwd(x, gamma, beta, want_y=True, eps=LN_EPS):
+    """x [..., C] -> (y or None, stats [rows, 2] = {mean, rstd})."""
+    L.require_gpu(x)
+    _tok(x)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+    y = torch.empty_like(x) if want_y else None
+    L.check(L.load().rssf_layernorm_fwd(L.ptr(x), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(y), L.ptr(stats),
+                                        rows, C, eps, L.dtype_code(x), L.stream()), "rssf_layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(dy, x, stats, gamma, dgamma, dbeta, dx_add=None):
+    """Returns dx (+ dx_add); accumulates into dgamma / dbeta."""
+    L.require_gpu(dy, x)
+    _tok(dy); _tok(x)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    if dx_add is not None:
+        _tok(dx_add)
+    L.check(L.load().rssf_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(_f32(gamma)), L.ptr(dx_add), L.ptr(dx),
+                                        L.ptr(_f32(dgamma)), L.ptr(_f32(dbeta)), rows, C, L.dtype_code(x), L.stream()),
+            "rssf_layernorm_bwd")
+    return dx
+
+
+def gate_pool_fwd(x, y, stats_x, stats_y, gamma, beta):
+    B, N, C = x.shape
+    pooled = torch.empty(B, 4, N, device=x.device, dtype=torch.float32)
+    argmax = torch.empty(B, 2, N, device=x.device, dtype=torch.int32)
+    L.check(L.load().rssf_gate_pool_fwd(L.ptr(_tok(x)), L.ptr(_tok(y)), L.ptr(stats_x), L.ptr(stats_y), L.ptr(_f32(gamma)),
+                                        L.ptr(_f32(beta)), L.ptr(pooled), L.ptr(argmax), B, N, C, L.dtype_code(x),
+                                        L.stream()), "rssf_gate_pool_fwd")
+    return pooled, argmax
+
+
+def gate_weights_fwd(pooled, k, wl, bl, H, W, want_logits=False):
+    """k: [2,2,7,7] (stream, {mean,max}, 7, 7); wl [2,2]; bl [2] -> gsig, omega (, logits) each [B,2,N]."""
+    B = pooled.shape[0]
+    N = H * W
+    gsig = torch.empty(B, 2, N, device=pooled.device, dtype=torch.float32)
+    omega = torch.empty_like(gsig)
+    logits = torch.empty_like(gsig) if want_logits else None
+    L.check(L.load().rssf_gate_weights_fwd(L.ptr(pooled), L.ptr(_f32(k)), L.ptr(_f32(wl)), L.ptr(_f32(bl)), L.ptr(gsig),
+                                           L.ptr(omega), L.ptr(logits), B, H, W, L.stream()), "rssf_gate_weights_fwd")
+    return gsig, omega, logits
+
+
+def gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W):
+    """Returns dpooled [B,4,N]; accumulates dk [2,2,7,7], dwl [2,2], dbl [2]."""
+    B = pooled.shape[0]
+    N = H * W
+    buf = torch.empty(B * 6 * N, device=pooled.device, dtype=torch.float32)   # [B][4][N] dpooled + [B][2][N] scratch
+    L.check(L.load().rssf_gate_weights_bwd(L.ptr(domega), L.ptr(pooled), L.ptr(gsig), L.ptr(omega), L.ptr(_f32(k)),
+                                           L.ptr(_f32(wl)), L.ptr(buf), L.ptr(_f32(dk)), L.ptr(_f32(dwl)), L.ptr(_f32(dbl)),
+                                           B, H, W, L.stream()), "rssf_gate_weights_bwd")
+    return buf[: B * 4 * N].view(B, 4, N)
+
+
+def gate_pool_bwd_(dpooled, argmax, dxhat, dyhat):
+    B, N, C = dxhat.shape
+    L.check(L.load().rssf_gate_pool_bwd(L.ptr(dpooled), L.ptr(argmax), L.ptr(_tok(dxhat)), L.ptr(_tok(dyhat)), B, N, C,
+                                        L.dtype_code(dxhat), L.stream()), "rssf_gate_pool_bwd")
+
+
+def _winattn_params(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads, out):
+    B, N, C = x.shape
+    p = L.WinAttnFwdParams()
+    p.x, p.y = x.data_ptr(), y.data_ptr()
+    p.stats_x, p.stats_y, p.omega = stats_x.data_ptr(), stats_y.data_ptr(), omega.data_ptr()
+    p.ln_gamma, p.ln_beta = _f32(ln_g).data_ptr(), _f32(ln_b).data_ptr()
+    for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo"):
+        setattr(p, n, _f32(w[n]).data_ptr())
+    p.out = 0 if out is None else out.data_ptr()
+    p.B, p.H, p.W, p.C, p.heads, p.window, p.dtype = B, H, W, C, heads, 7, L.dtype_code(x)
+    return p
+
+
+def winattn_fwd(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads=2):
+    """out = x + WindowCrossAttention(LN1(x)*omega0, LN1(y)*omega1).  w: dict wq,bq,wk,bk,wv,bv,wo,bo (fp32)."""
+    L.require_gpu(x, y)
+    _tok(x); _tok(y)
+    out = torch.empty_like(x)
+    p = _winattn_params(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads, out)
+    L.check(L.load().rssf_winattn_fwd(ctypes.byref(p), L.stream()), "rssf_winattn_fwd")
+    return out
+
+
+def winattn_bwd(dout, x, y, stats_x, stats_y, omega, ln_g, ln_b, w, gw, H, W, heads=2):
+    """Backward of the attention term.  gw: dict of fp32 grads (dwq..dbo) accumulated in place.
+    Returns dxhat, dyhat (grad w.r.t. LN1 outputs through the attention path) and domega [B,2,N]."""
+    L.require_gpu(dout, x, y)
+    _tok(dout)
+    B, N, C = x.shape
+    dxhat = torch.empty_like(x)
+    dyhat = torch.empty_like(y)
+    domega = torch.zeros(B, 2, N, device=x.device, dtype=torch.float32)
+    bp = L.WinAttnBwdParams()
+    bp.f = _winattn_params(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads, None)
+    bp.dout, bp.dxhat, bp.dyhat, bp.domega = dout.data_ptr(), dxhat.data_ptr(), dyhat.data_ptr(), domega.data_ptr()
+    for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo"):
+        setattr(bp, "d" + n, _f32(gw[n]).data_ptr())
+    L.check(L.load().rssf_winattn_bwd(ctypes.byref(bp), L.stream()), "rssf_winattn_bwd")
+    return dxhat, dyhat, domega
+
+
+def debug_mma(a, b):
+    K = a.shape[1]
+    d = torch.empty(3, 16, 16, device=a.device, dtype=torch.float32)
+    L.check(L.load().rssf_debug_mma(L.ptr(a.contiguous()), L.ptr(b.contiguous()), L.ptr(d), K, L.dtype_code(a), L.stream()),
+            "rssf_debug_mma")
+    return d

@@ -1,0 +1,166 @@
+"""GPU parity: gate + fused window cross-attention (HIP, through the C ABI) vs the CPU oracle and the
+golden vectors of the reference.  Runs on the MI355X only (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rssformer_cpu as O
+from oracle.procedural import proc_input
+from tests.helpers import golden, proc_params, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+F32_TOL = 2e-4     # fp32-I/O mode (exact f32 MFMA): rel. Frobenius error vs CPU fp32
+BF16_TOL = 2.5e-2  # bf16-I/O mode: storage rounding of activations + bf16 MFMA operands
+
+
+def _attn_params(C):
+    t = {k[len("attn."):]: v for k, v in O.block_template(C).items() if k.startswith("attn.")}
+    P = proc_params(t, requires_grad=False)
+    ln = proc_params({"norm1.weight": torch.empty(C), "norm1.bias": torch.empty(C)}, requires_grad=False)
+    return P, ln
+
+
+def _dev_weights(P):
+    w = {}
+    for n in ("q", "k", "v", "out"):
+        key = {"q": "wq", "k": "wk", "v": "wv", "out": "wo"}[n]
+        w[key] = P[f"attn.{n}_proj.weight"].to(DEV).contiguous()
+        w["b" + key[1]] = P[f"attn.{n}_proj.bias"].to(DEV).contiguous()
+    return w
+
+
+def _gate_k(P):
+    return torch.stack([P["atrous_block1.conv1.weight"][0], P["atrous_block2.conv1.weight"][0]]).to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mma_helpers(dtype):
+    from representationlearning_amd import ops
+    torch.manual_seed(0)
+    K = 32
+    a = torch.randn(16, K).to(dtype)
+    b = torch.randn(16, K).to(dtype)       # asymmetric, non-square-symmetric operands
+    d = ops.debug_mma(a.to(DEV), b.to(DEV)).cpu()
+    af, bf = a.float(), b.float()
+    E = af @ bf.T
+    assert rel_err(d[0], E) < 1e-5
+    Ek = E.to(dtype).float()
+    F = bf[:, :16] @ Ek
+    G = Ek.T @ Ek
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(d[1], F) < tol
+    assert rel_err(d[2], G) < tol
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 32), (777, 18), (64, 48), (4096, 128)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm(rows, C, dtype):
+    from representationlearning_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(rows, C)
+    g, b = torch.randn(C), torch.randn(C)
+    dy = torch.randn(rows, C)
+    xd = x.to(dtype)
+    xr = xd.float().requires_grad_()
+    gr, br = g.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-6)
+    yr.backward(dy.to(dtype).float())
+    y, st = ops.layernorm_fwd(xd.to(DEV), g.to(DEV), b.to(DEV))
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_err(y.float().cpu(), yr.detach()) < tol
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(dtype).to(DEV), xd.to(DEV), st, g.to(DEV), dg, db)
+    assert rel_err(dx.float().cpu(), xr.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    assert rel_err(dg.cpu(), gr.grad) < 1e-4
+    assert rel_err(db.cpu(), br.grad) < 1e-4
+
+
+CASES = [(1, 32, 7, 7), (2, 32, 10, 10), (1, 32, 14, 14), (1, 32, 20, 12), (1, 18, 9, 11), (1, 48, 8, 8)]
+
+
+def _run_forward(B, C, H, W, dtype):
+    """Returns (out_hip [B,N,C] fp32 cpu, logits_hip, oracle pieces)."""
+    from representationlearning_amd import ops
+    P, ln = _attn_params(C)
+    x = proc_input((B, H * W, C), 0.2)
+    y = proc_input((B, H * W, C), 0.8)
+    xd, yd = x.to(dtype).to(DEV), y.to(dtype).to(DEV)
+    g, b = ln["norm1.weight"].to(DEV), ln["norm1.bias"].to(DEV)
+    _, sx = ops.layernorm_fwd(xd, g, b, want_y=False)
+    _, sy = ops.layernorm_fwd(yd, g, b, want_y=False)
+    pooled, amax = ops.gate_pool_fwd(xd, yd, sx, sy, g, b)
+    gsig, omega, logits = ops.gate_weights_fwd(pooled, _gate_k(P), P["weight_levels.weight"].reshape(2, 2).to(DEV).contiguous(),
+                                               P["weight_levels.bias"].to(DEV), H, W, want_logits=True)
+    out = ops.winattn_fwd(xd, yd, sx, sy, omega, g, b, _dev_weights(P), H, W, 2)
+    torch.cuda.synchronize()
+    # oracle on the same (dtype-rounded) inputs
+    xr, yr = x.to(dtype).float(), y.to(dtype).float()
+    lnf = lambda t: torch.nn.functional.layer_norm(t, (C,), ln["norm1.weight"], ln["norm1.bias"], 1e-6)
+    _, _, _, lv = O.gate(lnf(xr), lnf(yr), P, "", H, W)
+    ref = xr + O.interlaced_attention(lnf(xr), lnf(yr), P, "", H, W)
+    return out.float().cpu(), logits.cpu().reshape(B, 2, H, W), ref, lv, (xr, P, ln)
+
+
+@pytest.mark.parametrize("B,C,H,W", CASES)
+def test_winattn_fwd_fp32_vs_oracle_and_golden(B, C, H, W):
+    out, logits, ref, lv, (xr, P, ln) = _run_forward(B, C, H, W, torch.float32)
+    assert rel_err(logits, lv) < 1e-5
+    assert rel_err(out, ref) < F32_TOL
+    # golden (reference itself): LN is applied inside our kernel, the golden case fed raw tokens -> compare the
+    # attention term on LN-free inputs by choosing identity LN?  The golden used x,y directly as LN outputs, so run
+    # the gate/attention with gamma=1,beta=0 stats {0,1}:
+    from representationlearning_amd import ops
+    g = golden(f"attn_B{B}_C{C}_H{H}_W{W}")
+    x = proc_input((B, H * W, C), 0.2).to(DEV)
+    y = proc_input((B, H * W, C), 0.8).to(DEV)
+    one, zero = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    st = torch.tensor([0.0, 1.0], device=DEV).repeat(B * H * W, 1).contiguous()
+    pooled, _ = ops.gate_pool_fwd(x, y, st, st, one, zero)
+    _, omega, lg = ops.gate_weights_fwd(pooled, _gate_k(P), P["weight_levels.weight"].reshape(2, 2).to(DEV).contiguous(),
+                                        P["weight_levels.bias"].to(DEV), H, W, want_logits=True)
+    o2 = ops.winattn_fwd(x, y, st, st, omega, one, zero, _dev_weights(P), H, W, 2)
+    assert rel_err(lg.cpu().reshape(B, 2, H, W), g["gate_logits"]) < 1e-5
+    assert rel_err((o2 - x).cpu(), g["out"]) < F32_TOL
+
+
+@pytest.mark.parametrize("B,C,H,W", CASES)
+def test_winattn_fwd_bf16(B, C, H, W):
+    out, logits, ref, lv, _ = _run_forward(B, C, H, W, torch.bfloat16)
+    assert rel_err(logits, lv) < 1e-4          # gate maps are fp32 end to end
+    assert rel_err(out, ref) < BF16_TOL
+
+
+def test_winattn_base_shape_properties():
+    """BASELINE config-2 geometry (B=16, C=32, 128x128): window independence + finite outputs at full size."""
+    from representationlearning_amd import ops
+    torch.manual_seed(3)
+    B, C, H, W = 16, 32, 128, 128
+    P, ln = _attn_params(C)
+    x = torch.randn(B, H * W, C, device=DEV, dtype=torch.bfloat16)
+    y = torch.randn(B, H * W, C, device=DEV, dtype=torch.bfloat16)
+    g, b = ln["norm1.weight"].to(DEV), ln["norm1.bias"].to(DEV)
+    _, sx = ops.layernorm_fwd(x, g, b, want_y=False)
+    _, sy = ops.layernorm_fwd(y, g, b, want_y=False)
+    omega = torch.full((B, 2, H * W), 0.5, device=DEV)
+    w = _dev_weights(P)
+    out = ops.winattn_fwd(x, y, sx, sy, omega, g, b, w, H, W, 2)
+    assert torch.isfinite(out.float()).all()
+    # perturbing one token of `high` changes only the outputs of its own 7x7 window (pad 2 before)
+    y2 = y.clone()
+    u, v = 40, 77
+    y2[3, u * W + v] += 1.0
+    _, sy2 = ops.layernorm_fwd(y2, g, b, want_y=False)
+    out2 = ops.winattn_fwd(x, y2, sx, sy2, omega, g, b, w, H, W, 2)
+    diff = (out2.float() - out.float()).abs().reshape(B, H, W, C).amax(-1)
+    assert diff[[0, 1, 2] + list(range(4, 16))].max() == 0
+    qh, qw = (u + 2) // 7, (v + 2) // 7
+    mask = torch.zeros(H, W, dtype=torch.bool, device=DEV)
+    mask[max(0, qh * 7 - 2): qh * 7 + 5, max(0, qw * 7 - 2): qw * 7 + 5] = True
+    assert diff[3][~mask].max() == 0 and diff[3][mask].max() > 0
+    # batch-permutation equivariance
+    perm = torch.randperm(B, device=DEV)
+    outp = ops.winattn_fwd(x[perm].contiguous(), y[perm].contiguous(), sx.view(B, -1, 2)[perm].reshape(-1, 2).contiguous(),
+                           sy.view(B, -1, 2)[perm].reshape(-1, 2).contiguous(), omega, g, b, w, H, W, 2)
+    assert torch.equal(outp, out[perm])
