@@ -61,3 +61,34 @@ def proc_labels(B, H, W, classes=6, block=4, phase=0):
     v = (i * 7 + (i // 3) * 5 + phase) % (classes + 1) - 1
     v = v.repeat_interleave(block, 1).repeat_interleave(block, 2)
     return v[:, :H, :W].contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------
+# Seeded pseudo-random state.  The sin-based tensors above are fine for single ops, but a whole network built
+# from them is numerically chaotic (train-mode BatchNorm over nearly-constant channels: the CPU oracle in fp32
+# and in fp64 already disagree by 20-80 % at stage 3/4), so multi-layer fixtures (transformer block, MLP,
+# full model) use weights drawn from a seeded CPU generator in sorted-key order instead: deterministic for a
+# given torch build, PyTorch-default-like scales, fp32-vs-fp64 distance ~6e-5 at the logits.
+def seeded_state(template, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name in sorted(template.keys()):
+        t = template[name]
+        if not torch.is_floating_point(t):
+            out[name] = torch.zeros_like(t)
+            continue
+        if t.dim() >= 2:
+            bound = math.sqrt(3.0 / t[0].numel())
+            v = (torch.rand(t.shape, generator=g) * 2 - 1) * bound
+        elif name.endswith("running_var"):
+            v = 1.0 + 0.2 * torch.rand(t.shape, generator=g)
+        elif name.endswith("weight"):
+            v = 1.0 + 0.1 * torch.randn(t.shape, generator=g)
+        else:
+            v = 0.05 * torch.randn(t.shape, generator=g)
+        out[name] = v.to(t.dtype)
+    return out
+
+
+def seeded_input(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))

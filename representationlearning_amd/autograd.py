@@ -1,0 +1,137 @@
+"""torch.autograd.Function shims: each forward/backward is a short sequence of librssf C-ABI calls.
+
+No arithmetic happens in Python here beyond allocating outputs and zeroing gradient accumulators; torch is
+the allocator / stream / autograd-graph plumbing.
+"""
+import torch
+
+from . import ops
+
+
+class GatedWindowCrossAttention(torch.autograd.Function):
+    """out = x + Attn(LN1(x), LN1(y)) for one GeneralTransformerBlock (modules/MTFM.py:107), i.e.
+    norm1 on both streams -> InterlacedPoolAttention2 (saliency gate, 7x7 windows, Mhca) -> residual.
+
+    x, y: channels-last tokens [B, N, C].  Saved for backward: x, y and the small fp32 maps only
+    (LN stats, pooled maps, gate sigmoids, omega); everything else is recomputed in the backward kernel.
+    """
+
+    @staticmethod
+    def forward(ctx, x, y, ln_g, ln_b, k1, k2, wl, bl, wq, bq, wk, bk, wv, bv, wo, bo, H, W, heads):
+        x = x.contiguous()
+        y = y.contiguous()
+        _, sx = ops.layernorm_fwd(x, ln_g, ln_b, want_y=False)
+        _, sy = ops.layernorm_fwd(y, ln_g, ln_b, want_y=False)
+        pooled, argmax = ops.gate_pool_fwd(x, y, sx, sy, ln_g, ln_b)
+        kk = torch.stack([k1[0], k2[0]]).contiguous()              # [2(stream), 2(mean,max), 7, 7]
+        wl2 = wl.reshape(2, 2).contiguous()
+        gsig, omega, _ = ops.gate_weights_fwd(pooled, kk, wl2, bl, H, W)
+        w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+        out = ops.winattn_fwd(x, y, sx, sy, omega, ln_g, ln_b, w, H, W, heads)
+        ctx.save_for_backward(x, y, sx, sy, pooled, argmax, gsig, omega, kk, wl2, ln_g, ln_b, wq, bq, wk, bk, wv, bv, wo, bo)
+        ctx.dims = (H, W, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, y, sx, sy, pooled, argmax, gsig, omega, kk, wl2, ln_g, ln_b, wq, bq, wk, bk, wv, bv, wo, bo) = ctx.saved_tensors
+        H, W, heads = ctx.dims
+        dout = dout.contiguous()
+        w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+        gw = {n: torch.zeros_like(t) for n, t in w.items()}
+        dxhat, dyhat, domega = ops.winattn_bwd(dout, x, y, sx, sy, omega, ln_g, ln_b, w, gw, H, W, heads)
+        dk = torch.zeros_like(kk)
+        dwl = torch.zeros_like(wl2)
+        dbl = torch.zeros(2, device=x.device, dtype=torch.float32)
+        dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, kk, wl2, dk, dwl, dbl, H, W)
+        ops.gate_pool_bwd_(dpooled, argmax, dxhat, dyhat)
+        dg = torch.zeros_like(ln_g)
+        db = torch.zeros_like(ln_b)
+        dx = ops.layernorm_bwd(dxhat, x, sx, ln_g, dg, db, dx_add=dout)      # + residual path
+        dy = ops.layernorm_bwd(dyhat, y, sy, ln_g, dg, db)
+        return (dx, dy, dg, db, dk[0:1].clone(), dk[1:2].clone(), dwl.reshape(2, 2, 1, 1), dbl,
+                gw["wq"], gw["bq"], gw["wk"], gw["bk"], gw["wv"], gw["bv"], gw["wo"], gw["bo"], None, None, None)
+
+
+class LayerNormTokens(torch.autograd.Function):
+    """nn.LayerNorm(C, eps=1e-6) over channels-last tokens (modules/MTFM.py:81, norm2)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b):
+        x = x.contiguous()
+        y, st = ops.layernorm_fwd(x, g, b)
+        ctx.save_for_backward(x, st, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, g = ctx.saved_tensors
+        dg = torch.zeros_like(g)
+        db = torch.zeros_like(g)
+        dx = ops.layernorm_bwd(dy.contiguous(), x, st, g, dg, db)
+        return dx, dg, db
+
+
+def _identity_ln(x):
+    B, N, C = x.shape
+    st = torch.tensor([0.0, 1.0], device=x.device, dtype=torch.float32).repeat(B * N, 1).contiguous()
+    return st, torch.ones(C, device=x.device), torch.zeros(C, device=x.device)
+
+
+class PrenormedGatedWindowCrossAttention(torch.autograd.Function):
+    """InterlacedPoolAttention2.forward on its own (multihead_isa_pool_attention.py:148-188): inputs are the
+    already-normalised token streams; returns the attention term only (no residual)."""
+
+    @staticmethod
+    def forward(ctx, x, y, k1, k2, wl, bl, wq, bq, wk, bk, wv, bv, wo, bo, H, W, heads):
+        x = x.contiguous()
+        y = y.contiguous()
+        st, one, zero = _identity_ln(x)
+        pooled, argmax = ops.gate_pool_fwd(x, y, st, st, one, zero)
+        kk = torch.stack([k1[0], k2[0]]).contiguous()
+        wl2 = wl.reshape(2, 2).contiguous()
+        gsig, omega, _ = ops.gate_weights_fwd(pooled, kk, wl2, bl, H, W)
+        w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+        out = ops.winattn_fwd(x, y, st, st, omega, one, zero, w, H, W, heads)
+        ctx.save_for_backward(x, y, st, pooled, argmax, gsig, omega, kk, wl2, one, zero, wq, bq, wk, bk, wv, bv, wo, bo)
+        ctx.dims = (H, W, heads)
+        return out - x
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, y, st, pooled, argmax, gsig, omega, kk, wl2, one, zero, wq, bq, wk, bk, wv, bv, wo, bo) = ctx.saved_tensors
+        H, W, heads = ctx.dims
+        w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+        gw = {n: torch.zeros_like(t) for n, t in w.items()}
+        dxhat, dyhat, domega = ops.winattn_bwd(dout.contiguous(), x, y, st, st, omega, one, zero, w, gw, H, W, heads)
+        dk = torch.zeros_like(kk)
+        dwl = torch.zeros_like(wl2)
+        dbl = torch.zeros(2, device=x.device, dtype=torch.float32)
+        dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, kk, wl2, dk, dwl, dbl, H, W)
+        ops.gate_pool_bwd_(dpooled, argmax, dxhat, dyhat)
+        return (dxhat, dyhat, dk[0:1].clone(), dk[1:2].clone(), dwl.reshape(2, 2, 1, 1), dbl,
+                gw["wq"], gw["bq"], gw["wk"], gw["bk"], gw["wv"], gw["bv"], gw["wo"], gw["bo"], None, None, None)
+
+
+class PlainWindowCrossAttention(torch.autograd.Function):
+    """Mhca on pre-grouped windows (modules/DAL.py:785-1030): x, y are [nWin, 49, C]; each window is treated as
+    one 7x7 image, with identity LN and unit gate, and the residual removed."""
+
+    @staticmethod
+    def forward(ctx, x, y, wq, bq, wk, bk, wv, bv, wo, bo, H, W, heads):
+        st, one, zero = _identity_ln(x)
+        omega = torch.ones(x.shape[0], 2, H * W, device=x.device, dtype=torch.float32)
+        w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+        out = ops.winattn_fwd(x, y, st, st, omega, one, zero, w, H, W, heads)
+        ctx.save_for_backward(x, y, st, omega, one, zero, wq, bq, wk, bk, wv, bv, wo, bo)
+        ctx.dims = (H, W, heads)
+        return out - x
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x, y, st, omega, one, zero, wq, bq, wk, bk, wv, bv, wo, bo) = ctx.saved_tensors
+        H, W, heads = ctx.dims
+        w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+        gw = {n: torch.zeros_like(t) for n, t in w.items()}
+        dxhat, dyhat, _ = ops.winattn_bwd(dout.contiguous(), x, y, st, st, omega, one, zero, w, gw, H, W, heads)
+        return (dxhat, dyhat, gw["wq"], gw["bq"], gw["wk"], gw["bk"], gw["wv"], gw["bv"], gw["wo"], gw["bo"], None, None, None)

@@ -1,0 +1,289 @@
+"""HRNetV2 backbone with one GeneralTransformerBlock per HighResolutionModule
+(reference: module/baseline/base_hrnet/_hrnet_rssformer.py:216-705).
+
+Same module tree / attribute names as the reference, hence identical state_dict keys.  Activations are kept in
+channels-last memory (NHWC physically) end to end — the layout the HIP kernels and the window attention want.
+STATUS: the 3x3/1x1 convolutions + BatchNorm of the HRNet body dispatch to ATen-ROCm (MIOpen) for now
+(DESIGN.md "next"); the transformer blocks run on the hand-written HIP kernels."""
+import torch
+import torch.nn as nn
+
+from .modules.MTFM import GeneralTransformerBlock
+
+BatchNorm2d = nn.BatchNorm2d
+BN_MOMENTUM = 0.1
+
+__all__ = ["HighResolutionNet", "HighResolutionModule", "hrnetv2_w18", "hrnetv2_w32", "hrnetv2_w40", "hrnetv2_w48"]
+
+
+def _table(c):
+    """Stage configuration for branch widths c = (c0, c1, c2, c3)."""
+    return dict(
+        stage1=dict(num_modules=1, num_branches=1, block="BOTTLENECK", num_blocks=(4,), num_channels=(64,), fuse_method="SUM"),
+        stage2=dict(num_modules=1, num_branches=2, block="BASIC", num_blocks=(4, 4), num_channels=c[:2], fuse_method="SUM"),
+        stage3=dict(num_modules=4, num_branches=3, block="BASIC", num_blocks=(4, 4, 4), num_channels=c[:3], fuse_method="SUM"),
+        stage4=dict(num_modules=3, num_branches=4, block="BASIC", num_blocks=(4, 4, 4, 4), num_channels=c[:4], fuse_method="SUM"))
+
+
+# widths of the reference's model_extra (:38-184); 'hrnetv2_w18' is a KeyError there (renamed 'hrnetv2_w32s', :39),
+# here both names resolve to the 18-wide table ("Tiny", SURVEY §8 variants).
+model_extra = {
+    "hrnetv2_w32s": _table((18, 36, 72, 144)),
+    "hrnetv2_w18": _table((18, 36, 72, 144)),
+    "hrnetv2_w32": _table((32, 64, 128, 256)),
+    "hrnetv2_w40": _table((40, 80, 160, 320)),
+    "hrnetv2_w48": _table((48, 96, 192, 384)),
+}
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        res = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + res)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(planes, momentum=BN_MOMENTUM)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
+        self.bn3 = BatchNorm2d(planes * self.expansion, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        res = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + res)
+
+
+blocks_dict = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
+
+
+def _down_chain(cin, cout, steps):
+    """`steps` stride-2 3x3 conv+BN stages; ReLU after all but the last; width changes at the last stage."""
+    seq = []
+    for k in range(steps):
+        last = k == steps - 1
+        co = cout if last else cin
+        layers = [nn.Conv2d(cin, co, 3, 2, 1, bias=False), BatchNorm2d(co, momentum=BN_MOMENTUM)]
+        if not last:
+            layers.append(nn.ReLU(False))
+        seq.append(nn.Sequential(*layers))
+    return nn.Sequential(*seq)
+
+
+class HighResolutionModule(nn.Module):
+    def __init__(self, num_branches, blocks, num_blocks, num_inchannels, num_channels, fuse_method,
+                 multi_scale_output=True):
+        super().__init__()
+        self._check_branches(num_branches, blocks, num_blocks, num_inchannels, num_channels)
+        self.num_inchannels = num_inchannels
+        self.fuse_method = fuse_method
+        self.num_branches = num_branches
+        self.multi_scale_output = multi_scale_output
+        self.branches = self._make_branches(num_branches, blocks, num_blocks, num_channels)
+        self.fuse_layers = self._make_fuse_layers()
+        self.relu = nn.ReLU(False)
+        self.transformer = GeneralTransformerBlock(num_channels[0], planes=num_channels[0], num_heads=2)
+
+    def _check_branches(self, num_branches, blocks, num_blocks, num_inchannels, num_channels):
+        for name, seq in (("NUM_BLOCKS", num_blocks), ("NUM_CHANNELS", num_channels), ("NUM_INCHANNELS", num_inchannels)):
+            if num_branches != len(seq):
+                raise ValueError("NUM_BRANCHES({}) <> {}({})".format(num_branches, name, len(seq)))
+
+    def _make_one_branch(self, i, block, num_blocks, num_channels, stride=1):
+        width = num_channels[i] * block.expansion
+        downsample = None
+        if stride != 1 or self.num_inchannels[i] != width:
+            downsample = nn.Sequential(nn.Conv2d(self.num_inchannels[i], width, kernel_size=1, stride=stride, bias=False),
+                                       BatchNorm2d(width, momentum=BN_MOMENTUM))
+        layers = [block(self.num_inchannels[i], num_channels[i], stride, downsample)]
+        self.num_inchannels[i] = width
+        layers += [block(width, num_channels[i]) for _ in range(1, num_blocks[i])]
+        return nn.Sequential(*layers)
+
+    def _make_branches(self, num_branches, block, num_blocks, num_channels):
+        return nn.ModuleList([self._make_one_branch(i, block, num_blocks, num_channels) for i in range(num_branches)])
+
+    def _make_fuse_layers(self):
+        if self.num_branches == 1:
+            return None
+        ch = self.num_inchannels
+        rows = []
+        for i in range(self.num_branches if self.multi_scale_output else 1):
+            row = []
+            for j in range(self.num_branches):
+                if j > i:
+                    row.append(nn.Sequential(nn.Conv2d(ch[j], ch[i], 1, 1, 0, bias=False),
+                                             BatchNorm2d(ch[i], momentum=BN_MOMENTUM),
+                                             nn.Upsample(scale_factor=2 ** (j - i), mode="nearest")))
+                elif j == i:
+                    row.append(None)
+                else:
+                    row.append(_down_chain(ch[j], ch[i], i - j))
+            rows.append(nn.ModuleList(row))
+        return nn.ModuleList(rows)
+
+    def get_num_inchannels(self):
+        return self.num_inchannels
+
+    def forward(self, x):
+        if self.num_branches == 1:
+            return [self.branches[0](x[0])]
+        x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        fused = []
+        for i in range(len(self.fuse_layers)):
+            low = 0
+            for j in range(1, self.num_branches):
+                low = low + (x[j] if j == i else self.fuse_layers[i][j](x[j]))
+            if i == 0:
+                y = self.transformer(low, x[0])        # residual comes from `low`; x[0] only feeds K/V (:430-431)
+            else:
+                y = self.fuse_layers[i][0](x[0]) + low
+            fused.append(self.relu(y))
+        return fused
+
+
+class HighResolutionNet(nn.Module):
+    def __init__(self, extra, norm_eval=True, zero_init_residual=False, frozen_stages=-1):
+        super().__init__()
+        self.norm_eval, self.frozen_stages, self.zero_init_residual, self.extra = norm_eval, frozen_stages, zero_init_residual, extra
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=3, stride=2, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.conv2 = nn.Conv2d(64, 64, kernel_size=3, stride=2, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+
+        self.stage1_cfg = extra["stage1"]
+        block = blocks_dict[self.stage1_cfg["block"]]
+        c1 = self.stage1_cfg["num_channels"][0]
+        self.layer1 = self._make_layer(block, 64, c1, self.stage1_cfg["num_blocks"][0])
+        pre = [c1 * block.expansion]
+        for s in (2, 3, 4):
+            cfg = extra["stage{}".format(s)]
+            setattr(self, "stage{}_cfg".format(s), cfg)
+            block = blocks_dict[cfg["block"]]
+            widths = [c * block.expansion for c in cfg["num_channels"]]
+            setattr(self, "transition{}".format(s - 1), self._make_transition_layer(pre, widths))
+            stage, pre = self._make_stage(cfg, widths)
+            setattr(self, "stage{}".format(s), stage)
+        self._frozen_stages()
+
+    def _make_transition_layer(self, pre, cur):
+        layers = []
+        for i in range(len(cur)):
+            if i < len(pre):
+                if cur[i] != pre[i]:
+                    layers.append(nn.Sequential(nn.Conv2d(pre[i], cur[i], 3, 1, 1, bias=False),
+                                                BatchNorm2d(cur[i], momentum=BN_MOMENTUM), nn.ReLU(inplace=True)))
+                else:
+                    layers.append(None)
+            else:
+                steps = i + 1 - len(pre)
+                seq = []
+                for j in range(steps):
+                    co = cur[i] if j == steps - 1 else pre[-1]
+                    seq.append(nn.Sequential(nn.Conv2d(pre[-1], co, 3, 2, 1, bias=False),
+                                             BatchNorm2d(co, momentum=BN_MOMENTUM), nn.ReLU(inplace=True)))
+                layers.append(nn.Sequential(*seq))
+        return nn.ModuleList(layers)
+
+    def _make_layer(self, block, inplanes, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                                       BatchNorm2d(planes * block.expansion, momentum=BN_MOMENTUM))
+        layers = [block(inplanes, planes, stride, downsample)]
+        layers += [block(planes * block.expansion, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def _frozen_stages(self):
+        if self.frozen_stages >= 0:
+            for m in (self.conv1, self.bn1, self.conv2, self.bn2):
+                for p in m.parameters():
+                    p.requires_grad = False
+        if self.frozen_stages == 1:
+            for p in self.layer1.parameters():
+                p.requires_grad = False
+
+    def _make_stage(self, cfg, num_inchannels, multi_scale_output=True):
+        block = blocks_dict[cfg["block"]]
+        mods = []
+        for i in range(cfg["num_modules"]):
+            mso = multi_scale_output or i != cfg["num_modules"] - 1
+            mods.append(HighResolutionModule(cfg["num_branches"], block, cfg["num_blocks"], num_inchannels,
+                                             cfg["num_channels"], cfg["fuse_method"], mso))
+            num_inchannels = mods[-1].get_num_inchannels()
+        return nn.Sequential(*mods), num_inchannels
+
+    def forward(self, x):
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.layer1(x)
+        ys = [x]
+        for s in (2, 3, 4):
+            trans = getattr(self, "transition{}".format(s - 1))
+            nb = getattr(self, "stage{}_cfg".format(s))["num_branches"]
+            xs = []
+            for i in range(nb):
+                if trans[i] is None:
+                    xs.append(ys[i])
+                else:
+                    xs.append(trans[i](ys[-1]))
+            ys = getattr(self, "stage{}".format(s))(xs)
+        return ys
+
+    def train(self, mode=True):
+        super().train(mode)
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
+
+
+def _factory(name):
+    def build(pretrained=False, weight_path=None, norm_eval=False, frozen_stages=-1):
+        model = HighResolutionNet(model_extra[name], norm_eval, zero_init_residual=False, frozen_stages=frozen_stages)
+        if pretrained:
+            if weight_path is None:
+                raise FileNotFoundError("pretrained=True needs weight_path: this build has no network access "
+                                        "(the reference downloads ImageNet HRNet weights, _hrnet_rssformer.py:32-37)")
+            model.load_state_dict(torch.load(weight_path, map_location="cpu"), strict=False)
+        return model
+    build.__name__ = name
+    return build
+
+
+hrnetv2_w18 = _factory("hrnetv2_w18")
+hrnetv2_w32 = _factory("hrnetv2_w32")
+hrnetv2_w40 = _factory("hrnetv2_w40")
+hrnetv2_w48 = _factory("hrnetv2_w48")

@@ -1,0 +1,51 @@
+"""The 'RSSFormer' model (reference: module/baseline/hrnet_aux.py:42-134): HRNet backbone with transformer
+blocks -> SimpleFusion8 neck -> 1x1 head + x4 bilinear (align_corners) -> loss (train) / softmax (eval)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...core import registry
+from ...core.config import ConfigModule
+from ..CGFL import SegmentationLossaux as SegmentationLoss
+from .base_hrnet.hrnet_encoder import HRNetEncoder
+
+
+class SimpleFusion8(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.fuse_conv = nn.Sequential(nn.Conv2d(in_channels, in_channels, 1), nn.BatchNorm2d(in_channels), nn.ReLU(True))
+
+    def forward(self, feat_list):
+        x0 = feat_list[0]
+        size = x0.shape[2:]
+        ups = [x0] + [F.interpolate(f, size=size, mode="bilinear", align_corners=True) for f in feat_list[1:]]
+        return self.fuse_conv(torch.cat(ups, dim=1)), x0
+
+
+@registry.MODEL.register("RSSFormer")
+class HRNetFusion(ConfigModule):
+    def __init__(self, config):
+        super().__init__(config)
+        self.backbone = HRNetEncoder(self.config.backbone)
+        self.neck = SimpleFusion8(self.config.neck.in_channels)
+        self.head = nn.Sequential(nn.Conv2d(self.config.head.in_channels, self.config.classes, 1),
+                                  nn.UpsamplingBilinear2d(scale_factor=self.config.head.upsample_scale))
+        self.loss = SegmentationLoss(self.config.loss)
+        # reference hard-codes Linear(32, 7) (:86); generalised to the branch-0 width so Tiny/Large exist
+        self.headaux = nn.Sequential(nn.Linear(self.backbone.output_channels()[0], 7))
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+
+    def forward(self, x, y=None):
+        feats = self.backbone(x)
+        fused, f0 = self.neck(feats)
+        aux = self.headaux(self.avg_pool(f0).flatten(1).float())
+        logit = self.head(fused)
+        if self.training:
+            return self.loss(logit, y["cls"].long(), aux)
+        return logit.float().softmax(dim=1)
+
+    def set_default_config(self):
+        self.config.update(dict(
+            backbone=dict(hrnet_type="hrnetv2_w48", pretrained=False, norm_eval=False, frozen_stages=-1, with_cp=False,
+                          with_gc=False),
+            neck=dict(in_channels=720), classes=7, head=dict(in_channels=720, upsample_scale=4.0), loss=dict(ce=dict())))

@@ -23,6 +23,14 @@ def _tok(t):
     return t
 
 
+def _same(*ts):
+    """All activation tensors of one call must share dtype/shape/device (the C ABI carries ONE dtype code)."""
+    a = ts[0]
+    for t in ts[1:]:
+        if t is not None and (t.dtype != a.dtype or t.shape != a.shape or t.device != a.device):
+            raise RuntimeError(f"librssf: mismatched activation tensors: {a.dtype}{tuple(a.shape)} vs {t.dtype}{tuple(t.shape)}")
+
+
 def layernorm_fwd(x, gamma, beta, want_y=True, eps=LN_EPS):
     """x [..., C] -> (y or None, stats [rows, 2] = {mean, rstd})."""
     L.require_gpu(x)
@@ -39,7 +47,7 @@ def layernorm_fwd(x, gamma, beta, want_y=True, eps=LN_EPS):
 def layernorm_bwd(dy, x, stats, gamma, dgamma, dbeta, dx_add=None):
     """Returns dx (+ dx_add); accumulates into dgamma / dbeta."""
     L.require_gpu(dy, x)
-    _tok(dy); _tok(x)
+    _tok(dy); _tok(x); _same(x, dy, dx_add)
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x)
@@ -52,6 +60,7 @@ def layernorm_bwd(dy, x, stats, gamma, dgamma, dbeta, dx_add=None):
 
 
 def gate_pool_fwd(x, y, stats_x, stats_y, gamma, beta):
+    _same(x, y)
     B, N, C = x.shape
     pooled = torch.empty(B, 4, N, device=x.device, dtype=torch.float32)
     argmax = torch.empty(B, 2, N, device=x.device, dtype=torch.int32)
@@ -85,6 +94,7 @@ def gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W):
 
 
 def gate_pool_bwd_(dpooled, argmax, dxhat, dyhat):
+    _same(dxhat, dyhat)
     B, N, C = dxhat.shape
     L.check(L.load().rssf_gate_pool_bwd(L.ptr(dpooled), L.ptr(argmax), L.ptr(_tok(dxhat)), L.ptr(_tok(dyhat)), B, N, C,
                                         L.dtype_code(dxhat), L.stream()), "rssf_gate_pool_bwd")
@@ -106,7 +116,7 @@ def _winattn_params(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads, o
 def winattn_fwd(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads=2):
     """out = x + WindowCrossAttention(LN1(x)*omega0, LN1(y)*omega1).  w: dict wq,bq,wk,bk,wv,bv,wo,bo (fp32)."""
     L.require_gpu(x, y)
-    _tok(x); _tok(y)
+    _tok(x); _tok(y); _same(x, y)
     out = torch.empty_like(x)
     p = _winattn_params(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads, out)
     L.check(L.load().rssf_winattn_fwd(ctypes.byref(p), L.stream()), "rssf_winattn_fwd")
@@ -117,7 +127,7 @@ def winattn_bwd(dout, x, y, stats_x, stats_y, omega, ln_g, ln_b, w, gw, H, W, he
     """Backward of the attention term.  gw: dict of fp32 grads (dwq..dbo) accumulated in place.
     Returns dxhat, dyhat (grad w.r.t. LN1 outputs through the attention path) and domega [B,2,N]."""
     L.require_gpu(dout, x, y)
-    _tok(dout)
+    _tok(dout); _same(x, y, dout)
     B, N, C = x.shape
     dxhat = torch.empty_like(x)
     dyhat = torch.empty_like(y)

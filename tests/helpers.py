@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from oracle.procedural import procedural_state
+from oracle.procedural import procedural_state, seeded_state
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -15,6 +15,14 @@ def golden(name):
 
 def proc_params(template, requires_grad=True):
     P = procedural_state(template)
+    for k, v in P.items():
+        if torch.is_floating_point(v) and requires_grad and "running" not in k:
+            v.requires_grad_()
+    return P
+
+
+def seeded_params(template, requires_grad=True, seed=1234):
+    P = seeded_state(template, seed)
     for k, v in P.items():
         if torch.is_floating_point(v) and requires_grad and "running" not in k:
             v.requires_grad_()

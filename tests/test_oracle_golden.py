@@ -5,8 +5,8 @@ import pytest
 import torch
 
 from oracle import rssformer_cpu as O
-from oracle.procedural import proc_input, proc_labels
-from tests.helpers import golden, proc_params, rel_err
+from oracle.procedural import proc_input, proc_labels, seeded_input, seeded_state
+from tests.helpers import golden, proc_params, rel_err, seeded_params
 
 TOL = 2e-5   # fp32 CPU vs fp32 CPU (different op order only)
 
@@ -58,9 +58,9 @@ def test_interlaced_attention(B, C, H, W):
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_transformer_block(B, C, H, W, mode):
     g = golden(f"block_{mode}_B{B}_C{C}_H{H}_W{W}")
-    P = proc_params(O.block_template(C))
-    low = proc_input((B, C, H, W), 0.1).requires_grad_()
-    high = proc_input((B, C, H, W), 0.9).requires_grad_()
+    P = seeded_params(O.block_template(C))
+    low = seeded_input((B, C, H, W), 11).requires_grad_()
+    high = seeded_input((B, C, H, W), 12).requires_grad_()
     out = O.transformer_block(low, high, P, "", mode == "train")
     assert rel_err(out.detach(), g["out"]) < TOL
     if mode == "train":
@@ -90,10 +90,10 @@ def test_kat_survey():
 def test_mlp(B, C, H, W):
     g = golden(f"mlp_B{B}_C{C}_H{H}_W{W}")
     t = {k[len("mlp."):]: v for k, v in O.block_template(C).items() if k.startswith("mlp.")}
-    P = proc_params(t)
-    z = proc_input((B, H * W, C), 0.5).requires_grad_()
+    P = seeded_params(t)
+    z = seeded_input((B, H * W, C), 21).requires_grad_()
     out = O.mlp_dwbn(z, P, "", H, W, True)
-    (out * proc_input(out.shape, 2.2)).sum().backward()
+    (out * seeded_input(out.shape, 22)).sum().backward()
     assert rel_err(out.detach(), g["out"]) < TOL
     assert rel_err(z.grad, g["gz"]) < 1e-4
     for k, p in P.items():
@@ -151,8 +151,8 @@ def test_state_dict_keys(variant):
 def test_full_model(variant, B, S, tag):
     """BASELINE config 1 (Tiny 2x3x256x256, one CPU train step) + small Base/Large."""
     g = golden(f"model_{tag}")
-    P = proc_params(O.model_template(variant))
-    x = proc_input((B, 3, S, S), 0.25, freq=0.0377)
+    P = seeded_params(O.model_template(variant))
+    x = seeded_input((B, 3, S, S), 7)
     y = proc_labels(B, S, S, 6, 8)
     taps = {}
     loss = O.model_forward(x, P, True, y, taps)
