@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — RSSFormer-Base training step throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = forward + CGFL loss + backward + gradient all-reduce (N>1) + global-norm clip + SGD on a fixed synthetic
+minibatch already resident in HBM: RSSFormer-Base (HRNetV2-W32 + 8 transformer blocks, 32.14 M params), 6 classes,
+per-GPU batch 16 x 3 x 512 x 512 (BASELINE configs[1] / [2]), bf16 activations with fp32 master weights.  Prints ONE
+JSON line on rank 0.  `roofline` times the fused window cross-attention forward kernel (the kernel BASELINE's
+north_star names; HBM-bound) with HIP events on the launch stream; `cpu_baseline` times the CPU
+restatement (oracle/) of the same step on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # fresh boxes have no MIOpen find-db: skip the exhaustive per-shape search
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FLOP_PER_IMG = 528.07e9        # fwd+bwd matmul/conv FLOPs per 512x512 image, Base
+MFMA_BF16_PEAK = 2.5e15
+
+
+def measure_window_attention(B, S, iters=30):
+    """Average duration of one rssf_winattn_fwd launch at the benchmark geometry (branch 0: C=32, (S/4)^2 tokens)."""
+    from representationlearning_amd import ops
+    H = W = S // 4
+    C = 32
+    dev = "cuda"
+    x = torch.randn(B, H * W, C, device=dev).bfloat16()
+    y = torch.randn(B, H * W, C, device=dev).bfloat16()
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    _, sx = ops.layernorm_fwd(x, g, b, want_y=False)
+    _, sy = ops.layernorm_fwd(y, g, b, want_y=False)
+    omega = torch.full((B, 2, H * W), 0.5, device=dev)
+    w = {}
+    for n in ("q", "k", "v", "o"):
+        w["w" + n] = (torch.randn(C, C, device=dev) / C ** 0.5).contiguous()
+        w["b" + n] = torch.zeros(C, device=dev)
+    for _ in range(5):
+        ops.winattn_fwd(x, y, sx, sy, omega, g, b, w, H, W, 2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.winattn_fwd(x, y, sx, sy, omega, g, b, w, H, W, 2)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    alg_bytes = 3 * B * H * W * C * 2                # read low, read high, write out (bf16)
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="winattn_fwd_kernel<bf16,Dims<32,2>>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, us_per_launch=round(ms * 1e3, 2), algorithmic_bytes=alg_bytes)
+
+
+def cpu_baseline(steps=2):
+    """CPU restatement of the same training step (oracle/, plain PyTorch fp32) on the host cores: Base, B=2, 512x512."""
+    from oracle import rssformer_cpu as O
+    from representationlearning_amd.configs import synthetic_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = O.default_init_({k: v.clone() for k, v in O.model_template("base").items()})
+    for k, v in P.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_()
+    x, y = synthetic_batch(2, 512, device="cpu")
+    params = [v for v in P.values() if v.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        O.model_forward(x, P, True, y).backward()
+        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 35.0)
+        opt.step()
+    step()
+    t = time.time()
+    for _ in range(steps):
+        step()
+    dt = (time.time() - t) / steps
+    return dict(value=round(2 / dt, 4), unit="images/s", cores=cores, kind="port",
+                sample="1 warm-up + %d timed steps of the CPU oracle (fp32, B=2, 3x512x512, fwd+loss+bwd+clip+SGD)" % steps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE: 16)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--variant", default="base")
+    ap.add_argument("--fp32", action="store_true", help="fp32 activations (parity mode) instead of bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true")
+    args = ap.parse_args()
+
+    from representationlearning_amd import _lib
+    from representationlearning_amd.configs import rssformer_config, synthetic_batch
+    from representationlearning_amd.core import registry
+    from representationlearning_amd.trainer import Trainer, init_distributed
+    _lib.load()                                   # fail loudly if the HIP library is missing
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback); the CPU oracle is only the baseline leg")
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    registry.register_all()
+    torch.manual_seed(2333)
+    model = registry.MODEL["RSSFormer"](rssformer_config(args.variant)).cuda()
+    trainer = Trainer(model, bf16=not args.fp32, sync_bn=not args.no_sync_bn)
+    img, lab = synthetic_batch(args.batch, args.size, seed=2333 + rank)
+    target = dict(cls=lab)
+
+    for _ in range(args.warmup):
+        loss = trainer.step(img, target)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(img, target)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        line = {
+            "metric": "train images/sec RSSFormer-Base 512x512 bf16", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": "RSSFormer-%s (HRNetV2 + 8 window-attention transformer blocks), %dx3x%dx%d per GPU, 6 classes, "
+                                   "fwd+CGFL loss+bwd+clip+SGD, random-init weights" % (args.variant, args.batch, args.size, args.size),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "sync_bn": (not args.no_sync_bn) and world > 1},
+            "final_loss": round(final_loss, 5),
+            "whole_step_mfma_frac": round(value * FLOP_PER_IMG / (world * MFMA_BF16_PEAK), 5),
+        }
+        if world == 1:
+            line["roofline"] = measure_window_attention(args.batch, args.size)
+            line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,7 +53,8 @@ int rssf_gate_pool_fwd(const void* x, const void* y, const float* stats_x, const
  * k [2][2][7][7], wl [2][2], bl [2]; gsig [B][2][N] (saved for bwd), omega [B][2][N], logits [B][2][N] (optional). */
 int rssf_gate_weights_fwd(const float* pooled, const float* k, const float* wl, const float* bl, float* gsig,
                           float* omega, float* logits, int B, int H, int W, void* stream);
-/* backward of gate_weights: domega [B][2][N] -> dpooled [B][4][N]; dk, dwl, dbl accumulated. */
+/* backward of gate_weights: domega [B][2][N] -> dpooled; dk, dwl, dbl accumulated (+=).
+ * `dpooled` must hold [B][6][N] floats: the first B*4*N are the result ([B][4][N]), the tail [B][2][N] is scratch. */
 int rssf_gate_weights_bwd(const float* domega, const float* pooled, const float* gsig, const float* omega,
                           const float* k, const float* wl, float* dpooled, float* dk, float* dwl, float* dbl,
                           int B, int H, int W, void* stream);
@@ -90,6 +91,60 @@ typedef struct {
   float* dwq; float* dbq; float* dwk; float* dbk; float* dwv; float* dbv; float* dwo; float* dbo;  /* += */
 } rssf_winattn_bwd_params;
 int rssf_winattn_bwd(const rssf_winattn_bwd_params* p, void* stream);
+
+/* ---- Convolution (implicit GEMM, MFMA) on channels-last activations ------------------------------------------
+ *      replaces aten::convolution at every nn.Conv2d of the path: HRNet 3x3 / 1x1 convs
+ *      (_hrnet_rssformer.py:216-287, 361-405, 512-546), neck + head (hrnet_aux.py:45-49, 78-81) and MlpDWBN's
+ *      fc1 / fc2 / fused {dw + dw6 + dw12} (ffn_block.py:219-228, 246-257).
+ * A convolution is a list of <= 19 "taps" (dy, dx), each with its own [Cout][Cin] slab of packed weights:
+ *   out(b, oy, ox, :) = bias + sum_t W_t * in(b, (oy*mul + dy_t)/div, (ox*mul + dx_t)/div, :)      (zero outside)
+ * forward:  mul = stride, div = 1, dy = ky*dil - pad.   dgrad: mul = 1, div = stride, dy = pad - ky*dil, with the
+ * transposed packing (`transpose` = 1) and in/out swapped. */
+/* rows of a packed slab are padded to this multiple (= the N tile the kernel will use for `cout` channels) */
+int rssf_conv_tile_n(int cout);
+/* elements of the packed weight buffer [ntaps][rowsP][colsP] for `dtype` */
+int64_t rssf_conv_packed_elems(int ntaps, int rows, int cols, int dtype);
+/* pack up to 3 torch-layout fp32 weights [Cout][Cin][k][k] (ksizes[i] = k) into per-tap slabs; tap t takes kernel
+ * position kpos_of_tap[t] (= ky*k + kx) of source src_of_tap[t].  transpose = 0: rows = Cout (forward);
+ * transpose = 1: rows = Cin (data gradient). */
+int rssf_conv_pack(const float* w0, const float* w1, const float* w2, const int* ksizes, int nsrc, const int* src_of_tap,
+                   const int* kpos_of_tap, int ntaps, int Cout, int Cin, int transpose, void* out, int dtype, void* stream);
+/* the gather convolution itself.  bias [Cout] optional; stats [2][Cout] optional: per-channel sum and sum of squares of
+ * the OUTPUT (incl. bias) atomically accumulated for the BatchNorm that follows (fused statistics). */
+int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bias, float* stats, int B, int IH, int IW,
+                     int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype,
+                     void* stream);
+/* weight gradient, accumulated (+=) into the torch-layout fp32 gradients of the source convs; dbias optional (+=). */
+int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes, int nsrc,
+                    const int* src_of_tap, const int* kpos_of_tap, float* dbias, int B, int IH, int IW, int Cin, int OH,
+                    int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx, int dtype, void* stream);
+
+/* ---- BatchNorm2d (+ activation + residual adds), channels-last: nn.BatchNorm2d / nn.SyncBatchNorm call sites of
+ *      _hrnet_rssformer.py, hrnet_aux.py:47 and ffn_block.py:222-234 (momentum 0.1, eps 1e-5) -------------------- */
+/* act: 0 none, 1 ReLU, 2 GELU(erf).  stats = [2][C] {sum, sumsq} over n samples (from rssf_conv_gather; all-reduced by
+ * the host for SyncBN).  Writes mean_invstd [2][C], scale_shift [2][C]; updates running stats when training. */
+int rssf_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float* mean_invstd, float* scale_shift, int C, double n, float momentum, float eps, int training,
+                     void* stream);
+/* y = act(raw*scale + shift + res_pre) + res_post   (res_* optional, same shape as raw) */
+int rssf_bn_apply(const void* raw, const float* scale_shift, const void* res_pre, const void* res_post, void* y,
+                  int64_t rows, int C, int act, int dtype, void* stream);
+/* sums [2][C] += { sum dz, sum dz*raw },  dz = dy * act'(raw*scale + shift + res_pre);  caller zeroes sums */
+int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, float* sums,
+                       int64_t rows, int C, int act, int dtype, void* stream);
+/* draw = d(loss)/d(raw); dres (optional) = dz = gradient of res_pre; dgamma/dbeta (optional) accumulated */
+int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift, const float* mean_invstd, const float* sums,
+                      const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
+                      double n, int training, int dtype, void* stream);
+
+/* ---- optimizer over flat fp32 buffers: the external `ever` trainer's clip_grad_norm_(35) + SGD(momentum .9,
+ *      wd 1e-4) of configs/base/loveda.py:68-77 as two launches over all parameters ----------------------- */
+/* out[0] = sum g^2 (zeroed inside, on the stream). */
+int rssf_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
+/* g' = grad_scale*g*clip + wd*p ; buf = first_step ? g' : mu*buf + g' ; p -= lr*buf
+ * clip = max_norm > 0 ? min(1, max_norm / (grad_scale*sqrt(*sqnorm) + 1e-6)) : 1   (device-side, no host sync). */
+int rssf_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, const float* sqnorm, float grad_scale,
+                  float max_norm, float lr, float momentum, float weight_decay, int first_step, void* stream);
 
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 /* D[16][16] = A[16][K] * B[16][K]^T through the library's MFMA tile helper (layout self-check). */

@@ -40,6 +40,19 @@ SIGNATURES = {
     "rssf_gate_pool_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_winattn_fwd": (c_int, [ctypes.POINTER(WinAttnFwdParams), c_void_p]),
     "rssf_winattn_bwd": (c_int, [ctypes.POINTER(WinAttnBwdParams), c_void_p]),
+    "rssf_conv_tile_n": (c_int, [c_int]),
+    "rssf_conv_packed_elems": (c_int64, [c_int, c_int, c_int, c_int]),
+    "rssf_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                               c_void_p, c_int, c_void_p]),
+    "rssf_conv_gather": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),
+    "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
+    "rssf_bn_bwd_reduce": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
+    "rssf_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_int, c_void_p]),
+    "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float,
+                              c_int, c_void_p]),
     "rssf_debug_mma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 

@@ -1,0 +1,283 @@
+// BatchNorm2d (train: batch statistics; eval: running statistics) fused with the activation and the residual
+// adds that surround it on the RSSFormer path, on channels-last activations.  Reference: nn.BatchNorm2d /
+// nn.SyncBatchNorm call sites in _hrnet_rssformer.py:216-287, 361-405, 512-546, hrnet_aux.py:45-49 and
+// ffn_block.py:222-234 (momentum 0.1, eps 1e-5, biased variance for normalisation, unbiased for running_var).
+//
+// The per-channel sums come from the producing convolution's epilogue (conv_fwd.hip), so forward is
+//   finalize (C threads)  ->  apply: y = act(raw*scale + shift + res_pre) + res_post      (one HBM pass)
+// and backward is
+//   reduce: s1 = sum dz, s2 = sum dz*raw   (dz = dy * act'(z))                            (one pass)
+//   apply : draw = scale * (dz - s1/n - xhat * sum(dz*xhat)/n),  dres_pre = dz            (one pass)
+// Cross-rank SyncBN = all-reduce of the tiny [2][C] buffers between the two launches (host side, RCCL).
+#include "common.cuh"
+using namespace rssf;
+
+namespace {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  return act == ACT_RELU ? fmaxf(z, 0.f) : act == ACT_GELU ? gelu_erf(z) : z;
+}
+__device__ __forceinline__ float act_bwd(float z, int act) {
+  return act == ACT_RELU ? (z > 0.f ? 1.f : 0.f) : act == ACT_GELU ? gelu_erf_grad(z) : 1.f;
+}
+
+// stats [2][C] = {sum, sumsq} over n samples  ->  mean/invstd, scale/shift; running stats updated in place.
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean_invstd,
+                                   float* __restrict__ scale_shift, int C, float n, float momentum, float eps, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    mean = stats[c] / n;
+    var = fmaxf(stats[C + c] / n - mean * mean, 0.f);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = rsqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  mean_invstd[c] = mean; mean_invstd[C + c] = invstd;
+  scale_shift[c] = sc; scale_shift[C + c] = beta[c] - mean * sc;
+}
+
+// elementwise over [rows][C]; thread = (row group, vector column); VEC elements per thread (VEC = Vec<T>::N or 1)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ raw, const float* __restrict__ ss, const T* __restrict__ res_pre,
+                                                       const T* __restrict__ res_post, T* __restrict__ y, int64_t rows, int C, int act) {
+  const int cols = C / VEC;
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cols) * VEC;
+    const int64_t off = i * VEC;
+    if constexpr (VEC > 1) {
+      Vec<T> v, rp, rq, o;
+      v.load(raw + off);
+      if (res_pre) rp.load(res_pre + off);
+      if (res_post) rq.load(res_post + off);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float z = v.get(e) * ss[c0 + e] + ss[C + c0 + e];
+        if (res_pre) z += rp.get(e);
+        float r = act_fwd(z, act);
+        if (res_post) r += rq.get(e);
+        o.set(e, r);
+      }
+      o.store(y + off);
+    } else {
+      float z = ldf(raw + off) * ss[c0] + ss[C + c0];
+      if (res_pre) z += ldf(res_pre + off);
+      float r = act_fwd(z, act);
+      if (res_post) r += ldf(res_post + off);
+      stf(y + off, r);
+    }
+  }
+}
+
+// s[0][c] += sum dz ; s[1][c] += sum dz*raw ; thread owns a fixed vector column and strides over rows.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
+                                                            const T* __restrict__ res_pre, float* __restrict__ sums, int64_t rows, int C,
+                                                            int act) {
+  extern __shared__ float sacc[];                         // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sacc[i] = 0.f;
+  __syncthreads();
+  const int cols = C / VEC;
+  const int rpb = blockDim.x / cols;                      // rows handled per block per pass (>= 1)
+  const int col = threadIdx.x % cols, rlocal = threadIdx.x / cols;
+  float a1[VEC], a2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+  if (rlocal < rpb) {
+    const int c0 = col * VEC;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rlocal; r < rows; r += (int64_t)gridDim.x * rpb) {
+      const int64_t off = r * C + c0;
+      if constexpr (VEC > 1) {
+        Vec<T> vd, vr, vp;
+        vd.load(dy + off); vr.load(raw + off);
+        if (res_pre) vp.load(res_pre + off);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float x = vr.get(e);
+          float z = x * ss[c0 + e] + ss[C + c0 + e];
+          if (res_pre) z += vp.get(e);
+          const float dz = vd.get(e) * act_bwd(z, act);
+          a1[e] += dz; a2[e] += dz * x;
+        }
+      } else {
+        const float x = ldf(raw + off);
+        float z = x * ss[c0] + ss[C + c0];
+        if (res_pre) z += ldf(res_pre + off);
+        const float dz = ldf(dy + off) * act_bwd(z, act);
+        a1[0] += dz; a2[0] += dz * x;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { atomicAdd(&sacc[c0 + e], a1[e]); atomicAdd(&sacc[C + c0 + e], a2[e]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&sums[i], sacc[i]);
+}
+
+// draw = scale*(dz - k1 - xhat*k2) (training) or scale*dz (eval);  dres (optional) = dz
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
+                                                           const float* __restrict__ mi, const float* __restrict__ sums,
+                                                           const T* __restrict__ res_pre, T* __restrict__ draw, T* __restrict__ dres,
+                                                           int64_t rows, int C, int act, float n, int training) {
+  const int cols = C / VEC;
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cols) * VEC;
+    const int64_t off = i * VEC;
+    float xv[VEC], dv[VEC], pv[VEC], o1[VEC], o2[VEC];
+    if constexpr (VEC > 1) {
+      Vec<T> vd, vr, vp;
+      vd.load(dy + off); vr.load(raw + off);
+      if (res_pre) vp.load(res_pre + off);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { xv[e] = vr.get(e); dv[e] = vd.get(e); pv[e] = res_pre ? vp.get(e) : 0.f; }
+    } else {
+      xv[0] = ldf(raw + off); dv[0] = ldf(dy + off); pv[0] = res_pre ? ldf(res_pre + off) : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = c0 + e;
+      const float sc = ss[c];
+      const float z = xv[e] * sc + ss[C + c] + pv[e];
+      const float dz = dv[e] * act_bwd(z, act);
+      o2[e] = dz;
+      if (training) {
+        const float mean = mi[c], invstd = mi[C + c];
+        const float s1 = sums[c], s2 = sums[C + c];
+        const float xhat = (xv[e] - mean) * invstd;
+        const float dot = (s2 - mean * s1) * invstd;        // sum dz * xhat
+        o1[e] = sc * (dz - s1 / n - xhat * dot / n);
+      } else {
+        o1[e] = sc * dz;
+      }
+    }
+    if constexpr (VEC > 1) {
+      Vec<T> w1, w2;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { w1.set(e, o1[e]); w2.set(e, o2[e]); }
+      w1.store(draw + off);
+      if (dres) w2.store(dres + off);
+    } else {
+      stf(draw + off, o1[0]);
+      if (dres) stf(dres + off, o2[0]);
+    }
+  }
+}
+
+// dgamma[c] += invstd*(s2 - mean*s1) ; dbeta[c] += s1
+__global__ void bn_param_grad_kernel(const float* __restrict__ sums, const float* __restrict__ mi, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dgamma[c] += (sums[C + c] - mi[c] * sums[c]) * mi[C + c];
+  dbeta[c] += sums[c];
+}
+
+int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+template <typename T>
+int apply_launch(const void* raw, const float* ss, const void* rp, const void* rq, void* y, int64_t rows, int C, int act, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  if (C % V == 0)
+    bn_apply_kernel<T, V><<<grid_for(rows * (C / V)), 256, 0, st>>>((const T*)raw, ss, (const T*)rp, (const T*)rq, (T*)y, rows, C, act);
+  else
+    bn_apply_kernel<T, 1><<<grid_for(rows * C), 256, 0, st>>>((const T*)raw, ss, (const T*)rp, (const T*)rq, (T*)y, rows, C, act);
+  return check_launch("bn_apply");
+}
+
+template <typename T>
+int reduce_launch(const void* dy, const void* raw, const float* ss, const void* rp, float* sums, int64_t rows, int C, int act, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  const size_t sh = 2 * C * sizeof(float);
+  if (C % V == 0 && C / V <= 256) {
+    const int rpb = 256 / (C / V);
+    int64_t blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 1024) blocks = 1024;
+    bn_bwd_reduce_kernel<T, V><<<(unsigned)blocks, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
+  } else {
+    if (C > 256) { set_error("bn_bwd_reduce: C=%d not supported on the scalar path", C); return RSSF_ERR_UNSUPPORTED; }
+    const int rpb = 256 / C;
+    int64_t blocks = (rows + rpb - 1) / rpb;
+    if (blocks > 1024) blocks = 1024;
+    bn_bwd_reduce_kernel<T, 1><<<(unsigned)blocks, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
+  }
+  return check_launch("bn_bwd_reduce");
+}
+
+template <typename T>
+int bwd_apply_launch(const void* dy, const void* raw, const float* ss, const float* mi, const float* sums, const void* rp, void* draw,
+                     void* dres, int64_t rows, int C, int act, float n, int training, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  if (C % V == 0)
+    bn_bwd_apply_kernel<T, V><<<grid_for(rows * (C / V)), 256, 0, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw,
+                                                                        (T*)dres, rows, C, act, n, training);
+  else
+    bn_bwd_apply_kernel<T, 1><<<grid_for(rows * C), 256, 0, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw,
+                                                                  (T*)dres, rows, C, act, n, training);
+  return check_launch("bn_bwd_apply");
+}
+}  // namespace
+
+extern "C" int rssf_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float* mean_invstd, float* scale_shift, int C, double n, float momentum, float eps, int training,
+                                void* stream) {
+  RSSF_REQUIRE(gamma && beta && mean_invstd && scale_shift && C > 0, "bn_finalize: bad arguments");
+  RSSF_REQUIRE(training ? (stats != nullptr && n >= 1) : (running_mean && running_var), "bn_finalize: missing statistics");
+  bn_finalize_kernel<<<(C + 127) / 128, 128, 0, (hipStream_t)stream>>>(stats, gamma, beta, running_mean, running_var, mean_invstd,
+                                                                      scale_shift, C, (float)n, momentum, eps, training);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int rssf_bn_apply(const void* raw, const float* scale_shift, const void* res_pre, const void* res_post, void* y, int64_t rows,
+                             int C, int act, int dtype, void* stream) {
+  RSSF_REQUIRE(raw && scale_shift && y && rows > 0 && C > 0 && act >= 0 && act <= 2, "bn_apply: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return apply_launch<float>(raw, scale_shift, res_pre, res_post, y, rows, C, act, st);
+  if (dtype == RSSF_BF16) return apply_launch<bf16_t>(raw, scale_shift, res_pre, res_post, y, rows, C, act, st);
+  set_error("bn_apply: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}
+
+extern "C" int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, float* sums,
+                                  int64_t rows, int C, int act, int dtype, void* stream) {
+  RSSF_REQUIRE(dy && raw && scale_shift && sums && rows > 0 && C > 0, "bn_bwd_reduce: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return reduce_launch<float>(dy, raw, scale_shift, res_pre, sums, rows, C, act, st);
+  if (dtype == RSSF_BF16) return reduce_launch<bf16_t>(dy, raw, scale_shift, res_pre, sums, rows, C, act, st);
+  set_error("bn_bwd_reduce: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}
+
+extern "C" int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift, const float* mean_invstd, const float* sums,
+                                 const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
+                                 double n, int training, int dtype, void* stream) {
+  RSSF_REQUIRE(dy && raw && scale_shift && mean_invstd && sums && draw && rows > 0 && C > 0, "bn_bwd_apply: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (dtype == RSSF_F32)
+    rc = bwd_apply_launch<float>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, rows, C, act, (float)n, training, st);
+  else if (dtype == RSSF_BF16)
+    rc = bwd_apply_launch<bf16_t>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, rows, C, act, (float)n, training, st);
+  else { set_error("bn_bwd_apply: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  if (rc) return rc;
+  if (dgamma && dbeta) {
+    bn_param_grad_kernel<<<(C + 127) / 128, 128, 0, st>>>(sums, mean_invstd, dgamma, dbeta, C);
+    return check_launch("bn_param_grad");
+  }
+  return RSSF_OK;
+}

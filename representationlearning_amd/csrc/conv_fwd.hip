@@ -1,0 +1,288 @@
+// Implicit-GEMM convolution, "gather" form, channels-last (NHWC) activations, MFMA.
+//
+// One kernel serves the forward convolution AND the data gradient (dgrad = the same gather with mirrored taps,
+// transposed weight slabs and, for stride-2 layers, a divisibility predicate on the source pixel).  Covers every
+// convolution on the RSSFormer path: HRNet 3x3 (s1/s2) and 1x1 convs (_hrnet_rssformer.py:216-287, 361-405,
+// 512-546), the neck/head 1x1 convs (hrnet_aux.py:45-49, 78-81) and MlpDWBN's fc1/fc2 and the fused
+// {1x1 + 3x3 dil 6 + 3x3 dil 12} sum (ffn_block.py:219-228, 246-257) as ONE 19-tap launch.
+//
+// GEMM view: M = B*OH*OW output pixels, N = Cout, K = taps * Cin.  Block tile 128 (pixels) x BN (channels),
+// 4 waves each 32 x BN; K is walked tap by tap in 64-byte channel chunks staged through LDS, with the next
+// chunk's global loads issued before the MFMAs of the current one (register double buffering).  Epilogue:
+// + bias, per-channel sum / sum-of-squares partials for the following BatchNorm (fused statistics: the
+// activation is not re-read for the mean/var pass), tile transposed through LDS for 16-byte coalesced stores.
+#include "conv.cuh"
+using namespace rssf;
+using namespace rssf::cv;
+
+namespace {
+
+struct ConvArgs {
+  const void* in;        // [B, IH, IW, Cin]
+  const void* wpk;       // [ntaps][CoutP][CinP]  (k = input channel contiguous, zero padded)
+  void* out;             // [B, OH, OW, Cout]
+  const float* bias;     // [Cout] or null
+  float* stats;          // [2][Cout] sum, sumsq (atomically accumulated) or null
+  int B, IH, IW, Cin, OH, OW, Cout, CinP, CoutP;
+  int mul, div;          // source row = (oy*mul + dy) / div   (div > 1: only when divisible)
+  Taps taps;
+};
+
+constexpr int BM = 128;
+
+template <typename T, int BNT>
+__global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
+  using MK = MmaK<T>;
+  constexpr int BK = MK::BK, V = Vec<T>::N, CPR = BK / V;      // 16-byte chunks per staged row (= 4)
+  constexpr int LDA = BK + LdsPad<T>::X;
+  constexpr int NI = BNT / 16;
+  constexpr int A_CHUNKS = BM * CPR / 256;                       // per thread (= 2)
+  constexpr int B_CHUNKS = (BNT * CPR + 255) / 256;
+  constexpr int LDC = BNT + LdsPad<T>::X;
+  constexpr int STAGE_ELEMS = (BM + BNT) * LDA;
+  constexpr int OUT_ELEMS = BM * LDC;
+  constexpr int LDS_ELEMS = STAGE_ELEMS > OUT_ELEMS ? STAGE_ELEMS : OUT_ELEMS;
+  __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
+  __shared__ float sstat[2 * BNT];
+  T* As = lds;
+  T* Bs = lds + BM * LDA;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
+  const int64_t M = (int64_t)a.B * a.OH * a.OW;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BNT;
+  const T* IN = reinterpret_cast<const T*>(a.in);
+  const T* W = reinterpret_cast<const T*>(a.wpk);
+  const bool vec_ok = (a.Cin % V) == 0;
+
+  // per-thread fixed A rows (pixels) and channel sub-chunk
+  int pb[A_CHUNKS], py[A_CHUNKS], px[A_CHUNKS];
+  bool pv[A_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < A_CHUNKS; ++i) {
+    const int row = (tid + i * 256) / CPR;
+    const int64_t m = m0 + row;
+    pv[i] = m < M;
+    const int64_t mm = pv[i] ? m : 0;
+    pb[i] = (int)(mm / ((int64_t)a.OH * a.OW));
+    const int rem = (int)(mm % ((int64_t)a.OH * a.OW));
+    py[i] = (rem / a.OW) * a.mul;
+    px[i] = (rem % a.OW) * a.mul;
+  }
+  const int sub = (tid % CPR) * V;
+
+  f32x4 acc[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
+
+  const int kchunks = a.CinP / BK;
+  const int nsteps = a.taps.n * kchunks;
+  Vec<T> ra[A_CHUNKS], rb[B_CHUNKS];
+
+  auto load_step = [&](int step) {
+    const int t = step / kchunks, kc = step % kchunks;
+    const int dy = a.taps.dy[t], dx = a.taps.dx[t];
+    const int c0 = kc * BK + sub;
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+      ra[i].raw = {0, 0, 0, 0};
+      int sy = py[i] + dy, sx = px[i] + dx;
+      bool ok = pv[i] && sy >= 0 && sx >= 0 && c0 < a.Cin;
+      if (a.div > 1) {
+        ok = ok && (sy % a.div == 0) && (sx % a.div == 0);
+        sy /= a.div; sx /= a.div;
+      }
+      ok = ok && sy < a.IH && sx < a.IW;
+      if (ok) {
+        const T* src = IN + (((int64_t)pb[i] * a.IH + sy) * a.IW + sx) * a.Cin + c0;
+        if (vec_ok) ra[i].load(src);
+        else
+#pragma unroll
+          for (int e = 0; e < V; ++e) if (c0 + e < a.Cin) ra[i].set(e, ldf(src + e));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / CPR;
+      rb[i].raw = {0, 0, 0, 0};
+      if (row < BNT) rb[i].load(W + ((int64_t)t * a.CoutP + n0 + row) * a.CinP + kc * BK + (c % CPR) * V);
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) ra[i].store(As + ((tid + i * 256) / CPR) * LDA + sub);
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) {
+      const int c = tid + i * 256;
+      if (c / CPR < BNT) rb[i].store(Bs + (c / CPR) * LDA + (c % CPR) * V);
+    }
+  };
+
+  load_step(0);
+  for (int step = 0; step < nsteps; ++step) {
+    store_step();
+    __syncthreads();
+    if (step + 1 < nsteps) load_step(step + 1);          // global loads in flight under the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += MK::KSTEP) {
+      typename MK::frag fa[2], fb[NI];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) fa[mi] = MK::load(As + (wave * 32 + mi * 16 + l15) * LDA + ks + grp * MK::KPL);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = MK::load(Bs + (ni * 16 + l15) * LDA + ks + grp * MK::KPL);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MK::mma(fa[mi], fb[ni], acc[mi][ni]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------
+  if (a.stats) {
+    for (int i = tid; i < 2 * BNT; i += 256) sstat[i] = 0.f;
+  }
+  T* Cs = lds;                                            // [BM][LDC]
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = n0 + ni * 16 + l15;
+    const float bv = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave * 32 + mi * 16 + grp * 4 + r;
+        const float v = acc[mi][ni][r] + bv;
+        stf(Cs + row * LDC + ni * 16 + l15, v);
+        if (m0 + row < M) { s1 += v; s2 += v * v; }
+      }
+    if (a.stats) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (grp == 0) { atomicAdd(&sstat[ni * 16 + l15], s1); atomicAdd(&sstat[BNT + ni * 16 + l15], s2); }
+    }
+  }
+  __syncthreads();
+  if (a.stats) {
+    for (int i = tid; i < BNT; i += 256)
+      if (n0 + i < a.Cout) { atomicAdd(a.stats + n0 + i, sstat[i]); atomicAdd(a.stats + a.Cout + n0 + i, sstat[BNT + i]); }
+  }
+  T* OUT = reinterpret_cast<T*>(a.out);
+  constexpr int OCPR = BNT / V;                          // 16-byte chunks per output row of the tile
+  const bool ovec = (a.Cout % V) == 0;
+  for (int c = tid; c < BM * OCPR; c += 256) {
+    const int row = c / OCPR, cc = (c % OCPR) * V;
+    const int64_t m = m0 + row;
+    const int col = n0 + cc;
+    if (m >= M || col >= a.Cout) continue;
+    T* dst = OUT + m * a.Cout + col;
+    if (ovec) {
+      Vec<T> v;
+      v.load(Cs + row * LDC + cc);
+      v.store(dst);
+    } else {
+      for (int e = 0; e < V && col + e < a.Cout; ++e) dst[e] = Cs[row * LDC + cc + e];
+    }
+  }
+}
+
+// ---- weight packing: torch [Cout][Cin][kh][kw] fp32  ->  [tap][RowsP][ColsP] T, k-contiguous, zero padded ------------
+// transpose == 0 (forward):  rows = Cout, cols = Cin, tap t <- kernel position kpos[t] of source conv src[t]
+// transpose == 1 (dgrad):    rows = Cin,  cols = Cout
+struct PackArgs {
+  const float* w[3];     // up to 3 source convs (the fused MLP sum); w[s] has kernel size ks[s] x ks[s]
+  int ks[3];
+  int nsrc;
+  int src_of_tap[MAX_TAPS];
+  int kpos_of_tap[MAX_TAPS];
+  int ntaps, Cout, Cin, RowsP, ColsP, transpose;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a, T* out) {
+  const int64_t total = (int64_t)a.ntaps * a.RowsP * a.ColsP;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)(i % a.ColsP), row = (int)((i / a.ColsP) % a.RowsP), t = (int)(i / ((int64_t)a.ColsP * a.RowsP));
+    const int co = a.transpose ? col : row, ci = a.transpose ? row : col;
+    float v = 0.f;
+    if (co < a.Cout && ci < a.Cin) {
+      const int s = a.src_of_tap[t], kk = a.ks[s] * a.ks[s];
+      v = a.w[s][((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[t]];
+    }
+    stf(out + i, v);
+  }
+}
+
+template <typename T>
+int launch_conv(const ConvArgs& a, int bnt, hipStream_t st) {
+  const int64_t M = (int64_t)a.B * a.OH * a.OW;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutP / bnt));
+  if (bnt == 32) conv_gather_kernel<T, 32><<<grid, 256, 0, st>>>(a);
+  else if (bnt == 64) conv_gather_kernel<T, 64><<<grid, 256, 0, st>>>(a);
+  else conv_gather_kernel<T, 128><<<grid, 256, 0, st>>>(a);
+  return check_launch("conv_gather");
+}
+
+int pick_bn(int cout) { return cout <= 32 ? 32 : cout <= 64 ? 64 : 128; }
+
+}  // namespace
+
+extern "C" int rssf_conv_tile_n(int cout) { return pick_bn(cout); }
+
+extern "C" int rssf_conv_pack(const float* w0, const float* w1, const float* w2, const int* ksizes, int nsrc,
+                              const int* src_of_tap, const int* kpos_of_tap, int ntaps, int Cout, int Cin, int transpose,
+                              void* out, int dtype, void* stream) {
+  RSSF_REQUIRE(w0 && ksizes && src_of_tap && kpos_of_tap && out && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 && ntaps <= MAX_TAPS,
+               "conv_pack: bad arguments");
+  PackArgs a;
+  a.w[0] = w0; a.w[1] = w1; a.w[2] = w2;
+  for (int i = 0; i < 3; ++i) a.ks[i] = i < nsrc ? ksizes[i] : 1;
+  a.nsrc = nsrc;
+  for (int t = 0; t < ntaps; ++t) { a.src_of_tap[t] = src_of_tap[t]; a.kpos_of_tap[t] = kpos_of_tap[t]; }
+  a.ntaps = ntaps; a.Cout = Cout; a.Cin = Cin; a.transpose = transpose;
+  const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
+  const int bk = dtype == RSSF_BF16 ? MmaK<bf16_t>::BK : MmaK<float>::BK;
+  a.RowsP = (rows + pick_bn(rows) - 1) / pick_bn(rows) * pick_bn(rows);
+  a.ColsP = (cols + bk - 1) / bk * bk;
+  const int64_t total = (int64_t)ntaps * a.RowsP * a.ColsP;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) pack_weights_kernel<float><<<blocks, 256, 0, st>>>(a, (float*)out);
+  else if (dtype == RSSF_BF16) pack_weights_kernel<bf16_t><<<blocks, 256, 0, st>>>(a, (bf16_t*)out);
+  else { set_error("conv_pack: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  return check_launch("conv_pack");
+}
+
+extern "C" int64_t rssf_conv_packed_elems(int ntaps, int rows, int cols, int dtype) {
+  const int bk = dtype == RSSF_BF16 ? MmaK<bf16_t>::BK : MmaK<float>::BK;
+  const int64_t rp = (rows + pick_bn(rows) - 1) / pick_bn(rows) * pick_bn(rows);
+  const int64_t cp = (cols + bk - 1) / bk * bk;
+  return (int64_t)ntaps * rp * cp;
+}
+
+extern "C" int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bias, float* stats, int B, int IH,
+                                int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy,
+                                const int* dx, int dtype, void* stream) {
+  RSSF_REQUIRE(in && wpk && out && dy && dx && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 &&
+                   ntaps >= 1 && ntaps <= MAX_TAPS && mul >= 1 && div >= 1,
+               "conv_gather: bad arguments");
+  ConvArgs a;
+  a.in = in; a.wpk = wpk; a.out = out; a.bias = bias; a.stats = stats;
+  a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
+  a.mul = mul; a.div = div;
+  a.taps.n = ntaps;
+  for (int t = 0; t < ntaps; ++t) { a.taps.dy[t] = dy[t]; a.taps.dx[t] = dx[t]; }
+  const int bnt = pick_bn(Cout);
+  const int bk = dtype == RSSF_BF16 ? MmaK<bf16_t>::BK : MmaK<float>::BK;
+  a.CoutP = (Cout + bnt - 1) / bnt * bnt;
+  a.CinP = (Cin + bk - 1) / bk * bk;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return launch_conv<float>(a, bnt, st);
+  if (dtype == RSSF_BF16) return launch_conv<bf16_t>(a, bnt, st);
+  set_error("conv_gather: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}

@@ -3,11 +3,13 @@
 
 Same module tree / attribute names as the reference, hence identical state_dict keys.  Activations are kept in
 channels-last memory (NHWC physically) end to end — the layout the HIP kernels and the window attention want.
-STATUS: the 3x3/1x1 convolutions + BatchNorm of the HRNet body dispatch to ATen-ROCm (MIOpen) for now
-(DESIGN.md "next"); the transformer blocks run on the hand-written HIP kernels."""
+Every Conv2d -> BatchNorm2d (-> ReLU / + residual) group runs as one fused autograd node on the hand-written
+implicit-GEMM / BN kernels (representationlearning_amd.nnf); nearest upsampling and the branch sums are still
+ATen elementwise kernels.  nn.Conv2d / nn.BatchNorm2d modules only hold the parameters."""
 import torch
 import torch.nn as nn
 
+from .... import nnf
 from .modules.MTFM import GeneralTransformerBlock
 
 BatchNorm2d = nn.BatchNorm2d
@@ -54,10 +56,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        res = x if self.downsample is None else self.downsample(x)
-        return self.relu(out + res)
+        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU)
+        res = x if self.downsample is None else nnf.run_sequential(self.downsample, x)
+        return nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU, res_pre=res)
 
 
 class Bottleneck(nn.Module):
@@ -76,11 +77,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        res = x if self.downsample is None else self.downsample(x)
-        return self.relu(out + res)
+        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU)
+        out = nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU)
+        res = x if self.downsample is None else nnf.run_sequential(self.downsample, x)
+        return nnf.conv_bn_act(out, self.conv3, self.bn3, nnf.ACT_RELU, res_pre=res)
 
 
 blocks_dict = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
@@ -157,16 +157,16 @@ class HighResolutionModule(nn.Module):
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        x = [self.branches[i](x[i]) for i in range(self.num_branches)]
+        x = [self.branches[i](x[i]) for i in range(self.num_branches)]          # Sequential of BasicBlocks
         fused = []
         for i in range(len(self.fuse_layers)):
             low = 0
             for j in range(1, self.num_branches):
-                low = low + (x[j] if j == i else self.fuse_layers[i][j](x[j]))
+                low = low + (x[j] if j == i else nnf.run_sequential(self.fuse_layers[i][j], x[j]))
             if i == 0:
                 y = self.transformer(low, x[0])        # residual comes from `low`; x[0] only feeds K/V (:430-431)
             else:
-                y = self.fuse_layers[i][0](x[0]) + low
+                y = nnf.run_sequential(self.fuse_layers[i][0], x[0]) + low
             fused.append(self.relu(y))
         return fused
 
@@ -245,8 +245,8 @@ class HighResolutionNet(nn.Module):
 
     def forward(self, x):
         x = x.contiguous(memory_format=torch.channels_last)
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
+        x = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU)
+        x = nnf.conv_bn_act(x, self.conv2, self.bn2, nnf.ACT_RELU)
         x = self.layer1(x)
         ys = [x]
         for s in (2, 3, 4):
@@ -257,7 +257,7 @@ class HighResolutionNet(nn.Module):
                 if trans[i] is None:
                     xs.append(ys[i])
                 else:
-                    xs.append(trans[i](ys[-1]))
+                    xs.append(nnf.run_sequential(trans[i], ys[-1]))
             ys = getattr(self, "stage{}".format(s))(xs)
         return ys
 

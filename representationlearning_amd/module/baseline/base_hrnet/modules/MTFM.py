@@ -46,7 +46,7 @@ class GeneralTransformerBlock(nn.Module):
         x1 = AG.GatedWindowCrossAttention.apply(xt, yt, self.norm1.weight, self.norm1.bias, *self.attn.gate_params(),
                                                 *self.attn.attn.proj_params(), H, W, self.num_heads)
         z = AG.LayerNormTokens.apply(x1, self.norm2.weight, self.norm2.bias)
-        x2 = x1 + self.mlp(z, H, W)
+        x2 = self.mlp(z, H, W, residual=x1)          # x1 + Mlp(LN2(x1)), residual fused into the last BN/GELU pass
         return x2.reshape(B, H, W, C).permute(0, 3, 1, 2)
 
     def extra_repr(self):

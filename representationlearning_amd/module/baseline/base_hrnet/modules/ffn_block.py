@@ -1,10 +1,12 @@
 """MlpDWBN (reference: modules/ffn_block.py:207-287): 1x1 conv -> SyncBN -> GELU -> {1x1 + 3x3 dil 6 + 3x3 dil 12}
 dense convs summed -> SyncBN -> GELU -> 1x1 conv -> SyncBN -> GELU.
 
-STATUS: the convolutions / batch-norms of this module currently dispatch to ATen-ROCm (MIOpen) on channels-last
-tensors; the fused implicit-GEMM HIP kernels replace them (hot-path table row A7).  nn.SyncBatchNorm is
-kept so the cross-rank statistics semantics of the reference hold under data parallelism."""
+Three fused launches-groups on the hand-written HIP kernels: fc1 -> BN -> GELU; the three hidden convolutions as ONE
+19-tap implicit GEMM (K = 19*4C) -> BN -> GELU; fc2 -> BN -> GELU (+ the block's residual).  nn.SyncBatchNorm modules
+are kept (state_dict + "always synchronised" semantics of the reference under data parallelism)."""
 import torch.nn as nn
+
+from ..... import nnf
 
 
 class MlpDWBN(nn.Module):
@@ -25,18 +27,21 @@ class MlpDWBN(nn.Module):
         self.act3 = act_layer()
         self.norm3 = nn.SyncBatchNorm(out_features)
 
-    def forward_nhwc(self, t):
-        """t: logical NCHW tensor in channels_last memory format."""
-        t = self.act1(self.norm1(self.fc1(t)))
-        t = self.dw(t) + self.dw6(t) + self.dw12(t)
-        t = self.act2(self.norm2(t))
-        return self.act3(self.norm3(self.fc2(t)))
+    def forward_nhwc(self, t, residual=None):
+        """t: logical NCHW tensor in channels_last memory; residual (optional) is added AFTER the last GELU."""
+        for a in (self.act1, self.act2, self.act3):
+            if not isinstance(a, nn.GELU):
+                raise NotImplementedError("MlpDWBN (HIP): GELU activations only (the RSSFormer configuration)")
+        t = nnf.conv_bn_act(t, self.fc1, self.norm1, nnf.ACT_GELU)
+        t = nnf.conv_bn_act(t, [self.dw, self.dw6, self.dw12], self.norm2, nnf.ACT_GELU)
+        return nnf.conv_bn_act(t, self.fc2, self.norm3, nnf.ACT_GELU, res_post=residual)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, residual=None):
         if x.dim() != 3:
             raise RuntimeError("Unsupported input shape: {}".format(x.shape))
         B, N, C = x.shape
         if N != H * W:
             raise RuntimeError("MlpDWBN (HIP): class-token inputs are not on the RSSFormer path")
         t = x.reshape(B, H, W, C).permute(0, 3, 1, 2)          # channels-last view, no copy
-        return self.forward_nhwc(t).permute(0, 2, 3, 1).reshape(B, N, -1)
+        r = None if residual is None else residual.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+        return self.forward_nhwc(t, r).permute(0, 2, 3, 1).reshape(B, N, -1)

@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import nnf
 from ...core import registry
 from ...core.config import ConfigModule
 from ..CGFL import SegmentationLossaux as SegmentationLoss
@@ -19,7 +20,8 @@ class SimpleFusion8(nn.Module):
         x0 = feat_list[0]
         size = x0.shape[2:]
         ups = [x0] + [F.interpolate(f, size=size, mode="bilinear", align_corners=True) for f in feat_list[1:]]
-        return self.fuse_conv(torch.cat(ups, dim=1)), x0
+        cat = torch.cat(ups, dim=1).contiguous(memory_format=torch.channels_last)
+        return nnf.run_sequential(self.fuse_conv, cat), x0
 
 
 @registry.MODEL.register("RSSFormer")
@@ -39,7 +41,7 @@ class HRNetFusion(ConfigModule):
         feats = self.backbone(x)
         fused, f0 = self.neck(feats)
         aux = self.headaux(self.avg_pool(f0).flatten(1).float())
-        logit = self.head(fused)
+        logit = self.head[1](nnf.conv_bias(fused, self.head[0]))
         if self.training:
             return self.loss(logit, y["cls"].long(), aux)
         return logit.float().softmax(dim=1)

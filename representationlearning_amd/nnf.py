@@ -1,0 +1,274 @@
+"""Fused functional layers of the RSSFormer path on top of the librssf C ABI:
+
+    conv_bn_act : Conv2d (one conv, or the MLP's three summed convs as ONE 19-tap launch) -> BatchNorm2d ->
+                  {none, ReLU, GELU} with an optional residual before and/or after the activation
+    conv_bias   : Conv2d with bias and nothing else (the segmentation head)
+
+Activations are logical-NCHW tensors in channels_last memory (physically NHWC); parameters stay in the nn.Conv2d /
+nn.BatchNorm2d modules of the mirror model (same state_dict as the reference).  Each op is ONE autograd node whose
+forward/backward are short sequences of C-ABI launches (no arithmetic in Python).  SyncBN = an all-reduce of the
+[2][C] statistics between two launches.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+_SYNC_ALL_BN = False          # set by the trainer: configs/base/loveda.py:107 train.sync_bn
+
+
+def set_sync_bn(flag):
+    global _SYNC_ALL_BN
+    _SYNC_ALL_BN = bool(flag)
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _ia(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+class ConvSpec:
+    """Tap list of a convolution (or of a sum of convolutions sharing input/output, stride 1)."""
+
+    def __init__(self, convs):
+        c0 = convs[0]
+        self.cin, self.cout = c0.in_channels, c0.out_channels
+        self.stride = c0.stride[0]
+        self.ksizes, self.src, self.kpos, self.dy, self.dx = [], [], [], [], []
+        for s, c in enumerate(convs):
+            k, d, p = c.kernel_size[0], c.dilation[0], c.padding[0]
+            if (c.in_channels, c.out_channels, c.stride[0]) != (self.cin, self.cout, self.stride) or c.groups != 1 \
+                    or c.kernel_size[0] != c.kernel_size[1] or c.padding[0] != c.padding[1] or c.dilation[0] != c.dilation[1]:
+                raise NotImplementedError("librssf conv: square, ungrouped convolutions sharing in/out/stride only")
+            self.ksizes.append(k)
+            for ky in range(k):
+                for kx in range(k):
+                    self.src.append(s)
+                    self.kpos.append(ky * k + kx)
+                    self.dy.append(ky * d - p)
+                    self.dx.append(kx * d - p)
+        self.ntaps = len(self.src)
+        if self.ntaps > 19 or len(convs) > 3:
+            raise NotImplementedError("librssf conv: at most 19 taps / 3 fused convolutions")
+        c = c0
+        self._out_hw = lambda h, w: ((h + 2 * c.padding[0] - c.dilation[0] * (c.kernel_size[0] - 1) - 1) // self.stride + 1,
+                                     (w + 2 * c.padding[0] - c.dilation[0] * (c.kernel_size[0] - 1) - 1) // self.stride + 1)
+
+    def out_hw(self, h, w):
+        return self._out_hw(h, w)
+
+
+_SPEC_CACHE = {}
+
+
+def spec_of(convs):
+    key = tuple(id(c) for c in convs)
+    sp = _SPEC_CACHE.get(key)
+    if sp is None:
+        sp = _SPEC_CACHE[key] = ConvSpec(convs)
+    return sp
+
+
+def _nhwc(x):
+    """logical NCHW -> [B,H,W,C] view; copies only if x is not channels-last."""
+    t = x.permute(0, 2, 3, 1)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def _pack(spec, weights, transpose, dtype, device):
+    lib = L.load()
+    code = L.RSSF_BF16 if dtype == torch.bfloat16 else L.RSSF_F32
+    rows, cols = (spec.cin, spec.cout) if transpose else (spec.cout, spec.cin)
+    n = lib.rssf_conv_packed_elems(spec.ntaps, rows, cols, code)
+    out = torch.empty(n, device=device, dtype=dtype)
+    w = [wt if wt.is_contiguous() else wt.contiguous() for wt in weights] + [None, None]
+    L.check(lib.rssf_conv_pack(L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), _ia(spec.ksizes), len(weights), _ia(spec.src), _ia(spec.kpos),
+                               spec.ntaps, spec.cout, spec.cin, int(transpose), L.ptr(out), code, L.stream()), "rssf_conv_pack")
+    return out
+
+
+def _conv_forward(spec, xh, weights, bias, stats):
+    B, H, W, C = xh.shape
+    OH, OW = spec.out_hw(H, W)
+    wpk = _pack(spec, weights, False, xh.dtype, xh.device)
+    out = torch.empty(B, OH, OW, spec.cout, device=xh.device, dtype=xh.dtype)
+    L.check(L.load().rssf_conv_gather(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), B, H, W, C, OH, OW, spec.cout,
+                                      spec.stride, 1, spec.ntaps, _ia(spec.dy), _ia(spec.dx), L.dtype_code(xh), L.stream()),
+            "rssf_conv_gather")
+    return out
+
+
+def _conv_dgrad(spec, dout, weights, in_shape):
+    B, H, W, C = in_shape
+    _, OH, OW, _ = dout.shape
+    wpk = _pack(spec, weights, True, dout.dtype, dout.device)
+    dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype)
+    L.check(L.load().rssf_conv_gather(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, B, OH, OW, spec.cout, H, W, C, 1, spec.stride,
+                                      spec.ntaps, _ia([-v for v in spec.dy]), _ia([-v for v in spec.dx]), L.dtype_code(dout),
+                                      L.stream()), "rssf_conv_gather(dgrad)")
+    return dx
+
+
+def _conv_wgrad(spec, dout, xh, weights, want_bias):
+    B, H, W, C = xh.shape
+    _, OH, OW, _ = dout.shape
+    dws = [torch.zeros_like(w, dtype=torch.float32, memory_format=torch.contiguous_format) for w in weights]
+    db = torch.zeros(spec.cout, device=xh.device, dtype=torch.float32) if want_bias else None
+    d = dws + [None, None]
+    L.check(L.load().rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), _ia(spec.ksizes), len(weights),
+                                     _ia(spec.src), _ia(spec.kpos), L.ptr(db), B, H, W, C, OH, OW, spec.cout, spec.stride, spec.ntaps,
+                                     _ia(spec.dy), _ia(spec.dx), L.dtype_code(xh), L.stream()), "rssf_conv_wgrad")
+    return dws, db
+
+
+class _ConvBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res_pre, res_post, gamma, beta, rmean, rvar, spec, act, training, momentum, eps, sync, nbias, *wb):
+        weights, biases = wb[:len(wb) - nbias], wb[len(wb) - nbias:]
+        L.require_gpu(x)
+        xh = _nhwc(x)
+        dev = x.device
+        bias = None
+        if nbias:
+            bias = biases[0] if nbias == 1 else torch.stack(biases).sum(0)      # summed convs: biases add
+            bias = bias.float().contiguous()
+        C = spec.cout
+        stats = torch.zeros(2, C, device=dev, dtype=torch.float32) if training else None
+        raw = _conv_forward(spec, xh, weights, bias, stats)
+        rows = raw.numel() // C
+        n = float(rows)
+        if training and sync and _world() > 1:
+            dist.all_reduce(stats)
+            n *= _world()
+        mi = torch.empty(2, C, device=dev, dtype=torch.float32)
+        ss = torch.empty(2, C, device=dev, dtype=torch.float32)
+        lib = L.load()
+        L.check(lib.rssf_bn_finalize(L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi), L.ptr(ss), C, n,
+                                     momentum, eps, int(training), L.stream()), "rssf_bn_finalize")
+        rp = None if res_pre is None else _nhwc(res_pre)
+        rq = None if res_post is None else _nhwc(res_post)
+        for r in (rp, rq):
+            if r is not None and (r.dtype != raw.dtype or r.shape != raw.shape):
+                raise RuntimeError("conv_bn_act: residual dtype/shape mismatch %s%s vs %s%s" % (r.dtype, tuple(r.shape), raw.dtype, tuple(raw.shape)))
+        y = torch.empty_like(raw)
+        L.check(lib.rssf_bn_apply(L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, L.dtype_code(raw), L.stream()),
+                "rssf_bn_apply")
+        ctx.save_for_backward(xh, raw, ss, mi, rp, *weights)
+        ctx.meta = (spec, act, training, n, sync, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec, act, training, n, sync, nbias, nw, has_pre, has_post, x_req = ctx.meta
+        xh, raw, ss, mi, rp = ctx.saved_tensors[:5]
+        weights = ctx.saved_tensors[5:]
+        dyh = _nhwc(dy)
+        if dyh.dtype != raw.dtype:
+            dyh = dyh.to(raw.dtype)
+        C = spec.cout
+        rows = raw.numel() // C
+        lib = L.load()
+        sums = torch.zeros(2, C, device=raw.device, dtype=torch.float32)
+        L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.dtype_code(raw),
+                                       L.stream()), "rssf_bn_bwd_reduce")
+        if training and sync and _world() > 1:
+            dist.all_reduce(sums)
+        draw = torch.empty_like(raw)
+        dres = torch.empty_like(raw) if has_pre else None
+        dgamma = torch.zeros(C, device=raw.device, dtype=torch.float32)
+        dbeta = torch.zeros(C, device=raw.device, dtype=torch.float32)
+        L.check(lib.rssf_bn_bwd_apply(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres),
+                                      L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), L.dtype_code(raw), L.stream()),
+                "rssf_bn_bwd_apply")
+        dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape)) if x_req else None
+        dws, db = _conv_wgrad(spec, draw, xh, weights, nbias > 0)
+        gb = [db] * nbias      # every summed conv's bias sees the same gradient
+        return (dx, None if dres is None else _nchw(dres), dy if has_post else None, dgamma, dbeta, None, None, None, None, None,
+                None, None, None, None, *dws, *gb)
+
+
+class _ConvBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, spec, weight, bias):
+        L.require_gpu(x)
+        xh = _nhwc(x)
+        out = _conv_forward(spec, xh, [weight], None if bias is None else bias.float().contiguous(), None)
+        ctx.save_for_backward(xh, weight)
+        ctx.meta = (spec, bias is not None, x.requires_grad)
+        return _nchw(out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec, has_bias, x_req = ctx.meta
+        xh, weight = ctx.saved_tensors
+        dyh = _nhwc(dy)
+        if dyh.dtype != xh.dtype:
+            dyh = dyh.to(xh.dtype)
+        dx = _nchw(_conv_dgrad(spec, dyh, [weight], xh.shape)) if x_req else None
+        dws, db = _conv_wgrad(spec, dyh, xh, [weight], has_bias)
+        return dx, None, dws[0], db
+
+
+def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None):
+    """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm."""
+    convs = convs if isinstance(convs, (list, tuple)) else [convs]
+    spec = spec_of(convs)
+    training = bn.training or not bn.track_running_stats
+    sync = isinstance(bn, nn.SyncBatchNorm) or _SYNC_ALL_BN
+    if training and bn.track_running_stats:
+        bn._rssf_steps = getattr(bn, "_rssf_steps", 0) + 1      # num_batches_tracked, flushed by flush_bn_counters()
+    weights = [c.weight for c in convs]
+    biases = [c.bias for c in convs if c.bias is not None]
+    if biases and len(biases) != len(convs):
+        raise NotImplementedError("conv_bn_act: either all or none of the summed convs carry a bias")
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    return _ConvBNAct.apply(x, res_pre, res_post, bn.weight, bn.bias, bn.running_mean, bn.running_var, spec, act, training, mom, bn.eps,
+                            sync, len(biases), *weights, *biases)
+
+
+def conv_bias(x, conv):
+    return _ConvBias.apply(x, spec_of([conv]), conv.weight, conv.bias)
+
+
+def flush_bn_counters(model):
+    """Materialise the lazily counted `num_batches_tracked` buffers (kept off the hot path: 330 tiny launches)."""
+    for m in model.modules():
+        k = getattr(m, "_rssf_steps", 0)
+        if k and getattr(m, "num_batches_tracked", None) is not None:
+            m.num_batches_tracked += k
+            m._rssf_steps = 0
+
+
+def run_sequential(seq, x):
+    """Execute an nn.Sequential of the reference's shape (Conv2d, BatchNorm2d[, ReLU][, Upsample] or nested
+    Sequentials thereof) through the fused ops."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Sequential):
+            x = run_sequential(m, x)
+            i += 1
+        elif isinstance(m, nn.Conv2d):
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.modules.batchnorm._BatchNorm):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                x = conv_bn_act(x, m, mods[i + 1], ACT_RELU if relu else ACT_NONE)
+                i += 3 if relu else 2
+            else:
+                x = conv_bias(x, m)
+                i += 1
+        else:
+            x = m(x)           # nn.Upsample (nearest / bilinear): ATen elementwise kernels for now
+            i += 1
+    return x

@@ -141,6 +141,20 @@ def winattn_bwd(dout, x, y, stats_x, stats_y, omega, ln_g, ln_b, w, gw, H, W, he
     return dxhat, dyhat, domega
 
 
+def grad_sqnorm(flat_grad, out):
+    """out[0] = ||flat_grad||^2 (fp32, on the current stream)."""
+    L.require_gpu(flat_grad)
+    L.check(L.load().rssf_grad_sqnorm(L.ptr(_f32(flat_grad)), flat_grad.numel(), L.ptr(out), L.stream()), "rssf_grad_sqnorm")
+    return out
+
+
+def sgd_step_(flat_p, flat_g, flat_m, sqnorm, grad_scale, max_norm, lr, momentum, weight_decay, first_step):
+    L.require_gpu(flat_p, flat_g, flat_m)
+    L.check(L.load().rssf_sgd_step(L.ptr(_f32(flat_p)), L.ptr(_f32(flat_g)), L.ptr(_f32(flat_m)), flat_p.numel(), L.ptr(sqnorm),
+                                   float(grad_scale), float(max_norm), float(lr), float(momentum), float(weight_decay),
+                                   int(bool(first_step)), L.stream()), "rssf_sgd_step")
+
+
 def debug_mma(a, b):
     K = a.shape[1]
     d = torch.empty(3, 16, 16, device=a.device, dtype=torch.float32)

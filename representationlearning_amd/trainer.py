@@ -1,0 +1,153 @@
+"""Data-parallel training step for RSSFormer (the slice of the external `ever` `th_amp_ddp` trainer the path needs:
+train.py:79 + configs/base/loveda.py:68-113 of the reference): bf16 compute with fp32 master weights, sum of
+`*loss` entries, gradient all-reduce over RCCL overlapped with backward, global-norm clip (35) + SGD(0.9, wd 1e-4)
+with poly LR.  Trainer internals of `ever` are un-vendored => "parity unpinned" (SURVEY.md §8c); the semantics
+implemented here are torch.optim.SGD / clip_grad_norm_ / DDP-mean-of-shard-gradients.
+
+MI355X-first layout: all parameters live in ONE flat fp32 buffer (and one flat gradient buffer + one momentum
+buffer), so gradient exchange is a handful of large flat buckets (xGMI is per-link bound: few big collectives),
+the clip norm is one reduction and the optimizer is one fused HIP launch (csrc/optim.hip).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+
+
+class FlatParams:
+    """Re-seats every parameter (and its .grad) of `model` as a view into flat fp32 buffers."""
+
+    def __init__(self, model):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + (s + 3) // 4 * 4)     # 16-byte aligned slices
+        n = self.offsets[-1]
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.mom = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
+            v = self.flat[o:o + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.grad[o:o + p.numel()].view_as(p)
+        self.numel = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-seat the views
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+
+class GradBuckets:
+    """Flat gradient buckets all-reduced (sum) as soon as every parameter in them has its gradient, i.e. in
+    reverse-registration (= roughly reverse-autograd) order on the communicator's own stream."""
+
+    def __init__(self, flat, nbuckets=6, group=None):
+        self.flat, self.group = flat, group
+        n = flat.numel
+        target = max(1, n // nbuckets)
+        self.bounds = []          # (start, end) over the flat buffer, built from the END (last layers first)
+        self.members = []         # parameter indices per bucket
+        end, cur = n, []
+        for i in range(len(flat.params) - 1, -1, -1):
+            cur.append(i)
+            if end - flat.offsets[i] >= target or i == 0:
+                self.bounds.append((flat.offsets[i], end))
+                self.members.append(cur)
+                end, cur = flat.offsets[i], []
+        self.bucket_of = {}
+        for b, mem in enumerate(self.members):
+            for i in mem:
+                self.bucket_of[i] = b
+        self.pending = [len(m) for m in self.members]
+        self.handles = []
+        self.launched = [False] * len(self.members)
+        for i, p in enumerate(flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            b = self.bucket_of[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
+        s, e = self.bounds[b]
+        self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def begin(self):
+        self.pending = [len(m) for m in self.members]
+        self.launched = [False] * len(self.members)
+        self.handles = []
+
+    def finish(self):
+        """Launch buckets whose parameters never received a gradient (headaux: the aux head gets none), then wait."""
+        for b in range(len(self.members)):
+            self._launch(b)
+        for h in self.handles:
+            h.wait()
+
+
+def poly_lr(base_lr, power, max_iters, it):
+    return base_lr * (1.0 - min(it, max_iters - 1) / max_iters) ** power     # configs/base/loveda.py:93-99
+
+
+class Trainer:
+    def __init__(self, model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=35.0, power=0.9, max_iters=30000,
+                 bf16=True, sync_bn=True, nbuckets=6):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if self.world > 1 and sync_bn:          # configs/base/loveda.py:107-108 (train.sync_bn=True)
+            model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        self.model = model
+        self.flat = FlatParams(model)
+        self.buckets = GradBuckets(self.flat, nbuckets) if self.world > 1 else None
+        self.hp = dict(base_lr=base_lr, momentum=momentum, wd=weight_decay, max_norm=max_norm, power=power, max_iters=max_iters)
+        self.bf16 = bf16
+        self.it = 0
+        self.sqnorm = torch.zeros(1, device=self.flat.flat.device, dtype=torch.float32)
+
+    def step(self, img, target):
+        """One optimisation step; returns the (detached, on-device) loss."""
+        self.model.train()
+        self.flat.zero_grad()
+        if self.buckets is not None:
+            self.buckets.begin()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
+            out = self.model(img, target)
+        loss = sum(v for k, v in out.items() if k.endswith("loss"))
+        loss.backward()
+        if self.buckets is not None:
+            self.buckets.finish()
+        hp = self.hp
+        ops.grad_sqnorm(self.flat.grad, self.sqnorm)
+        ops.sgd_step_(self.flat.flat, self.flat.grad, self.flat.mom, self.sqnorm, 1.0 / self.world, hp["max_norm"],
+                      poly_lr(hp["base_lr"], hp["power"], hp["max_iters"], self.it), hp["momentum"], hp["wd"], self.it == 0)
+        self.it += 1
+        return loss.detach()
+
+
+def init_distributed():
+    """One process per GPU; rendezvous from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    return rank, local, world

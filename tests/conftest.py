@@ -1,4 +1,5 @@
 import os
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # fresh boxes have no MIOpen find-db: skip the exhaustive per-shape search
 import sys
 
 import pytest

@@ -1,0 +1,103 @@
+"""CPU: host-side logic of the product package (no kernels run): config merge, registry, state_dict compatibility
+with the reference, tap lists, LR schedule, loud failure without a GPU, and oracle isolation."""
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+from tests.helpers import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_merge_and_overrides():
+    from representationlearning_amd.core.config import AttrDict, apply_overrides
+    c = AttrDict.wrap(dict(a=dict(b=1, c=dict(d=2)), e=3))
+    c.merge(dict(a=dict(c=dict(d=5, f=6))))
+    assert c.a.b == 1 and c.a.c.d == 5 and c.a.c.f == 6 and c.e == 3
+    apply_overrides(c, ["a.c.d", "7", "e", "x"])          # scripts/train.sh-style `key value` pairs
+    assert c.a.c.d == 7 and c.e == "x"
+
+
+@pytest.mark.parametrize("variant", ["tiny", "base", "large"])
+def test_state_dict_identical_to_reference(variant):
+    """Key ORDER, names and shapes equal the reference model's (fixture captured from the reference itself)."""
+    from representationlearning_amd.configs import rssformer_config
+    from representationlearning_amd.core import registry
+    registry.register_all()
+    m = registry.MODEL["RSSFormer"](rssformer_config(variant))
+    g = golden(f"keys_{variant}")
+    sd = m.state_dict()
+    assert list(sd.keys()) == g["names"].tolist()
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == g["shapes"].tolist()
+    assert sum(p.numel() for p in m.parameters()) == int(g["nparams"])
+
+
+def test_registry_call_forms_and_errors():
+    from representationlearning_amd.core import registry
+    from representationlearning_amd.module.baseline.base_hrnet._hrnet_rssformer import HighResolutionModule, BasicBlock
+    registry.register_all()
+    assert "RSSFormer" in registry.MODEL and "hrnetv2_w32" in registry.MODEL and "HRNetEncoder" in registry.MODEL
+    with pytest.raises(ValueError):       # _hrnet_rssformer.py:313-326 of the reference
+        HighResolutionModule(2, BasicBlock, (4,), [32, 64], (32, 64), "SUM")
+    from representationlearning_amd.module.baseline.base_hrnet.modules.DAL import Mhca
+    with pytest.raises(AssertionError):   # DAL.py:700-702
+        Mhca(30, 4)
+
+
+def test_conv_spec_taps():
+    from representationlearning_amd.nnf import ConvSpec
+    s = ConvSpec([nn.Conv2d(8, 8, 3, 2, 1)])
+    assert s.ntaps == 9 and s.dy[0] == -1 and s.dx[8] == 1 and s.out_hw(16, 15) == (8, 8)
+    f = ConvSpec([nn.Conv2d(8, 8, 1), nn.Conv2d(8, 8, 3, 1, 6, 6), nn.Conv2d(8, 8, 3, 1, 12, 12)])
+    assert f.ntaps == 19 and sorted(set(f.dy)) == [-12, -6, 0, 6, 12] and f.src.count(0) == 1 and f.out_hw(10, 10) == (10, 10)
+    with pytest.raises(NotImplementedError):
+        ConvSpec([nn.Conv2d(8, 8, 3, groups=2)])
+
+
+def test_poly_lr_and_synthetic_batch():
+    from representationlearning_amd.trainer import poly_lr
+    from representationlearning_amd.configs import synthetic_batch
+    assert poly_lr(0.01, 0.9, 30000, 0) == pytest.approx(0.01)
+    assert 0 < poly_lr(0.01, 0.9, 30000, 29999) < 1e-5
+    img, lab = synthetic_batch(2, 64, device="cpu")
+    assert img.shape == (2, 3, 64, 64) and lab.shape == (2, 64, 64) and lab.min() >= -1 and lab.max() <= 5
+    assert (lab[:, :16, :16] == lab[:, :1, :1]).all()        # 16x16 constant blocks
+
+
+def test_ops_fail_loudly_without_gpu():
+    """No CPU fallback: a CPU tensor is an error, not a silent eager path."""
+    from representationlearning_amd import ops, nnf
+    x = torch.randn(2, 10, 32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layernorm_fwd(x, torch.ones(32), torch.zeros(32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nnf.conv_bias(torch.randn(1, 8, 4, 4), nn.Conv2d(8, 8, 1))
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    bad = []
+    for root, _, files in os.walk(os.path.join(ROOT, "representationlearning_amd")):
+        for f in files:
+            if f.endswith(".py") and pat.search(open(os.path.join(root, f)).read()):
+                bad.append(f)
+    assert not bad, bad
+    for f in ("train.py", "eval.py"):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            assert not pat.search(open(p).read()), f
+
+
+def test_miou_metric():
+    from representationlearning_amd.metric import PixelMetric
+    m = PixelMetric(3)
+    y_true = torch.tensor([0, 0, 1, 1, 2, 2, -1])
+    y_pred = torch.tensor([0, 1, 1, 1, 2, 0, 2])
+    keep = y_true != -1
+    m.forward(y_true[keep], y_pred[keep])
+    iou = m.iou()
+    assert iou[0] == pytest.approx(1 / 3) and iou[1] == pytest.approx(2 / 3) and iou[2] == pytest.approx(1 / 2)
+    assert m.miou() == pytest.approx((1 / 3 + 2 / 3 + 1 / 2) / 3)
