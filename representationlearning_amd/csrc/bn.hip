@@ -88,14 +88,16 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
   extern __shared__ float sacc[];                         // [2][C]
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sacc[i] = 0.f;
   __syncthreads();
-  const int cols = C / VEC;
+  const int allcols = C / VEC;
+  const int colbase = blockIdx.y * 256;                   // column blocks of <= 256 vector columns
+  const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
   const int rpb = blockDim.x / cols;                      // rows handled per block per pass (>= 1)
   const int col = threadIdx.x % cols, rlocal = threadIdx.x / cols;
   float a1[VEC], a2[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
   if (rlocal < rpb) {
-    const int c0 = col * VEC;
+    const int c0 = (colbase + col) * VEC;
     for (int64_t r = (int64_t)blockIdx.x * rpb + rlocal; r < rows; r += (int64_t)gridDim.x * rpb) {
       const int64_t off = r * C + c0;
       if constexpr (VEC > 1) {
@@ -122,7 +124,11 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
     for (int e = 0; e < VEC; ++e) { atomicAdd(&sacc[c0 + e], a1[e]); atomicAdd(&sacc[C + c0 + e], a2[e]); }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&sums[i], sacc[i]);
+  for (int i = threadIdx.x; i < cols * VEC; i += blockDim.x) {
+    const int c = colbase * VEC + i;
+    atomicAdd(&sums[c], sacc[c]);
+    atomicAdd(&sums[C + c], sacc[C + c]);
+  }
 }
 
 // draw = scale*(dz - k1 - xhat*k2) (training) or scale*dz (eval);  dres (optional) = dz
@@ -204,18 +210,17 @@ template <typename T>
 int reduce_launch(const void* dy, const void* raw, const float* ss, const void* rp, float* sums, int64_t rows, int C, int act, hipStream_t st) {
   constexpr int V = Vec<T>::N;
   const size_t sh = 2 * C * sizeof(float);
-  if (C % V == 0 && C / V <= 256) {
-    const int rpb = 256 / (C / V);
-    int64_t blocks = (rows + rpb - 1) / rpb;
-    if (blocks > 1024) blocks = 1024;
-    bn_bwd_reduce_kernel<T, V><<<(unsigned)blocks, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
-  } else {
-    if (C > 256) { set_error("bn_bwd_reduce: C=%d not supported on the scalar path", C); return RSSF_ERR_UNSUPPORTED; }
-    const int rpb = 256 / C;
-    int64_t blocks = (rows + rpb - 1) / rpb;
-    if (blocks > 1024) blocks = 1024;
-    bn_bwd_reduce_kernel<T, 1><<<(unsigned)blocks, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
-  }
+  const int vec = (C % V == 0) ? V : 1;
+  const int cols = C / vec;
+  const int cblocks = (cols + 255) / 256;
+  const int rpb = 256 / (cols < 256 ? cols : 256);
+  int64_t blocks = (rows + rpb - 1) / rpb;
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid((unsigned)blocks, (unsigned)cblocks);
+  if (vec == V)
+    bn_bwd_reduce_kernel<T, V><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
+  else
+    bn_bwd_reduce_kernel<T, 1><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
   return check_launch("bn_bwd_reduce");
 }
 

@@ -30,7 +30,7 @@ def test_full_model_fp32(variant, B, S, tag):
     x = seeded_input((B, 3, S, S), 7).to(DEV)
     y = proc_labels(B, S, S, 6, 8).to(DEV)
     taps = {}
-    m.head.register_forward_hook(lambda mod, i, o: taps.__setitem__("logits", o))
+    m.head[1].register_forward_hook(lambda mod, i, o: taps.__setitem__("logits", o))
     loss = m(x, dict(cls=y))["fc_loss"]
     loss.backward()
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))      # north_star: 1e-3 rel
