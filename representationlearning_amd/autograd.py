@@ -5,7 +5,7 @@ the allocator / stream / autograd-graph plumbing.
 """
 import torch
 
-from . import ops
+from . import nnf, ops
 
 
 class GatedWindowCrossAttention(torch.autograd.Function):
@@ -30,6 +30,7 @@ class GatedWindowCrossAttention(torch.autograd.Function):
         out = ops.winattn_fwd(x, y, sx, sy, omega, ln_g, ln_b, w, H, W, heads)
         ctx.save_for_backward(x, y, sx, sy, pooled, argmax, gsig, omega, kk, wl2, ln_g, ln_b, wq, bq, wk, bk, wv, bv, wo, bo)
         ctx.dims = (H, W, heads)
+        ctx.params = dict(ln_g=ln_g, ln_b=ln_b, wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
         return out
 
     @staticmethod
@@ -38,19 +39,21 @@ class GatedWindowCrossAttention(torch.autograd.Function):
         H, W, heads = ctx.dims
         dout = dout.contiguous()
         w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
-        gw = {n: torch.zeros_like(t) for n, t in w.items()}
+        P = ctx.params
+        tg = {n: nnf.grad_target(P[n]) for n in P}            # kernels accumulate straight into .grad when possible
+        gw = {n: tg[n][0] for n in w}
         dxhat, dyhat, domega = ops.winattn_bwd(dout, x, y, sx, sy, omega, ln_g, ln_b, w, gw, H, W, heads)
         dk = torch.zeros_like(kk)
         dwl = torch.zeros_like(wl2)
         dbl = torch.zeros(2, device=x.device, dtype=torch.float32)
         dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, kk, wl2, dk, dwl, dbl, H, W)
         ops.gate_pool_bwd_(dpooled, argmax, dxhat, dyhat)
-        dg = torch.zeros_like(ln_g)
-        db = torch.zeros_like(ln_b)
+        dg, db = tg["ln_g"][0], tg["ln_b"][0]
         dx = ops.layernorm_bwd(dxhat, x, sx, ln_g, dg, db, dx_add=dout)      # + residual path
         dy = ops.layernorm_bwd(dyhat, y, sy, ln_g, dg, db)
-        return (dx, dy, dg, db, dk[0:1].clone(), dk[1:2].clone(), dwl.reshape(2, 2, 1, 1), dbl,
-                gw["wq"], gw["bq"], gw["wk"], gw["bk"], gw["wv"], gw["bv"], gw["wo"], gw["bo"], None, None, None)
+        r = {n: nnf.grad_result(P[n], tg[n][0], tg[n][1]) for n in P}
+        return (dx, dy, r["ln_g"], r["ln_b"], dk[0:1].clone(), dk[1:2].clone(), dwl.reshape(2, 2, 1, 1), dbl,
+                r["wq"], r["bq"], r["wk"], r["bk"], r["wv"], r["bv"], r["wo"], r["bo"], None, None, None)
 
 
 class LayerNormTokens(torch.autograd.Function):
@@ -61,15 +64,16 @@ class LayerNormTokens(torch.autograd.Function):
         x = x.contiguous()
         y, st = ops.layernorm_fwd(x, g, b)
         ctx.save_for_backward(x, st, g)
+        ctx.params = (g, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, st, g = ctx.saved_tensors
-        dg = torch.zeros_like(g)
-        db = torch.zeros_like(g)
+        pg, pb = ctx.params
+        (dg, gd), (db, bd) = nnf.grad_target(pg), nnf.grad_target(pb)
         dx = ops.layernorm_bwd(dy.contiguous(), x, st, g, dg, db)
-        return dx, dg, db
+        return dx, nnf.grad_result(pg, dg, gd), nnf.grad_result(pb, db, bd)
 
 
 def _identity_ln(x):

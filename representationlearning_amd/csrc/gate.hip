@@ -101,13 +101,18 @@ __global__ void __launch_bounds__(256) gate_weights_bwd1_kernel(const float* __r
     dpre[o + p] = dg0 * g0 * (1.f - g0);
     dpre[o + N + p] = dg1 * g1 * (1.f - g1);
   }
+  __shared__ float red[6];
+  if (threadIdx.x < 6) red[threadIdx.x] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < 6; ++i) a[i] = wave_sum(a[i]);
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) atomicAdd(&dwl[i], a[i]);
-    atomicAdd(&dbl[0], a[4]); atomicAdd(&dbl[1], a[5]);
+    for (int i = 0; i < 6; ++i) atomicAdd(&red[i], a[i]);
   }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(&dwl[threadIdx.x], red[threadIdx.x]);          // one global atomic per block
+  else if (threadIdx.x < 6) atomicAdd(&dbl[threadIdx.x - 4], red[threadIdx.x]);
 }
 
 // stage 2: dpooled = conv^T(dpre, k) ; dk += sum_pixels dpre * shifted(pooled)

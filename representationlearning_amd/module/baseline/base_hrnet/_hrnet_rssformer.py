@@ -244,6 +244,8 @@ class HighResolutionNet(nn.Module):
         return nn.Sequential(*mods), num_inchannels
 
     def forward(self, x):
+        if torch.is_autocast_enabled():          # activation dtype policy: bf16 activations, fp32 parameters/statistics
+            x = x.to(torch.get_autocast_dtype("cuda"))
         x = x.contiguous(memory_format=torch.channels_last)
         x = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU)
         x = nnf.conv_bn_act(x, self.conv2, self.bn2, nnf.ACT_RELU)

@@ -26,6 +26,36 @@ def set_sync_bn(flag):
     _SYNC_ALL_BN = bool(flag)
 
 
+# ---- direct gradient accumulation ---------------------------------------------------------------------------------
+# With the trainer's flat gradient buffer every parameter already owns a zeroed fp32 `.grad` view, and every librssf
+# backward kernel ACCUMULATES (+=) its parameter gradients.  So the kernels write straight into `.grad` (no per-tensor
+# zero-fill, no AccumulateGrad add: ~2 k tiny launches per step) and the autograd node returns None for them; the
+# trainer's bucket hook is invoked by hand instead.
+_DIRECT = False
+_PARAM_READY = None
+
+
+def set_direct_grad(flag, on_ready=None):
+    global _DIRECT, _PARAM_READY
+    _DIRECT, _PARAM_READY = bool(flag), on_ready
+
+
+def grad_target(p):
+    """(buffer the kernels accumulate into, True if that buffer IS p.grad)."""
+    if _DIRECT and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous():
+        return p.grad, True
+    return torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format), False
+
+
+def grad_result(p, buf, direct):
+    """What the autograd node returns for parameter p."""
+    if direct:
+        if _PARAM_READY is not None:
+            _PARAM_READY(p)
+        return None
+    return buf
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -120,16 +150,14 @@ def _conv_dgrad(spec, dout, weights, in_shape):
     return dx
 
 
-def _conv_wgrad(spec, dout, xh, weights, want_bias):
+def _conv_wgrad(spec, dout, xh, dws, db):
+    """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional)."""
     B, H, W, C = xh.shape
     _, OH, OW, _ = dout.shape
-    dws = [torch.zeros_like(w, dtype=torch.float32, memory_format=torch.contiguous_format) for w in weights]
-    db = torch.zeros(spec.cout, device=xh.device, dtype=torch.float32) if want_bias else None
-    d = dws + [None, None]
-    L.check(L.load().rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), _ia(spec.ksizes), len(weights),
+    d = list(dws) + [None, None]
+    L.check(L.load().rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), _ia(spec.ksizes), len(dws),
                                      _ia(spec.src), _ia(spec.kpos), L.ptr(db), B, H, W, C, OH, OW, spec.cout, spec.stride, spec.ntaps,
                                      _ia(spec.dy), _ia(spec.dx), L.dtype_code(xh), L.stream()), "rssf_conv_wgrad")
-    return dws, db
 
 
 class _ConvBNAct(torch.autograd.Function):
@@ -166,6 +194,7 @@ class _ConvBNAct(torch.autograd.Function):
                 "rssf_bn_apply")
         ctx.save_for_backward(xh, raw, ss, mi, rp, *weights)
         ctx.meta = (spec, act, training, n, sync, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
+        ctx.params = (gamma, beta, weights, biases)
         return _nchw(y)
 
     @staticmethod
@@ -186,16 +215,24 @@ class _ConvBNAct(torch.autograd.Function):
             dist.all_reduce(sums)
         draw = torch.empty_like(raw)
         dres = torch.empty_like(raw) if has_pre else None
-        dgamma = torch.zeros(C, device=raw.device, dtype=torch.float32)
-        dbeta = torch.zeros(C, device=raw.device, dtype=torch.float32)
+        p_gamma, p_beta, p_weights, p_biases = ctx.params
+        dgamma, dg_direct = grad_target(p_gamma)
+        dbeta, db_direct = grad_target(p_beta)
         L.check(lib.rssf_bn_bwd_apply(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres),
                                       L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), L.dtype_code(raw), L.stream()),
                 "rssf_bn_bwd_apply")
         dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape)) if x_req else None
-        dws, db = _conv_wgrad(spec, draw, xh, weights, nbias > 0)
-        gb = [db] * nbias      # every summed conv's bias sees the same gradient
-        return (dx, None if dres is None else _nchw(dres), dy if has_post else None, dgamma, dbeta, None, None, None, None, None,
-                None, None, None, None, *dws, *gb)
+        wt = [grad_target(w) for w in p_weights]
+        db = torch.zeros(C, device=raw.device, dtype=torch.float32) if nbias else None
+        _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db)
+        gws = [grad_result(w, t[0], t[1]) for w, t in zip(p_weights, wt)]
+        gbs = []
+        for b in p_biases:      # every summed conv's bias sees the same gradient
+            tb, direct = grad_target(b)
+            tb += db
+            gbs.append(grad_result(b, tb, direct))
+        return (dx, None if dres is None else _nchw(dres), dy if has_post else None, grad_result(p_gamma, dgamma, dg_direct),
+                grad_result(p_beta, dbeta, db_direct), None, None, None, None, None, None, None, None, None, *gws, *gbs)
 
 
 class _ConvBias(torch.autograd.Function):
@@ -206,6 +243,7 @@ class _ConvBias(torch.autograd.Function):
         out = _conv_forward(spec, xh, [weight], None if bias is None else bias.float().contiguous(), None)
         ctx.save_for_backward(xh, weight)
         ctx.meta = (spec, bias is not None, x.requires_grad)
+        ctx.params = (weight, bias)
         return _nchw(out)
 
     @staticmethod
@@ -216,8 +254,11 @@ class _ConvBias(torch.autograd.Function):
         if dyh.dtype != xh.dtype:
             dyh = dyh.to(xh.dtype)
         dx = _nchw(_conv_dgrad(spec, dyh, [weight], xh.shape)) if x_req else None
-        dws, db = _conv_wgrad(spec, dyh, xh, [weight], has_bias)
-        return dx, None, dws[0], db
+        p_w, p_b = ctx.params
+        tw, wd = grad_target(p_w)
+        tb, bd = grad_target(p_b) if has_bias else (None, False)
+        _conv_wgrad(spec, dyh, xh, [tw], tb)
+        return dx, None, grad_result(p_w, tw, wd), (grad_result(p_b, tb, bd) if has_bias else None)
 
 
 def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None):

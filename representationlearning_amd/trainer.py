@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import ops
+from . import nnf, ops
 
 
 class FlatParams:
@@ -70,8 +70,15 @@ class GradBuckets:
         self.pending = [len(m) for m in self.members]
         self.handles = []
         self.launched = [False] * len(self.members)
+        self.index_of = {id(p): i for i, p in enumerate(flat.params)}
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def param_ready(self, p):
+        """Called by the fused backward nodes that accumulate straight into p.grad (no AccumulateGrad hook fires)."""
+        i = self.index_of.get(id(p))
+        if i is not None:
+            self._make_hook(i)(p)
 
     def _make_hook(self, i):
         def hook(param):
@@ -114,6 +121,8 @@ class Trainer:
         self.model = model
         self.flat = FlatParams(model)
         self.buckets = GradBuckets(self.flat, nbuckets) if self.world > 1 else None
+        nnf.set_sync_bn(sync_bn and self.world > 1)
+        nnf.set_direct_grad(True, self.buckets.param_ready if self.buckets is not None else None)
         self.hp = dict(base_lr=base_lr, momentum=momentum, wd=weight_decay, max_norm=max_norm, power=power, max_iters=max_iters)
         self.bf16 = bf16
         self.it = 0
