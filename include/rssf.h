@@ -114,10 +114,14 @@ int rssf_conv_pack(const float* w0, const float* w1, const float* w2, const int*
 int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bias, float* stats, int B, int IH, int IW,
                      int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype,
                      void* stream);
-/* weight gradient, accumulated (+=) into the torch-layout fp32 gradients of the source convs; dbias optional (+=). */
+/* weight gradient, accumulated (+=) into the torch-layout fp32 gradients of the source convs; dbias optional (+=).
+ * workspace: fp32 scratch of rssf_conv_wgrad_workspace_elems() elements for the split-K partials (two-stage
+ * reduction); NULL selects the slower atomic path. */
+int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Cin, int Cout, int ntaps);
 int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes, int nsrc,
-                    const int* src_of_tap, const int* kpos_of_tap, float* dbias, int B, int IH, int IW, int Cin, int OH,
-                    int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx, int dtype, void* stream);
+                    const int* src_of_tap, const int* kpos_of_tap, float* dbias, float* workspace, int B, int IH, int IW,
+                    int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx, int dtype,
+                    void* stream);
 
 /* ---- BatchNorm2d (+ activation + residual adds), channels-last: nn.BatchNorm2d / nn.SyncBatchNorm call sites of
  *      _hrnet_rssformer.py, hrnet_aux.py:47 and ffn_block.py:222-234 (momentum 0.1, eps 1e-5) -------------------- */
@@ -137,6 +141,18 @@ int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift,
                       const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
                       double n, int training, int dtype, void* stream);
 
+/* ---- Up-sampling, channels-last ------------------------------------------------------------------------------
+ * bilinear with align_corners=True: F.interpolate x3 in SimpleFusion8 (hrnet_aux.py:61-65), UpsamplingBilinear2d(x4)
+ * of the head (:80).  backward = 0: in [B,IH,IW,C] -> out [B,OH,OW,C];  backward = 1: `in` is the gradient
+ * [B,OH,OW,C], `out` receives the input gradient [B,IH,IW,C] (gather form, no atomics). */
+int rssf_upsample_bilinear(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int backward, int dtype,
+                           void* stream);
+/* nearest up-sampling by an integer factor fused with the running branch sum of the HRNet fuse layers
+ * (_hrnet_rssformer.py:380, 424-427).  backward = 0: out [B,IH*s,IW*s,C] = (acc ? acc : 0) + up(in);
+ * backward = 1: `in` is the output gradient, `out` [B,IH,IW,C] = its s x s block sums (acc ignored). */
+int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B, int IH, int IW, int scale, int C, int backward,
+                              int dtype, void* stream);
+
 /* ---- optimizer over flat fp32 buffers: the external `ever` trainer's clip_grad_norm_(35) + SGD(momentum .9,
  *      wd 1e-4) of configs/base/loveda.py:68-77 as two launches over all parameters ----------------------- */
 /* out[0] = sum g^2 (zeroed inside, on the stream). */
@@ -149,6 +165,8 @@ int rssf_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, cons
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 /* D[16][16] = A[16][K] * B[16][K]^T through the library's MFMA tile helper (layout self-check). */
 int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, void* stream);
+/* probe of the LDS transpose read (ds_read_b64_tr_b16): lds[i] = i, lane l reads at element address addr[l] */
+int rssf_debug_trread(const int* addr, short* out, void* stream);
 
 #ifdef __cplusplus
 }

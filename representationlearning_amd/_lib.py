@@ -45,14 +45,18 @@ SIGNATURES = {
     "rssf_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_void_p, c_int, c_void_p]),
     "rssf_conv_gather": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
-    "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv_wgrad_workspace_elems": (c_int64, [c_int] * 6),
+    "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),
     "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_reduce": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_int, c_void_p]),
+    "rssf_upsample_bilinear": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "rssf_upsample_nearest_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float,
                               c_int, c_void_p]),
+    "rssf_debug_trread": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_mma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 

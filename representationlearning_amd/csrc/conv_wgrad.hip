@@ -2,12 +2,22 @@
 //
 //   dW[tap][co][ci] = sum_p dout[p][co] * in[src(p, tap)][ci]          (autograd of conv_fwd.hip)
 //
-// GEMM view per tap: M = Cout, N = Cin, K = B*OH*OW pixels.  Both operands are stored pixel-major in HBM
-// (channels contiguous), but the MFMA wants the contraction axis contiguous per lane, so each 64-pixel slab is
-// transposed on its way into LDS ([channel][pixel] images; one lane per pixel => conflict-free 2-byte stores).
-// A block owns one (tap, 64x64 co x ci tile, pixel range); partial sums are atomically added straight into the
-// fp32 torch-layout gradient [Cout][Cin][kh][kw] (the fused 19-tap MLP conv scatters to its three source convs).
-// Optional bias gradient (sum_p dout) for convolutions that are not followed by a BatchNorm.
+// GEMM view per tap: M = Cout, N = Cin, K = B*OH*OW pixels.  Both operands live pixel-major in HBM (channels
+// contiguous) while the MFMA wants the contraction axis (pixels) contiguous per lane.  gfx950's LDS transpose read
+// (ds_read_b64_tr_b16) does that for free: slabs of 64 pixels are staged ROW-MAJOR ([pixel][channel], plain 16-byte
+// copies, coalesced) and each lane's 8 K-values come from two transpose reads.  Semantics measured on MI355X
+// (tests/test_gpu_conv.py::test_lds_transpose_read): within a 16-lane group, lane i receives element (i % 4) of the
+// 8-byte chunks addressed by lanes 4j + i/4, j = 0..3; so when lanes 4j..4j+3 address the four quarters of row j of a
+// [4][16] sub-tile, lane i gets column i of it.  fp32 (parity mode) needs no transpose: the 16x16x4 f32 MFMA takes one
+// K value per lane, a plain ds_read_b32 of the row-major slab.
+//
+// A block owns one (co, ci) tile and a pixel range and keeps the accumulators of ALL taps of a tap group in registers
+// (<= 9), so the dout slab is staged once per 64 pixels, the shifted input slab once per tap, with the next tap's
+// global loads in flight under the current tap's MFMAs.  Split-K partials go to a caller-provided fp32 workspace and a
+// second tiny kernel adds their sum into the torch-layout gradient [Cout][Cin][kh][kw] (the fused 19-tap MLP conv
+// scatters to its three source convs); measured: per-element atomics from ~1000 blocks cost 300-470 us per call,
+// ~10x the GEMM itself.  (Without a workspace the kernel falls back to atomics.)
+// Optional bias gradient (sum_p dout) for convolutions without a following BatchNorm.
 #include "conv.cuh"
 using namespace rssf;
 using namespace rssf::cv;
@@ -20,123 +30,239 @@ struct WgradArgs {
   float* dw[3];          // torch-layout fp32 grads of up to 3 source convs
   int ks[3];
   float* dbias;          // [Cout] or null
+  float* partial;        // [ksplit][ntaps][Cout][Cin] fp32 split-K partials (two-stage reduction) or null (atomics)
+  int ntaps_total;
   int src_of_tap[MAX_TAPS];
   int kpos_of_tap[MAX_TAPS];
-  int B, IH, IW, Cin, OH, OW, Cout, stride, ksplit, ctiles_m, ctiles_n;
+  int B, IH, IW, Cin, OH, OW, Cout, stride, ksplit, ctiles_m, ctiles_n, tap0, ntap;
   Taps taps;
 };
 
-constexpr int TM = 64, TN = 64;
+constexpr int KP = 64;   // pixels per staged slab
 
-template <typename T>
+typedef __attribute__((ext_vector_type(4))) short v4s;
+
+// A/B fragment of the K-step starting at pixel row `k0` for the 16 channels starting at column `c0` of a row-major
+// slab [KP][ld]; bf16: two transpose reads (rows k0+8g..+3 and +4..+7); f32: one element, row k0+g.
+template <typename T> struct SlabFrag;
+template <> struct SlabFrag<bf16_t> {
+  static __device__ __forceinline__ bf16x8 load(const bf16_t* slab, int ld, int k0, int c0, int lane) {
+    const int grp = lane >> 4, i = lane & 15;
+    const bf16_t* p = slab + (k0 + grp * 8 + (i >> 2)) * ld + c0 + (i & 3) * 4;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * ld));
+    union { struct { v4s a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+  }
+};
+template <> struct SlabFrag<float> {
+  static __device__ __forceinline__ float load(const float* slab, int ld, int k0, int c0, int lane) {
+    return slab[(k0 + (lane >> 4)) * ld + c0 + (lane & 15)];
+  }
+};
+
+template <typename T, int TMN, int TG>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   using MK = MmaK<T>;
   constexpr int V = Vec<T>::N;
-  constexpr int KP = 64;                                   // pixels per staged slab
-  constexpr int LDT = KP + LdsPad<T>::X;
-  constexpr int CH_CHUNKS = TM / V;                        // 16-byte chunks per pixel row of a 64-channel tile
-  __shared__ __attribute__((aligned(16))) T DT[TM * LDT];  // dout^T [co][pixel]
-  __shared__ __attribute__((aligned(16))) T XT[TN * LDT];  // in^T   [ci][pixel]
+  constexpr int LD = TMN + LdsPad<T>::X;
+  constexpr int CPR = TMN / V;                           // 16-byte chunks per slab row
+  constexpr int CHUNKS = (KP * CPR + 255) / 256;         // per thread per operand
+  constexpr int WI = TMN / 32;                           // 16x16 tiles per wave along each axis (wave grid 2x2)
+  __shared__ __attribute__((aligned(16))) T DS[KP * LD];  // dout slab [pixel][co]
+  __shared__ __attribute__((aligned(16))) T XS[KP * LD];  // in   slab [pixel][ci]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   int bid = blockIdx.x;
   const int cit = bid % a.ctiles_n; bid /= a.ctiles_n;
-  const int cot = bid % a.ctiles_m; bid /= a.ctiles_m;
-  const int tap = bid;
-  const int co0 = cot * TM, ci0 = cit * TN;
+  const int cot = bid;
+  const int co0 = cot * TMN, ci0 = cit * TMN;
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
   const int64_t per = ((M + a.ksplit - 1) / a.ksplit + KP - 1) / KP * KP;
   const int64_t kbeg = (int64_t)blockIdx.y * per, kend = kbeg + per < M ? kbeg + per : M;
   const T* DO = reinterpret_cast<const T*>(a.dout);
   const T* IN = reinterpret_cast<const T*>(a.in);
-  const int dy = a.taps.dy[tap], dx = a.taps.dx[tap];
   const bool ovec = (a.Cout % V) == 0, ivec = (a.Cin % V) == 0;
   const int wm = wave >> 1, wn = wave & 1;
 
-  f32x4 acc[2][2];
+  f32x4 acc[TG][WI][WI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int t = 0; t < TG; ++t)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+      for (int j = 0; j < WI; ++j) acc[t][i][j] = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  const bool do_bias = a.dbias && tap == 0 && cit == 0;
+  const bool do_bias = a.dbias && a.tap0 == 0 && cit == 0;
+
+  // per-thread staging slots: chunk c -> (pixel row, 16-byte column)
+  int srow[CHUNKS], scol[CHUNKS];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) { const int id = tid + c * 256; srow[c] = id / CPR; scol[c] = (id % CPR) * V; }
+
+  Vec<T> rx[CHUNKS];
+  int pb[CHUNKS], py[CHUNKS], px[CHUNKS];
+  bool pv[CHUNKS];
+
+  auto load_x = [&](int t) {      // gather the input slab of tap t into registers
+    const int dy = a.taps.dy[a.tap0 + t], dx = a.taps.dx[a.tap0 + t];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      rx[c].raw = {0, 0, 0, 0};
+      const int sy = py[c] * a.stride + dy, sx = px[c] * a.stride + dx;
+      const int ch = ci0 + scol[c];
+      if (pv[c] && srow[c] < KP && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW && ch < a.Cin) {
+        const T* src = IN + (((int64_t)pb[c] * a.IH + sy) * a.IW + sx) * a.Cin + ch;
+        if (ivec) rx[c].load(src);
+        else for (int e = 0; e < V; ++e) if (ch + e < a.Cin) rx[c].set(e, ldf(src + e));
+      }
+    }
+  };
 
   for (int64_t k0 = kbeg; k0 < kend; k0 += KP) {
-    // ---- stage: lane = pixel, each wave takes a quarter of the channel chunks ------------------------------------
-    const int64_t p = k0 + lane;
-    const bool pvalid = p < kend;
-    int b = 0, oy = 0, ox = 0;
-    if (pvalid) {
-      b = (int)(p / ((int64_t)a.OH * a.OW));
-      const int rem = (int)(p % ((int64_t)a.OH * a.OW));
-      oy = rem / a.OW; ox = rem % a.OW;
-    }
-    const int sy = oy * a.stride + dy, sx = ox * a.stride + dx;
-    const bool svalid = pvalid && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW;
-    const T* drow = DO + p * a.Cout;
-    const T* xrow = IN + (((int64_t)b * a.IH + sy) * a.IW + sx) * a.Cin;
-    for (int ch = wave; ch < CH_CHUNKS; ch += 4) {
-      const int c = ch * V;
-      Vec<T> vd, vx;
-      vd.raw = {0, 0, 0, 0}; vx.raw = {0, 0, 0, 0};
-      if (pvalid && co0 + c < a.Cout) {
-        if (ovec) vd.load(drow + co0 + c);
-        else for (int e = 0; e < V; ++e) if (co0 + c + e < a.Cout) vd.set(e, ldf(drow + co0 + c + e));
-      }
-      if (svalid && ci0 + c < a.Cin) {
-        if (ivec) vx.load(xrow + ci0 + c);
-        else for (int e = 0; e < V; ++e) if (ci0 + c + e < a.Cin) vx.set(e, ldf(xrow + ci0 + c + e));
-      }
+    // ---- pixel coordinates of this thread's rows; stage the dout slab ---------------------------------------------
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        stf(DT + (c + e) * LDT + lane, vd.get(e));
-        stf(XT + (c + e) * LDT + lane, vx.get(e));
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int64_t p = k0 + srow[c];
+      pv[c] = srow[c] < KP && p < kend;
+      const int64_t pp = pv[c] ? p : 0;
+      pb[c] = (int)(pp / ((int64_t)a.OH * a.OW));
+      const int rem = (int)(pp % ((int64_t)a.OH * a.OW));
+      py[c] = rem / a.OW; px[c] = rem % a.OW;
+      if (srow[c] < KP) {
+        Vec<T> vd;
+        vd.raw = {0, 0, 0, 0};
+        const int ch = co0 + scol[c];
+        if (pv[c] && ch < a.Cout) {
+          const T* src = DO + p * a.Cout + ch;
+          if (ovec) vd.load(src);
+          else for (int e = 0; e < V; ++e) if (ch + e < a.Cout) vd.set(e, ldf(src + e));
+        }
+        vd.store(DS + srow[c] * LD + scol[c]);
       }
     }
-    __syncthreads();
-    // ---- MFMA: each wave a 32 (co) x 32 (ci) sub-tile, K = 64 pixels -------------------------------------------------
+    load_x(0);
 #pragma unroll
-    for (int ks = 0; ks < KP; ks += MK::KSTEP) {
-      typename MK::frag fa[2], fb[2];
+    for (int t = 0; t < TG; ++t) {
+      if (t < a.ntap) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = MK::load(DT + (wm * 32 + i * 16 + l15) * LDT + ks + grp * MK::KPL);
-        fb[i] = MK::load(XT + (wn * 32 + i * 16 + l15) * LDT + ks + grp * MK::KPL);
+        for (int c = 0; c < CHUNKS; ++c)
+          if (srow[c] < KP) rx[c].store(XS + srow[c] * LD + scol[c]);
+        __syncthreads();
+        if (t + 1 < TG && t + 1 < a.ntap) load_x(t + 1);        // next tap's gather in flight under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < KP; ks += MK::KSTEP) {
+          typename MK::frag fa[WI], fb[WI];
+#pragma unroll
+          for (int i = 0; i < WI; ++i) {
+            fa[i] = SlabFrag<T>::load(DS, LD, ks, (wm * WI + i) * 16, lane);
+            fb[i] = SlabFrag<T>::load(XS, LD, ks, (wn * WI + i) * 16, lane);
+          }
+#pragma unroll
+          for (int i = 0; i < WI; ++i)
+#pragma unroll
+            for (int j = 0; j < WI; ++j) acc[t][i][j] = MK::mma(fa[i], fb[j], acc[t][i][j]);
+        }
+        if (t == 0 && do_bias && tid < TMN) {
+          float s = 0.f;
+          for (int k = 0; k < KP; ++k) s += ldf(DS + k * LD + tid);
+          bsum += s;
+        }
+        __syncthreads();
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = MK::mma(fa[i], fb[j], acc[i][j]);
     }
-    if (do_bias && tid < TM) {
-      float s = 0.f;
-      for (int k = 0; k < KP; ++k) s += ldf(DT + tid * LDT + k);
-      bsum += s;
-    }
-    __syncthreads();
   }
 
   // ---- flush: rows = co (4*grp + r), cols = ci (l15) -----------------------------------------------------------------
-  const int s = a.src_of_tap[tap], kk = a.ks[s] * a.ks[s], kpos = a.kpos_of_tap[tap];
-  float* dw = a.dw[s];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int t = 0; t < TG; ++t) {
+    if (t >= a.ntap) continue;
+    const int tap = a.tap0 + t;
+    const int s = a.src_of_tap[tap], kk = a.ks[s] * a.ks[s], kpos = a.kpos_of_tap[tap];
+    float* dw = a.dw[s];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + wm * 32 + i * 16 + grp * 4 + r, ci = ci0 + wn * 32 + j * 16 + l15;
-        if (co < a.Cout && ci < a.Cin) atomicAdd(dw + ((int64_t)co * a.Cin + ci) * kk + kpos, acc[i][j][r]);
-      }
-  if (do_bias && tid < TM && co0 + tid < a.Cout) atomicAdd(a.dbias + co0 + tid, bsum);
+      for (int j = 0; j < WI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + (wm * WI + i) * 16 + grp * 4 + r, ci = ci0 + (wn * WI + j) * 16 + l15;
+          if (co >= a.Cout || ci >= a.Cin) continue;
+          if (a.partial) a.partial[(((int64_t)blockIdx.y * a.ntaps_total + tap) * a.Cout + co) * a.Cin + ci] = acc[t][i][j][r];
+          else atomicAdd(dw + ((int64_t)co * a.Cin + ci) * kk + kpos, acc[t][i][j][r]);
+        }
+  }
+  if (do_bias && tid < TMN && co0 + tid < a.Cout) atomicAdd(a.dbias + co0 + tid, bsum);
+}
+
+// second stage of the split-K reduction: dw[torch layout] += sum_k partial[k][tap][co][ci]
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
+  const int64_t per = (int64_t)a.ntaps_total * a.Cout * a.Cin;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < a.ksplit; ++k) s += a.partial[(int64_t)k * per + i];
+    const int ci = (int)(i % a.Cin), co = (int)((i / a.Cin) % a.Cout), tap = (int)(i / ((int64_t)a.Cin * a.Cout));
+    const int sc = a.src_of_tap[tap], kk = a.ks[sc] * a.ks[sc];
+    a.dw[sc][((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[tap]] += s;
+  }
+}
+
+int tile_of(int cout, int cin) { return (cout <= 32 && cin <= 32) ? 32 : 64; }
+
+// split-K factor: enough blocks to fill the chip (~4 per CU) but at least 4 slabs of 64 pixels each
+int pick_ksplit(int cout, int cin, int64_t M) {
+  const int t = tile_of(cout, cin);
+  const int tiles = ((cout + t - 1) / t) * ((cin + t - 1) / t);
+  int64_t ks = 1024 / tiles;
+  const int64_t maxks = (M + 4 * KP - 1) / (4 * KP);
+  if (ks > maxks) ks = maxks;
+  if (ks < 1) ks = 1;
+  return (int)ks;
+}
+
+template <typename T, int TMN>
+int launch_group(WgradArgs& a, int tap0, int ntap, hipStream_t st) {
+  a.tap0 = tap0; a.ntap = ntap;
+  a.ctiles_m = (a.Cout + TMN - 1) / TMN; a.ctiles_n = (a.Cin + TMN - 1) / TMN;
+  const int tiles = a.ctiles_m * a.ctiles_n;
+  dim3 grid((unsigned)tiles, (unsigned)a.ksplit);
+  if (ntap == 1) conv_wgrad_kernel<T, TMN, 1><<<grid, 256, 0, st>>>(a);
+  else conv_wgrad_kernel<T, TMN, 9><<<grid, 256, 0, st>>>(a);
+  return check_launch("conv_wgrad");
+}
+
+template <typename T>
+int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
+  // tap groups: consecutive taps of one source conv (1 for a 1x1, 9 for a 3x3)
+  int t = 0;
+  while (t < ntaps) {
+    int n = 1;
+    while (t + n < ntaps && n < 9 && a.src_of_tap[t + n] == a.src_of_tap[t]) ++n;
+    const int rc = tile_of(a.Cout, a.Cin) == 32 ? launch_group<T, 32>(a, t, n, st) : launch_group<T, 64>(a, t, n, st);
+    if (rc) return rc;
+    t += n;
+  }
+  if (a.partial) {
+    const int64_t per = (int64_t)ntaps * a.Cout * a.Cin;
+    int blocks = (int)((per + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(a);
+    return check_launch("conv_wgrad_reduce");
+  }
+  return RSSF_OK;
 }
 
 }  // namespace
 
+extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Cin, int Cout, int ntaps) {
+  return (int64_t)pick_ksplit(Cout, Cin, (int64_t)B * OH * OW) * ntaps * Cout * Cin;
+}
+
 extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
-                               int nsrc, const int* src_of_tap, const int* kpos_of_tap, float* dbias, int B, int IH, int IW,
-                               int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx,
-                               int dtype, void* stream) {
+                               int nsrc, const int* src_of_tap, const int* kpos_of_tap, float* dbias, float* workspace, int B,
+                               int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy,
+                               const int* dx, int dtype, void* stream) {
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
@@ -149,18 +275,11 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
     a.taps.dy[t] = dy[t]; a.taps.dx[t] = dx[t];
   }
   a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.stride = stride;
-  a.ctiles_m = (Cout + TM - 1) / TM; a.ctiles_n = (Cin + TN - 1) / TN;
-  const int tiles = ntaps * a.ctiles_m * a.ctiles_n;
-  const int64_t M = (int64_t)B * OH * OW;
-  int64_t ks = 2048 / tiles;                      // aim at ~8 blocks per CU
-  const int64_t maxks = (M + 255) / 256;          // at least 4 slabs per block
-  if (ks > maxks) ks = maxks;
-  if (ks < 1) ks = 1;
-  a.ksplit = (int)ks;
-  dim3 grid((unsigned)tiles, (unsigned)ks);
+  a.partial = workspace; a.ntaps_total = ntaps;
+  a.ksplit = pick_ksplit(Cout, Cin, (int64_t)B * OH * OW);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RSSF_F32) conv_wgrad_kernel<float><<<grid, 256, 0, st>>>(a);
-  else if (dtype == RSSF_BF16) conv_wgrad_kernel<bf16_t><<<grid, 256, 0, st>>>(a);
-  else { set_error("conv_wgrad: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
-  return check_launch("conv_wgrad");
+  if (dtype == RSSF_F32) return launch_all<float>(a, ntaps, st);
+  if (dtype == RSSF_BF16) return launch_all<bf16_t>(a, ntaps, st);
+  set_error("conv_wgrad: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
 }

@@ -28,6 +28,25 @@ __global__ void debug_mma_kernel(const T* a, const T* b, float* d, int K) {
 }
 }  // namespace
 
+namespace {
+// probe of ds_read_b64_tr_b16: LDS holds lds[i] = i; lane l passes element address addr[l]; out[l*4+j] = result elem j
+__global__ void debug_trread_kernel(const int* addr, short* out) {
+  __shared__ __attribute__((aligned(16))) short lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = (short)i;
+  __syncthreads();
+  const int lane = threadIdx.x;
+  typedef __attribute__((ext_vector_type(4))) short v4s;
+  v4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(lds + addr[lane]));
+  for (int j = 0; j < 4; ++j) out[lane * 4 + j] = v[j];
+}
+}  // namespace
+
+extern "C" int rssf_debug_trread(const int* addr, short* out, void* stream) {
+  RSSF_REQUIRE(addr && out, "debug_trread: bad arguments");
+  debug_trread_kernel<<<1, 64, 0, (hipStream_t)stream>>>(addr, out);
+  return check_launch("debug_trread");
+}
+
 extern "C" int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, void* stream) {
   RSSF_REQUIRE(a && b && d && K >= 16 && K % 16 == 0, "debug_mma: bad arguments");
   hipStream_t st = (hipStream_t)stream;

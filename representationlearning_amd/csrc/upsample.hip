@@ -1,0 +1,233 @@
+// Up-sampling on channels-last activations:
+//   bilinear, align_corners=True  — F.interpolate(..., 'bilinear', align_corners=True) x3 in SimpleFusion8
+//                                   (hrnet_aux.py:61-65) and nn.UpsamplingBilinear2d(x4) of the head (:80)
+//   nearest (integer factor) fused with the running branch sum — nn.Upsample(mode='nearest') of the HRNet fuse
+//                                   layers (_hrnet_rssformer.py:380) followed by `low = low + ...` (:424-427)
+// Both backward passes are written as GATHERS (each input pixel sums the output pixels that read it), so there
+// are no atomics: the ATen scatter-add backward costs 13 ms per call in bf16 on this shape, this one is HBM-bound.
+#include "common.cuh"
+using namespace rssf;
+
+namespace {
+
+__device__ __forceinline__ float src_coord(int o, float scale) { return scale * (float)o; }
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bilinear_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int IH, int IW, int OH,
+                                                           int OW, int C, float sy, float sx) {
+  const int cols = C / VEC;
+  const int64_t total = (int64_t)B * OH * OW * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % cols);
+    int64_t p = i / cols;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const float fy = src_coord(oy, sy), fx = src_coord(ox, sx);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < IH ? y0 + 1 : IH - 1, x1 = x0 + 1 < IW ? x0 + 1 : IW - 1;
+    const float wy = fy - y0, wx = fx - x0;
+    const T* base = in + (int64_t)b * IH * IW * C + cv * VEC;
+    const T* p00 = base + ((int64_t)y0 * IW + x0) * C;
+    const T* p01 = base + ((int64_t)y0 * IW + x1) * C;
+    const T* p10 = base + ((int64_t)y1 * IW + x0) * C;
+    const T* p11 = base + ((int64_t)y1 * IW + x1) * C;
+    T* dst = out + (((int64_t)b * OH + oy) * OW + ox) * C + cv * VEC;
+    const float w00 = (1.f - wy) * (1.f - wx), w01 = (1.f - wy) * wx, w10 = wy * (1.f - wx), w11 = wy * wx;
+    if constexpr (VEC > 1) {
+      Vec<T> a, bq, c, d, o;
+      a.load(p00); bq.load(p01); c.load(p10); d.load(p11);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.set(e, w00 * a.get(e) + w01 * bq.get(e) + w10 * c.get(e) + w11 * d.get(e));
+      o.store(dst);
+    } else {
+      stf(dst, w00 * ldf(p00) + w01 * ldf(p01) + w10 * ldf(p10) + w11 * ldf(p11));
+    }
+  }
+}
+
+// din(iy,ix) = sum over output pixels (oy,ox) of coef_y(oy,iy) * coef_x(ox,ix) * dout(oy,ox)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bilinear_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int IH, int IW, int OH,
+                                                           int OW, int C, float sy, float sx) {
+  const int cols = C / VEC;
+  const int64_t total = (int64_t)B * IH * IW * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % cols);
+    int64_t p = i / cols;
+    const int ix = (int)(p % IW); p /= IW;
+    const int iy = (int)(p % IH);
+    const int b = (int)(p / IH);
+    int oy_lo = 0, oy_hi = OH - 1, ox_lo = 0, ox_hi = OW - 1;
+    if (sy > 0.f) {
+      oy_lo = (int)floorf((iy - 1) / sy); oy_hi = (int)ceilf((iy + 1) / sy);
+      if (oy_lo < 0) oy_lo = 0;
+      if (oy_hi > OH - 1) oy_hi = OH - 1;
+    }
+    if (sx > 0.f) {
+      ox_lo = (int)floorf((ix - 1) / sx); ox_hi = (int)ceilf((ix + 1) / sx);
+      if (ox_lo < 0) ox_lo = 0;
+      if (ox_hi > OW - 1) ox_hi = OW - 1;
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float fy = src_coord(oy, sy);
+      const int y0 = (int)fy, y1 = y0 + 1 < IH ? y0 + 1 : IH - 1;
+      const float wy = fy - y0;
+      const float cy = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+      if (cy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float fx = src_coord(ox, sx);
+        const int x0 = (int)fx, x1 = x0 + 1 < IW ? x0 + 1 : IW - 1;
+        const float wx = fx - x0;
+        const float cx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+        if (cx == 0.f) continue;
+        const T* src = dout + (((int64_t)b * OH + oy) * OW + ox) * C + cv * VEC;
+        const float w = cy * cx;
+        if constexpr (VEC > 1) {
+          Vec<T> v;
+          v.load(src);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] += w * v.get(e);
+        } else {
+          acc[0] += w * ldf(src);
+        }
+      }
+    }
+    T* dst = din + (((int64_t)b * IH + iy) * IW + ix) * C + cv * VEC;
+    if constexpr (VEC > 1) {
+      Vec<T> o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+      o.store(dst);
+    } else {
+      stf(dst, acc[0]);
+    }
+  }
+}
+
+// out = (acc ? acc : 0) + nearest_up(in, s)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) nearest_add_fwd_kernel(const T* __restrict__ acc, const T* __restrict__ in, T* __restrict__ out, int B,
+                                                              int IH, int IW, int s, int C) {
+  const int cols = C / VEC, OH = IH * s, OW = IW * s;
+  const int64_t total = (int64_t)B * OH * OW * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % cols);
+    int64_t p = i / cols;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const T* src = in + (((int64_t)b * IH + oy / s) * IW + ox / s) * C + cv * VEC;
+    const int64_t o = i * VEC;
+    if constexpr (VEC > 1) {
+      Vec<T> v, a, r;
+      v.load(src);
+      if (acc) a.load(acc + o);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) r.set(e, v.get(e) + (acc ? a.get(e) : 0.f));
+      r.store(out + o);
+    } else {
+      stf(out + o, ldf(src) + (acc ? ldf(acc + o) : 0.f));
+    }
+  }
+}
+
+// din(iy,ix) = sum of the s x s block of dout
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) nearest_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int IH, int IW, int s, int C) {
+  const int cols = C / VEC, OW = IW * s, OH = IH * s;
+  const int64_t total = (int64_t)B * IH * IW * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % cols);
+    int64_t p = i / cols;
+    const int ix = (int)(p % IW); p /= IW;
+    const int iy = (int)(p % IH);
+    const int b = (int)(p / IH);
+    float a[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+    for (int dy = 0; dy < s; ++dy)
+      for (int dx = 0; dx < s; ++dx) {
+        const T* src = dout + (((int64_t)b * OH + iy * s + dy) * OW + ix * s + dx) * C + cv * VEC;
+        if constexpr (VEC > 1) {
+          Vec<T> v;
+          v.load(src);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) a[e] += v.get(e);
+        } else {
+          a[0] += ldf(src);
+        }
+      }
+    if constexpr (VEC > 1) {
+      Vec<T> o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o.set(e, a[e]);
+      o.store(din + i * VEC);
+    } else {
+      stf(din + i, a[0]);
+    }
+  }
+}
+
+int grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+template <typename T>
+int bilinear_launch(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int backward, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
+  const bool vec = C % V == 0;
+  const int64_t px = (int64_t)B * (backward ? IH * IW : OH * OW);
+  const int g = grid_for(px * (vec ? C / V : C));
+  if (!backward) {
+    if (vec) bilinear_fwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, sy, sx);
+    else bilinear_fwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, sy, sx);
+  } else {
+    if (vec) bilinear_bwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, sy, sx);
+    else bilinear_bwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, sy, sx);
+  }
+  return check_launch(backward ? "upsample_bilinear_bwd" : "upsample_bilinear_fwd");
+}
+
+template <typename T>
+int nearest_launch(const void* acc, const void* in, void* out, int B, int IH, int IW, int s, int C, int backward, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  const bool vec = C % V == 0;
+  const int64_t px = (int64_t)B * IH * IW * (backward ? 1 : s * s);
+  const int g = grid_for(px * (vec ? C / V : C));
+  if (!backward) {
+    if (vec) nearest_add_fwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)acc, (const T*)in, (T*)out, B, IH, IW, s, C);
+    else nearest_add_fwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)acc, (const T*)in, (T*)out, B, IH, IW, s, C);
+  } else {
+    if (vec) nearest_bwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, s, C);
+    else nearest_bwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, s, C);
+  }
+  return check_launch(backward ? "upsample_nearest_bwd" : "upsample_nearest_add");
+}
+}  // namespace
+
+extern "C" int rssf_upsample_bilinear(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int backward, int dtype,
+                                      void* stream) {
+  RSSF_REQUIRE(in && out && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0, "upsample_bilinear: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return bilinear_launch<float>(in, out, B, IH, IW, OH, OW, C, backward, st);
+  if (dtype == RSSF_BF16) return bilinear_launch<bf16_t>(in, out, B, IH, IW, OH, OW, C, backward, st);
+  set_error("upsample_bilinear: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}
+
+extern "C" int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B, int IH, int IW, int scale, int C, int backward,
+                                         int dtype, void* stream) {
+  RSSF_REQUIRE(in && out && B > 0 && IH > 0 && IW > 0 && scale >= 1 && C > 0, "upsample_nearest_add: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return nearest_launch<float>(acc, in, out, B, IH, IW, scale, C, backward, st);
+  if (dtype == RSSF_BF16) return nearest_launch<bf16_t>(acc, in, out, B, IH, IW, scale, C, backward, st);
+  set_error("upsample_nearest_add: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}

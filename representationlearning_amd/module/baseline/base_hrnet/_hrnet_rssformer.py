@@ -4,8 +4,8 @@
 Same module tree / attribute names as the reference, hence identical state_dict keys.  Activations are kept in
 channels-last memory (NHWC physically) end to end — the layout the HIP kernels and the window attention want.
 Every Conv2d -> BatchNorm2d (-> ReLU / + residual) group runs as one fused autograd node on the hand-written
-implicit-GEMM / BN kernels (representationlearning_amd.nnf); nearest upsampling and the branch sums are still
-ATen elementwise kernels.  nn.Conv2d / nn.BatchNorm2d modules only hold the parameters."""
+implicit-GEMM / BN kernels (representationlearning_amd.nnf), nearest upsampling is fused with the branch sum;
+the remaining branch adds / ReLU are ATen elementwise kernels.  nn.Conv2d / nn.BatchNorm2d modules only hold the parameters."""
 import torch
 import torch.nn as nn
 
@@ -160,9 +160,17 @@ class HighResolutionModule(nn.Module):
         x = [self.branches[i](x[i]) for i in range(self.num_branches)]          # Sequential of BasicBlocks
         fused = []
         for i in range(len(self.fuse_layers)):
-            low = 0
+            low = None
             for j in range(1, self.num_branches):
-                low = low + (x[j] if j == i else nnf.run_sequential(self.fuse_layers[i][j], x[j]))
+                if j == i:
+                    low = x[j] if low is None else low + x[j]
+                elif j > i:      # 1x1 conv + BN, then nearest upsample fused with the running sum
+                    fl = self.fuse_layers[i][j]
+                    t = nnf.conv_bn_act(x[j], fl[0], fl[1])
+                    low = nnf.upsample_nearest_add(low, t, int(fl[2].scale_factor))
+                else:
+                    t = nnf.run_sequential(self.fuse_layers[i][j], x[j])
+                    low = t if low is None else low + t
             if i == 0:
                 y = self.transformer(low, x[0])        # residual comes from `low`; x[0] only feeds K/V (:430-431)
             else:

@@ -19,7 +19,7 @@ class SimpleFusion8(nn.Module):
     def forward(self, feat_list):
         x0 = feat_list[0]
         size = x0.shape[2:]
-        ups = [x0] + [F.interpolate(f, size=size, mode="bilinear", align_corners=True) for f in feat_list[1:]]
+        ups = [x0] + [nnf.upsample_bilinear(f, size) for f in feat_list[1:]]
         cat = torch.cat(ups, dim=1).contiguous(memory_format=torch.channels_last)
         return nnf.run_sequential(self.fuse_conv, cat), x0
 
@@ -41,7 +41,10 @@ class HRNetFusion(ConfigModule):
         feats = self.backbone(x)
         fused, f0 = self.neck(feats)
         aux = self.headaux(self.avg_pool(f0).flatten(1).float())
-        logit = self.head[1](nnf.conv_bias(fused, self.head[0]))
+        lg = nnf.conv_bias(fused, self.head[0])
+        sc = self.head[1].scale_factor
+        logit = nnf.upsample_bilinear(lg, (int(lg.shape[2] * sc), int(lg.shape[3] * sc)))
+        self._last_logits = logit          # debug tap used by the parity tests
         if self.training:
             return self.loss(logit, y["cls"].long(), aux)
         return logit.float().softmax(dim=1)

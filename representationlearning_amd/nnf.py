@@ -155,8 +155,10 @@ def _conv_wgrad(spec, dout, xh, dws, db):
     B, H, W, C = xh.shape
     _, OH, OW, _ = dout.shape
     d = list(dws) + [None, None]
-    L.check(L.load().rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), _ia(spec.ksizes), len(dws),
-                                     _ia(spec.src), _ia(spec.kpos), L.ptr(db), B, H, W, C, OH, OW, spec.cout, spec.stride, spec.ntaps,
+    lib = L.load()
+    ws = torch.empty(lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, spec.cout, spec.ntaps), device=xh.device, dtype=torch.float32)
+    L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), _ia(spec.ksizes), len(dws),
+                                     _ia(spec.src), _ia(spec.kpos), L.ptr(db), L.ptr(ws), B, H, W, C, OH, OW, spec.cout, spec.stride, spec.ntaps,
                                      _ia(spec.dy), _ia(spec.dx), L.dtype_code(xh), L.stream()), "rssf_conv_wgrad")
 
 
@@ -261,6 +263,65 @@ class _ConvBias(torch.autograd.Function):
         return dx, None, grad_result(p_w, tw, wd), (grad_result(p_b, tb, bd) if has_bias else None)
 
 
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, OH, OW):
+        L.require_gpu(x)
+        xh = _nhwc(x)
+        B, IH, IW, C = xh.shape
+        out = torch.empty(B, OH, OW, C, device=x.device, dtype=x.dtype)
+        L.check(L.load().rssf_upsample_bilinear(L.ptr(xh), L.ptr(out), B, IH, IW, OH, OW, C, 0, L.dtype_code(xh), L.stream()),
+                "rssf_upsample_bilinear")
+        ctx.shape = (B, IH, IW, OH, OW, C)
+        return _nchw(out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, IH, IW, OH, OW, C = ctx.shape
+        dyh = _nhwc(dy)
+        dx = torch.empty(B, IH, IW, C, device=dy.device, dtype=dy.dtype)
+        L.check(L.load().rssf_upsample_bilinear(L.ptr(dyh), L.ptr(dx), B, IH, IW, OH, OW, C, 1, L.dtype_code(dyh), L.stream()),
+                "rssf_upsample_bilinear(bwd)")
+        return _nchw(dx), None, None
+
+
+class _NearestAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, acc, x, scale):
+        L.require_gpu(x)
+        xh = _nhwc(x)
+        B, IH, IW, C = xh.shape
+        ah = None
+        if acc is not None:
+            ah = _nhwc(acc)
+            if ah.dtype != xh.dtype or ah.shape != (B, IH * scale, IW * scale, C):
+                raise RuntimeError("upsample_nearest_add: accumulator dtype/shape mismatch")
+        out = torch.empty(B, IH * scale, IW * scale, C, device=x.device, dtype=x.dtype)
+        L.check(L.load().rssf_upsample_nearest_add(L.ptr(ah), L.ptr(xh), L.ptr(out), B, IH, IW, scale, C, 0, L.dtype_code(xh), L.stream()),
+                "rssf_upsample_nearest_add")
+        ctx.shape = (B, IH, IW, scale, C, acc is not None)
+        return _nchw(out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, IH, IW, scale, C, has_acc = ctx.shape
+        dyh = _nhwc(dy)
+        dx = torch.empty(B, IH, IW, C, device=dy.device, dtype=dy.dtype)
+        L.check(L.load().rssf_upsample_nearest_add(None, L.ptr(dyh), L.ptr(dx), B, IH, IW, scale, C, 1, L.dtype_code(dyh), L.stream()),
+                "rssf_upsample_nearest_add(bwd)")
+        return (dy if has_acc else None), _nchw(dx), None
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=True)."""
+    return _Bilinear.apply(x, int(size[0]), int(size[1]))
+
+
+def upsample_nearest_add(acc, x, scale):
+    """(acc or 0) + nn.Upsample(scale_factor=scale, mode='nearest')(x)."""
+    return _NearestAdd.apply(acc, x, int(scale))
+
+
 def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None):
     """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm."""
     convs = convs if isinstance(convs, (list, tuple)) else [convs]
@@ -309,7 +370,13 @@ def run_sequential(seq, x):
             else:
                 x = conv_bias(x, m)
                 i += 1
-        else:
-            x = m(x)           # nn.Upsample (nearest / bilinear): ATen elementwise kernels for now
+        elif isinstance(m, nn.Upsample) and m.mode == "nearest":
+            x = upsample_nearest_add(None, x, int(m.scale_factor))
             i += 1
+        elif isinstance(m, (nn.Upsample, nn.UpsamplingBilinear2d)) and m.mode == "bilinear" and m.align_corners:
+            s = m.scale_factor
+            x = upsample_bilinear(x, (int(x.shape[2] * s), int(x.shape[3] * s)))
+            i += 1
+        else:
+            raise NotImplementedError("run_sequential: no HIP kernel for %s on the RSSFormer path" % type(m).__name__)
     return x

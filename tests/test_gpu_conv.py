@@ -146,3 +146,60 @@ def test_conv_base_shape_linearity_bf16():
     ya, yb, yab = f(a), f(b), f((a.float() + b.float()).bfloat16())
     assert torch.isfinite(yab).all()
     assert rel_err((ya + yb).cpu(), yab.cpu()) < 2e-2
+
+
+@pytest.mark.parametrize("B,C,IH,IW,OH,OW", [(2, 64, 6, 5, 12, 10), (1, 256, 2, 1, 16, 8), (2, 6, 8, 8, 32, 32), (1, 18, 5, 7, 20, 28)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_bilinear(B, C, IH, IW, OH, OW, dtype):
+    from representationlearning_amd import nnf
+    torch.manual_seed(2)
+    x = torch.randn(B, C, IH, IW).to(dtype).float()
+    xr = x.clone().requires_grad_()
+    yr = F.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=True)
+    gy = torch.randn_like(yr).to(dtype).float()
+    yr.backward(gy)
+    xd = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = nnf.upsample_bilinear(xd, (OH, OW))
+    y.backward(gy.to(DEV).to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(y.detach().float().cpu(), yr.detach()) < tol
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < tol
+
+
+@pytest.mark.parametrize("B,C,H,W,s", [(2, 32, 5, 7, 2), (1, 36, 3, 3, 4), (1, 64, 2, 2, 8)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_nearest_add(B, C, H, W, s, dtype):
+    from representationlearning_amd import nnf
+    torch.manual_seed(4)
+    x = torch.randn(B, C, H, W).to(dtype).float()
+    acc = torch.randn(B, C, H * s, W * s).to(dtype).float()
+    xr, ar = x.clone().requires_grad_(), acc.clone().requires_grad_()
+    yr = ar + F.interpolate(xr, scale_factor=s, mode="nearest")
+    gy = torch.randn_like(yr).to(dtype).float()
+    yr.backward(gy)
+    cl = torch.channels_last
+    xd = x.to(DEV).to(dtype).contiguous(memory_format=cl).requires_grad_()
+    ad = acc.to(DEV).to(dtype).contiguous(memory_format=cl).requires_grad_()
+    y = nnf.upsample_nearest_add(ad, xd, s)
+    y.backward(gy.to(DEV).to(dtype))
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert rel_err(y.detach().float().cpu(), yr.detach()) < tol
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < tol
+    assert rel_err(ad.grad.float().cpu(), ar.grad) < 1e-6
+    y2 = nnf.upsample_nearest_add(None, xd, s)
+    assert rel_err(y2.detach().float().cpu(), F.interpolate(x, scale_factor=s, mode="nearest")) < tol
+
+
+def test_lds_transpose_read():
+    """Semantics of ds_read_b64_tr_b16 that conv_wgrad.hip relies on: in each 16-lane group, lane i receives element
+    (i % 4) of the 8-byte chunks addressed by lanes 4j + i/4 (j = 0..3)."""
+    from representationlearning_amd import _lib as L
+    addr = torch.tensor([(l >> 4) * 256 + ((l & 15) >> 2) * 40 + (l & 3) * 4 for l in range(64)], dtype=torch.int32, device=DEV)
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    L.check(L.load().rssf_debug_trread(L.ptr(addr), L.ptr(out), L.stream()), "rssf_debug_trread")
+    got = out.cpu().view(64, 4)
+    a = addr.cpu().tolist()
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        want = [a[g * 16 + 4 * j + i // 4] + i % 4 for j in range(4)]      # lds[k] == k
+        assert got[l].tolist() == want, (l, got[l].tolist(), want)
