@@ -47,15 +47,24 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
   scale_shift[c] = sc; scale_shift[C + c] = beta[c] - mean * sc;
 }
 
-// elementwise over [rows][C]; thread = (row group, vector column); VEC elements per thread (VEC = Vec<T>::N or 1)
+// elementwise over [rows][C].  Thread layout: blockDim = (cols, rpb) with cols = min(C/VEC, 256) vector columns, so a
+// thread keeps ONE channel group for its whole grid-stride loop over rows: scale/shift sit in registers and there is
+// no per-element index arithmetic; consecutive threads still touch consecutive 16-byte chunks (fully coalesced).
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ raw, const float* __restrict__ ss, const T* __restrict__ res_pre,
                                                        const T* __restrict__ res_post, T* __restrict__ y, int64_t rows, int C, int act) {
-  const int cols = C / VEC;
-  const int64_t total = rows * cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cols) * VEC;
-    const int64_t off = i * VEC;
+  const int allcols = C / VEC;
+  const int colbase = blockIdx.y * 256;
+  const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
+  const int rpb = 256 / cols;
+  const int col = threadIdx.x % cols, rlocal = threadIdx.x / cols;
+  if (rlocal >= rpb) return;
+  const int c0 = (colbase + col) * VEC;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
+  for (int64_t r = (int64_t)blockIdx.x * rpb + rlocal; r < rows; r += (int64_t)gridDim.x * rpb) {
+    const int64_t off = r * C + c0;
     if constexpr (VEC > 1) {
       Vec<T> v, rp, rq, o;
       v.load(raw + off);
@@ -63,19 +72,19 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ raw
       if (res_post) rq.load(res_post + off);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float z = v.get(e) * ss[c0 + e] + ss[C + c0 + e];
+        float z = v.get(e) * sc[e] + sh[e];
         if (res_pre) z += rp.get(e);
-        float r = act_fwd(z, act);
-        if (res_post) r += rq.get(e);
-        o.set(e, r);
+        float t = act_fwd(z, act);
+        if (res_post) t += rq.get(e);
+        o.set(e, t);
       }
       o.store(y + off);
     } else {
-      float z = ldf(raw + off) * ss[c0] + ss[C + c0];
+      float z = ldf(raw + off) * sc[0] + sh[0];
       if (res_pre) z += ldf(res_pre + off);
-      float r = act_fwd(z, act);
-      if (res_post) r += ldf(res_post + off);
-      stf(y + off, r);
+      float t = act_fwd(z, act);
+      if (res_post) t += ldf(res_post + off);
+      stf(y + off, t);
     }
   }
 }
@@ -131,17 +140,31 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// draw = scale*(dz - k1 - xhat*k2) (training) or scale*dz (eval);  dres (optional) = dz
+// draw = scale*(dz - k1 - xhat*k2) (training) or scale*dz (eval);  dres (optional) = dz.   Same thread layout as
+// bn_apply_kernel: per-channel constants (scale, shift, mean, invstd, k1, k2) are computed once per thread.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
                                                            const float* __restrict__ mi, const float* __restrict__ sums,
                                                            const T* __restrict__ res_pre, T* __restrict__ draw, T* __restrict__ dres,
                                                            int64_t rows, int C, int act, float n, int training) {
-  const int cols = C / VEC;
-  const int64_t total = rows * cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cols) * VEC;
-    const int64_t off = i * VEC;
+  const int allcols = C / VEC;
+  const int colbase = blockIdx.y * 256;
+  const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
+  const int rpb = 256 / cols;
+  const int col = threadIdx.x % cols, rlocal = threadIdx.x / cols;
+  if (rlocal >= rpb) return;
+  const int c0 = (colbase + col) * VEC;
+  float sc[VEC], sh[VEC], mean[VEC], istd[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int c = c0 + e;
+    sc[e] = ss[c]; sh[e] = ss[C + c]; mean[e] = mi[c]; istd[e] = mi[C + c];
+    const float s1 = sums[c], s2 = sums[C + c];
+    k1[e] = s1 / n;
+    k2[e] = (s2 - mean[e] * s1) * istd[e] / n;             // sum(dz*xhat)/n
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rpb + rlocal; r < rows; r += (int64_t)gridDim.x * rpb) {
+    const int64_t off = r * C + c0;
     float xv[VEC], dv[VEC], pv[VEC], o1[VEC], o2[VEC];
     if constexpr (VEC > 1) {
       Vec<T> vd, vr, vp;
@@ -154,20 +177,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const int c = c0 + e;
-      const float sc = ss[c];
-      const float z = xv[e] * sc + ss[C + c] + pv[e];
+      const float z = xv[e] * sc[e] + sh[e] + pv[e];
       const float dz = dv[e] * act_bwd(z, act);
       o2[e] = dz;
-      if (training) {
-        const float mean = mi[c], invstd = mi[C + c];
-        const float s1 = sums[c], s2 = sums[C + c];
-        const float xhat = (xv[e] - mean) * invstd;
-        const float dot = (s2 - mean * s1) * invstd;        // sum dz * xhat
-        o1[e] = sc * (dz - s1 / n - xhat * dot / n);
-      } else {
-        o1[e] = sc * dz;
-      }
+      o1[e] = training ? sc[e] * (dz - k1[e] - (xv[e] - mean[e]) * istd[e] * k2[e]) : sc[e] * dz;
     }
     if constexpr (VEC > 1) {
       Vec<T> w1, w2;
@@ -191,18 +204,22 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ sums, const float
   dbeta[c] += sums[c];
 }
 
-int grid_for(int64_t total) {
-  int64_t b = (total + 255) / 256;
-  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+// (row blocks, column blocks of <= 256 vector columns) for the fixed-column thread layout
+dim3 grid2d(int64_t rows, int C, int vec) {
+  const int cols = C / vec;
+  const int cblocks = (cols + 255) / 256;
+  const int rpb = 256 / (cols < 256 ? cols : 256);
+  int64_t blocks = (rows + rpb - 1) / rpb;
+  if (blocks > 2048) blocks = 2048;
+  return dim3((unsigned)blocks, (unsigned)cblocks);
 }
 
 template <typename T>
 int apply_launch(const void* raw, const float* ss, const void* rp, const void* rq, void* y, int64_t rows, int C, int act, hipStream_t st) {
   constexpr int V = Vec<T>::N;
-  if (C % V == 0)
-    bn_apply_kernel<T, V><<<grid_for(rows * (C / V)), 256, 0, st>>>((const T*)raw, ss, (const T*)rp, (const T*)rq, (T*)y, rows, C, act);
-  else
-    bn_apply_kernel<T, 1><<<grid_for(rows * C), 256, 0, st>>>((const T*)raw, ss, (const T*)rp, (const T*)rq, (T*)y, rows, C, act);
+  const dim3 grid = grid2d(rows, C, (C % V == 0) ? V : 1);
+  if (C % V == 0) bn_apply_kernel<T, V><<<grid, 256, 0, st>>>((const T*)raw, ss, (const T*)rp, (const T*)rq, (T*)y, rows, C, act);
+  else bn_apply_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)raw, ss, (const T*)rp, (const T*)rq, (T*)y, rows, C, act);
   return check_launch("bn_apply");
 }
 
@@ -228,12 +245,13 @@ template <typename T>
 int bwd_apply_launch(const void* dy, const void* raw, const float* ss, const float* mi, const float* sums, const void* rp, void* draw,
                      void* dres, int64_t rows, int C, int act, float n, int training, hipStream_t st) {
   constexpr int V = Vec<T>::N;
+  const dim3 grid = grid2d(rows, C, (C % V == 0) ? V : 1);
   if (C % V == 0)
-    bn_bwd_apply_kernel<T, V><<<grid_for(rows * (C / V)), 256, 0, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw,
-                                                                        (T*)dres, rows, C, act, n, training);
+    bn_bwd_apply_kernel<T, V><<<grid, 256, 0, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, rows, C,
+                                                    act, n, training);
   else
-    bn_bwd_apply_kernel<T, 1><<<grid_for(rows * C), 256, 0, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw,
-                                                                  (T*)dres, rows, C, act, n, training);
+    bn_bwd_apply_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, rows, C,
+                                                    act, n, training);
   return check_launch("bn_bwd_apply");
 }
 }  // namespace

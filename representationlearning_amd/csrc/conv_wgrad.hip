@@ -197,14 +197,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 }
 
 // second stage of the split-K reduction: dw[torch layout] += sum_k partial[k][tap][co][ci]
+constexpr int RK = 16;   // partials summed per thread in the second stage (blockIdx.y walks the k chunks)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
   const int64_t per = (int64_t)a.ntaps_total * a.Cout * a.Cin;
+  const int kb = blockIdx.y * RK, ke = kb + RK < a.ksplit ? kb + RK : a.ksplit;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
     float s = 0.f;
-    for (int k = 0; k < a.ksplit; ++k) s += a.partial[(int64_t)k * per + i];
+    for (int k = kb; k < ke; ++k) s += a.partial[(int64_t)k * per + i];
     const int ci = (int)(i % a.Cin), co = (int)((i / a.Cin) % a.Cout), tap = (int)(i / ((int64_t)a.Cin * a.Cout));
     const int sc = a.src_of_tap[tap], kk = a.ks[sc] * a.ks[sc];
-    a.dw[sc][((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[tap]] += s;
+    float* dst = a.dw[sc] + ((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[tap];
+    if (gridDim.y == 1) *dst += s;
+    else atomicAdd(dst, s);             // <= ksplit/16 adds per address
   }
 }
 
@@ -214,7 +218,7 @@ int tile_of(int cout, int cin) { return (cout <= 32 && cin <= 32) ? 32 : 64; }
 int pick_ksplit(int cout, int cin, int64_t M) {
   const int t = tile_of(cout, cin);
   const int tiles = ((cout + t - 1) / t) * ((cin + t - 1) / t);
-  int64_t ks = 1024 / tiles;
+  int64_t ks = 512 / tiles;            // ~2 resident blocks per CU; more only multiplies the partial traffic
   const int64_t maxks = (M + 4 * KP - 1) / (4 * KP);
   if (ks > maxks) ks = maxks;
   if (ks < 1) ks = 1;
@@ -247,7 +251,7 @@ int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
     const int64_t per = (int64_t)ntaps * a.Cout * a.Cin;
     int blocks = (int)((per + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(a);
+    wgrad_reduce_kernel<<<dim3((unsigned)blocks, (unsigned)((a.ksplit + RK - 1) / RK)), 256, 0, st>>>(a);
     return check_launch("conv_wgrad_reduce");
   }
   return RSSF_OK;
