@@ -153,6 +153,16 @@ int rssf_upsample_bilinear(const void* in, void* out, int B, int IH, int IW, int
 int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B, int IH, int IW, int scale, int C, int backward,
                               int dtype, void* stream);
 
+/* ---- CGFL loss: SegmentationLossaux.forward (module/CGFL.py:201-227) -> MCTransAuxLoss (losses/auxloss.py:257-305)
+ *      -> softmax_focalloss (module/CGFL.py:72-101), on channels-last logits [B, HW, K] and int64 labels [B, HW] ---- */
+/* acc: fp32 scratch [B][5] (zeroed inside); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);
+ * out[0] = loss, out[1] = backward coefficient (detached modulating bracket / n_valid). */
+int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* aux, float* acc, float* out, int B, int HW, int K,
+                       int KA, int ignore_index, int dtype, void* stream);
+/* dlogits = dloss * out[1] * (softmax(logits) - onehot(label)) on valid pixels, 0 on ignored ones; dloss may be NULL (=1) */
+int rssf_cgfl_loss_bwd(const void* logits, const int64_t* labels, const float* out, const float* dloss, void* dlogits, int B, int HW,
+                       int K, int ignore_index, int dtype, void* stream);
+
 /* ---- optimizer over flat fp32 buffers: the external `ever` trainer's clip_grad_norm_(35) + SGD(momentum .9,
  *      wd 1e-4) of configs/base/loveda.py:68-77 as two launches over all parameters ----------------------- */
 /* out[0] = sum g^2 (zeroed inside, on the stream). */

@@ -1,0 +1,128 @@
+// CGFL segmentation loss, forward and backward, on channels-last logits [B, H*W, K].
+// Reference: SegmentationLossaux.forward (module/CGFL.py:201-227) -> MCTransAuxLoss.forward (losses/auxloss.py:257-305)
+// -> softmax_focalloss (module/CGFL.py:72-101).  Closed form:
+//     fg      = (y > 0) & (y != ignore)
+//     lab_b   = [any non-fg pixel in sample b, any fg pixel in sample b, 0, 0, ...]             (one-hot sum of unique(fg_b))
+//     l1_b    = sum_c 1 / (1 + exp|aux_bc - lab_bc|) / (2B)                                      (local batch size)
+//     CE      = mean over valid pixels of -log softmax(logit)[y]
+//     loss    = CE * [ sum_{all pixels} (1 - p[max(y,0)]) * (1 - l1_b/7) / (n_valid + B) ]        (bracket detached)
+// One pass over the logits for the forward (per-sample partial sums via block reduction + atomics), a 1-block
+// finalize, one pass for the backward (softmax recomputed: nothing but the logits is kept).  HBM-bound.
+#include "common.cuh"
+using namespace rssf;
+
+namespace {
+constexpr int MAXK = 32;
+
+// acc[b] = { ce_sum, n_valid, sum(1-p_y), any_fg, any_nonfg }
+template <typename T>
+__global__ void __launch_bounds__(256) loss_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ acc,
+                                                       int HW, int K, int ignore_index) {
+  const int b = blockIdx.y;
+  float ce = 0.f, nv = 0.f, sm = 0.f, fg = 0.f, bg = 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int64_t pix = (int64_t)b * HW + p;
+    const T* lg = logits + pix * K;
+    const int y = (int)labels[pix];
+    const bool valid = y != ignore_index;
+    float v[MAXK], mx = -INFINITY;
+    for (int k = 0; k < K; ++k) { v[k] = ldf(lg + k); mx = fmaxf(mx, v[k]); }
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += __expf(v[k] - mx);
+    const int yy = valid ? y : 0;
+    const float logp = v[yy] - mx - __logf(se);
+    if (valid) { ce -= logp; nv += 1.f; }
+    sm += 1.f - __expf(logp);
+    if (valid && y > 0) fg = 1.f; else bg = 1.f;
+  }
+  ce = wave_sum(ce); nv = wave_sum(nv); sm = wave_sum(sm); fg = wave_max(fg); bg = wave_max(bg);
+  __shared__ float red[4][5];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = ce; red[w][1] = nv; red[w][2] = sm; red[w][3] = fg; red[w][4] = bg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* a = acc + b * 5;
+    atomicAdd(a + 0, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    atomicAdd(a + 1, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    atomicAdd(a + 2, red[0][2] + red[1][2] + red[2][2] + red[3][2]);
+    if (fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])) > 0.f) atomicMax((int*)(a + 3), __float_as_int(1.f));
+    if (fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])) > 0.f) atomicMax((int*)(a + 4), __float_as_int(1.f));
+  }
+}
+
+// out[0] = loss, out[1] = gradient coefficient = bracket / n_valid  (d loss / d logit = coef * (p - onehot) on valid pixels)
+__global__ void loss_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ aux, float* __restrict__ out, int B, int KA) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float ce = 0.f, nv = 0.f, mf = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* a = acc + b * 5;
+    float l1 = 0.f;
+    for (int c = 0; c < KA; ++c) {
+      const float lab = c == 0 ? a[4] : (c == 1 ? a[3] : 0.f);
+      l1 += 1.f / (1.f + expf(fabsf(aux[b * KA + c] - lab)));
+    }
+    l1 /= (2.f * B);
+    ce += a[0]; nv += a[1];
+    mf += a[2] * (1.f - l1 / 7.f);
+  }
+  const float bracket = mf / (nv + (float)B);
+  out[0] = (ce / nv) * bracket;
+  out[1] = bracket / nv;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) loss_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                       const float* __restrict__ coef, const float* __restrict__ dloss, T* __restrict__ dlogits,
+                                                       int64_t npix, int K, int ignore_index) {
+  const float g = coef[1] * (dloss ? dloss[0] : 1.f);
+  for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+    const T* lg = logits + pix * K;
+    T* dg = dlogits + pix * K;
+    const int y = (int)labels[pix];
+    if (y == ignore_index) {
+      for (int k = 0; k < K; ++k) stf(dg + k, 0.f);
+      continue;
+    }
+    float v[MAXK], mx = -INFINITY;
+    for (int k = 0; k < K; ++k) { v[k] = ldf(lg + k); mx = fmaxf(mx, v[k]); }
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) { v[k] = __expf(v[k] - mx); se += v[k]; }
+    const float inv = 1.f / se;
+    for (int k = 0; k < K; ++k) stf(dg + k, g * (v[k] * inv - (k == y ? 1.f : 0.f)));
+  }
+}
+}  // namespace
+
+extern "C" int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* aux, float* acc, float* out, int B, int HW, int K,
+                                  int KA, int ignore_index, int dtype, void* stream) {
+  RSSF_REQUIRE(logits && labels && aux && acc && out && B > 0 && HW > 0 && K > 0 && K <= MAXK && KA >= 2, "cgfl_loss_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * 5 * B, st);
+  if (e != hipSuccess) { set_error("cgfl_loss_fwd: memset failed: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
+  int bx = (HW + 255) / 256;
+  if (bx > 128) bx = 128;
+  dim3 grid((unsigned)bx, (unsigned)B);
+  if (dtype == RSSF_F32) loss_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)logits, labels, acc, HW, K, ignore_index);
+  else if (dtype == RSSF_BF16) loss_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)logits, labels, acc, HW, K, ignore_index);
+  else { set_error("cgfl_loss_fwd: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  int rc = check_launch("cgfl_loss_fwd");
+  if (rc) return rc;
+  loss_finalize_kernel<<<1, 64, 0, st>>>(acc, aux, out, B, KA);
+  return check_launch("cgfl_loss_finalize");
+}
+
+extern "C" int rssf_cgfl_loss_bwd(const void* logits, const int64_t* labels, const float* out, const float* dloss, void* dlogits, int B,
+                                  int HW, int K, int ignore_index, int dtype, void* stream) {
+  RSSF_REQUIRE(logits && labels && out && dlogits && B > 0 && HW > 0 && K > 0 && K <= MAXK, "cgfl_loss_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t npix = (int64_t)B * HW;
+  int64_t blocks = (npix + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == RSSF_F32)
+    loss_bwd_kernel<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)logits, labels, out, dloss, (float*)dlogits, npix, K, ignore_index);
+  else if (dtype == RSSF_BF16)
+    loss_bwd_kernel<bf16_t><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)logits, labels, out, dloss, (bf16_t*)dlogits, npix, K,
+                                                              ignore_index);
+  else { set_error("cgfl_loss_bwd: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  return check_launch("cgfl_loss_bwd");
+}

@@ -1,5 +1,7 @@
 """MCTransAuxLoss (reference: losses/auxloss.py:253-322): image-level "which of {background, foreground} occur"
-targets vs the aux scores -> a per-sample scalar l1_b that modulates the focal term (no gradient to the aux head)."""
+targets vs the aux scores -> a per-sample scalar l1_b that modulates the focal term (no gradient to the aux head).
+On the training path this arithmetic runs inside the fused HIP loss kernel (csrc/loss.hip); this module is the
+stand-alone form of the same formula for callers that want l1 itself (tiny [B,7] tensors)."""
 import torch
 import torch.nn as nn
 

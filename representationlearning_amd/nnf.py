@@ -322,6 +322,40 @@ def upsample_nearest_add(acc, x, scale):
     return _NearestAdd.apply(acc, x, int(scale))
 
 
+class _CGFLLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, aux, ignore_index):
+        L.require_gpu(logits, labels, aux)
+        lh = _nhwc(logits)
+        B, H, W, K = lh.shape
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64 or labels.shape != (B, H, W):
+            raise RuntimeError("cgfl_loss: labels must be int64 [B,H,W]")
+        auxf = aux.detach().float().contiguous()
+        acc = torch.empty(B, 5, device=lh.device, dtype=torch.float32)
+        out = torch.empty(2, device=lh.device, dtype=torch.float32)
+        L.check(L.load().rssf_cgfl_loss_fwd(L.ptr(lh), L.ptr(labels), L.ptr(auxf), L.ptr(acc), L.ptr(out), B, H * W, K, auxf.shape[1],
+                                            ignore_index, L.dtype_code(lh), L.stream()), "rssf_cgfl_loss_fwd")
+        ctx.save_for_backward(lh, labels, out)
+        ctx.ignore_index = ignore_index
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lh, labels, out = ctx.saved_tensors
+        B, H, W, K = lh.shape
+        dl = torch.empty_like(lh)
+        d = dloss.detach().float().reshape(1).contiguous()
+        L.check(L.load().rssf_cgfl_loss_bwd(L.ptr(lh), L.ptr(labels), L.ptr(out), L.ptr(d), L.ptr(dl), B, H * W, K, ctx.ignore_index,
+                                            L.dtype_code(lh), L.stream()), "rssf_cgfl_loss_bwd")
+        return _nchw(dl), None, None, None      # the aux head receives no gradient (the bracket is detached, CGFL.py:75-97)
+
+
+def cgfl_loss(logits, labels, aux, ignore_index=-1):
+    """SegmentationLossaux 'ce' branch: logits logical NCHW (channels-last), labels int64 [B,H,W], aux [B,7]."""
+    return _CGFLLoss.apply(logits, labels, aux, int(ignore_index))
+
+
 def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None):
     """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm."""
     convs = convs if isinstance(convs, (list, tuple)) else [convs]

@@ -203,3 +203,38 @@ def test_lds_transpose_read():
         g, i = l >> 4, l & 15
         want = [a[g * 16 + 4 * j + i // 4] + i % 4 for j in range(4)]      # lds[k] == k
         assert got[l].tolist() == want, (l, got[l].tolist(), want)
+
+
+@pytest.mark.parametrize("tag", ["mixed", "one_all_ignore", "no_fg", "all_fg"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cgfl_loss_vs_golden(tag, dtype):
+    """HIP loss kernels vs the golden vectors of the reference's SegmentationLossaux (incl. edge cases)."""
+    from oracle.procedural import proc_input
+    from tests.helpers import golden
+    from representationlearning_amd import nnf
+    g = golden(f"loss_{tag}")
+    y = torch.from_numpy(g["y"]).to(DEV)
+    lg = (proc_input((3, 6, 12, 10), 0.4) * 2.0).to(dtype)
+    aux = proc_input((3, 7), 1.3).to(DEV).requires_grad_()
+    ld = lg.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    loss = nnf.cgfl_loss(ld, y, aux)
+    loss.backward()
+    f32 = dtype == torch.float32
+    assert abs(float(loss.detach()) - float(g["loss"])) < (2e-6 if f32 else 5e-3) * max(1.0, abs(float(g["loss"])))
+    assert rel_err(ld.grad.float().cpu(), g["glogits"]) < (1e-5 if f32 else 1e-2)
+    assert aux.grad is None
+
+
+def test_cgfl_loss_full_size_properties():
+    """BASELINE config-2 size (16 x 6 x 512 x 512): finite, gradient sums to zero over classes, zero on ignored pixels."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(0)
+    lg = torch.randn(16, 6, 512, 512, device=DEV).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = torch.randint(-1, 6, (16, 512, 512), device=DEV)
+    aux = torch.randn(16, 7, device=DEV)
+    loss = nnf.cgfl_loss(lg, y, aux)
+    loss.backward()
+    assert torch.isfinite(loss) and float(loss) > 0
+    gsum = lg.grad.float().sum(1)
+    assert float(gsum.abs().max()) < 1e-6
+    assert float(lg.grad.float().abs().sum(1)[y == -1].max()) == 0.0
