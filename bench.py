@@ -61,35 +61,66 @@ def measure_window_attention(B, S, iters=30):
                 frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, us_per_launch=round(ms * 1e3, 2), algorithmic_bytes=alg_bytes)
 
 
-def cpu_baseline(steps=2):
-    """CPU restatement of the same training step (oracle/, plain PyTorch fp32) on the host cores: Base, B=2, 512x512."""
+def _cpu_baseline_child(threads, batch, max_steps):
+    """Runs in a subprocess: prints one line per finished step so the parent can stop it at its deadline."""
+    torch.set_num_threads(threads)
     from oracle import rssformer_cpu as O
     from representationlearning_amd.configs import synthetic_batch
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     P = O.default_init_({k: v.clone() for k, v in O.model_template("base").items()})
-    for k, v in P.items():
-        if v.is_floating_point() and "running" not in k:
+    for v in P.values():
+        if v.is_floating_point():
             v.requires_grad_()
-    x, y = synthetic_batch(2, 512, device="cpu")
+    for k in P:
+        if "running" in k:
+            P[k].requires_grad_(False)
+    x, y = synthetic_batch(batch, 512, device="cpu")
     params = [v for v in P.values() if v.requires_grad]
     opt = torch.optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=1e-4)
-
-    def step():
+    for i in range(max_steps + 1):
+        t = time.time()
         opt.zero_grad(set_to_none=True)
         O.model_forward(x, P, True, y).backward()
         torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], 35.0)
         opt.step()
-    step()
-    t = time.time()
-    for _ in range(steps):
-        step()
-    dt = (time.time() - t) / steps
-    return dict(value=round(2 / dt, 4), unit="images/s", cores=cores, kind="port",
-                sample="1 warm-up + %d timed steps of the CPU oracle (fp32, B=2, 3x512x512, fwd+loss+bwd+clip+SGD)" % steps)
+        print("CPU_STEP %d %.4f" % (i, time.time() - t), flush=True)
+
+
+def cpu_baseline(budget_s=90.0, batch=2, max_steps=3):
+    """CPU restatement of the same training step (oracle/, plain PyTorch fp32) on the host cores: Base, 512x512.
+    Bounded: a subprocess is given `budget_s` seconds; step 0 is warm-up, the finished timed steps are averaged."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 32)      # oneDNN does not scale past a few dozen threads at this size
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(threads), str(batch), str(max_steps)]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
+    times, deadline = [], time.time() + budget_s
+    import select
+    while time.time() < deadline:
+        r, _, _ = select.select([proc.stdout], [], [], max(0.0, min(1.0, deadline - time.time())))
+        if r:
+            line = proc.stdout.readline()
+            if not line:
+                break
+            if line.startswith("CPU_STEP"):
+                _, i, dt = line.split()
+                if int(i) > 0:
+                    times.append(float(dt))
+        elif proc.poll() is not None:
+            break
+    if proc.poll() is None:
+        proc.kill()
+    if not times:
+        return dict(value=None, unit="images/s", cores=threads, kind="port",
+                    sample="no timed step of the CPU oracle (fp32, B=%d, 3x512x512) finished within %.0f s" % (batch, budget_s))
+    dt = sum(times) / len(times)
+    return dict(value=round(batch / dt, 4), unit="images/s", cores=threads, kind="port",
+                sample="1 warm-up + %d timed steps of the CPU oracle (fp32, B=%d, 3x512x512, fwd+loss+bwd+clip+SGD), %d threads"
+                       % (len(times), batch, threads))
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
+        _cpu_baseline_child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

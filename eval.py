@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""eval.py — surface of the reference's RSSFormer-TIP2023/eval.py (:17-24, :32-81): `evaluate(ckpt_path, config_path,
+use_tta)`: load a checkpoint (DDP `module.` prefix stripped, :37-38), softmax -> argmax -> ignore(-1) mask -> confusion
+matrix -> mIoU.  TTA and the LoveDA loader are not part of this round: without a dataset the
+synthetic validation tiles are used."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def remove_module_prefix(state):
+    return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+
+
+def evaluate(ckpt_path, config_path="baseline.hrnetw32", use_tta=False, batches=None):
+    from representationlearning_amd import _lib
+    from representationlearning_amd.configs import config_by_name, synthetic_batch
+    from representationlearning_amd.core import registry
+    from representationlearning_amd.core.config import AttrDict
+    from train import evaluate_cls_fn
+    if use_tta:
+        raise NotImplementedError("eval.py: test-time augmentation (module/tta.py) is a later row (SURVEY.md §8f rank 2)")
+    _lib.load()
+    registry.register_all()
+    cfg = AttrDict.wrap(config_by_name(config_path))
+    model = registry.MODEL[cfg.model.type](cfg.model.params)
+    if ckpt_path:
+        model.load_state_dict(remove_module_prefix(torch.load(ckpt_path, map_location="cpu")))
+    model = model.cuda().eval()
+    if batches is None:
+        batches = [synthetic_batch(4, 512, classes=cfg.model.params.classes, seed=7)]
+    return evaluate_cls_fn(model, batches, cfg.model.params.classes)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description="Eval methods")
+    ap.add_argument("--ckpt_path", type=str, default=None)
+    ap.add_argument("--config_path", type=str, default="baseline.hrnetw32")
+    ap.add_argument("--tta", type=bool, default=False)
+    a = ap.parse_args()
+    evaluate(a.ckpt_path, a.config_path, a.tta)

@@ -17,3 +17,20 @@ def synthetic_batch(B, S, classes=6, seed=2333, device="cuda"):
     lab = torch.randint(-1, classes, (B, (S + 15) // 16, (S + 15) // 16), generator=g)
     lab = lab.repeat_interleave(16, 1).repeat_interleave(16, 2)[:, :S, :S].contiguous()
     return img.to(device), lab.to(device)
+
+
+def config_by_name(name):
+    """Dotted config names of the reference (configs/baseline/hrnetw32.py + configs/base/loveda.py): model params +
+    the optimizer / LR / train sections the trainer reads.  `classes` follows BASELINE (6); the reference's LoveDA
+    config uses 7 (configs/baseline/hrnetw32.py:19) — override with `model.params.classes 7`."""
+    variants = {"baseline.hrnetw32": "base", "baseline.hrnetw18": "tiny", "baseline.hrnetw48": "large"}
+    if name not in variants:
+        raise KeyError("unknown config '%s' (built: %s)" % (name, ", ".join(sorted(variants))))
+    return dict(
+        model=dict(type="RSSFormer", params=rssformer_config(variants[name])),
+        optimizer=dict(type="sgd", params=dict(momentum=0.9, weight_decay=0.0001), grad_clip=dict(max_norm=35, norm_type=2)),
+        learning_rate=dict(type="poly", params=dict(base_lr=0.01, power=0.9, max_iters=30000)),
+        train=dict(forward_times=1, num_iters=30000, eval_per_epoch=True, summary_grads=False, summary_weights=False,
+                   distributed=True, apex_sync_bn=True, sync_bn=True, eval_after_train=True, log_interval_step=50,
+                   save_ckpt_interval_epoch=1000, eval_interval_epoch=20),
+        test=dict())
