@@ -70,14 +70,16 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ raw
       v.load(raw + off);
       if (res_pre) rp.load(res_pre + off);
       if (res_post) rq.load(res_post + off);
+      float ov[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float z = v.get(e) * sc[e] + sh[e];
         if (res_pre) z += rp.get(e);
         float t = act_fwd(z, act);
         if (res_post) t += rq.get(e);
-        o.set(e, t);
+        ov[e] = t;
       }
+      o.set_all(ov);
       o.store(y + off);
     } else {
       float z = ldf(raw + off) * sc[0] + sh[0];
@@ -184,8 +186,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     }
     if constexpr (VEC > 1) {
       Vec<T> w1, w2;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) { w1.set(e, o1[e]); w2.set(e, o2[e]); }
+      w1.set_all(o1); w2.set_all(o2);
       w1.store(draw + off);
       if (dres) w2.store(dres + off);
     } else {

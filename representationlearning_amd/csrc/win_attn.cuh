@@ -72,6 +72,34 @@ template <> struct Chain<float> {
   static __device__ __forceinline__ float frag(const f32x4& v, int r) { return v[r]; }
 };
 
+// Packed form of a C-layout tile that is only ever used again as an MFMA operand (halves the registers in bf16).
+template <typename T> struct Packed;
+template <> struct Packed<bf16_t> {
+  typedef s16x4 type;
+  static __device__ __forceinline__ type pack(const f32x4& v) { return pack_bf16x4(v); }
+  static __device__ __forceinline__ f32x4 mma(type a, type b, f32x4 acc) { return Mma<bf16_t>::mma(a, b, acc); }
+  static __device__ __forceinline__ f32x4 mma_lds_a(const bf16_t* A, int lda, int k0, type b, f32x4 acc) {
+    const int lane = threadIdx.x & 63;
+    return Mma<bf16_t>::mma(Mma<bf16_t>::load(A + (lane & 15) * lda + k0 + (lane >> 4) * 4), b, acc);
+  }
+};
+template <> struct Packed<float> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ type pack(const f32x4& v) { return v; }
+  static __device__ __forceinline__ f32x4 mma(const type& a, const type& b, f32x4 acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = Mma<float>::mma(a[r], b[r], acc);
+    return acc;
+  }
+  static __device__ __forceinline__ f32x4 mma_lds_a(const float* A, int lda, int k0, const type& b, f32x4 acc) {
+    const int lane = threadIdx.x & 63;
+    const float* pa = A + (lane & 15) * lda + k0 + (lane >> 4) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = Mma<float>::mma(pa[r], b[r], acc);
+    return acc;
+  }
+};
+
 // D += X * Y where both operands come from C-layout register tiles whose row axis (4g+r) is the K axis.
 template <typename T>
 __device__ __forceinline__ f32x4 mma_chain(const f32x4& a, const f32x4& b, f32x4 acc) {
@@ -126,27 +154,59 @@ __device__ __forceinline__ void load_gated_tiles(const rssf_winattn_fwd_params& 
   constexpr int V = Vec<T>::N;
   if constexpr (DM::C % V == 0) {
     constexpr int cpr = DM::CP / V;
-    for (int e = lane; e < LP * cpr; e += 64) {
+    constexpr int ITERS = (LP * cpr + 63) / 64;
+    // branch-free: every lane issues all its global loads back to back (dead / padded slots read token 0 and are
+    // zeroed afterwards), so the HBM latency is paid once per window instead of once per iteration.
+    Vec<T> vx[ITERS], vy[ITERS];
+    float2 sx[ITERS], sy[ITERS];
+    int pp[ITERS];
+    bool ok[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int e = lane + it * 64;
       const int t = e / cpr, c0 = (e % cpr) * V;
       const int n = slot_token(g, qh, qw, t);
-      Vec<T> ox, oy;
-      ox.raw = {0, 0, 0, 0}; oy.raw = {0, 0, 0, 0};
-      if (n >= 0 && c0 < DM::C) {
-        const int64_t f = (int64_t)n * DM::C + c0;
-        Vec<T> vx, vy;
-        vx.load(X + img * DM::C + f);
-        vy.load(Y + img * DM::C + f);
-        const float2 sx = *reinterpret_cast<const float2*>(p.stats_x + (img + n) * 2);
-        const float2 sy = *reinterpret_cast<const float2*>(p.stats_y + (img + n) * 2);
-        int pp = (int)(f % g.N);
+      ok[it] = n >= 0 && c0 < DM::C && e < LP * cpr;
+      const int nn = ok[it] ? n : 0, cc = ok[it] ? c0 : 0;
+      const int64_t f = (int64_t)nn * DM::C + cc;
+      vx[it].load(X + img * DM::C + f);
+      vy[it].load(Y + img * DM::C + f);
+      sx[it] = *reinterpret_cast<const float2*>(p.stats_x + (img + nn) * 2);
+      sy[it] = *reinterpret_cast<const float2*>(p.stats_y + (img + nn) * 2);
+      pp[it] = (int)(f % g.N);
+    }
+    const bool contiguous = g.N % DM::C == 0;   // the V gate weights of a chunk are contiguous (no wrap inside a token row)
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int e = lane + it * 64;
+      if (e >= LP * cpr) break;
+      const int t = e / cpr, c0 = (e % cpr) * V;
+      float w0[V], w1[V];
+      if (contiguous) {
+#pragma unroll
+        for (int i = 0; i < V; i += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(om0 + pp[it] + i);
+          const float4 c = *reinterpret_cast<const float4*>(om0 + g.N + pp[it] + i);
+          w0[i] = a.x; w0[i + 1] = a.y; w0[i + 2] = a.z; w0[i + 3] = a.w;
+          w1[i] = c.x; w1[i + 1] = c.y; w1[i + 2] = c.z; w1[i + 3] = c.w;
+        }
+      } else {
+        int q = pp[it];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-          const float ga = sLn[c0 + i], be = sLn[DM::CP + c0 + i];
-          ox.set(i, ((vx.get(i) - sx.x) * sx.y * ga + be) * om0[pp]);
-          oy.set(i, ((vy.get(i) - sy.x) * sy.y * ga + be) * om0[g.N + pp]);
-          if (++pp == g.N) pp = 0;
+          w0[i] = om0[q]; w1[i] = om0[g.N + q];
+          if (++q == g.N) q = 0;
         }
       }
+      float fx[V], fy[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float ga = sLn[c0 + i], be = sLn[DM::CP + c0 + i];
+        fx[i] = ok[it] ? ((vx[it].get(i) - sx[it].x) * sx[it].y * ga + be) * w0[i] : 0.f;
+        fy[i] = ok[it] ? ((vy[it].get(i) - sy[it].x) * sy[it].y * ga + be) * w1[i] : 0.f;
+      }
+      Vec<T> ox, oy;
+      ox.set_all(fx); oy.set_all(fy);
       ox.store(xs + t * ldx + c0);
       oy.store(ys + t * ldx + c0);
     }

@@ -10,7 +10,9 @@
 // workgroup share the projection weights in LDS.  Everything between the single global read of the two
 // 49xC tiles and the single global write stays in LDS / registers.  All matmuls run "transposed"
 // (channels x tokens) so that every MFMA result lands in exactly the register layout the next MFMA wants
-// as an operand (q,k -> S^T -> P^T -> O^T -> out^T); only q^T,k^T (for M = q^T k) and v^T go through LDS.
+// as an operand (q,k -> S^T -> P^T -> O^T -> out^T).  q and k are projected in both orientations (one for S^T, one for
+// M = q^T k and v for O^T = v^T P^T), which costs 16 extra MFMAs per window and removes every LDS round trip after the
+// tile load: LDS holds only the two gated input tiles and the weights.
 // The kernel is HBM-bound (0.27 GFLOP vs 3.1 MB per image-block); MFMA just keeps the
 // arithmetic out of the way.
 #include "win_attn.cuh"
@@ -21,26 +23,75 @@ namespace {
 
 template <typename T, typename DM> struct FwdLayout {
   static constexpr int LDX = DM::CP + Pad<T>::X;     // xs/ys rows  [token][channel]
-  static constexpr int LDT = LP + Pad<T>::X;         // qT/kT/vT rows [virtual channel][token]
   static constexpr int LDW = DM::CP + Pad<T>::X;     // Wq/Wk/Wv rows [virtual channel][in channel]
   static constexpr int LDO = DM::CV + Pad<T>::X;     // Wo rows [out channel][virtual channel]
-  static constexpr int REGION = ((LP * LDX > DM::CV * LDT ? LP * LDX : DM::CV * LDT) + 7) / 8 * 8;
+  static constexpr int REGION = (LP * LDX + 7) / 8 * 8;
   static constexpr int W_ELEMS = 3 * DM::CV * LDW + DM::CP * LDO;
   static constexpr int F_ELEMS = 3 * DM::CV + 3 * DM::CP;   // biases + LN affine (fp32)
   static constexpr size_t SHARED_OFF = (sizeof(T) * W_ELEMS + sizeof(float) * F_ELEMS + 15) / 16 * 16;
-  static constexpr size_t WAVE_BYTES = sizeof(T) * 3 * REGION;
+  static constexpr size_t WAVE_BYTES = sizeof(T) * 2 * REGION;
   // waves per workgroup: as many (<= 4) as fit the 160 KiB LDS of one CU
   static constexpr int WAVES = (SHARED_OFF + 4 * WAVE_BYTES <= 160 * 1024) ? 4 : (SHARED_OFF + 2 * WAVE_BYTES <= 160 * 1024) ? 2 : 1;
   static constexpr size_t BYTES = SHARED_OFF + WAVE_BYTES * WAVES;
 };
 
+// projection tile: D(16x16) = A[16 rows][K] * B[16 rows][K]^T with the widest MFMA the dtype / K allow
+template <typename T>
+__device__ __forceinline__ f32x4 proj_tile(const T* A, int lda, const T* B, int ldb, int K) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x & 63;
+  if constexpr (sizeof(T) == 2) {
+    if (K % 32 == 0) {                       // v_mfma_f32_16x16x32_bf16: half the instructions of the K=16 form
+      const T* pa = A + (lane & 15) * lda + (lane >> 4) * 8;
+      const T* pb = B + (lane & 15) * ldb + (lane >> 4) * 8;
+      for (int k = 0; k < K; k += 32)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(pa + k), *reinterpret_cast<const bf16x8*>(pb + k),
+                                                      acc, 0, 0, 0);
+      return acc;
+    }
+  }
+  return mma_tile<T>(A, lda, B, ldb, K, acc);
+}
+
+// 8-byte (bf16) / 16-byte (f32) access to 4 consecutive channels of one token
+template <typename T> struct Quad;
+template <> struct Quad<bf16_t> {
+  typedef uint2 raw;
+  static __device__ __forceinline__ raw load_raw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ void unpack(const raw& u, float (&v)[4]) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    uint2 u;
+    u.x = f2bf2(v[0], v[1]);
+    u.y = f2bf2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = u;
+  }
+};
+template <> struct Quad<float> {
+  typedef float4 raw;
+  static __device__ __forceinline__ raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void unpack(const raw& u, float (&v)[4]) { v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 u = *reinterpret_cast<const float4*>(p);
+    v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
 template <typename T, typename DM>
-__global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64)) winattn_fwd_kernel(rssf_winattn_fwd_params p, Geom g) {
+__global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) == 2 && DM::C <= 32) ? 3 : 1)) winattn_fwd_kernel(rssf_winattn_fwd_params p, Geom g) {
   using LY = FwdLayout<T, DM>;
-  constexpr int LDX = LY::LDX, LDT = LY::LDT, LDW = LY::LDW, LDO = LY::LDO;
+  constexpr int LDX = LY::LDX, LDW = LY::LDW, LDO = LY::LDO;
   constexpr int C = DM::C, CP = DM::CP, CV = DM::CV, MT = DM::MT, CT = DM::CT, TPH = DM::TPH, D = DM::D;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // ---- workgroup-shared: weights as T (A operands), biases / LN affine fp32 ------------------------------
+  // ---- workgroup-shared: weights as T (MFMA operands), biases / LN affine fp32 ---------------------------------
   T* sWq = reinterpret_cast<T*>(smem_raw);           // [CV][LDW]  virtual rows, k = real input channel
   T* sWk = sWq + CV * LDW;
   T* sWv = sWk + CV * LDW;
@@ -49,9 +100,8 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64)) winattn_fwd_ke
   float* sLn = sB + 3 * CV + CP;                     // gamma[CP] beta[CP]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, grp = lane >> 4;
-  T* regA = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)wave * 3 * LY::REGION;   // xs -> qT
-  T* regB = regA + LY::REGION;                                                                  // ys -> kT
-  T* regC = regB + LY::REGION;                                                                  //       vT
+  T* xs = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)wave * 2 * LY::REGION;   // [LP][LDX] gated LN(x)
+  T* ys = xs + LY::REGION;                                                                    // [LP][LDX] gated LN(y)
 
   for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
     const int m = i / LDW, k = i % LDW;
@@ -92,51 +142,70 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64)) winattn_fwd_ke
 
     // ---- 1. load both 49xC tiles, LayerNorm (given stats) * gate weight -> LDS as T, zero padded ------
     wave_sync();
-    load_gated_tiles<T, DM>(p, g, sLn, X, Y, om0, img, qh, qw, regA, regB, LDX, lane);
+    load_gated_tiles<T, DM>(p, g, sLn, X, Y, om0, img, qh, qw, xs, ys, LDX, lane);
+    // residual values of the tokens / channels this lane will store (issued now, consumed in step 4)
+    typename Quad<T>::raw xres[NT][CT];
+    int ntok[NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      ntok[qt] = slot_token(g, qh, qw, qt * 16 + l15);
+      if constexpr (C % 4 == 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c0 = ct * 16 + grp * 4;
+          const int64_t off = (img + (ntok[qt] >= 0 ? ntok[qt] : 0)) * C + (c0 < C ? c0 : 0);
+          xres[qt][ct] = Quad<T>::load_raw(X + off);
+        }
+      }
+    }
     wave_sync();
 
-    // ---- 2. projections (transposed): q^T,k^T [virtual channel][token] kept in C-layout registers,
-    //         v^T staged only (goes to LDS in step 3) -----------------------------------------------------
-    f32x4 q[MT][NT], k[MT][NT], v[MT][NT];
+    // ---- 2. projections.  Everything downstream is register-chained, so q and k are produced in BOTH orientations:
+    //         transposed  q^T,k^T [channel][token] (k-slot = channel)  -> operands of S^T = k q^T
+    //         straight    q,k,v   [token][channel] (k-slot = token)    -> operands of M = q^T k and of O^T = v^T P^T
+    using PK = Packed<T>;
+    typename PK::type qT[MT][NT], kT[MT][NT], vN[NT][MT];
+    f32x4 Macc[DM::HEADS][TPH][TPH];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int mrow = mt * 16 + grp * 4;
+    for (int h = 0; h < DM::HEADS; ++h)
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq;
-        aq = mma_tile<T>(sWq + mt * 16 * LDW, LDW, regA + tt * 16 * LDX, LDX, CP, aq);
-        ak = mma_tile<T>(sWk + mt * 16 * LDW, LDW, regB + tt * 16 * LDX, LDX, CP, ak);
-        av = mma_tile<T>(sWv + mt * 16 * LDW, LDW, regB + tt * 16 * LDX, LDX, CP, av);
+      for (int i = 0; i < TPH; ++i)
+#pragma unroll
+        for (int j = 0; j < TPH; ++j) Macc[h][i][j] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      typename PK::type qN[MT], kN[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int mrow = mt * 16 + grp * 4, mcol = mt * 16 + l15;
+        f32x4 aq = proj_tile<T>(sWq + mt * 16 * LDW, LDW, xs + tt * 16 * LDX, LDX, CP);
+        f32x4 ak = proj_tile<T>(sWk + mt * 16 * LDW, LDW, ys + tt * 16 * LDX, LDX, CP);
+        f32x4 nq = proj_tile<T>(xs + tt * 16 * LDX, LDX, sWq + mt * 16 * LDW, LDW, CP);
+        f32x4 nk = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWk + mt * 16 * LDW, LDW, CP);
+        f32x4 nv = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWv + mt * 16 * LDW, LDW, CP);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           aq[r] = (aq[r] + sB[mrow + r]) * scale;
           ak[r] += sB[CV + mrow + r];
-          av[r] += sB[2 * CV + mrow + r];
+          const bool live = tt * 16 + grp * 4 + r < g.L;          // tokens >= 49 must not enter M (DAL.py:1003)
+          nq[r] = live ? (nq[r] + sB[mcol]) * scale : 0.f;
+          nk[r] += sB[CV + mcol];
+          nv[r] += sB[2 * CV + mcol];
         }
-        q[mt][tt] = aq; k[mt][tt] = ak; v[mt][tt] = av;
+        qT[mt][tt] = PK::pack(aq); kT[mt][tt] = PK::pack(ak); qN[mt] = PK::pack(nq); kN[mt] = PK::pack(nk);
+        vN[tt][mt] = PK::pack(nv);
       }
+      // M_h += q_h^T k_h over this token tile (k-slot = token: both operands are C-layout rows)
+#pragma unroll
+      for (int h = 0; h < DM::HEADS; ++h)
+#pragma unroll
+        for (int i = 0; i < TPH; ++i)
+#pragma unroll
+          for (int j = 0; j < TPH; ++j) Macc[h][i][j] = PK::mma(qN[h * TPH + i], kN[h * TPH + j], Macc[h][i][j]);
     }
-    wave_sync();   // all reads of xs/ys done before the regions are reused
 
-    // ---- 3. q^T, k^T (tokens >= 49 zeroed: they must not enter M) and v^T to LDS, channel-major ----------
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        const int tok = tt * 16 + l15;
-        const bool live = tok < g.L;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = mt * 16 + grp * 4 + r;
-          stf(regA + m * LDT + tok, live ? q[mt][tt][r] : 0.f);
-          stf(regB + m * LDT + tok, live ? k[mt][tt][r] : 0.f);
-          stf(regC + m * LDT + tok, live ? v[mt][tt][r] : 0.f);
-        }
-      }
-    wave_sync();
-
-    // ---- 4. per head: alpha from M = q^T k; per query tile: S^T = k q^T, softmax over keys, O^T = v^T P^T -
-    f32x4 o[MT][NT];
+    // ---- 3. per head: alpha from M; per query tile: S^T = k q^T, softmax over keys, O^T = v^T P^T ------------------------
+    typename PK::type o[MT][NT];
 #pragma unroll
     for (int h = 0; h < DM::HEADS; ++h) {
       // channel alpha = sigmoid(mean(M) + max(M)),  M = q_h^T k_h  (d x d)   (DAL.py:1003-1010)
@@ -144,15 +213,12 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64)) winattn_fwd_ke
 #pragma unroll
       for (int it = 0; it < TPH; ++it)
 #pragma unroll
-        for (int jt = 0; jt < TPH; ++jt) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          acc = mma_tile<T>(regA + (h * DM::DP + it * 16) * LDT, LDT, regB + (h * DM::DP + jt * 16) * LDT, LDT, LP, acc);
+        for (int jt = 0; jt < TPH; ++jt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = it * 16 + grp * 4 + r, j = jt * 16 + l15;
-            if (i < D && j < D) { msum += acc[r]; mmax = fmaxf(mmax, acc[r]); }
+            if (i < D && j < D) { msum += Macc[h][it][jt][r]; mmax = fmaxf(mmax, Macc[h][it][jt][r]); }
           }
-        }
       msum = wave_sum(msum);
       mmax = wave_max(mmax);
       const float alpha = sigmoidf(msum / (float)(D * D) + mmax);
@@ -164,7 +230,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64)) winattn_fwd_ke
         for (int kt = 0; kt < NT; ++kt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int mt = h * TPH; mt < (h + 1) * TPH; ++mt) acc = mma_chain<T>(k[mt][kt], q[mt][qt], acc);
+          for (int mt = h * TPH; mt < (h + 1) * TPH; ++mt) acc = PK::mma(kT[mt][kt], qT[mt][qt], acc);
           s[kt] = acc;
         }
         // softmax over the 49 live keys (no mask, no bias: DAL.py:959,996)
@@ -186,36 +252,47 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64)) winattn_fwd_ke
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = alpha / sum;      // fold alpha into the normalisation: o = alpha * (P v)
+        typename PK::type pk[NT];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
-        // O^T[dcol][query] = sum_key v^T[dcol][key] P^T[key][query]
+          pk[kt] = PK::pack(s[kt]);
+        }
+        // O^T[dcol][query] = sum_key v[key][dcol] P^T[key][query]   (A = straight v tile: row index = dcol lane, k-slot = key)
 #pragma unroll
         for (int mt = h * TPH; mt < (h + 1) * TPH; ++mt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kt = 0; kt < NT; ++kt) acc = mma_lds_chain<T>(regC + mt * 16 * LDT, LDT, kt * 16, s[kt], acc);
-          o[mt][qt] = acc;
+          for (int kt = 0; kt < NT; ++kt) acc = PK::mma(vN[kt][mt], pk[kt], acc);
+          o[mt][qt] = PK::pack(acc);
         }
       }
     }
 
-    // ---- 5. out-projection (transposed) + bias + residual, store live tokens --------------------------------
+    // ---- 4. out-projection (transposed) + bias + residual; each lane stores 4 consecutive channels of one token ----------
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
-      const int n = slot_token(g, qh, qw, qt * 16 + l15);
+      const int n = ntok[qt];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc = mma_lds_chain<T>(sWo + ct * 16 * LDO, LDO, mt * 16, o[mt][qt], acc);
-        if (n < 0) continue;
+        for (int mt = 0; mt < MT; ++mt) acc = PK::mma_lds_a(sWo + ct * 16 * LDO, LDO, mt * 16, o[mt][qt], acc);
         const int c0 = ct * 16 + grp * 4;
         const int64_t off = (img + n) * C + c0;
+        if constexpr (C % 4 == 0) {
+          float xr[4];
+          Quad<T>::unpack(xres[qt][ct], xr);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c0 + r < C) stf(OUT + off + r, ldf(X + off + r) + acc[r] + sB[3 * CV + c0 + r]);
+          for (int r = 0; r < 4; ++r) xr[r] += acc[r] + sB[3 * CV + (c0 < C ? c0 : 0) + r];
+          if (n >= 0 && c0 < C) Quad<T>::store(OUT + off, xr);
+        } else {
+          if (n < 0) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (c0 + r < C) stf(OUT + off + r, ldf(X + off + r) + acc[r] + sB[3 * CV + c0 + r]);
+        }
       }
     }
   }

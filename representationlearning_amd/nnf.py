@@ -21,9 +21,12 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 _SYNC_ALL_BN = False          # set by the trainer: configs/base/loveda.py:107 train.sync_bn
 
 
-def set_sync_bn(flag):
-    global _SYNC_ALL_BN
-    _SYNC_ALL_BN = bool(flag)
+_FORCE_COLLECTIVES = False    # issue the SyncBN all-reduces even on a 1-rank group (plumbing tests)
+
+
+def set_sync_bn(flag, force=False):
+    global _SYNC_ALL_BN, _FORCE_COLLECTIVES
+    _SYNC_ALL_BN, _FORCE_COLLECTIVES = bool(flag), bool(force)
 
 
 # ---- direct gradient accumulation ---------------------------------------------------------------------------------
@@ -178,7 +181,7 @@ class _ConvBNAct(torch.autograd.Function):
         raw = _conv_forward(spec, xh, weights, bias, stats)
         rows = raw.numel() // C
         n = float(rows)
-        if training and sync and _world() > 1:
+        if training and sync and (_world() > 1 or _FORCE_COLLECTIVES):
             dist.all_reduce(stats)
             n *= _world()
         mi = torch.empty(2, C, device=dev, dtype=torch.float32)
@@ -213,7 +216,7 @@ class _ConvBNAct(torch.autograd.Function):
         sums = torch.zeros(2, C, device=raw.device, dtype=torch.float32)
         L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.dtype_code(raw),
                                        L.stream()), "rssf_bn_bwd_reduce")
-        if training and sync and _world() > 1:
+        if training and sync and (_world() > 1 or _FORCE_COLLECTIVES):
             dist.all_reduce(sums)
         draw = torch.empty_like(raw)
         dres = torch.empty_like(raw) if has_pre else None

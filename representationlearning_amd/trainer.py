@@ -116,12 +116,12 @@ class Trainer:
     def __init__(self, model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=35.0, power=0.9, max_iters=30000,
                  bf16=True, sync_bn=True, nbuckets=6):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        if self.world > 1 and sync_bn:          # configs/base/loveda.py:107-108 (train.sync_bn=True)
-            model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        # RSSF_FORCE_DP=1 exercises the collective plumbing (buckets, SyncBN all-reduces) even on one rank (tests)
+        dp = self.world > 1 or (dist.is_initialized() and os.environ.get("RSSF_FORCE_DP") == "1")
         self.model = model
         self.flat = FlatParams(model)
-        self.buckets = GradBuckets(self.flat, nbuckets) if self.world > 1 else None
-        nnf.set_sync_bn(sync_bn and self.world > 1)
+        self.buckets = GradBuckets(self.flat, nbuckets) if dp else None
+        nnf.set_sync_bn(sync_bn and dp, force=dp and self.world == 1)
         nnf.set_direct_grad(True, self.buckets.param_ready if self.buckets is not None else None)
         self.hp = dict(base_lr=base_lr, momentum=momentum, wd=weight_decay, max_norm=max_norm, power=power, max_iters=max_iters)
         self.bf16 = bf16
