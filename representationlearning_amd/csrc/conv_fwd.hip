@@ -28,15 +28,16 @@ struct ConvArgs {
   Taps taps;
 };
 
-constexpr int BM = 128;
-
-template <typename T, int BNT>
+template <typename T, int BM, int BNT>
 __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   using MK = MmaK<T>;
   constexpr int BK = MK::BK, V = Vec<T>::N, CPR = BK / V;      // 16-byte chunks per staged row (= 4)
   constexpr int LDA = BK + LdsPad<T>::X;
-  constexpr int NI = BNT / 16;
-  constexpr int A_CHUNKS = BM * CPR / 256;                       // per thread (= 2)
+  constexpr int WM = BM / 32, WN = 4 / WM;                       // wave grid: WM along pixels x WN along channels
+  constexpr int WCOLS = BNT / WN;                                // channels per wave
+  constexpr int NI = WCOLS / 16;
+  static_assert(NI >= 1, "tile too narrow for the wave grid");
+  constexpr int A_CHUNKS = BM * CPR / 256;                       // per thread
   constexpr int B_CHUNKS = (BNT * CPR + 255) / 256;
   constexpr int LDC = BNT + LdsPad<T>::X;
   constexpr int STAGE_ELEMS = (BM + BNT) * LDA;
@@ -48,6 +49,7 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   T* Bs = lds + BM * LDA;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
+  const int wave_m = wave % WM, wave_n = wave / WM;
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BNT;
@@ -130,9 +132,9 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
     for (int ks = 0; ks < BK; ks += MK::KSTEP) {
       typename MK::frag fa[2], fb[NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) fa[mi] = MK::load(As + (wave * 32 + mi * 16 + l15) * LDA + ks + grp * MK::KPL);
+      for (int mi = 0; mi < 2; ++mi) fa[mi] = MK::load(As + (wave_m * 32 + mi * 16 + l15) * LDA + ks + grp * MK::KPL);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) fb[ni] = MK::load(Bs + (ni * 16 + l15) * LDA + ks + grp * MK::KPL);
+      for (int ni = 0; ni < NI; ++ni) fb[ni] = MK::load(Bs + (wave_n * WCOLS + ni * 16 + l15) * LDA + ks + grp * MK::KPL);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -148,22 +150,23 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   T* Cs = lds;                                            // [BM][LDC]
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int col = n0 + ni * 16 + l15;
+    const int lcol = wave_n * WCOLS + ni * 16 + l15;
+    const int col = n0 + lcol;
     const float bv = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = wave * 32 + mi * 16 + grp * 4 + r;
+        const int row = wave_m * 32 + mi * 16 + grp * 4 + r;
         const float v = acc[mi][ni][r] + bv;
-        stf(Cs + row * LDC + ni * 16 + l15, v);
+        stf(Cs + row * LDC + lcol, v);
         if (m0 + row < M) { s1 += v; s2 += v * v; }
       }
     if (a.stats) {
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (grp == 0) { atomicAdd(&sstat[ni * 16 + l15], s1); atomicAdd(&sstat[BNT + ni * 16 + l15], s2); }
+      if (grp == 0) { atomicAdd(&sstat[lcol], s1); atomicAdd(&sstat[BNT + lcol], s2); }
     }
   }
   __syncthreads();
@@ -216,17 +219,33 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a, T* out) {
   }
 }
 
-template <typename T>
-int launch_conv(const ConvArgs& a, int bnt, hipStream_t st) {
-  const int64_t M = (int64_t)a.B * a.OH * a.OW;
-  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(a.CoutP / bnt));
-  if (bnt == 32) conv_gather_kernel<T, 32><<<grid, 256, 0, st>>>(a);
-  else if (bnt == 64) conv_gather_kernel<T, 64><<<grid, 256, 0, st>>>(a);
-  else conv_gather_kernel<T, 128><<<grid, 256, 0, st>>>(a);
-  return check_launch("conv_gather");
+int pick_bn(int cout) { return cout <= 32 ? 32 : cout <= 64 ? 64 : 128; }
+
+// Tile choice: the widest tile that still gives the chip >= 2 blocks per CU; small feature maps (32x32, 16x16 at
+// B=16) otherwise run on a quarter of the CUs.
+void pick_tile(int64_t M, int cout, int& bm, int& bnt) {
+  const int bmax = pick_bn(cout);
+  const int cand[4][2] = {{128, bmax}, {64, bmax}, {64, bmax > 32 ? bmax / 2 : 32}, {64, 32}};
+  int64_t best = -1;
+  for (int i = 0; i < 4; ++i) {
+    const int64_t blocks = ((M + cand[i][0] - 1) / cand[i][0]) * ((cout + cand[i][1] - 1) / cand[i][1]);
+    if (blocks >= 512) { bm = cand[i][0]; bnt = cand[i][1]; return; }
+    if (blocks > best) { best = blocks; bm = cand[i][0]; bnt = cand[i][1]; }
+  }
 }
 
-int pick_bn(int cout) { return cout <= 32 ? 32 : cout <= 64 ? 64 : 128; }
+template <typename T>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  const int64_t M = (int64_t)a.B * a.OH * a.OW;
+  int bm, bnt;
+  pick_tile(M, a.Cout, bm, bnt);
+  dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((a.Cout + bnt - 1) / bnt));
+#define RSSF_CONV(BMv, BNv) conv_gather_kernel<T, BMv, BNv><<<grid, 256, 0, st>>>(a)
+  if (bm == 128) { if (bnt == 32) RSSF_CONV(128, 32); else if (bnt == 64) RSSF_CONV(128, 64); else RSSF_CONV(128, 128); }
+  else           { if (bnt == 32) RSSF_CONV(64, 32);  else if (bnt == 64) RSSF_CONV(64, 64);  else RSSF_CONV(64, 128); }
+#undef RSSF_CONV
+  return check_launch("conv_gather");
+}
 
 }  // namespace
 
@@ -281,8 +300,8 @@ extern "C" int rssf_conv_gather(const void* in, const void* wpk, void* out, cons
   a.CoutP = (Cout + bnt - 1) / bnt * bnt;
   a.CinP = (Cin + bk - 1) / bk * bk;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RSSF_F32) return launch_conv<float>(a, bnt, st);
-  if (dtype == RSSF_BF16) return launch_conv<bf16_t>(a, bnt, st);
+  if (dtype == RSSF_F32) return launch_conv<float>(a, st);
+  if (dtype == RSSF_BF16) return launch_conv<bf16_t>(a, st);
   set_error("conv_gather: unsupported dtype %d", dtype);
   return RSSF_ERR_UNSUPPORTED;
 }
