@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   int bid = blockIdx.x;
   const int cit = bid % a.ctiles_n; bid /= a.ctiles_n;
-  const int cot = bid;
+  const int cot = bid % a.ctiles_m; bid /= a.ctiles_m;
+  const int tbase = a.tap0 + (TG == 1 ? bid : 0);        // TG == 1: the taps of the group are spread over blockIdx.x
   const int co0 = cot * TMN, ci0 = cit * TMN;
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
   const int64_t per = ((M + a.ksplit - 1) / a.ksplit + KP - 1) / KP * KP;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < WI; ++j) acc[t][i][j] = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  const bool do_bias = a.dbias && a.tap0 == 0 && cit == 0;
+  const bool do_bias = a.dbias && tbase == 0 && cit == 0;
 
   // per-thread staging slots: chunk c -> (pixel row, 16-byte column)
   int srow[CHUNKS], scol[CHUNKS];
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   bool pv[CHUNKS];
 
   auto load_x = [&](int t) {      // gather the input slab of tap t into registers
-    const int dy = a.taps.dy[a.tap0 + t], dx = a.taps.dx[a.tap0 + t];
+    const int dy = a.taps.dy[tbase + t], dx = a.taps.dx[tbase + t];
 #pragma unroll
     for (int c = 0; c < CHUNKS; ++c) {
       rx[c].raw = {0, 0, 0, 0};
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     load_x(0);
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-      if (t < a.ntap) {
+      if (TG == 1 || t < a.ntap) {
 #pragma unroll
         for (int c = 0; c < CHUNKS; ++c)
           if (srow[c] < KP) rx[c].store(XS + srow[c] * LD + scol[c]);
@@ -177,8 +178,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   // ---- flush: rows = co (4*grp + r), cols = ci (l15) -----------------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < TG; ++t) {
-    if (t >= a.ntap) continue;
-    const int tap = a.tap0 + t;
+    if (TG > 1 && t >= a.ntap) continue;
+    const int tap = tbase + t;
     const int s = a.src_of_tap[tap], kk = a.ks[s] * a.ks[s], kpos = a.kpos_of_tap[tap];
     float* dw = a.dw[s];
 #pragma unroll
@@ -212,13 +213,21 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
   }
 }
 
-int tile_of(int cout, int cin) { return (cout <= 32 && cin <= 32) ? 32 : 64; }
+// Tiling: 32x32 output tile with all 9 taps of a 3x3 in registers for the 32-channel layers (few FLOPs per pixel:
+// stage dout once per slab); 64x64 / 128x128 tiles with ONE tap per block for wider layers (light registers -> many
+// resident blocks hide the gather latency; 128x128 doubles the FLOPs per staged byte for the MLP's 128-channel convs).
+int tile_of(int cout, int cin) {
+  const int m = cout < cin ? cout : cin;
+  return (cout <= 32 && cin <= 32) ? 32 : (m >= 128 ? 128 : 64);
+}
+bool taps_in_registers(int cout, int cin) { return tile_of(cout, cin) == 32; }
 
-// split-K factor: enough blocks to fill the chip (~4 per CU) but at least 4 slabs of 64 pixels each
-int pick_ksplit(int cout, int cin, int64_t M) {
+// split-K factor: ~1024 blocks in flight, at least 4 slabs of 64 pixels each
+int pick_ksplit(int cout, int cin, int ntaps, int64_t M) {
   const int t = tile_of(cout, cin);
-  const int tiles = ((cout + t - 1) / t) * ((cin + t - 1) / t);
-  int64_t ks = 512 / tiles;            // ~2 resident blocks per CU; more only multiplies the partial traffic
+  int64_t par = (int64_t)((cout + t - 1) / t) * ((cin + t - 1) / t);
+  if (!taps_in_registers(cout, cin)) par *= (ntaps >= 9 ? 9 : 1);
+  int64_t ks = (t == 32 ? 512 : 1024) / par;
   const int64_t maxks = (M + 4 * KP - 1) / (4 * KP);
   if (ks > maxks) ks = maxks;
   if (ks < 1) ks = 1;
@@ -230,9 +239,14 @@ int launch_group(WgradArgs& a, int tap0, int ntap, hipStream_t st) {
   a.tap0 = tap0; a.ntap = ntap;
   a.ctiles_m = (a.Cout + TMN - 1) / TMN; a.ctiles_n = (a.Cin + TMN - 1) / TMN;
   const int tiles = a.ctiles_m * a.ctiles_n;
-  dim3 grid((unsigned)tiles, (unsigned)a.ksplit);
-  if (ntap == 1) conv_wgrad_kernel<T, TMN, 1><<<grid, 256, 0, st>>>(a);
-  else conv_wgrad_kernel<T, TMN, 9><<<grid, 256, 0, st>>>(a);
+  if constexpr (TMN == 32) {
+    dim3 grid((unsigned)tiles, (unsigned)a.ksplit);
+    if (ntap == 1) conv_wgrad_kernel<T, TMN, 1><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_kernel<T, TMN, 9><<<grid, 256, 0, st>>>(a);
+  } else {
+    dim3 grid((unsigned)(tiles * ntap), (unsigned)a.ksplit);
+    conv_wgrad_kernel<T, TMN, 1><<<grid, 256, 0, st>>>(a);
+  }
   return check_launch("conv_wgrad");
 }
 
@@ -240,10 +254,12 @@ template <typename T>
 int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
   // tap groups: consecutive taps of one source conv (1 for a 1x1, 9 for a 3x3)
   int t = 0;
+  const int tile = tile_of(a.Cout, a.Cin);
   while (t < ntaps) {
     int n = 1;
     while (t + n < ntaps && n < 9 && a.src_of_tap[t + n] == a.src_of_tap[t]) ++n;
-    const int rc = tile_of(a.Cout, a.Cin) == 32 ? launch_group<T, 32>(a, t, n, st) : launch_group<T, 64>(a, t, n, st);
+    const int rc = tile == 32 ? launch_group<T, 32>(a, t, n, st) : tile == 64 ? launch_group<T, 64>(a, t, n, st)
+                                                                              : launch_group<T, 128>(a, t, n, st);
     if (rc) return rc;
     t += n;
   }
@@ -260,7 +276,7 @@ int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
 }  // namespace
 
 extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Cin, int Cout, int ntaps) {
-  return (int64_t)pick_ksplit(Cout, Cin, (int64_t)B * OH * OW) * ntaps * Cout * Cin;
+  return (int64_t)pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW) * ntaps * Cout * Cin;
 }
 
 extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
@@ -280,7 +296,7 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
   }
   a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.stride = stride;
   a.partial = workspace; a.ntaps_total = ntaps;
-  a.ksplit = pick_ksplit(Cout, Cin, (int64_t)B * OH * OW);
+  a.ksplit = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RSSF_F32) return launch_all<float>(a, ntaps, st);
   if (dtype == RSSF_BF16) return launch_all<bf16_t>(a, ntaps, st);
