@@ -169,8 +169,10 @@ int rssf_cgfl_loss_bwd(const void* logits, const int64_t* labels, const float* o
 int rssf_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
 /* g' = grad_scale*g*clip + wd*p ; buf = first_step ? g' : mu*buf + g' ; p -= lr*buf
  * clip = max_norm > 0 ? min(1, max_norm / (grad_scale*sqrt(*sqnorm) + 1e-6)) : 1   (device-side, no host sync). */
+/* lr_dev (optional): device pointer to the learning rate, read at execution time (hipGraph replay); else `lr`. */
 int rssf_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, const float* sqnorm, float grad_scale,
-                  float max_norm, float lr, float momentum, float weight_decay, int first_step, void* stream);
+                  float max_norm, const float* lr_dev, float lr, float momentum, float weight_decay, int first_step,
+                  void* stream);
 
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 /* D[16][16] = A[16][K] * B[16][K]^T through the library's MFMA tile helper (layout self-check). */

@@ -56,8 +56,8 @@ SIGNATURES = {
     "rssf_cgfl_loss_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "rssf_cgfl_loss_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
-    "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_float,
-                              c_int, c_void_p]),
+    "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p, c_float, c_float,
+                              c_float, c_int, c_void_p]),
     "rssf_debug_trread": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_mma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }

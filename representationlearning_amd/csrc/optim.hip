@@ -29,7 +29,9 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
 // clip = min(1, max_norm / (s*sqrt(sqnorm) + 1e-6))   (torch.nn.utils.clip_grad_norm_), s = grad_scale (1/world).
 __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                   int64_t n, const float* __restrict__ sqnorm, float grad_scale,
-                                                  float max_norm, float lr, float momentum, float wd, int first_step) {
+                                                  float max_norm, const float* __restrict__ lr_ptr, float lr_host, float momentum,
+                                                  float wd, int first_step) {
+  const float lr = lr_ptr ? *lr_ptr : lr_host;     // device-resident LR: the launch can live in a replayed hipGraph
   float coef = grad_scale;
   if (max_norm > 0.f) {
     const float nrm = grad_scale * sqrtf(*sqnorm);
@@ -75,13 +77,14 @@ extern "C" int rssf_grad_sqnorm(const float* g, int64_t n, float* out, void* str
 }
 
 extern "C" int rssf_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, const float* sqnorm, float grad_scale,
-                             float max_norm, float lr, float momentum, float weight_decay, int first_step, void* stream) {
+                             float max_norm, const float* lr_dev, float lr, float momentum, float weight_decay, int first_step,
+                             void* stream) {
   RSSF_REQUIRE(p && g && momentum_buf && n > 0, "sgd_step: bad arguments");
   RSSF_REQUIRE(max_norm <= 0.f || sqnorm, "sgd_step: clipping needs the squared-norm buffer");
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  sgd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, momentum_buf, n, sqnorm, grad_scale, max_norm, lr, momentum,
-                                                                  weight_decay, first_step);
+  sgd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, g, momentum_buf, n, sqnorm, grad_scale, max_norm, lr_dev, lr,
+                                                                  momentum, weight_decay, first_step);
   return check_launch("sgd_step");
 }

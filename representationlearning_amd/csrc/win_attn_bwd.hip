@@ -533,7 +533,9 @@ int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) 
   int blocks = (g.nWin + LY::WAVES - 1) / LY::WAVES;
   if (blocks > 512) blocks = 512;           // persistent-ish: fewer weight-gradient flushes
   auto kern = winattn_bwd_kernel<T, DM, ACC_LDS>;
-  if (LY::BYTES > 64 * 1024) {
+  static bool attr_set = false;     // idempotent per instantiation; kept out of replayed hipGraph captures
+  if (LY::BYTES > 64 * 1024 && !attr_set) {
+    attr_set = true;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES);
     if (e != hipSuccess) { set_error("winattn_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   }

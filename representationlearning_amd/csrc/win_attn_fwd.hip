@@ -305,7 +305,9 @@ int launch_fwd(const rssf_winattn_fwd_params* p, const Geom& g, hipStream_t st) 
   int blocks = (g.nWin + LY::WAVES - 1) / LY::WAVES;
   if (blocks > 4096) blocks = 4096;
   auto kern = winattn_fwd_kernel<T, DM>;
-  if (LY::BYTES > 64 * 1024) {
+  static bool attr_set = false;     // idempotent per instantiation; kept out of replayed hipGraph captures
+  if (LY::BYTES > 64 * 1024 && !attr_set) {
+    attr_set = true;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES);
     if (e != hipSuccess) { set_error("winattn_fwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   }

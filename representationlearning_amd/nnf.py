@@ -380,11 +380,14 @@ def conv_bias(x, conv):
     return _ConvBias.apply(x, spec_of([conv]), conv.weight, conv.bias)
 
 
-def flush_bn_counters(model):
-    """Materialise the lazily counted `num_batches_tracked` buffers (kept off the hot path: 330 tiny launches)."""
+def flush_bn_counters(model, extra=0):
+    """Materialise the lazily counted `num_batches_tracked` buffers (kept off the hot path: 330 tiny launches).
+    `extra`: steps executed by hipGraph replay (no Python ran for them)."""
     for m in model.modules():
-        k = getattr(m, "_rssf_steps", 0)
-        if k and getattr(m, "num_batches_tracked", None) is not None:
+        if getattr(m, "num_batches_tracked", None) is None or not hasattr(m, "_rssf_steps"):
+            continue
+        k = m._rssf_steps + extra
+        if k:
             m.num_batches_tracked += k
             m._rssf_steps = 0
 

@@ -148,11 +148,12 @@ def grad_sqnorm(flat_grad, out):
     return out
 
 
-def sgd_step_(flat_p, flat_g, flat_m, sqnorm, grad_scale, max_norm, lr, momentum, weight_decay, first_step):
+def sgd_step_(flat_p, flat_g, flat_m, sqnorm, grad_scale, max_norm, lr, momentum, weight_decay, first_step, lr_dev=None):
+    """lr_dev: optional 1-element fp32 device tensor holding the LR (read at execution time: hipGraph-replay safe)."""
     L.require_gpu(flat_p, flat_g, flat_m)
     L.check(L.load().rssf_sgd_step(L.ptr(_f32(flat_p)), L.ptr(_f32(flat_g)), L.ptr(_f32(flat_m)), flat_p.numel(), L.ptr(sqnorm),
-                                   float(grad_scale), float(max_norm), float(lr), float(momentum), float(weight_decay),
-                                   int(bool(first_step)), L.stream()), "rssf_sgd_step")
+                                   float(grad_scale), float(max_norm), L.ptr(lr_dev), float(lr), float(momentum),
+                                   float(weight_decay), int(bool(first_step)), L.stream()), "rssf_sgd_step")
 
 
 def debug_mma(a, b):

@@ -108,13 +108,21 @@ class GradBuckets:
             h.wait()
 
 
+def flush_bn_counters(trainer):
+    """num_batches_tracked += steps taken (eager steps counted per layer, graph replays counted once per replay)."""
+    nnf.flush_bn_counters(trainer.model, extra=trainer._replayed - trainer._replayed_flushed)
+    trainer._replayed_flushed = trainer._replayed
+
+
 def poly_lr(base_lr, power, max_iters, it):
     return base_lr * (1.0 - min(it, max_iters - 1) / max_iters) ** power     # configs/base/loveda.py:93-99
 
 
 class Trainer:
     def __init__(self, model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=35.0, power=0.9, max_iters=30000,
-                 bf16=True, sync_bn=True, nbuckets=6):
+                 bf16=True, sync_bn=True, nbuckets=6, use_graph=True):
+        self._replayed = 0
+        self._replayed_flushed = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         # RSSF_FORCE_DP=1 exercises the collective plumbing (buckets, SyncBN all-reduces) even on one rank (tests)
         dp = self.world > 1 or (dist.is_initialized() and os.environ.get("RSSF_FORCE_DP") == "1")
@@ -126,10 +134,21 @@ class Trainer:
         self.hp = dict(base_lr=base_lr, momentum=momentum, wd=weight_decay, max_norm=max_norm, power=power, max_iters=max_iters)
         self.bf16 = bf16
         self.it = 0
-        self.sqnorm = torch.zeros(1, device=self.flat.flat.device, dtype=torch.float32)
+        dev = self.flat.flat.device
+        self.sqnorm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.lr_dev = torch.zeros(1, device=dev, dtype=torch.float32)
+        # Whole-step hipGraph: the step is ~3 k short launches and the Python/launch overhead (~65 ms) exceeds the GPU
+        # time, so after `graph_warmup` eager steps the step (fwd + loss + bwd + clip + SGD) is captured once and
+        # replayed.  Single-GPU only by default: capturing RCCL collectives is left off until it can be validated on a
+        # multi-GPU box (RSSF_GRAPH=1 forces it, RSSF_GRAPH=0 disables graphs).
+        env = os.environ.get("RSSF_GRAPH")
+        self.use_graph = (env == "1") or (env != "0" and use_graph and not dp)
+        self.graph_warmup = 3
+        self.graph = None
+        self._static = None
+        self._side = None
 
-    def step(self, img, target):
-        """One optimisation step; returns the (detached, on-device) loss."""
+    def _eager_step(self, img, target):
         self.model.train()
         self.flat.zero_grad()
         if self.buckets is not None:
@@ -142,10 +161,55 @@ class Trainer:
             self.buckets.finish()
         hp = self.hp
         ops.grad_sqnorm(self.flat.grad, self.sqnorm)
-        ops.sgd_step_(self.flat.flat, self.flat.grad, self.flat.mom, self.sqnorm, 1.0 / self.world, hp["max_norm"],
-                      poly_lr(hp["base_lr"], hp["power"], hp["max_iters"], self.it), hp["momentum"], hp["wd"], self.it == 0)
-        self.it += 1
+        ops.sgd_step_(self.flat.flat, self.flat.grad, self.flat.mom, self.sqnorm, 1.0 / self.world, hp["max_norm"], 0.0,
+                      hp["momentum"], hp["wd"], False, lr_dev=self.lr_dev)
         return loss.detach()
+
+    def _capture(self, img, target):
+        self._static = (img.clone(), {k: v.clone() for k, v in target.items()})
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                self._static_loss = self._eager_step(*self._static)
+        except Exception as e:       # fall back to eager launches, loudly
+            print("[rssf] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), flush=True)
+            self.use_graph = False
+            torch.cuda.synchronize()
+            return False
+        self.graph = g
+        return True
+
+    def step(self, img, target):
+        """One optimisation step; returns the (detached, on-device) loss."""
+        hp = self.hp
+        self.lr_dev.fill_(poly_lr(hp["base_lr"], hp["power"], hp["max_iters"], self.it))
+        if self.use_graph and self.it >= self.graph_warmup:
+            if self.graph is None and not self._capture(img, target):
+                loss = self._eager_step(img, target)
+            else:
+                s_img, s_tgt = self._static
+                if img.data_ptr() != s_img.data_ptr():
+                    s_img.copy_(img)
+                for k, v in target.items():
+                    if v.data_ptr() != s_tgt[k].data_ptr():
+                        s_tgt[k].copy_(v)
+                self.graph.replay()
+                self._replayed += 1
+                loss = self._static_loss
+        elif self.use_graph:
+            # warm-up steps run on a side stream, as hipGraph capture requires (the autograd threads and lazily
+            # initialised library state must have seen a non-default stream before the capture starts)
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                loss = self._eager_step(img, target)
+            torch.cuda.current_stream().wait_stream(self._side)
+        else:
+            loss = self._eager_step(img, target)
+        self.it += 1
+        return loss
 
 
 def init_distributed():

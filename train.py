@@ -73,7 +73,8 @@ def main():
             print("iter %d  fc_loss %.5f" % (it, float(loss)), flush=True)
     if rank == 0:
         os.makedirs(args.model_dir, exist_ok=True)
-        nnf.flush_bn_counters(model)
+        from representationlearning_amd.trainer import flush_bn_counters
+        flush_bn_counters(trainer)
         path = os.path.join(args.model_dir, "model-%d.pth" % trainer.it)
         torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)   # reference-compatible keys
         print("saved", path)
