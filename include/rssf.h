@@ -24,6 +24,10 @@ extern "C" {
 #endif
 
 typedef enum { RSSF_F32 = 0, RSSF_BF16 = 1 } rssf_dtype;
+/* per-channel BatchNorm statistics are accumulated into this many interleaved copies (slot = block index mod slots) to
+ * spread same-address atomics; every statistics buffer below is [RSSF_BN_SLOTS][2][C] fp32 and consumers sum the slots */
+#define RSSF_BN_SLOTS 16
+#define RSSF_BN_BWD_SLOTS 4
 typedef enum {
   RSSF_OK = 0,
   RSSF_ERR_BAD_ARG = -1,
@@ -109,7 +113,7 @@ int64_t rssf_conv_packed_elems(int ntaps, int rows, int cols, int dtype);
  * transpose = 1: rows = Cin (data gradient). */
 int rssf_conv_pack(const float* w0, const float* w1, const float* w2, const int* ksizes, int nsrc, const int* src_of_tap,
                    const int* kpos_of_tap, int ntaps, int Cout, int Cin, int transpose, void* out, int dtype, void* stream);
-/* the gather convolution itself.  bias [Cout] optional; stats [2][Cout] optional: per-channel sum and sum of squares of
+/* the gather convolution itself.  bias [Cout] optional; stats [RSSF_BN_SLOTS][2][Cout] optional: per-channel sum and sum of squares of
  * the OUTPUT (incl. bias) atomically accumulated for the BatchNorm that follows (fused statistics). */
 int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bias, float* stats, int B, int IH, int IW,
                      int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype,
@@ -125,7 +129,7 @@ int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, fl
 
 /* ---- BatchNorm2d (+ activation + residual adds), channels-last: nn.BatchNorm2d / nn.SyncBatchNorm call sites of
  *      _hrnet_rssformer.py, hrnet_aux.py:47 and ffn_block.py:222-234 (momentum 0.1, eps 1e-5) -------------------- */
-/* act: 0 none, 1 ReLU, 2 GELU(erf).  stats = [2][C] {sum, sumsq} over n samples (from rssf_conv_gather; all-reduced by
+/* act: 0 none, 1 ReLU, 2 GELU(erf).  stats = [RSSF_BN_SLOTS][2][C] {sum, sumsq} over n samples (from rssf_conv_gather; all-reduced by
  * the host for SyncBN).  Writes mean_invstd [2][C], scale_shift [2][C]; updates running stats when training. */
 int rssf_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float* mean_invstd, float* scale_shift, int C, double n, float momentum, float eps, int training,
@@ -133,7 +137,8 @@ int rssf_bn_finalize(const float* stats, const float* gamma, const float* beta, 
 /* y = act(raw*scale + shift + res_pre) + res_post   (res_* optional, same shape as raw) */
 int rssf_bn_apply(const void* raw, const float* scale_shift, const void* res_pre, const void* res_post, void* y,
                   int64_t rows, int C, int act, int dtype, void* stream);
-/* sums [2][C] += { sum dz, sum dz*raw },  dz = dy * act'(raw*scale + shift + res_pre);  caller zeroes sums */
+/* sums [RSSF_BN_BWD_SLOTS][2][C] fp32, zeroed by the caller: slot (block mod slots) += { sum dz, sum dz*raw },
+ * dz = dy * act'(raw*scale + shift + res_pre).  rssf_bn_bwd_apply sums the slots (all-reduce the whole buffer for SyncBN) */
 int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, float* sums,
                        int64_t rows, int C, int act, int dtype, void* stream);
 /* draw = d(loss)/d(raw); dres (optional) = dz = gradient of res_pre; dgamma/dbeta (optional) accumulated */

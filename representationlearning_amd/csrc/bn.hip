@@ -31,8 +31,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
   if (c >= C) return;
   float mean, var;
   if (training) {
-    mean = stats[c] / n;
-    var = fmaxf(stats[C + c] / n - mean * mean, 0.f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < RSSF_BN_SLOTS; ++k) { s1 += stats[k * 2 * C + c]; s2 += stats[k * 2 * C + C + c]; }
+    mean = s1 / n;
+    var = fmaxf(s2 / n - mean * mean, 0.f);
     if (running_mean) {
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
@@ -107,38 +109,68 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
   float a1[VEC], a2[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
-  if (rlocal < rpb) {
-    const int c0 = (colbase + col) * VEC;
-    for (int64_t r = (int64_t)blockIdx.x * rpb + rlocal; r < rows; r += (int64_t)gridDim.x * rpb) {
-      const int64_t off = r * C + c0;
-      if constexpr (VEC > 1) {
-        Vec<T> vd, vr, vp;
-        vd.load(dy + off); vr.load(raw + off);
-        if (res_pre) vp.load(res_pre + off);
+  const bool active = rlocal < rpb;
+  const int c0 = (colbase + col) * VEC;
+  if (active) {
+    float sc[VEC], sh[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const float x = vr.get(e);
-          float z = x * ss[c0 + e] + ss[C + c0 + e];
-          if (res_pre) z += vp.get(e);
-          const float dz = vd.get(e) * act_bwd(z, act);
-          a1[e] += dz; a2[e] += dz * x;
-        }
-      } else {
+    for (int e = 0; e < VEC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    auto body = [&](const Vec<T>& vd, const Vec<T>& vr, const Vec<T>& vp) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float x = vr.get(e);
+        float z = x * sc[e] + sh[e];
+        if (res_pre) z += vp.get(e);
+        const float dz = vd.get(e) * act_bwd(z, act);
+        a1[e] += dz; a2[e] += dz * x;
+      }
+    };
+    int64_t r = (int64_t)blockIdx.x * rpb + rlocal;
+    if constexpr (VEC > 1) {
+      for (; r + stride < rows; r += 2 * stride) {          // two rows in flight per thread
+        const int64_t o0 = r * C + c0, o1 = (r + stride) * C + c0;
+        Vec<T> d0, r0, p0, d1, r1, p1;
+        d0.load(dy + o0); r0.load(raw + o0); d1.load(dy + o1); r1.load(raw + o1);
+        if (res_pre) { p0.load(res_pre + o0); p1.load(res_pre + o1); }
+        body(d0, r0, p0); body(d1, r1, p1);
+      }
+      for (; r < rows; r += stride) {
+        const int64_t o0 = r * C + c0;
+        Vec<T> d0, r0, p0;
+        d0.load(dy + o0); r0.load(raw + o0);
+        if (res_pre) p0.load(res_pre + o0);
+        body(d0, r0, p0);
+      }
+    } else {
+      for (; r < rows; r += stride) {
+        const int64_t off = r * C + c0;
         const float x = ldf(raw + off);
-        float z = x * ss[c0] + ss[C + c0];
+        float z = x * sc[0] + sh[0];
         if (res_pre) z += ldf(res_pre + off);
         const float dz = ldf(dy + off) * act_bwd(z, act);
         a1[0] += dz; a2[0] += dz * x;
       }
     }
+  }
+  // lanes that share a column inside a wave (cols divides 64) are folded with shuffles before touching LDS
+  const bool fold = (64 % cols) == 0;
+  if (fold) {
+    for (int o = 32; o >= cols; o >>= 1) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { a1[e] += __shfl_xor(a1[e], o, 64); a2[e] += __shfl_xor(a2[e], o, 64); }
+    }
+  }
+  if (active && (!fold || (threadIdx.x & 63) < cols)) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { atomicAdd(&sacc[c0 + e], a1[e]); atomicAdd(&sacc[C + c0 + e], a2[e]); }
   }
   __syncthreads();
+  float* slot = sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * C;
   for (int i = threadIdx.x; i < cols * VEC; i += blockDim.x) {
     const int c = colbase * VEC + i;
-    atomicAdd(&sums[c], sacc[c]);
-    atomicAdd(&sums[C + c], sacc[C + c]);
+    atomicAdd(&slot[c], sacc[c]);
+    atomicAdd(&slot[C + c], sacc[C + c]);
   }
 }
 
@@ -148,61 +180,85 @@ template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
                                                            const float* __restrict__ mi, const float* __restrict__ sums,
                                                            const T* __restrict__ res_pre, T* __restrict__ draw, T* __restrict__ dres,
-                                                           int64_t rows, int C, int act, float n, int training) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
+                                                           int act, float n, int training) {
   const int allcols = C / VEC;
   const int colbase = blockIdx.y * 256;
   const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
   const int rpb = 256 / cols;
   const int col = threadIdx.x % cols, rlocal = threadIdx.x / cols;
-  if (rlocal >= rpb) return;
+  const bool active = rlocal < rpb;
   const int c0 = (colbase + col) * VEC;
+  const int64_t stride = (int64_t)gridDim.x * rpb;
+  int64_t r = (int64_t)blockIdx.x * rpb + rlocal;
+  // the first row's operands and the per-channel constants are requested before the slot totals are folded, so that
+  // the fold's load -> LDS -> barrier chain overlaps with them (each thread only sees a handful of rows)
+  Vec<T> vd, vr, vp;
+  bool have = active && r < rows;
+  if constexpr (VEC > 1) {
+    if (have) {
+      vd.load(dy + r * C + c0); vr.load(raw + r * C + c0);
+      if (res_pre) vp.load(res_pre + r * C + c0);
+    }
+  }
   float sc[VEC], sh[VEC], mean[VEC], istd[VEC], k1[VEC], k2[VEC];
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; mean[e] = mi[c0 + e]; istd[e] = mi[C + c0 + e]; }
+  }
+  extern __shared__ float tot[];                           // [2][cols*VEC] slot totals of this block's channels
+  for (int i = threadIdx.x; i < 2 * cols * VEC; i += blockDim.x) {
+    const int half = i / (cols * VEC), c = colbase * VEC + i % (cols * VEC);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < RSSF_BN_BWD_SLOTS; ++k) t += sums[(size_t)k * 2 * C + half * C + c];
+    tot[i] = t;
+  }
+  __syncthreads();
+  if (!active) return;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
     const int c = c0 + e;
-    sc[e] = ss[c]; sh[e] = ss[C + c]; mean[e] = mi[c]; istd[e] = mi[C + c];
-    const float s1 = sums[c], s2 = sums[C + c];
+    const float s1 = tot[col * VEC + e], s2 = tot[cols * VEC + col * VEC + e];
+    const float dot = (s2 - mean[e] * s1) * istd[e];        // sum dz*xhat
     k1[e] = s1 / n;
-    k2[e] = (s2 - mean[e] * s1) * istd[e] / n;             // sum(dz*xhat)/n
+    k2[e] = dot / n;
+    if (dgamma && blockIdx.x == 0 && rlocal == 0) { dgamma[c] += dot; dbeta[c] += s1; }     // one writer per channel
   }
-  for (int64_t r = (int64_t)blockIdx.x * rpb + rlocal; r < rows; r += (int64_t)gridDim.x * rpb) {
-    const int64_t off = r * C + c0;
-    float xv[VEC], dv[VEC], pv[VEC], o1[VEC], o2[VEC];
-    if constexpr (VEC > 1) {
-      Vec<T> vd, vr, vp;
-      vd.load(dy + off); vr.load(raw + off);
-      if (res_pre) vp.load(res_pre + off);
+  if constexpr (VEC > 1) {
+    while (have) {
+      const int64_t off = r * C + c0, rn = r + stride;
+      const bool have_next = rn < rows;
+      Vec<T> nd, nr, np;
+      if (have_next) {
+        nd.load(dy + rn * C + c0); nr.load(raw + rn * C + c0);
+        if (res_pre) np.load(res_pre + rn * C + c0);
+      }
+      float o1[VEC], o2[VEC];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { xv[e] = vr.get(e); dv[e] = vd.get(e); pv[e] = res_pre ? vp.get(e) : 0.f; }
-    } else {
-      xv[0] = ldf(raw + off); dv[0] = ldf(dy + off); pv[0] = res_pre ? ldf(res_pre + off) : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float z = xv[e] * sc[e] + sh[e] + pv[e];
-      const float dz = dv[e] * act_bwd(z, act);
-      o2[e] = dz;
-      o1[e] = training ? sc[e] * (dz - k1[e] - (xv[e] - mean[e]) * istd[e] * k2[e]) : sc[e] * dz;
-    }
-    if constexpr (VEC > 1) {
+      for (int e = 0; e < VEC; ++e) {
+        const float x = vr.get(e);
+        const float z = x * sc[e] + sh[e] + (res_pre ? vp.get(e) : 0.f);
+        const float dz = vd.get(e) * act_bwd(z, act);
+        o2[e] = dz;
+        o1[e] = training ? sc[e] * (dz - k1[e] - (x - mean[e]) * istd[e] * k2[e]) : sc[e] * dz;
+      }
       Vec<T> w1, w2;
       w1.set_all(o1); w2.set_all(o2);
       w1.store(draw + off);
       if (dres) w2.store(dres + off);
-    } else {
-      stf(draw + off, o1[0]);
-      if (dres) stf(dres + off, o2[0]);
+      vd = nd; vr = nr; vp = np; r = rn; have = have_next;
+    }
+  } else {
+    for (; r < rows; r += stride) {
+      const int64_t off = r * C + c0;
+      const float x = ldf(raw + off);
+      const float z = x * sc[0] + sh[0] + (res_pre ? ldf(res_pre + off) : 0.f);
+      const float dz = ldf(dy + off) * act_bwd(z, act);
+      stf(draw + off, training ? sc[0] * (dz - k1[0] - (x - mean[0]) * istd[0] * k2[0]) : sc[0] * dz);
+      if (dres) stf(dres + off, dz);
     }
   }
-}
-
-// dgamma[c] += invstd*(s2 - mean*s1) ; dbeta[c] += s1
-__global__ void bn_param_grad_kernel(const float* __restrict__ sums, const float* __restrict__ mi, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  dgamma[c] += (sums[C + c] - mi[c] * sums[c]) * mi[C + c];
-  dbeta[c] += sums[c];
 }
 
 // (row blocks, column blocks of <= 256 vector columns) for the fixed-column thread layout
@@ -232,8 +288,8 @@ int reduce_launch(const void* dy, const void* raw, const float* ss, const void* 
   const int cols = C / vec;
   const int cblocks = (cols + 255) / 256;
   const int rpb = 256 / (cols < 256 ? cols : 256);
-  int64_t blocks = (rows + rpb - 1) / rpb;
-  if (blocks > 256) blocks = 256;          // every block ends with 2C global atomics on the same addresses
+  int64_t blocks = (rows + 4 * rpb - 1) / (4 * rpb);      // >= 4 rows per thread; measured best cap on MI355X: 512
+  if (blocks > 512) blocks = 512;        // every block ends with 2C global atomics, spread over RSSF_BN_BWD_SLOTS copies
   dim3 grid((unsigned)blocks, (unsigned)cblocks);
   if (vec == V)
     bn_bwd_reduce_kernel<T, V><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
@@ -244,15 +300,16 @@ int reduce_launch(const void* dy, const void* raw, const float* ss, const void* 
 
 template <typename T>
 int bwd_apply_launch(const void* dy, const void* raw, const float* ss, const float* mi, const float* sums, const void* rp, void* draw,
-                     void* dres, int64_t rows, int C, int act, float n, int training, hipStream_t st) {
+                     void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act, float n, int training, hipStream_t st) {
   constexpr int V = Vec<T>::N;
   const dim3 grid = grid2d(rows, C, (C % V == 0) ? V : 1);
+  const size_t sh = 2 * sizeof(float) * (C < 256 * V ? C : 256 * V);
   if (C % V == 0)
-    bn_bwd_apply_kernel<T, V><<<grid, 256, 0, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, rows, C,
-                                                    act, n, training);
+    bn_bwd_apply_kernel<T, V><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, dgamma,
+                                                    dbeta, rows, C, act, n, training);
   else
-    bn_bwd_apply_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, rows, C,
-                                                    act, n, training);
+    bn_bwd_apply_kernel<T, 1><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, dgamma,
+                                                    dbeta, rows, C, act, n, training);
   return check_launch("bn_bwd_apply");
 }
 }  // namespace
@@ -291,17 +348,14 @@ extern "C" int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* s
                                  const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
                                  double n, int training, int dtype, void* stream) {
   RSSF_REQUIRE(dy && raw && scale_shift && mean_invstd && sums && draw && rows > 0 && C > 0, "bn_bwd_apply: bad arguments");
+  RSSF_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_apply: dgamma and dbeta go together");
   hipStream_t st = (hipStream_t)stream;
-  int rc;
   if (dtype == RSSF_F32)
-    rc = bwd_apply_launch<float>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, rows, C, act, (float)n, training, st);
-  else if (dtype == RSSF_BF16)
-    rc = bwd_apply_launch<bf16_t>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, rows, C, act, (float)n, training, st);
-  else { set_error("bn_bwd_apply: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
-  if (rc) return rc;
-  if (dgamma && dbeta) {
-    bn_param_grad_kernel<<<(C + 127) / 128, 128, 0, st>>>(sums, mean_invstd, dgamma, dbeta, C);
-    return check_launch("bn_param_grad");
-  }
-  return RSSF_OK;
+    return bwd_apply_launch<float>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, dgamma, dbeta, rows, C, act, (float)n,
+                                   training, st);
+  if (dtype == RSSF_BF16)
+    return bwd_apply_launch<bf16_t>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, dgamma, dbeta, rows, C, act, (float)n,
+                                    training, st);
+  set_error("bn_bwd_apply: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
 }

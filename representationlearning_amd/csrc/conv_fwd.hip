@@ -22,7 +22,7 @@ struct ConvArgs {
   const void* wpk;       // [ntaps][CoutP][CinP]  (k = input channel contiguous, zero padded)
   void* out;             // [B, OH, OW, Cout]
   const float* bias;     // [Cout] or null
-  float* stats;          // [2][Cout] sum, sumsq (atomically accumulated) or null
+  float* stats;          // [RSSF_BN_SLOTS][2][Cout] sum, sumsq (atomically accumulated, slot = block % slots) or null
   int B, IH, IW, Cin, OH, OW, Cout, CinP, CoutP;
   int mul, div;          // source row = (oy*mul + dy) / div   (div > 1: only when divisible)
   Taps taps;
@@ -171,8 +171,9 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   }
   __syncthreads();
   if (a.stats) {
+    float* slot = a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * a.Cout;      // spread the same-address atomics
     for (int i = tid; i < BNT; i += 256)
-      if (n0 + i < a.Cout) { atomicAdd(a.stats + n0 + i, sstat[i]); atomicAdd(a.stats + a.Cout + n0 + i, sstat[BNT + i]); }
+      if (n0 + i < a.Cout) { atomicAdd(slot + n0 + i, sstat[i]); atomicAdd(slot + a.Cout + n0 + i, sstat[BNT + i]); }
   }
   T* OUT = reinterpret_cast<T*>(a.out);
   constexpr int OCPR = BNT / V;                          // 16-byte chunks per output row of the tile

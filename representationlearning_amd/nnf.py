@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import _lib as L
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+BN_SLOTS, BN_BWD_SLOTS = 16, 4            # RSSF_BN_SLOTS / RSSF_BN_BWD_SLOTS of include/rssf.h
 _SYNC_ALL_BN = False          # set by the trainer: configs/base/loveda.py:107 train.sync_bn
 
 
@@ -177,7 +178,7 @@ class _ConvBNAct(torch.autograd.Function):
             bias = biases[0] if nbias == 1 else torch.stack(biases).sum(0)      # summed convs: biases add
             bias = bias.float().contiguous()
         C = spec.cout
-        stats = torch.zeros(2, C, device=dev, dtype=torch.float32) if training else None
+        stats = torch.zeros(BN_SLOTS, 2, C, device=dev, dtype=torch.float32) if training else None
         raw = _conv_forward(spec, xh, weights, bias, stats)
         rows = raw.numel() // C
         n = float(rows)
@@ -213,7 +214,7 @@ class _ConvBNAct(torch.autograd.Function):
         C = spec.cout
         rows = raw.numel() // C
         lib = L.load()
-        sums = torch.zeros(2, C, device=raw.device, dtype=torch.float32)
+        sums = torch.zeros(BN_BWD_SLOTS, 2, C, device=raw.device, dtype=torch.float32)
         L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.dtype_code(raw),
                                        L.stream()), "rssf_bn_bwd_reduce")
         if training and sync and (_world() > 1 or _FORCE_COLLECTIVES):
