@@ -48,33 +48,35 @@ template <> struct Elem<bf16_t> {
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return Elem<T>::ld(p); }
 template <typename T> __device__ __forceinline__ void stf(T* p, float v) { Elem<T>::st(p, v); }
 
-// Vector access: VEC elements (16 bytes for bf16 x8, 16 bytes for f32 x4)
+// Vector access: VEC elements (16 bytes for bf16 x8, 16 bytes for f32 x4).  `raw` is a native ext-vector (not HIP's
+// uint4/float4 struct-of-union): arrays of Vec then always scalarise into VGPRs (the struct form was seen demoted to
+// scratch memory once a staging array was written under a branch).
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 template <typename T> struct Vec;
 template <> struct Vec<float> {
   static constexpr int N = 4;
-  float4 raw;
-  __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
-  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = raw; }
-  __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
-  __device__ __forceinline__ void set(int i, float v) { (&raw.x)[i] = v; }
-  __device__ __forceinline__ void set_all(const float (&v)[4]) { raw = make_float4(v[0], v[1], v[2], v[3]); }
+  f32x4 raw;
+  __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const f32x4*>(p); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = raw; }
+  __device__ __forceinline__ float get(int i) const { return raw[i]; }
+  __device__ __forceinline__ void set(int i, float v) { raw[i] = v; }
+  __device__ __forceinline__ void set_all(const float (&v)[4]) { raw = f32x4{v[0], v[1], v[2], v[3]}; }
 };
 template <> struct Vec<bf16_t> {
   static constexpr int N = 8;
-  uint4 raw;
-  __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
-  __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  u32x4 raw;
+  __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<u32x4*>(p) = raw; }
   __device__ __forceinline__ float get(int i) const {
-    uint32_t w = (&raw.x)[i >> 1];
+    const uint32_t w = raw[i >> 1];
     return (i & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
   }
   __device__ __forceinline__ void set(int i, float v) {
-    uint32_t& w = (&raw.x)[i >> 1];
-    uint32_t h = f2bf(v);
-    w = (i & 1) ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
+    const uint32_t w = raw[i >> 1], h = f2bf(v);
+    raw[i >> 1] = (i & 1) ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
   }
   __device__ __forceinline__ void set_all(const float (&v)[8]) {     // 4 x v_cvt_pk_bf16_f32
-    raw.x = f2bf2(v[0], v[1]); raw.y = f2bf2(v[2], v[3]); raw.z = f2bf2(v[4], v[5]); raw.w = f2bf2(v[6], v[7]);
+    raw = u32x4{f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7])};
   }
 };
 

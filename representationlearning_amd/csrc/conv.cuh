@@ -33,6 +33,31 @@ template <> struct MmaK<float> {
   }
 };
 
+// Workgroups are dispatched round-robin over the 8 XCDs (observed: block b runs on XCD b % 8), each with a private 4 MiB
+// L2.  Work items that share operands (the taps of one pixel range, the channel tiles of one pixel tile, neighbouring
+// pixel tiles) are therefore numbered so that they land on ONE XCD back to back: logical = (b % 8) * per + b / 8, with
+// per = ceil(total / 8) and a grid of 8 * per blocks (logical >= total: the block exits).  Speed only, never correctness.
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t xcd_logical(unsigned b, int per) { return (int64_t)(b & 7u) * per + (b >> 3); }
+#endif
+inline int xcd_per(int64_t total) { return (int)((total + 7) / 8); }
+
+// halo-tiled 3x3 / stride-1 bf16 kernel (conv_halo.hip), dispatched from rssf_conv_gather
+struct HaloArgs {
+  const bf16_t* in;      // [B, H, W, Cin]
+  const bf16_t* wpk;     // [9][CoutP][CinP]
+  bf16_t* out;           // [B, H, W, Cout]
+  const float* bias;
+  float* stats;          // [RSSF_BN_SLOTS][2][Cout] or null
+  int B, H, W, Cin, Cout, CinP, CoutP;
+  int tiles_y, tiles_x, ntiles_n, xcd_per;
+  int64_t total;
+  int dy[9], dx[9];
+};
+
+bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, int ntaps, const int* dy, const int* dx);
+int launch_halo(HaloArgs a, hipStream_t st);
+
 template <typename T> struct LdsPad;
 template <> struct LdsPad<bf16_t> { static constexpr int X = 8; };   // +16 B per row: conflict-free ds_read_b128
 template <> struct LdsPad<float> { static constexpr int X = 4; };

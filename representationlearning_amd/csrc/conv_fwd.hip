@@ -24,11 +24,17 @@ struct ConvArgs {
   const float* bias;     // [Cout] or null
   float* stats;          // [RSSF_BN_SLOTS][2][Cout] sum, sumsq (atomically accumulated, slot = block % slots) or null
   int B, IH, IW, Cin, OH, OW, Cout, CinP, CoutP;
+  int ntiles_n, xcd_per;
+  int64_t total;
   int mul, div;          // source row = (oy*mul + dy) / div   (div > 1: only when divisible)
   Taps taps;
 };
 
-template <typename T, int BM, int BNT>
+// VOK: Cin is a multiple of the 16-byte vector -> branch-free staging (loads from a clamped address, invalid rows zeroed
+// when they are written to LDS) so that all of a step's global loads are in flight together; any control flow around a
+// load makes the compiler drain vmcnt at the join, which serialises the loads (measured: 8 dependent round trips per
+// step in the weight-gradient kernel).  !VOK (the 3-channel stem, the 18-channel Small variant): element-wise gather.
+template <typename T, int BM, int BNT, bool VOK>
 __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   using MK = MmaK<T>;
   constexpr int BK = MK::BK, V = Vec<T>::N, CPR = BK / V;      // 16-byte chunks per staged row (= 4)
@@ -51,11 +57,12 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wave_m = wave % WM, wave_n = wave / WM;
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BNT;
+  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);   // channel tiles of a pixel tile, then neighbouring pixel tiles, on one XCD
+  if (q >= a.total) return;
+  const int64_t m0 = (q / a.ntiles_n) * BM;
+  const int n0 = (int)(q % a.ntiles_n) * BNT;
   const T* IN = reinterpret_cast<const T*>(a.in);
   const T* W = reinterpret_cast<const T*>(a.wpk);
-  const bool vec_ok = (a.Cin % V) == 0;
 
   // per-thread fixed A rows (pixels) and channel sub-chunk
   int pb[A_CHUNKS], py[A_CHUNKS], px[A_CHUNKS];
@@ -83,13 +90,13 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   const int nsteps = a.taps.n * kchunks;
   Vec<T> ra[A_CHUNKS], rb[B_CHUNKS];
 
+  bool rok[A_CHUNKS];
   auto load_step = [&](int step) {
     const int t = step / kchunks, kc = step % kchunks;
     const int dy = a.taps.dy[t], dx = a.taps.dx[t];
     const int c0 = kc * BK + sub;
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
-      ra[i].raw = {0, 0, 0, 0};
       int sy = py[i] + dy, sx = px[i] + dx;
       bool ok = pv[i] && sy >= 0 && sx >= 0 && c0 < a.Cin;
       if (a.div > 1) {
@@ -97,25 +104,32 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
         sy /= a.div; sx /= a.div;
       }
       ok = ok && sy < a.IH && sx < a.IW;
-      if (ok) {
-        const T* src = IN + (((int64_t)pb[i] * a.IH + sy) * a.IW + sx) * a.Cin + c0;
-        if (vec_ok) ra[i].load(src);
-        else
+      const int64_t off = ok ? (((int64_t)pb[i] * a.IH + sy) * a.IW + sx) * a.Cin + c0 : 0;
+      if constexpr (VOK) {
+        ra[i].load(IN + off);                             // unconditional; masked in store_step
+        rok[i] = ok;
+      } else {
+        ra[i].raw = {0, 0, 0, 0};
+        if (ok)
 #pragma unroll
-          for (int e = 0; e < V; ++e) if (c0 + e < a.Cin) ra[i].set(e, ldf(src + e));
+          for (int e = 0; e < V; ++e) if (c0 + e < a.Cin) ra[i].set(e, ldf(IN + off + e));
+        rok[i] = true;
       }
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
       const int c = tid + i * 256;
-      const int row = c / CPR;
-      rb[i].raw = {0, 0, 0, 0};
-      if (row < BNT) rb[i].load(W + ((int64_t)t * a.CoutP + n0 + row) * a.CinP + kc * BK + (c % CPR) * V);
+      const int row = (c / CPR) % BNT;                     // surplus threads re-read a valid row (not stored)
+      rb[i].load(W + ((int64_t)t * a.CoutP + n0 + row) * a.CinP + kc * BK + (c % CPR) * V);
     }
   };
   auto store_step = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) ra[i].store(As + ((tid + i * 256) / CPR) * LDA + sub);
+    for (int i = 0; i < A_CHUNKS; ++i) {
+      Vec<T> v = ra[i];
+      if (!rok[i]) v.raw = {0, 0, 0, 0};
+      v.store(As + ((tid + i * 256) / CPR) * LDA + sub);
+    }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
       const int c = tid + i * 256;
@@ -236,12 +250,20 @@ void pick_tile(int64_t M, int cout, int& bm, int& bnt) {
 }
 
 template <typename T>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+int launch_conv(ConvArgs a, hipStream_t st) {
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
   int bm, bnt;
   pick_tile(M, a.Cout, bm, bnt);
-  dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((a.Cout + bnt - 1) / bnt));
-#define RSSF_CONV(BMv, BNv) conv_gather_kernel<T, BMv, BNv><<<grid, 256, 0, st>>>(a)
+  a.ntiles_n = (a.Cout + bnt - 1) / bnt;
+  a.total = ((M + bm - 1) / bm) * a.ntiles_n;
+  a.xcd_per = xcd_per(a.total);
+  dim3 grid((unsigned)a.xcd_per * 8);
+  const bool vok = (a.Cin % Vec<T>::N) == 0;
+#define RSSF_CONV(BMv, BNv)                                                   \
+  do {                                                                        \
+    if (vok) conv_gather_kernel<T, BMv, BNv, true><<<grid, 256, 0, st>>>(a);  \
+    else conv_gather_kernel<T, BMv, BNv, false><<<grid, 256, 0, st>>>(a);     \
+  } while (0)
   if (bm == 128) { if (bnt == 32) RSSF_CONV(128, 32); else if (bnt == 64) RSSF_CONV(128, 64); else RSSF_CONV(128, 128); }
   else           { if (bnt == 32) RSSF_CONV(64, 32);  else if (bnt == 64) RSSF_CONV(64, 64);  else RSSF_CONV(64, 128); }
 #undef RSSF_CONV
@@ -301,6 +323,13 @@ extern "C" int rssf_conv_gather(const void* in, const void* wpk, void* out, cons
   a.CoutP = (Cout + bnt - 1) / bnt * bnt;
   a.CinP = (Cin + bk - 1) / bk * bk;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_BF16 && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx)) {
+    HaloArgs h;
+    h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats;
+    h.B = B; h.H = IH; h.W = IW; h.Cin = Cin; h.Cout = Cout; h.CinP = a.CinP; h.CoutP = a.CoutP;
+    for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
+    return launch_halo(h, st);
+  }
   if (dtype == RSSF_F32) return launch_conv<float>(a, st);
   if (dtype == RSSF_BF16) return launch_conv<bf16_t>(a, st);
   set_error("conv_gather: unsupported dtype %d", dtype);

@@ -1,0 +1,194 @@
+// 3x3 / stride-1 / "same" convolution on channels-last bf16 activations, halo-tiled (gfx950 MFMA).
+//
+// The HRNet BasicBlock / Bottleneck / fuse 3x3 convolutions (_hrnet_rssformer.py:216-287) are small-channel
+// (32..256) and at B=16 all cost the same 4.8 GFLOP; in the generic gather kernel (conv_fwd.hip) they are bound by
+// the per-tap global->LDS staging (every input pixel is fetched nine times, two barriers per four MFMAs).  Here a
+// block owns a TH x 16 pixel tile: per 32-channel chunk it stages the (TH+2) x 18 input halo ONCE plus the nine
+// [BN][32] weight slabs, and then runs all nine taps out of LDS with shifted A-operand addresses - 9 x MI x NI
+// MFMAs per barrier pair, the next chunk's global loads in flight underneath.  The data gradient is the same kernel
+// with mirrored taps and transposed weight slabs (the host passes those, exactly as for rssf_conv_gather).
+//
+// Epilogue identical to the gather kernel: + bias, fused BatchNorm statistics (slotted atomics), LDS transpose
+// for 16-byte coalesced stores.
+#include "conv.cuh"
+using namespace rssf;
+using namespace rssf::cv;
+
+namespace rssf {
+namespace cv {
+
+namespace {
+
+constexpr int TW = 16, KC = 32, LDK = KC + 8;             // 80-byte LDS rows: conflict-free ds_read_b128
+
+template <int TH, int BN>
+__global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
+  constexpr int MI = TH / 4, NI = BN / 16, HP = (TH + 2) * (TW + 2), BMP = TH * TW;
+  constexpr int A_ELEMS = HP * LDK, B_ELEMS = 9 * BN * LDK, LDC = BN + 8;
+  constexpr int A_LOADS = (HP * 4 + 255) / 256, B_LOADS = (9 * BN * 4 + 255) / 256;
+  constexpr int LDS_ELEMS = (A_ELEMS + B_ELEMS) > BMP * LDC ? (A_ELEMS + B_ELEMS) : BMP * LDC;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
+  __shared__ float sstat[2 * BN];
+  bf16_t* As = lds;
+  bf16_t* Bs = lds + A_ELEMS;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
+  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);
+  if (q >= a.total) return;
+  int t = (int)(q / a.ntiles_n);
+  const int tx = t % a.tiles_x; t /= a.tiles_x;
+  const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = (int)(q % a.ntiles_n) * BN;
+
+  // fixed per-thread staging slots
+  const bf16_t* asrc[A_LOADS];
+  bool aok[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int idx = tid + i * 256, p = idx >> 2;
+    const int gy = y0 - 1 + p / (TW + 2), gx = x0 - 1 + p % (TW + 2);
+    aok[i] = idx < HP * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    asrc[i] = a.in + (((int64_t)b * a.H + (aok[i] ? gy : 0)) * a.W + (aok[i] ? gx : 0)) * a.Cin + (idx & 3) * 8;
+  }
+  Vec<bf16_t> ra[A_LOADS], rb[B_LOADS];
+  bool rok[A_LOADS];
+  // branch-free staging: every load is issued (from a clamped address), out-of-image / out-of-channel slots are zeroed
+  // when written to LDS, so the chunk's loads are all in flight together
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      rok[i] = aok[i] && kc * KC + ((tid + i * 256) & 3) * 8 < a.Cin;
+      ra[i].load(rok[i] ? asrc[i] + kc * KC : a.in);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int idx = tid + i * 256, row = (idx >> 2) % (9 * BN);          // row = tap*BN + n
+      rb[i].load(a.wpk + ((int64_t)(row / BN) * a.CoutP + n0 + row % BN) * a.CinP + kc * KC + (idx & 3) * 8);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      Vec<bf16_t> v = ra[i];
+      if (!rok[i]) v.raw = {0, 0, 0, 0};
+      if (idx < HP * 4) v.store(As + (idx >> 2) * LDK + (idx & 3) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < 9 * BN * 4) rb[i].store(Bs + (idx >> 2) * LDK + (idx & 3) * 8);
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = a.CinP / KC;
+  load_chunk(0);
+  for (int kc = 0; kc < nchunks; ++kc) {
+    store_chunk();
+    __syncthreads();
+    if (kc + 1 < nchunks) load_chunk(kc + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = a.dy[tap], dx = a.dx[tap];
+      bf16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        fa[mi] = *reinterpret_cast<const bf16x8*>(As + ((wave * MI + mi + 1 + dy) * (TW + 2) + l15 + 1 + dx) * LDK + grp * 8);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        fb[ni] = *reinterpret_cast<const bf16x8*>(Bs + (tap * BN + ni * 16 + l15) * LDK + grp * 8);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, BatchNorm partial statistics, transposed store ------------------------------------------------
+  if (a.stats)
+    for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
+  bf16_t* Cs = lds;                                       // [TH*16][LDC]
+  if (a.stats) __syncthreads();
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int lcol = ni * 16 + l15, col = n0 + lcol;
+    const float bv = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int py = wave * MI + mi;
+      const bool yok = y0 + py < a.H;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = grp * 4 + r;
+        const float v = acc[mi][ni][r] + bv;
+        stf(Cs + (py * TW + px) * LDC + lcol, v);
+        if (yok && x0 + px < a.W) { s1 += v; s2 += v * v; }
+      }
+    }
+    if (a.stats) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (grp == 0) { atomicAdd(&sstat[lcol], s1); atomicAdd(&sstat[BN + lcol], s2); }
+    }
+  }
+  __syncthreads();
+  if (a.stats) {
+    float* slot = a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * a.Cout;
+    for (int i = tid; i < BN; i += 256)
+      if (n0 + i < a.Cout) { atomicAdd(slot + n0 + i, sstat[i]); atomicAdd(slot + a.Cout + n0 + i, sstat[BN + i]); }
+  }
+  constexpr int OCPR = BN / 8;
+  const bool ovec = (a.Cout % 8) == 0;
+  for (int c = tid; c < BMP * OCPR; c += 256) {
+    const int pix = c / OCPR, cc = (c % OCPR) * 8;
+    const int gy = y0 + pix / TW, gx = x0 + pix % TW, col = n0 + cc;
+    if (gy >= a.H || gx >= a.W || col >= a.Cout) continue;
+    bf16_t* dst = a.out + (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + col;
+    if (ovec) {
+      Vec<bf16_t> v;
+      v.load(Cs + pix * LDC + cc);
+      v.store(dst);
+    } else {
+      for (int e = 0; e < 8 && col + e < a.Cout; ++e) dst[e] = Cs[pix * LDC + cc + e];
+    }
+  }
+}
+
+}  // namespace
+
+// true when the halo kernel covers this call (bf16 only; the caller checked the dtype)
+bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, int ntaps, const int* dy, const int* dx) {
+  if (mul != 1 || div != 1 || IH != OH || IW != OW || ntaps != 9 || (Cin % 8) != 0) return false;
+  for (int t = 0; t < 9; ++t)
+    if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1) return false;
+  return true;
+}
+
+int launch_halo(HaloArgs a, hipStream_t st) {
+  const int tx = (a.W + TW - 1) / TW;
+  const int64_t tiles8 = (int64_t)a.B * ((a.H + 7) / 8) * tx;
+  int th = 8, bn = 32;
+  if (a.Cout >= 64 && tiles8 * ((a.Cout + 63) / 64) >= 512) bn = 64;
+  else if (tiles8 * ((a.Cout + 31) / 32) < 512) th = 4;
+  a.tiles_x = tx;
+  a.tiles_y = (a.H + th - 1) / th;
+  a.ntiles_n = (a.Cout + bn - 1) / bn;
+  a.total = (int64_t)a.B * a.tiles_y * a.tiles_x * a.ntiles_n;
+  a.xcd_per = xcd_per(a.total);
+  dim3 grid((unsigned)a.xcd_per * 8);
+  if (th == 8 && bn == 64) conv3x3_halo_kernel<8, 64><<<grid, 256, 0, st>>>(a);
+  else if (th == 8) conv3x3_halo_kernel<8, 32><<<grid, 256, 0, st>>>(a);
+  else conv3x3_halo_kernel<4, 32><<<grid, 256, 0, st>>>(a);
+  return check_launch("conv3x3_halo");
+}
+
+}  // namespace cv
+}  // namespace rssf

@@ -34,7 +34,7 @@ struct WgradArgs {
   int ntaps_total;
   int src_of_tap[MAX_TAPS];
   int kpos_of_tap[MAX_TAPS];
-  int B, IH, IW, Cin, OH, OW, Cout, stride, ksplit, ctiles_m, ctiles_n, tap0, ntap;
+  int B, IH, IW, Cin, OH, OW, Cout, stride, ksplit, ctiles_m, ctiles_n, tap0, ntap, inner, xcd_per;
   Taps taps;
 };
 
@@ -62,11 +62,15 @@ template <> struct SlabFrag<float> {
   }
 };
 
-template <typename T, int TMN, int TG>
+// VOK: Cout and Cin are multiples of the 16-byte vector -> branch-free staging (see conv_fwd.hip): loads are issued
+// unconditionally from a clamped address and invalid rows are zeroed when they are written to LDS.
+template <typename T, int TMN, int TG, bool VOK>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   using MK = MmaK<T>;
   constexpr int V = Vec<T>::N;
-  constexpr int LD = TMN + LdsPad<T>::X;
+  // +32 B per bf16 row: the four rows a 16-lane group touches in one transpose read land in disjoint 32-byte bank
+  // groups (with +16 B they overlap pairwise: measured 33 % of LDS cycles lost to conflicts)
+  constexpr int LD = TMN + (sizeof(T) == 2 ? 16 : LdsPad<T>::X);
   constexpr int CPR = TMN / V;                           // 16-byte chunks per slab row
   constexpr int CHUNKS = (KP * CPR + 255) / 256;         // per thread per operand
   constexpr int WI = TMN / 32;                           // 16x16 tiles per wave along each axis (wave grid 2x2)
@@ -74,17 +78,21 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) T XS[KP * LD];  // in   slab [pixel][ci]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
-  int bid = blockIdx.x;
+  // logical order: the (tile, tap) blocks of one pixel range are consecutive on one XCD (they share the dout slab and,
+  // shifted, the input rows), successive ranges of an XCD are adjacent in memory
+  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);
+  if (q >= (int64_t)a.inner * a.ksplit) return;
+  const int range = (int)(q / a.inner);
+  int bid = (int)(q % a.inner);
   const int cit = bid % a.ctiles_n; bid /= a.ctiles_n;
   const int cot = bid % a.ctiles_m; bid /= a.ctiles_m;
   const int tbase = a.tap0 + (TG == 1 ? bid : 0);        // TG == 1: the taps of the group are spread over blockIdx.x
   const int co0 = cot * TMN, ci0 = cit * TMN;
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
   const int64_t per = ((M + a.ksplit - 1) / a.ksplit + KP - 1) / KP * KP;
-  const int64_t kbeg = (int64_t)blockIdx.y * per, kend = kbeg + per < M ? kbeg + per : M;
+  const int64_t kbeg = (int64_t)range * per, kend = kbeg + per < M ? kbeg + per : M;
   const T* DO = reinterpret_cast<const T*>(a.dout);
   const T* IN = reinterpret_cast<const T*>(a.in);
-  const bool ovec = (a.Cout % V) == 0, ivec = (a.Cin % V) == 0;
   const int wm = wave >> 1, wn = wave & 1;
 
   f32x4 acc[TG][WI][WI];
@@ -102,56 +110,72 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int c = 0; c < CHUNKS; ++c) { const int id = tid + c * 256; srow[c] = id / CPR; scol[c] = (id % CPR) * V; }
 
-  Vec<T> rx[CHUNKS];
+  Vec<T> rx[CHUNKS], rd[CHUNKS];
   int pb[CHUNKS], py[CHUNKS], px[CHUNKS];
-  bool pv[CHUNKS];
+  bool pv[CHUNKS], dok[CHUNKS], xok[CHUNKS];
 
-  auto load_x = [&](int t) {      // gather the input slab of tap t into registers
-    const int dy = a.taps.dy[tbase + t], dx = a.taps.dx[tbase + t];
-#pragma unroll
-    for (int c = 0; c < CHUNKS; ++c) {
-      rx[c].raw = {0, 0, 0, 0};
-      const int sy = py[c] * a.stride + dy, sx = px[c] * a.stride + dx;
-      const int ch = ci0 + scol[c];
-      if (pv[c] && srow[c] < KP && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW && ch < a.Cin) {
-        const T* src = IN + (((int64_t)pb[c] * a.IH + sy) * a.IW + sx) * a.Cin + ch;
-        if (ivec) rx[c].load(src);
-        else for (int e = 0; e < V; ++e) if (ch + e < a.Cin) rx[c].set(e, ldf(src + e));
-      }
-    }
-  };
-
-  for (int64_t k0 = kbeg; k0 < kend; k0 += KP) {
-    // ---- pixel coordinates of this thread's rows; stage the dout slab ---------------------------------------------
+  auto set_slab = [&](int64_t k0) {   // pixel coordinates of this thread's rows of the slab starting at pixel k0 + its dout rows
 #pragma unroll
     for (int c = 0; c < CHUNKS; ++c) {
       const int64_t p = k0 + srow[c];
       pv[c] = srow[c] < KP && p < kend;
-      const int64_t pp = pv[c] ? p : 0;
-      pb[c] = (int)(pp / ((int64_t)a.OH * a.OW));
-      const int rem = (int)(pp % ((int64_t)a.OH * a.OW));
+      const int pp = pv[c] ? (int)p : 0;                  // M < 2^31 (checked by the host entry)
+      pb[c] = pp / (a.OH * a.OW);
+      const int rem = pp % (a.OH * a.OW);
       py[c] = rem / a.OW; px[c] = rem % a.OW;
-      if (srow[c] < KP) {
-        Vec<T> vd;
-        vd.raw = {0, 0, 0, 0};
-        const int ch = co0 + scol[c];
-        if (pv[c] && ch < a.Cout) {
-          const T* src = DO + p * a.Cout + ch;
-          if (ovec) vd.load(src);
-          else for (int e = 0; e < V; ++e) if (ch + e < a.Cout) vd.set(e, ldf(src + e));
-        }
-        vd.store(DS + srow[c] * LD + scol[c]);
+      const int ch = co0 + scol[c];
+      dok[c] = pv[c] && ch < a.Cout;
+      const int64_t off = dok[c] ? (int64_t)pp * a.Cout + ch : 0;
+      if constexpr (VOK) {
+        rd[c].load(DO + off);
+      } else {
+        rd[c].raw = {0, 0, 0, 0};
+        if (dok[c])
+          for (int e = 0; e < V; ++e) if (ch + e < a.Cout) rd[c].set(e, ldf(DO + off + e));
       }
     }
-    load_x(0);
+  };
+  auto load_x = [&](int t) {      // gather the input slab of tap t into registers
+    const int dy = a.taps.dy[tbase + t], dx = a.taps.dx[tbase + t];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const int sy = py[c] * a.stride + dy, sx = px[c] * a.stride + dx;
+      const int ch = ci0 + scol[c];
+      xok[c] = pv[c] && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW && ch < a.Cin;
+      const int64_t off = xok[c] ? (((int64_t)pb[c] * a.IH + sy) * a.IW + sx) * a.Cin + ch : 0;
+      if constexpr (VOK) {
+        rx[c].load(IN + off);
+      } else {
+        rx[c].raw = {0, 0, 0, 0};
+        if (xok[c])
+          for (int e = 0; e < V; ++e) if (ch + e < a.Cin) rx[c].set(e, ldf(IN + off + e));
+      }
+    }
+  };
+
+  // Software pipeline over (slab, tap) steps: the operands of the NEXT step (next tap of this slab, or the dout rows and
+  // first tap of the next slab) are requested right after the barrier that publishes the current step, so the global
+  // latency runs under the MFMAs instead of in front of them.
+  if (kbeg < kend) { set_slab(kbeg); load_x(0); }
+  for (int64_t k0 = kbeg; k0 < kend; k0 += KP) {
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
       if (TG == 1 || t < a.ntap) {
 #pragma unroll
         for (int c = 0; c < CHUNKS; ++c)
-          if (srow[c] < KP) rx[c].store(XS + srow[c] * LD + scol[c]);
+          if (srow[c] < KP) {
+            if (t == 0) {
+              Vec<T> v = rd[c];
+              if (VOK && !dok[c]) v.raw = {0, 0, 0, 0};
+              v.store(DS + srow[c] * LD + scol[c]);
+            }
+            Vec<T> v = rx[c];
+            if (VOK && !xok[c]) v.raw = {0, 0, 0, 0};
+            v.store(XS + srow[c] * LD + scol[c]);
+          }
         __syncthreads();
-        if (t + 1 < TG && t + 1 < a.ntap) load_x(t + 1);        // next tap's gather in flight under the MFMAs
+        if (t + 1 < TG && t + 1 < a.ntap) load_x(t + 1);
+        else if (k0 + KP < kend) { set_slab(k0 + KP); load_x(0); }
 #pragma unroll
         for (int ks = 0; ks < KP; ks += MK::KSTEP) {
           typename MK::frag fa[WI], fb[WI];
@@ -190,7 +214,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + (wm * WI + i) * 16 + grp * 4 + r, ci = ci0 + (wn * WI + j) * 16 + l15;
           if (co >= a.Cout || ci >= a.Cin) continue;
-          if (a.partial) a.partial[(((int64_t)blockIdx.y * a.ntaps_total + tap) * a.Cout + co) * a.Cin + ci] = acc[t][i][j][r];
+          if (a.partial) a.partial[(((int64_t)range * a.ntaps_total + tap) * a.Cout + co) * a.Cin + ci] = acc[t][i][j][r];
           else atomicAdd(dw + ((int64_t)co * a.Cin + ci) * kk + kpos, acc[t][i][j][r]);
         }
   }
@@ -226,7 +250,7 @@ bool taps_in_registers(int cout, int cin) { return tile_of(cout, cin) == 32; }
 int pick_ksplit(int cout, int cin, int ntaps, int64_t M) {
   const int t = tile_of(cout, cin);
   int64_t par = (int64_t)((cout + t - 1) / t) * ((cin + t - 1) / t);
-  if (!taps_in_registers(cout, cin)) par *= (ntaps >= 9 ? 9 : 1);
+  if (!taps_in_registers(cout, cin)) par *= ntaps;
   int64_t ks = (t == 32 ? 512 : 1024) / par;
   const int64_t maxks = (M + 4 * KP - 1) / (4 * KP);
   if (ks > maxks) ks = maxks;
@@ -239,13 +263,16 @@ int launch_group(WgradArgs& a, int tap0, int ntap, hipStream_t st) {
   a.tap0 = tap0; a.ntap = ntap;
   a.ctiles_m = (a.Cout + TMN - 1) / TMN; a.ctiles_n = (a.Cin + TMN - 1) / TMN;
   const int tiles = a.ctiles_m * a.ctiles_n;
-  if constexpr (TMN == 32) {
-    dim3 grid((unsigned)tiles, (unsigned)a.ksplit);
-    if (ntap == 1) conv_wgrad_kernel<T, TMN, 1><<<grid, 256, 0, st>>>(a);
-    else conv_wgrad_kernel<T, TMN, 9><<<grid, 256, 0, st>>>(a);
+  a.inner = TMN == 32 ? tiles : tiles * ntap;
+  a.xcd_per = xcd_per((int64_t)a.inner * a.ksplit);
+  dim3 grid((unsigned)a.xcd_per * 8);
+  const bool vok = (a.Cout % Vec<T>::N) == 0 && (a.Cin % Vec<T>::N) == 0;
+  if (TMN == 32 && ntap != 1) {
+    if (vok) conv_wgrad_kernel<T, TMN, (TMN == 32 ? 9 : 1), true><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_kernel<T, TMN, (TMN == 32 ? 9 : 1), false><<<grid, 256, 0, st>>>(a);
   } else {
-    dim3 grid((unsigned)(tiles * ntap), (unsigned)a.ksplit);
-    conv_wgrad_kernel<T, TMN, 1><<<grid, 256, 0, st>>>(a);
+    if (vok) conv_wgrad_kernel<T, TMN, 1, true><<<grid, 256, 0, st>>>(a);
+    else conv_wgrad_kernel<T, TMN, 1, false><<<grid, 256, 0, st>>>(a);
   }
   return check_launch("conv_wgrad");
 }
@@ -255,6 +282,11 @@ int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
   // tap groups: consecutive taps of one source conv (1 for a 1x1, 9 for a 3x3)
   int t = 0;
   const int tile = tile_of(a.Cout, a.Cin);
+  if (tile != 32) {          // one tap per block: all taps (of all source convs) in a single launch
+    const int rc = tile == 64 ? launch_group<T, 64>(a, 0, ntaps, st) : launch_group<T, 128>(a, 0, ntaps, st);
+    if (rc) return rc;
+    t = ntaps;
+  }
   while (t < ntaps) {
     int n = 1;
     while (t + n < ntaps && n < 9 && a.src_of_tap[t + n] == a.src_of_tap[t]) ++n;
@@ -286,6 +318,7 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
+  RSSF_REQUIRE((int64_t)B * OH * OW < (int64_t)1 << 31, "conv_wgrad: more than 2^31 output pixels");
   WgradArgs a;
   a.dout = dout; a.in = in; a.dw[0] = dw0; a.dw[1] = dw1; a.dw[2] = dw2; a.dbias = dbias;
   for (int i = 0; i < 3; ++i) a.ks[i] = i < nsrc ? ksizes[i] : 1;
