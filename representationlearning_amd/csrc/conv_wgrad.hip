@@ -221,19 +221,34 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   if (do_bias && tid < TMN && co0 + tid < a.Cout) atomicAdd(a.dbias + co0 + tid, bsum);
 }
 
-// second stage of the split-K reduction: dw[torch layout] += sum_k partial[k][tap][co][ci]
-constexpr int RK = 16;   // partials summed per thread in the second stage (blockIdx.y walks the k chunks)
+// second stage of the split-K reduction: dw[torch layout] += sum_k partial[k][tap][co][ci].  A block owns 32 consecutive
+// gradient elements (128-byte rows of the partial planes); its 8 thread groups walk interleaved k planes with four
+// loads in flight each, fold through LDS, and one thread per element does the (non-atomic) read-modify-write.
+constexpr int RI = 32, RG = 8;
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
+  __shared__ float red[RG][RI];
   const int64_t per = (int64_t)a.ntaps_total * a.Cout * a.Cin;
-  const int kb = blockIdx.y * RK, ke = kb + RK < a.ksplit ? kb + RK : a.ksplit;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+  const int ii = threadIdx.x % RI, kg = threadIdx.x / RI;
+  const int64_t i = (int64_t)blockIdx.x * RI + ii;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < per) {
+    const float* p = a.partial + i;
+    int k = kg;
+    for (; k + 3 * RG < a.ksplit; k += 4 * RG) {
+      s0 += p[(int64_t)k * per]; s1 += p[(int64_t)(k + RG) * per];
+      s2 += p[(int64_t)(k + 2 * RG) * per]; s3 += p[(int64_t)(k + 3 * RG) * per];
+    }
+    for (; k < a.ksplit; k += RG) s0 += p[(int64_t)k * per];
+  }
+  red[kg][ii] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kg == 0 && i < per) {
     float s = 0.f;
-    for (int k = kb; k < ke; ++k) s += a.partial[(int64_t)k * per + i];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) s += red[g][ii];
     const int ci = (int)(i % a.Cin), co = (int)((i / a.Cin) % a.Cout), tap = (int)(i / ((int64_t)a.Cin * a.Cout));
     const int sc = a.src_of_tap[tap], kk = a.ks[sc] * a.ks[sc];
-    float* dst = a.dw[sc] + ((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[tap];
-    if (gridDim.y == 1) *dst += s;
-    else atomicAdd(dst, s);             // <= ksplit/16 adds per address
+    a.dw[sc][((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[tap]] += s;
   }
 }
 
@@ -246,12 +261,12 @@ int tile_of(int cout, int cin) {
 }
 bool taps_in_registers(int cout, int cin) { return tile_of(cout, cin) == 32; }
 
-// split-K factor: ~1024 blocks in flight, at least 4 slabs of 64 pixels each
+// split-K factor: 512..1024 blocks in flight, at least 4 slabs of 64 pixels each
 int pick_ksplit(int cout, int cin, int ntaps, int64_t M) {
   const int t = tile_of(cout, cin);
   int64_t par = (int64_t)((cout + t - 1) / t) * ((cin + t - 1) / t);
   if (!taps_in_registers(cout, cin)) par *= ntaps;
-  int64_t ks = (t == 32 ? 512 : 1024) / par;
+  int64_t ks = (t == 128 ? 512 : 1024) / par;        // measured on MI355X (tools_wgrad_bench.py sweep)
   const int64_t maxks = (M + 4 * KP - 1) / (4 * KP);
   if (ks > maxks) ks = maxks;
   if (ks < 1) ks = 1;
@@ -297,9 +312,7 @@ int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
   }
   if (a.partial) {
     const int64_t per = (int64_t)ntaps * a.Cout * a.Cin;
-    int blocks = (int)((per + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    wgrad_reduce_kernel<<<dim3((unsigned)blocks, (unsigned)((a.ksplit + RK - 1) / RK)), 256, 0, st>>>(a);
+    wgrad_reduce_kernel<<<(unsigned)((per + RI - 1) / RI), 256, 0, st>>>(a);
     return check_launch("conv_wgrad_reduce");
   }
   return RSSF_OK;
