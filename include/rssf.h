@@ -113,6 +113,23 @@ int64_t rssf_conv_packed_elems(int ntaps, int rows, int cols, int dtype);
  * transpose = 1: rows = Cin (data gradient). */
 int rssf_conv_pack(const float* w0, const float* w1, const float* w2, const int* ksizes, int nsrc, const int* src_of_tap,
                    const int* kpos_of_tap, int ntaps, int Cout, int Cin, int transpose, void* out, int dtype, void* stream);
+/* Batched packing: ONE launch re-packs every convolution of the model (both layouts) after an optimizer step.
+ * `jobs` is a DEVICE array of rssf_pack_job; `block_map` a DEVICE array of nblocks {job index, chunk index} pairs, one
+ * per 1024-element chunk of each job's output (chunks of a job: ceil(packed_elems / 1024)). */
+#define RSSF_MAX_TAPS 19
+#define RSSF_PACK_CHUNK 1024
+typedef struct rssf_pack_job {
+  const float* w[3];              /* torch-layout fp32 sources (w[i] unused for i >= nsrc) */
+  void* out;                      /* packed slabs [ntaps][rows_p][cols_p] of the batch dtype */
+  int ks[3];
+  int nsrc, ntaps, cout, cin, rows_p, cols_p, transpose;
+  int src_of_tap[RSSF_MAX_TAPS];
+  int kpos_of_tap[RSSF_MAX_TAPS];
+} rssf_pack_job;
+/* rows_p / cols_p of the packed slabs for a (rows, cols) weight matrix (rows = cout, or cin when transposed) */
+int rssf_conv_packed_rows(int rows);
+int rssf_conv_packed_cols(int cols, int dtype);
+int rssf_conv_pack_batch(const rssf_pack_job* jobs, const int* block_map, int nblocks, int dtype, void* stream);
 /* the gather convolution itself.  bias [Cout] optional; stats [RSSF_BN_SLOTS][2][Cout] optional: per-channel sum and sum of squares of
  * the OUTPUT (incl. bias) atomically accumulated for the BatchNorm that follows (fused statistics). */
 int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bias, float* stats, int B, int IH, int IW,

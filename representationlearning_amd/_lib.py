@@ -27,6 +27,15 @@ class WinAttnBwdParams(ctypes.Structure):
         "dout", "dxhat", "dyhat", "domega", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv", "dwo", "dbo")]
 
 
+MAX_TAPS, PACK_CHUNK = 19, 1024      # RSSF_MAX_TAPS, RSSF_PACK_CHUNK
+
+
+class PackJob(ctypes.Structure):       # rssf_pack_job
+    _fields_ = [("w", c_void_p * 3), ("out", c_void_p), ("ks", c_int * 3)] + [
+        (n, c_int) for n in ("nsrc", "ntaps", "cout", "cin", "rows_p", "cols_p", "transpose")] + [
+        ("src_of_tap", c_int * MAX_TAPS), ("kpos_of_tap", c_int * MAX_TAPS)]
+
+
 # name -> (restype, argtypes); every symbol include/rssf.h declares must appear here (tests check it)
 SIGNATURES = {
     "rssf_version": (ctypes.c_char_p, []),
@@ -42,6 +51,9 @@ SIGNATURES = {
     "rssf_winattn_bwd": (c_int, [ctypes.POINTER(WinAttnBwdParams), c_void_p]),
     "rssf_conv_tile_n": (c_int, [c_int]),
     "rssf_conv_packed_elems": (c_int64, [c_int, c_int, c_int, c_int]),
+    "rssf_conv_packed_rows": (c_int, [c_int]),
+    "rssf_conv_packed_cols": (c_int, [c_int, c_int]),
+    "rssf_conv_pack_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rssf_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_void_p, c_int, c_void_p]),
     "rssf_conv_gather": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),

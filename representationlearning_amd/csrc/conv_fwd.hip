@@ -234,6 +234,27 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a, T* out) {
   }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) pack_batch_kernel(const rssf_pack_job* __restrict__ jobs, const int* __restrict__ block_map) {
+  const rssf_pack_job& j = jobs[block_map[2 * blockIdx.x]];
+  const int64_t total = (int64_t)j.ntaps * j.rows_p * j.cols_p;
+  const int64_t base = (int64_t)block_map[2 * blockIdx.x + 1] * RSSF_PACK_CHUNK;
+  T* out = reinterpret_cast<T*>(j.out);
+#pragma unroll
+  for (int u = 0; u < RSSF_PACK_CHUNK / 256; ++u) {
+    const int64_t i = base + u * 256 + threadIdx.x;
+    if (i >= total) break;
+    const int col = (int)(i % j.cols_p), row = (int)((i / j.cols_p) % j.rows_p), t = (int)(i / ((int64_t)j.cols_p * j.rows_p));
+    const int co = j.transpose ? col : row, ci = j.transpose ? row : col;
+    float v = 0.f;
+    if (co < j.cout && ci < j.cin) {
+      const int s = j.src_of_tap[t], kk = j.ks[s] * j.ks[s];
+      v = j.w[s][((int64_t)co * j.cin + ci) * kk + j.kpos_of_tap[t]];
+    }
+    stf(out + i, v);
+  }
+}
+
 int pick_bn(int cout) { return cout <= 32 ? 32 : cout <= 64 ? 64 : 128; }
 
 // Tile choice: the widest tile that still gives the chip >= 2 blocks per CU; small feature maps (32x32, 16x16 at
@@ -297,6 +318,20 @@ extern "C" int rssf_conv_pack(const float* w0, const float* w1, const float* w2,
   else if (dtype == RSSF_BF16) pack_weights_kernel<bf16_t><<<blocks, 256, 0, st>>>(a, (bf16_t*)out);
   else { set_error("conv_pack: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
   return check_launch("conv_pack");
+}
+
+extern "C" int rssf_conv_packed_rows(int rows) { return (rows + pick_bn(rows) - 1) / pick_bn(rows) * pick_bn(rows); }
+extern "C" int rssf_conv_packed_cols(int cols, int dtype) {
+  const int bk = dtype == RSSF_BF16 ? MmaK<bf16_t>::BK : MmaK<float>::BK;
+  return (cols + bk - 1) / bk * bk;
+}
+extern "C" int rssf_conv_pack_batch(const rssf_pack_job* jobs, const int* block_map, int nblocks, int dtype, void* stream) {
+  RSSF_REQUIRE(jobs && block_map && nblocks > 0, "conv_pack_batch: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) pack_batch_kernel<float><<<nblocks, 256, 0, st>>>(jobs, block_map);
+  else if (dtype == RSSF_BF16) pack_batch_kernel<bf16_t><<<nblocks, 256, 0, st>>>(jobs, block_map);
+  else { set_error("conv_pack_batch: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  return check_launch("conv_pack_batch");
 }
 
 extern "C" int64_t rssf_conv_packed_elems(int ntaps, int rows, int cols, int dtype) {

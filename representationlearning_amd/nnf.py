@@ -120,7 +120,146 @@ def _nchw(t):
     return t.permute(0, 3, 1, 2)
 
 
+# ---- per-step scratch: one zero-fill and one weight re-pack per training step ----------------------------------------
+# A training step needs ~700 small zeroed fp32 buffers (BatchNorm statistics, bias-gradient sums) and re-packs the
+# weights of ~330 convolutions twice (forward and data-gradient layouts).  Done per call that is ~1400 tiny launches
+# (4.7 ms of GPU time and as much host time per step on MI355X).  The trainer brackets a step with step_begin():
+#   * ZeroPool: one flat fp32 buffer, zeroed by ONE memset, handed out in 16-byte-aligned slices (sized from the
+#     previous step's demand; a request that does not fit falls back to torch.zeros),
+#   * PackPlan: every (ConvSpec, layout) packed during the first step is recorded; from then on ONE
+#     rssf_conv_pack_batch launch per step refreshes all of them (parameters live in the trainer's flat buffer, so
+#     their addresses are stable) and _pack() returns views of the plan's buffer.
+class ZeroPool:
+    def __init__(self):
+        self.buf, self.off, self.need, self.last_need, self.active = None, 0, 0, 0, False
+
+    def begin(self, device):
+        if self.last_need and (self.buf is None or self.buf.numel() < self.last_need or self.buf.device != device):
+            self.buf = torch.zeros(self.last_need, device=device, dtype=torch.float32)
+        elif self.buf is not None and self.off:
+            self.buf[:self.off].zero_()                   # only what the previous step handed out
+        self.off, self.need, self.active = 0, 0, True
+
+    def end(self):
+        self.last_need = max(self.last_need, self.need)
+        self.active = False
+
+    def zeros(self, n, device):
+        n4 = (n + 3) // 4 * 4
+        self.need += n4
+        if not self.active or self.buf is None or self.off + n4 > self.buf.numel() or self.buf.device != device:
+            return torch.zeros(n, device=device, dtype=torch.float32)
+        out = self.buf[self.off:self.off + n]
+        self.off += n4
+        return out
+
+
+class PackPlan:
+    def __init__(self):
+        self.jobs, self.views, self.fresh, self.built = {}, {}, False, False
+        self.recording = False
+
+    def record(self, key, spec, weights, transpose, dtype):
+        if self.recording and key not in self.jobs and all(w.is_contiguous() and w.dtype == torch.float32 for w in weights):
+            self.jobs[key] = (spec, list(weights), transpose, dtype)
+
+    def build(self):
+        """Allocate the packed buffers and the device-side job table for everything recorded so far."""
+        lib = L.load()
+        if not self.jobs:
+            return
+        self.by_dtype = {}
+        for dtype in {j[3] for j in self.jobs.values()}:
+            code = L.RSSF_BF16 if dtype == torch.bfloat16 else L.RSSF_F32
+            keys = [k for k, j in self.jobs.items() if j[3] == dtype]
+            dev = self.jobs[keys[0]][1][0].device
+            sizes = []
+            for k in keys:
+                spec, ws, tr, _ = self.jobs[k]
+                rows, cols = (spec.cin, spec.cout) if tr else (spec.cout, spec.cin)
+                sizes.append(lib.rssf_conv_packed_elems(spec.ntaps, rows, cols, code))
+            offs, tot = [], 0
+            for n in sizes:
+                offs.append(tot)
+                tot += (n + 7) // 8 * 8
+            flat = torch.empty(tot, device=dev, dtype=dtype)
+            arr = (L.PackJob * len(keys))()
+            bmap = []
+            for i, k in enumerate(keys):
+                spec, ws, tr, _ = self.jobs[k]
+                rows, cols = (spec.cin, spec.cout) if tr else (spec.cout, spec.cin)
+                j = arr[i]
+                for s_, w in enumerate(ws):
+                    j.w[s_] = w.data_ptr()
+                    j.ks[s_] = spec.ksizes[s_]
+                for s_ in range(len(ws), 3):
+                    j.ks[s_] = 1
+                j.out = flat.data_ptr() + offs[i] * flat.element_size()
+                j.nsrc, j.ntaps, j.cout, j.cin, j.transpose = len(ws), spec.ntaps, spec.cout, spec.cin, int(tr)
+                j.rows_p, j.cols_p = lib.rssf_conv_packed_rows(rows), lib.rssf_conv_packed_cols(cols, code)
+                for t in range(spec.ntaps):
+                    j.src_of_tap[t], j.kpos_of_tap[t] = spec.src[t], spec.kpos[t]
+                self.views[k] = flat[offs[i]:offs[i] + sizes[i]]
+                bmap += [(i, c) for c in range((sizes[i] + L.PACK_CHUNK - 1) // L.PACK_CHUNK)]
+            jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            bmap_dev = torch.tensor(bmap, dtype=torch.int32).to(dev).contiguous()
+            ptrs = [w.data_ptr() for k in keys for w in self.jobs[k][1]]
+            self.by_dtype[dtype] = (code, flat, jobs_dev, bmap_dev, len(bmap), keys, ptrs)
+        self.built = True
+
+    def refresh(self):
+        """Re-pack everything from the current parameter values (one launch per dtype)."""
+        lib = L.load()
+        for dtype, (code, flat, jobs_dev, bmap_dev, nb, keys, ptrs) in self.by_dtype.items():
+            if ptrs != [w.data_ptr() for k in keys for w in self.jobs[k][1]]:
+                raise RuntimeError("PackPlan: a recorded convolution weight moved in memory (parameters must stay in the flat buffer)")
+            L.check(lib.rssf_conv_pack_batch(L.ptr(jobs_dev), L.ptr(bmap_dev), nb, code, L.stream()), "rssf_conv_pack_batch")
+        self.fresh = True
+
+    def lookup(self, key):
+        return self.views.get(key) if (self.built and self.fresh) else None
+
+
+_ZERO_POOL = ZeroPool()
+_PACK_PLAN = None
+
+
+def step_begin(device, plan=None):
+    """Trainer hook: start of a training step (zero pool reset + batched weight packing)."""
+    global _PACK_PLAN
+    _ZERO_POOL.begin(device)
+    _PACK_PLAN = plan
+    if plan is not None:
+        if plan.built:
+            plan.refresh()
+        else:
+            plan.recording = True
+
+
+def step_end():
+    """Trainer hook: end of a training step (the parameters are about to change / have changed)."""
+    global _PACK_PLAN
+    _ZERO_POOL.end()
+    if _PACK_PLAN is not None:
+        plan = _PACK_PLAN
+        if plan.recording and not plan.built:
+            plan.recording = False
+            plan.build()
+        plan.fresh = False
+    _PACK_PLAN = None
+
+
+def _zeros(n, device):
+    return _ZERO_POOL.zeros(n, device)
+
+
 def _pack(spec, weights, transpose, dtype, device):
+    key = (id(spec), bool(transpose), dtype)
+    if _PACK_PLAN is not None:
+        v = _PACK_PLAN.lookup(key)
+        if v is not None:
+            return v
+        _PACK_PLAN.record(key, spec, weights, transpose, dtype)
     lib = L.load()
     code = L.RSSF_BF16 if dtype == torch.bfloat16 else L.RSSF_F32
     rows, cols = (spec.cin, spec.cout) if transpose else (spec.cout, spec.cin)
@@ -178,7 +317,7 @@ class _ConvBNAct(torch.autograd.Function):
             bias = biases[0] if nbias == 1 else torch.stack(biases).sum(0)      # summed convs: biases add
             bias = bias.float().contiguous()
         C = spec.cout
-        stats = torch.zeros(BN_SLOTS, 2, C, device=dev, dtype=torch.float32) if training else None
+        stats = _zeros(BN_SLOTS * 2 * C, dev) if training else None
         raw = _conv_forward(spec, xh, weights, bias, stats)
         rows = raw.numel() // C
         n = float(rows)
@@ -214,7 +353,7 @@ class _ConvBNAct(torch.autograd.Function):
         C = spec.cout
         rows = raw.numel() // C
         lib = L.load()
-        sums = torch.zeros(BN_BWD_SLOTS, 2, C, device=raw.device, dtype=torch.float32)
+        sums = _zeros(BN_BWD_SLOTS * 2 * C, raw.device)
         L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.dtype_code(raw),
                                        L.stream()), "rssf_bn_bwd_reduce")
         if training and sync and (_world() > 1 or _FORCE_COLLECTIVES):
@@ -229,7 +368,7 @@ class _ConvBNAct(torch.autograd.Function):
                 "rssf_bn_bwd_apply")
         dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape)) if x_req else None
         wt = [grad_target(w) for w in p_weights]
-        db = torch.zeros(C, device=raw.device, dtype=torch.float32) if nbias else None
+        db = _zeros(C, raw.device) if nbias else None
         _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db)
         gws = [grad_result(w, t[0], t[1]) for w, t in zip(p_weights, wt)]
         gbs = []

@@ -144,6 +144,7 @@ class Trainer:
         env = os.environ.get("RSSF_GRAPH")
         self.use_graph = (env == "1") or (env != "0" and use_graph and not dp)
         self.graph_warmup = 3
+        self.pack_plan = nnf.PackPlan() if os.environ.get("RSSF_PACK_PLAN", "1") != "0" else None
         self.graph = None
         self._static = None
         self._side = None
@@ -153,10 +154,15 @@ class Trainer:
         self.flat.zero_grad()
         if self.buckets is not None:
             self.buckets.begin()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
-            out = self.model(img, target)
-        loss = sum(v for k, v in out.items() if k.endswith("loss"))
-        loss.backward()
+        # one zero-fill and one weight re-pack for the whole step (nnf.ZeroPool / nnf.PackPlan)
+        nnf.step_begin(self.flat.flat.device, self.pack_plan)
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
+                out = self.model(img, target)
+            loss = sum(v for k, v in out.items() if k.endswith("loss"))
+            loss.backward()
+        finally:
+            nnf.step_end()
         if self.buckets is not None:
             self.buckets.finish()
         hp = self.hp
