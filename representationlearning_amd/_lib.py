@@ -8,7 +8,7 @@ import os
 import torch  # noqa: F401  (must be imported first: it brings in the HIP runtime librssf links against)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librssf.so")
+LIB_PATH = os.environ.get("RSSF_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "librssf.so")
 
 RSSF_F32, RSSF_BF16 = 0, 1
 

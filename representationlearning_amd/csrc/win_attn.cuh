@@ -144,6 +144,39 @@ __device__ __forceinline__ f32x4 mma_chain_lds<float>(const f32x4& a, const floa
   return acc;
 }
 
+// Fragment whose K axis is the ROW axis of a row-major LDS tile buf[row][ld] (e.g. a token-major activation tile used
+// with K = tokens, or a weight matrix used transposed): 16 columns c0.. (fragment row/col index = l15) x 16 rows k0..
+// in chain slot order (slot 4g + r).  bf16: ONE ds_read_b64_tr_b16 (lanes 4j..4j+3 of a 16-lane group address the four
+// 8-byte quarters of row k0 + 4g + j; lane i receives column i of that [4][16] sub-tile - measured semantics, see
+// conv_wgrad.hip); f32: four plain reads (the 16x16x4 MFMA takes one K value per lane).  This replaces the second,
+// channel-major copy of every operand the backward used to stage.
+typedef __attribute__((ext_vector_type(4))) short v4s_t;
+template <typename T> struct RowFrag;
+template <> struct RowFrag<bf16_t> {
+  static __device__ __forceinline__ s16x4 load(const bf16_t* buf, int ld, int k0, int c0) {
+    const int lane = threadIdx.x & 63, grp = lane >> 4, i = lane & 15;
+    const bf16_t* p = buf + (k0 + grp * 4 + (i >> 2)) * ld + c0 + (i & 3) * 4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p));
+  }
+};
+template <> struct RowFrag<float> {
+  static __device__ __forceinline__ f32x4 load(const float* buf, int ld, int k0, int c0) {
+    const int lane = threadIdx.x & 63;
+    const float* p = buf + (k0 + (lane >> 4) * 4) * ld + c0 + (lane & 15);
+    return f32x4{p[0], p[ld], p[2 * ld], p[3 * ld]};
+  }
+};
+// D += A^T-view * chain:  A operand = columns c0.. of buf with K = rows k0..k0+15, B operand chained from registers
+template <typename T>
+__device__ __forceinline__ f32x4 mma_row_chain(const T* buf, int ld, int c0, int k0, const f32x4& b, f32x4 acc) {
+  return Packed<T>::mma(RowFrag<T>::load(buf, ld, k0, c0), Packed<T>::pack(b), acc);
+}
+// both operands with K along the rows of their LDS tiles
+template <typename T>
+__device__ __forceinline__ f32x4 mma_row_row(const T* A, int lda, int ca, const T* Bm, int ldb, int cb, int k0, f32x4 acc) {
+  return Packed<T>::mma(RowFrag<T>::load(A, lda, k0, ca), RowFrag<T>::load(Bm, ldb, k0, cb), acc);
+}
+
 // Load the two 49xC tiles of one window, apply LayerNorm (precomputed {mean,rstd}) and the gate weight
 // omega[(n*C+c) mod N] (the reference's view-scramble), write them to LDS as T with
 // zero rows for padded / dead slots and zero columns C..Cp.  16-byte lane accesses when C % VEC == 0.

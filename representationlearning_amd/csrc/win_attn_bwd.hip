@@ -3,10 +3,12 @@
 // incl. the three gradient paths into q/k — softmax, mean(M), argmax-routed max(M) — SURVEY App. C).
 //
 // One wavefront per window.  The forward is recomputed from (x, y, LN stats, omega) so nothing but the
-// block inputs is saved; HBM traffic = read x, y, dout + write dxhat, dyhat.  All operands that are reused
-// with a different contraction axis are staged in LDS twice (token-major for K = channels, channel-major
-// for K = tokens); softmax / dS tiles stay in registers and are computed in both orientations instead of
-// being transposed through LDS.  Weight gradients are accumulated in LDS per workgroup and flushed once.
+// block inputs is saved; HBM traffic = read x, y, dout + write dxhat, dyhat.  Every operand is staged in LDS ONCE,
+// token-major; contractions over the token axis read it through the LDS transpose read (RowFrag, win_attn.cuh), which
+// keeps the per-wave footprint at 6 tiles (was 11 + transposed weight copies) so that 4 waves fit a CU instead of 2;
+// O and dU never touch LDS: they are formed in both register orientations by swapping MFMA operands.
+// Softmax / dS tiles stay in registers and are computed in both orientations instead of being transposed through LDS.
+// Weight gradients are accumulated in LDS per workgroup and flushed once.
 #include "win_attn.cuh"
 using namespace rssf;
 using namespace rssf::wa;
@@ -17,15 +19,13 @@ template <typename T, typename DM, bool ACC_LDS> struct BwdLayout {
   static constexpr int P = Pad<T>::X;
   static constexpr int LDX = DM::CP + P;     // XS/YS/GS   [token][in channel]
   static constexpr int LDV = DM::CV + P;     // QS/KS/VS   [token][virtual channel]
-  static constexpr int LDT = LP + P;         // *T buffers [virtual channel][token]
   static constexpr int LDW = DM::CP + P;     // Wq/Wk/Wv/WoT rows = virtual channel, k = real channel
-  static constexpr int LDM = DM::CV + P;     // WqT/WkT/WvT  rows = real channel,    k = virtual channel
   static constexpr int LDD = DM::DP + P;     // dM / dM^T scratch
   static constexpr int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
-  static constexpr int REGION = (max3(LP * LDX, LP * LDV, DM::CV * LDT) + 7) / 8 * 8;
-  static constexpr int NREG = 11;
+  static constexpr int REGION = (max3(LP * LDX, LP * LDV, 0) + 7) / 8 * 8;
+  static constexpr int NREG = 6;             // XS YS GS | QS KS VS (later dq dk dv)   - all token-major
   static constexpr int SCRATCH = (2 * DM::DP * LDD + 7) / 8 * 8;
-  static constexpr int W_ELEMS = 4 * DM::CV * LDW + 3 * DM::CP * LDM;
+  static constexpr int W_ELEMS = 4 * DM::CV * LDW;
   static constexpr int F_ELEMS = 3 * DM::CV + 2 * DM::CP;                       // bq bk bv, gamma beta
   static constexpr int A_ELEMS = ACC_LDS ? 4 * DM::CV * DM::CP + 3 * DM::CV + DM::CP : 0;
   static constexpr size_t SHARED_OFF = (sizeof(T) * W_ELEMS + sizeof(float) * (F_ELEMS + A_ELEMS) + 15) / 16 * 16;
@@ -61,35 +61,37 @@ __device__ __forceinline__ void load_plain_tile(const Geom& g, const T* src, int
   }
 }
 
-// C-layout tile (rows = virtual channel mt*16+4g+r, col = token tt*16+l15) -> token-major buffer [token][ld]
+// C-layout tile (rows = virtual channel mt*16+4g+r, col = token tt*16+l15) -> token-major buffer [token][ld]: the four
+// values of a lane are contiguous, one 8-byte (bf16) / 16-byte (f32) LDS store; dead tokens (>= L) are written as zero
+// so that contractions over the token axis see only the 49 live slots.
+// 4 consecutive elements of a global row: one 8-byte (bf16) / 16-byte (f32) access
+template <typename T> struct Quad4;
+template <> struct Quad4<bf16_t> {
+  typedef uint2 raw;
+  static __device__ __forceinline__ raw load(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ f32x4 unpack(const raw& u) {
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  }
+};
+template <> struct Quad4<float> {
+  typedef f32x4 raw;
+  static __device__ __forceinline__ raw load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ f32x4 unpack(const raw& u) { return u; }
+};
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) { *reinterpret_cast<s16x4*>(p) = pack_bf16x4(v); }
+__device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <typename T>
-__device__ __forceinline__ void store_tok_major(T* buf, int ld, int mt, int tt, const f32x4& v, int l15, int grp) {
-  T* p = buf + (tt * 16 + l15) * ld + mt * 16 + grp * 4;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) stf(p + r, v[r]);
-}
-// ... -> channel-major buffer [channel][ldt]; dead tokens (>= L) written as zero
-template <typename T>
-__device__ __forceinline__ void store_ch_major(T* buf, int ldt, int mt, int tt, const f32x4& v, int l15, int grp, int L) {
+__device__ __forceinline__ void store_tok_major(T* buf, int ld, int mt, int tt, const f32x4& v, int l15, int grp, int L) {
   const int tok = tt * 16 + l15;
-  const bool live = tok < L;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) stf(buf + (mt * 16 + grp * 4 + r) * ldt + tok, live ? v[r] : 0.f);
-}
-// B-operand "chain" tile gathered from a token-major LDS buffer: rows (k-slots) = tokens t0+4g+r, col = channel c
-template <typename T>
-__device__ __forceinline__ f32x4 gather_rows(const T* buf, int ld, int t0, int c, int grp) {
-  f32x4 v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = ldf(buf + (t0 + grp * 4 + r) * ld + c);
-  return v;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  store4(buf + tok * ld + mt * 16 + grp * 4, tok < L ? v : z);
 }
 
 template <typename T, typename DM, bool ACC_LDS>
 __global__ void __launch_bounds__((BwdLayout<T, DM, ACC_LDS>::WAVES * 64))
 winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   using LY = BwdLayout<T, DM, ACC_LDS>;
-  constexpr int LDX = LY::LDX, LDV = LY::LDV, LDT = LY::LDT, LDW = LY::LDW, LDM = LY::LDM, LDD = LY::LDD;
+  constexpr int LDX = LY::LDX, LDV = LY::LDV, LDW = LY::LDW, LDD = LY::LDD;
   constexpr int C = DM::C, CP = DM::CP, CV = DM::CV, MT = DM::MT, CT = DM::CT, TPH = DM::TPH, D = DM::D, DP = DM::DP;
   const rssf_winattn_fwd_params& p = bp.f;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -97,20 +99,15 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   T* sWk = sWq + CV * LDW;
   T* sWv = sWk + CV * LDW;
   T* sWoT = sWv + CV * LDW;                      // [CV][LDW]  WoT[m][c] = Wo[c][m]
-  T* sWqT = sWoT + CV * LDW;                     // [CP][LDM]  WqT[c][m] = Wq[m][c]
-  T* sWkT = sWqT + CP * LDM;
-  T* sWvT = sWkT + CP * LDM;
-  float* sB = reinterpret_cast<float*>(sWvT + CP * LDM);   // bq bk bv [CV]
+  float* sB = reinterpret_cast<float*>(sWoT + CV * LDW);   // bq bk bv [CV]
   float* sLn = sB + 3 * CV;                      // gamma, beta [CP]
   float* aW = sLn + 2 * CP;                      // accumulators: dWq dWk dWv [CV][CP], dWo^T [CV][CP], dbq dbk dbv [CV], dbo [CP]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, grp = lane >> 4;
   T* base = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)wave * (LY::NREG * LY::REGION + LY::SCRATCH);
   T* XS = base;                 T* YS = XS + LY::REGION;   T* GS = YS + LY::REGION;
-  T* QS = GS + LY::REGION;      T* KS = QS + LY::REGION;   T* VS = KS + LY::REGION;
-  T* QT = VS + LY::REGION;      T* KT = QT + LY::REGION;   T* VT = KT + LY::REGION;   // later dq^T, dk^T, dv^T
-  T* OT = VT + LY::REGION;      T* DUT = OT + LY::REGION;
-  T* dMs = DUT + LY::REGION;    T* dMTs = dMs + DP * LDD;
+  T* QS = GS + LY::REGION;      T* KS = QS + LY::REGION;   T* VS = KS + LY::REGION;    // later dq, dk, dv (head by head)
+  T* dMs = VS + LY::REGION;     T* dMTs = dMs + DP * LDD;
 
   for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
     const int m = i / LDW, k = i % LDW;
@@ -120,14 +117,6 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
     stf(sWk + i, ok ? p.wk[rc * C + k] : 0.f);
     stf(sWv + i, ok ? p.wv[rc * C + k] : 0.f);
     stf(sWoT + i, ok ? p.wo[k * C + rc] : 0.f);
-  }
-  for (int i = threadIdx.x; i < CP * LDM; i += blockDim.x) {
-    const int c = i / LDM, m = i % LDM;
-    const int rc = m < CV ? real_ch<DM>(m) : -1;
-    const bool ok = rc >= 0 && c < C;
-    stf(sWqT + i, ok ? p.wq[rc * C + c] : 0.f);
-    stf(sWkT + i, ok ? p.wk[rc * C + c] : 0.f);
-    stf(sWvT + i, ok ? p.wv[rc * C + c] : 0.f);
   }
   for (int i = threadIdx.x; i < CV; i += blockDim.x) {
     const int rc = real_ch<DM>(i);
@@ -166,6 +155,22 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   T* DYH = reinterpret_cast<T*>(bp.dyhat);
   const int wpi = g.QH * g.QW;
 
+  // Parameter gradients live in registers across ALL windows of this wave (the kernel is LDS-bound to one wave per
+  // SIMD, so VGPRs are free) and are folded into the workgroup's LDS accumulators once at the end; measured before:
+  // ~60 LDS float atomics per lane per window kept the LDS pipe busy 20x longer than all other LDS traffic together.
+  f32x4 gWq[MT][CT], gWk[MT][CT], gWv[MT][CT], gWo[MT][CT];
+  f32x4 gbq[MT], gbk[MT], gbv[MT];
+  float gbo = 0.f;
+  const typename Packed<T>::type ones = Packed<T>::pack(f32x4{1.f, 1.f, 1.f, 1.f});
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      gWq[mt][ct] = {0.f, 0.f, 0.f, 0.f}; gWk[mt][ct] = gWq[mt][ct]; gWv[mt][ct] = gWq[mt][ct]; gWo[mt][ct] = gWq[mt][ct];
+    }
+    gbq[mt] = {0.f, 0.f, 0.f, 0.f}; gbk[mt] = gbq[mt]; gbv[mt] = gbq[mt];
+  }
+
   for (int wi = blockIdx.x * LY::WAVES + wave; wi < g.nWin; wi += gridDim.x * LY::WAVES) {
     const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;
     const int64_t img = (int64_t)b * g.N;
@@ -178,7 +183,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
     load_plain_tile<T, DM>(g, DOUT, img, qh, qw, GS, LDX, lane);
     wave_sync();
 
-    // ---- S2: projections; stage q,k,v both token-major (K = channels) and channel-major (K = tokens) --------
+    // ---- S2: projections; q,k,v staged token-major (K = tokens contractions read them through RowFrag) --------
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int mrow = mt * 16 + grp * 4;
@@ -194,22 +199,17 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           ak[r] += sB[CV + mrow + r];
           av[r] += sB[2 * CV + mrow + r];
         }
-        store_tok_major<T>(QS, LDV, mt, tt, aq, l15, grp);
-        store_tok_major<T>(KS, LDV, mt, tt, ak, l15, grp);
-        store_tok_major<T>(VS, LDV, mt, tt, av, l15, grp);
-        store_ch_major<T>(QT, LDT, mt, tt, aq, l15, grp, g.L);
-        store_ch_major<T>(KT, LDT, mt, tt, ak, l15, grp, g.L);
-        store_ch_major<T>(VT, LDT, mt, tt, av, l15, grp, g.L);
+        store_tok_major<T>(QS, LDV, mt, tt, aq, l15, grp, g.L);
+        store_tok_major<T>(KS, LDV, mt, tt, ak, l15, grp, g.L);
+        store_tok_major<T>(VS, LDV, mt, tt, av, l15, grp, g.L);
       }
     }
     wave_sync();
 
     // dbo += sum_tokens dout   (columns of GS)
-    for (int c = lane; c < CP; c += 64) {
-      float s = 0.f;
-      for (int t = 0; t < g.L; ++t) s += ldf(GS + t * LDX + c);
-      acc_b(3, c, s);
-    }
+    static_assert(CP <= 64, "dbo: one lane per padded channel");
+    if (lane < CP)
+      for (int t = 0; t < g.L; ++t) gbo += ldf(GS + t * LDX + lane);
 
     f32x4 dxt[CT][NT], dyt[CT][NT];     // d(x~)^T, d(y~)^T accumulators: rows = real channel, col = token
 #pragma unroll
@@ -228,7 +228,8 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
 #pragma unroll
         for (int jt = 0; jt < TPH; ++jt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          acc = mma_tile<T>(QT + (hoff + it * 16) * LDT, LDT, KT + (hoff + jt * 16) * LDT, LDT, LP, acc);
+#pragma unroll
+          for (int k0 = 0; k0 < LP; k0 += 16) acc = mma_row_row<T>(QS, LDV, hoff + it * 16, KS, LDV, hoff + jt * 16, k0, acc);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = it * 16 + grp * 4 + r, j = jt * 16 + l15;
@@ -258,7 +259,11 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
         }
 
       // ---- S4: orientation 1 (rows = keys, col = query): P, U = P v, dalpha, dS -> dq -------------------------
+      // U, O = alpha U and dU are ALSO formed with rows = query, col = channel (operand order swapped): in that
+      // orientation they chain straight into dWo (here) and dv (S5) from registers - no LDS copies of O / dU.
       f32x4 dq[TPH][NT], dk[TPH][NT], dv[TPH][NT];
+      typename Packed<T>::type dUq[NT][TPH];               // alpha * dO, rows = query, col = head channel
+
       float smx[NT], sinv[NT], srs[NT];
       float dalpha = 0.f;
 #pragma unroll
@@ -292,21 +297,27 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
         smx[qt] = mx; sinv[qt] = inv;
-        // U^T = v^T P^T ; O = alpha U -> OT ; dalpha += <dO, U> ; dU = alpha dO
+        // U[q][m] = sum_key P[q][key] v[key][m] ; dalpha += <dO, U> ; O = alpha U -> dWo ; dU = alpha dO (both orientations)
 #pragma unroll
         for (int mi = 0; mi < TPH; ++mi) {
-          f32x4 u = {0.f, 0.f, 0.f, 0.f};
+          f32x4 u = {0.f, 0.f, 0.f, 0.f}, dO = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kt = 0; kt < NT; ++kt) u = mma_lds_chain<T>(VT + (hoff + mi * 16) * LDT, LDT, kt * 16, s[kt], u);
+          for (int kt = 0; kt < NT; ++kt)
+            u = Packed<T>::mma(Packed<T>::pack(s[kt]), RowFrag<T>::load(VS, LDV, kt * 16, hoff + mi * 16), u);
+          dO = mma_tile<T>(GS + qt * 16 * LDX, LDX, sWoT + (hoff + mi * 16) * LDW, LDW, CP, dO);    // rows = query, col = channel
           f32x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            dalpha += dU[mi][qt][r] * u[r];
+            dalpha += dO[r] * u[r];
             o[r] = alpha * u[r];
+            dO[r] *= alpha;
             dU[mi][qt][r] *= alpha;
           }
-          store_ch_major<T>(OT, LDT, h * TPH + mi, qt, o, l15, grp, g.L);
-          store_ch_major<T>(DUT, LDT, h * TPH + mi, qt, dU[mi][qt], l15, grp, g.L);
+          dUq[qt][mi] = Packed<T>::pack(dO);
+          const typename Packed<T>::type op = Packed<T>::pack(o);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)      // dWo^T[m][c] += sum_q O[q][m] dout[q][c]   (dout rows of dead slots are zero)
+            gWo[h * TPH + mi][ct] = Packed<T>::mma(op, RowFrag<T>::load(GS, LDX, qt * 16, ct * 16), gWo[h * TPH + mi][ct]);
         }
         // dP^T[key][query] = sum_m v[key][m] dU[query][m]
         f32x4 dp[NT];
@@ -332,25 +343,11 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
         for (int mi = 0; mi < TPH; ++mi) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kt = 0; kt < NT; ++kt) acc = mma_lds_chain<T>(KT + (hoff + mi * 16) * LDT, LDT, kt * 16, dp[kt], acc);
+          for (int kt = 0; kt < NT; ++kt) acc = mma_row_chain<T>(KS, LDV, hoff + mi * 16, kt * 16, dp[kt], acc);
           dq[mi][qt] = acc;
         }
       }
       dalpha = wave_sum(dalpha);            // each tile element lives in exactly one lane: plain sum
-      wave_sync();                          // OT / DUT rows of this head complete
-
-      // dWo[c][m] (m in this head) = sum_t dout[t][c] O[t][m]
-#pragma unroll
-      for (int mi = 0; mi < TPH; ++mi)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int tt = 0; tt < NT; ++tt)
-            acc = mma_lds_chain<T>(OT + (hoff + mi * 16) * LDT, LDT, tt * 16, gather_rows<T>(GS, LDX, tt * 16, ct * 16 + l15, grp), acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc_w(3, hoff + mi * 16 + grp * 4 + r, ct * 16 + l15, acc[r]);
-        }
 
       // ---- S5: orientation 2 (rows = queries, col = key): dS -> dk, P -> dv ---------------------------------------
 #pragma unroll
@@ -378,8 +375,8 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = ak;
 #pragma unroll
           for (int qt = 0; qt < NT; ++qt) {
-            ak = mma_lds_chain<T>(QT + (hoff + mi * 16) * LDT, LDT, qt * 16, ds2[qt], ak);
-            av = mma_lds_chain<T>(DUT + (hoff + mi * 16) * LDT, LDT, qt * 16, p2[qt], av);
+            ak = mma_row_chain<T>(QS, LDV, hoff + mi * 16, qt * 16, ds2[qt], ak);
+            av = Packed<T>::mma(dUq[qt][mi], Packed<T>::pack(p2[qt]), av);      // dv^T[m][key] = sum_q dU[q][m] P[q][key]
           }
           dk[mi][kt] = ak; dv[mi][kt] = av;
         }
@@ -407,108 +404,164 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           f32x4 aq = dq[mi][tt], ak = dk[mi][tt];
 #pragma unroll
           for (int mj = 0; mj < TPH; ++mj) {
-            // k^T / q^T tiles (rows = channel mj*16+4g+r, col = token) gathered from the token-major copies
-            f32x4 kt4, qt4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              kt4[r] = ldf(KS + (tt * 16 + l15) * LDV + hoff + mj * 16 + grp * 4 + r);
-              qt4[r] = ldf(QS + (tt * 16 + l15) * LDV + hoff + mj * 16 + grp * 4 + r);
-            }
-            aq = mma_lds_chain<T>(dMs + mi * 16 * LDD, LDD, mj * 16, kt4, aq);
-            ak = mma_lds_chain<T>(dMTs + mi * 16 * LDD, LDD, mj * 16, qt4, ak);
+            // dq^T += dM k^T, dk^T += dM^T q^T: both operands k-contiguous in LDS (K = head channels mj*16..)
+            aq = mma_tile<T>(dMs + mi * 16 * LDD + mj * 16, LDD, KS + tt * 16 * LDV + hoff + mj * 16, LDV, 16, aq);
+            ak = mma_tile<T>(dMTs + mi * 16 * LDD + mj * 16, LDD, QS + tt * 16 * LDV + hoff + mj * 16, LDV, 16, ak);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) aq[r] *= scale;       // q = (W x + b) * scale
           dq[mi][tt] = aq; dk[mi][tt] = ak;
         }
-      wave_sync();   // every read of QT/KT/VT rows of this head is done -> reuse them for dq^T, dk^T, dv^T
+      wave_sync();   // every read of the QS/KS/VS columns of this head is done -> reuse them for dq, dk, dv
 
       // ---- S7: stage gradients of the projection outputs; bias grads; input grads --------------------------------
 #pragma unroll
       for (int mi = 0; mi < TPH; ++mi) {
-        float sq[4] = {0.f, 0.f, 0.f, 0.f}, sk[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-          store_ch_major<T>(QT, LDT, h * TPH + mi, tt, dq[mi][tt], l15, grp, g.L);
-          store_ch_major<T>(KT, LDT, h * TPH + mi, tt, dk[mi][tt], l15, grp, g.L);
-          store_ch_major<T>(VT, LDT, h * TPH + mi, tt, dv[mi][tt], l15, grp, g.L);
+          store_tok_major<T>(QS, LDV, h * TPH + mi, tt, dq[mi][tt], l15, grp, g.L);
+          store_tok_major<T>(KS, LDV, h * TPH + mi, tt, dk[mi][tt], l15, grp, g.L);
+          store_tok_major<T>(VS, LDV, h * TPH + mi, tt, dv[mi][tt], l15, grp, g.L);
           const bool live = tt * 16 + l15 < g.L;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+          for (int r = 0; r < 4; ++r)
             if (!live) { dq[mi][tt][r] = 0.f; dk[mi][tt][r] = 0.f; dv[mi][tt][r] = 0.f; }
-            sq[r] += dq[mi][tt][r]; sk[r] += dk[mi][tt][r]; sv[r] += dv[mi][tt][r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) {
-            sq[r] += __shfl_xor(sq[r], o, 64); sk[r] += __shfl_xor(sk[r], o, 64); sv[r] += __shfl_xor(sv[r], o, 64);
-          }
-          if (l15 == 0) {
-            const int m = hoff + mi * 16 + grp * 4 + r;
-            acc_b(0, m, sq[r]); acc_b(1, m, sk[r]); acc_b(2, m, sv[r]);
-          }
         }
         // d(x~)^T[c][t] += sum_m Wq[m][c] dq[m][t] ;  d(y~)^T += Wk^T dk + Wv^T dv
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int tt = 0; tt < NT; ++tt) {
-            dxt[ct][tt] = mma_lds_chain<T>(sWqT + ct * 16 * LDM, LDM, hoff + mi * 16, dq[mi][tt], dxt[ct][tt]);
-            dyt[ct][tt] = mma_lds_chain<T>(sWkT + ct * 16 * LDM, LDM, hoff + mi * 16, dk[mi][tt], dyt[ct][tt]);
-            dyt[ct][tt] = mma_lds_chain<T>(sWvT + ct * 16 * LDM, LDM, hoff + mi * 16, dv[mi][tt], dyt[ct][tt]);
+            dxt[ct][tt] = mma_row_chain<T>(sWq, LDW, ct * 16, hoff + mi * 16, dq[mi][tt], dxt[ct][tt]);
+            dyt[ct][tt] = mma_row_chain<T>(sWk, LDW, ct * 16, hoff + mi * 16, dk[mi][tt], dyt[ct][tt]);
+            dyt[ct][tt] = mma_row_chain<T>(sWv, LDW, ct * 16, hoff + mi * 16, dv[mi][tt], dyt[ct][tt]);
           }
       }
     }
     wave_sync();
 
-    // ---- S8: weight gradients dW[m][c] = sum_t d(proj)^T[m][t] * in[t][c] -------------------------------------------
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq, av = aq;
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-          const f32x4 xg = gather_rows<T>(XS, LDX, tt * 16, ct * 16 + l15, grp);
-          const f32x4 yg = gather_rows<T>(YS, LDX, tt * 16, ct * 16 + l15, grp);
-          aq = mma_lds_chain<T>(QT + mt * 16 * LDT, LDT, tt * 16, xg, aq);
-          ak = mma_lds_chain<T>(KT + mt * 16 * LDT, LDT, tt * 16, yg, ak);
-          av = mma_lds_chain<T>(VT + mt * 16 * LDT, LDT, tt * 16, yg, av);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = mt * 16 + grp * 4 + r, c = ct * 16 + l15;
-          acc_w(0, m, c, aq[r]); acc_w(1, m, c, ak[r]); acc_w(2, m, c, av[r]);
-        }
-      }
-
-    // ---- S9: dxhat = d(x~) * omega0, dyhat = d(y~) * omega1 ; domega += d(x~) * LN(x) ----------------------------------
+    // ---- S8: weight gradients dW[m][c] = sum_t d(proj)[t][m] * in[t][c]; bias gradients = the same contraction against
+    //      a column of ones (every column of the gb* tiles holds the row sum; column 0 is flushed) ------------------------
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
-      const int n = slot_token(g, qh, qw, tt * 16 + l15);
-      if (n < 0) continue;
-      const float2 sx = *reinterpret_cast<const float2*>(p.stats_x + (img + n) * 2);
-      const float2 sy = *reinterpret_cast<const float2*>(p.stats_y + (img + n) * 2);
+      typename Packed<T>::type fx[CT], fy[CT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct) {
+        fx[ct] = RowFrag<T>::load(XS, LDX, tt * 16, ct * 16);
+        fy[ct] = RowFrag<T>::load(YS, LDX, tt * 16, ct * 16);
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = ct * 16 + grp * 4 + r;
-          if (c >= C) continue;
-          const int64_t f = (int64_t)n * C + c;
-          const int pp = (int)(f % g.N);
-          const int64_t off = img * C + f;
-          const float xh = (ldf(X + off) - sx.x) * sx.y * sLn[c] + sLn[CP + c];
-          const float yh = (ldf(Y + off) - sy.x) * sy.y * sLn[c] + sLn[CP + c];
-          stf(DXH + off, dxt[ct][tt][r] * om0[pp]);
-          stf(DYH + off, dyt[ct][tt][r] * om0[g.N + pp]);
-          atomicAdd(dom0 + pp, dxt[ct][tt][r] * xh);
-          atomicAdd(dom0 + g.N + pp, dyt[ct][tt][r] * yh);
+      for (int mt = 0; mt < MT; ++mt) {
+        const typename Packed<T>::type fq = RowFrag<T>::load(QS, LDV, tt * 16, mt * 16), fk = RowFrag<T>::load(KS, LDV, tt * 16, mt * 16),
+                                       fv = RowFrag<T>::load(VS, LDV, tt * 16, mt * 16);
+        gbq[mt] = Packed<T>::mma(fq, ones, gbq[mt]);
+        gbk[mt] = Packed<T>::mma(fk, ones, gbk[mt]);
+        gbv[mt] = Packed<T>::mma(fv, ones, gbv[mt]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          gWq[mt][ct] = Packed<T>::mma(fq, fx[ct], gWq[mt][ct]);
+          gWk[mt][ct] = Packed<T>::mma(fk, fy[ct], gWk[mt][ct]);
+          gWv[mt][ct] = Packed<T>::mma(fv, fy[ct], gWv[mt][ct]);
         }
+      }
+    }
+
+    // ---- S9: dxhat = d(x~) * omega0, dyhat = d(y~) * omega1 ; domega += d(x~) * LN(x) ----------------------------------
+    // A lane owns 4 consecutive channels (4g..4g+3 of tile ct) of token tt*16 + l15.  Vector path (C and N multiples of
+    // 4: the 4 gate weights are contiguous and never wrap): all global loads of a token tile are issued branch-free
+    // (dead / padded slots read token 0) before anything is consumed; 8-byte stores; only the stores / atomics are
+    // predicated.
+    if ((C % 4 == 0) && (g.N % 4 == 0)) {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int n = slot_token(g, qh, qw, tt * 16 + l15);
+        const int nn = n >= 0 ? n : 0;
+        const float2 sx = *reinterpret_cast<const float2*>(p.stats_x + (img + nn) * 2);
+        const float2 sy = *reinterpret_cast<const float2*>(p.stats_y + (img + nn) * 2);
+        typename Quad4<T>::raw rx[CT], ry[CT];
+        f32x4 w0[CT], w1[CT];
+        int pp[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c0 = ct * 16 + grp * 4;
+          const int cc = c0 < C ? c0 : 0;
+          const int64_t f = (int64_t)nn * C + cc;
+          pp[ct] = (int)(f % g.N);
+          rx[ct] = Quad4<T>::load(X + img * C + f);
+          ry[ct] = Quad4<T>::load(Y + img * C + f);
+          w0[ct] = *reinterpret_cast<const f32x4*>(om0 + pp[ct]);
+          w1[ct] = *reinterpret_cast<const f32x4*>(om0 + g.N + pp[ct]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c0 = ct * 16 + grp * 4;
+          if (n < 0 || c0 >= C) continue;
+          const f32x4 xv = Quad4<T>::unpack(rx[ct]), yv = Quad4<T>::unpack(ry[ct]);
+          f32x4 ox, oy, gx, gy;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ga = sLn[c0 + r], be = sLn[CP + c0 + r];
+            ox[r] = dxt[ct][tt][r] * w0[ct][r];
+            oy[r] = dyt[ct][tt][r] * w1[ct][r];
+            gx[r] = dxt[ct][tt][r] * ((xv[r] - sx.x) * sx.y * ga + be);
+            gy[r] = dyt[ct][tt][r] * ((yv[r] - sy.x) * sy.y * ga + be);
+          }
+          const int64_t off = img * C + (int64_t)n * C + c0;
+          store4(DXH + off, ox);
+          store4(DYH + off, oy);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(dom0 + pp[ct] + r, gx[r]);
+            atomicAdd(dom0 + g.N + pp[ct] + r, gy[r]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int n = slot_token(g, qh, qw, tt * 16 + l15);
+        if (n < 0) continue;
+        const float2 sx = *reinterpret_cast<const float2*>(p.stats_x + (img + n) * 2);
+        const float2 sy = *reinterpret_cast<const float2*>(p.stats_y + (img + n) * 2);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = ct * 16 + grp * 4 + r;
+            if (c >= C) continue;
+            const int64_t f = (int64_t)n * C + c;
+            const int pp = (int)(f % g.N);
+            const int64_t off = img * C + f;
+            const float xh = (ldf(X + off) - sx.x) * sx.y * sLn[c] + sLn[CP + c];
+            const float yh = (ldf(Y + off) - sy.x) * sy.y * sLn[c] + sLn[CP + c];
+            stf(DXH + off, dxt[ct][tt][r] * om0[pp]);
+            stf(DYH + off, dyt[ct][tt][r] * om0[g.N + pp]);
+            atomicAdd(dom0 + pp, dxt[ct][tt][r] * xh);
+            atomicAdd(dom0 + g.N + pp, dyt[ct][tt][r] * yh);
+          }
+      }
     }
   }
+
+  // ---- fold this wave's register accumulators into the workgroup accumulators (or straight into HBM) -------------------
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + grp * 4 + r, c = ct * 16 + l15;
+        acc_w(0, m, c, gWq[mt][ct][r]); acc_w(1, m, c, gWk[mt][ct][r]); acc_w(2, m, c, gWv[mt][ct][r]);
+        acc_w(3, m, c, gWo[mt][ct][r]);
+      }
+    if (l15 == 0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + grp * 4 + r;
+        acc_b(0, m, gbq[mt][r]); acc_b(1, m, gbk[mt][r]); acc_b(2, m, gbv[mt][r]);
+      }
+  }
+  if (lane < CP) acc_b(3, lane, gbo);
 
   if (ACC_LDS) {
     __syncthreads();
