@@ -252,6 +252,133 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
   }
 }
 
+// ---- halo-tiled weight gradient of the 3x3 / stride-1 / "same" bf16 convolutions (HRNet BasicBlock / Bottleneck) -------
+// A block owns one 32 x 32 (co, ci) tile and a run of 8 x 16-pixel spatial tiles.  Per spatial tile it stages the dout tile
+// [128 px][32 co] and the input HALO [10 x 18 px][32 ci] once (pixel-major, plain 16-byte copies, next tile's global loads
+// in flight under the MFMAs) and all nine taps contract out of LDS: the tap only shifts the row index of the input
+// operand's transpose reads.  Each wave owns one 16 x 16 sub-tile of every tap (9 accumulators, no cross-wave reduction).
+// Versus the generic kernel (a block per tap, the dout slab and a shifted input slab re-staged per 64 pixels): 4x less
+// L2 -> LDS traffic, two barriers per 36 MFMAs per wave instead of per 2, and the split-K factor (= partial planes the
+// second stage has to fold) drops to ntiles / 8.
+struct WgradHaloArgs {
+  const bf16_t* dout;    // [B, H, W, Cout]
+  const bf16_t* in;      // [B, H, W, Cin]
+  float* partial;        // [ksplit][9][Cout][Cin]
+  int B, H, W, Cin, Cout, tiles_y, tiles_x, ntiles, tiles_per_block, npairs, ptiles_n, xcd_per;
+  int64_t total;
+  int dy[9], dx[9];
+};
+constexpr int HTH = 8, HTW = 16, HHP = (HTH + 2) * (HTW + 2), HNPX = HTH * HTW, HCT = 32, HLD = HCT + 16;
+
+__global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
+  constexpr int X_LOADS = (HHP * 4 + 255) / 256, D_LOADS = HNPX * 4 / 256;
+  __shared__ __attribute__((aligned(16))) bf16_t XH[HHP * HLD];
+  __shared__ __attribute__((aligned(16))) bf16_t DS[HNPX * HLD];
+  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);       // the (co, ci) tiles of one pixel range share an XCD's L2
+  if (q >= a.total) return;
+  const int pair = (int)(q % a.npairs), range = (int)(q / a.npairs);
+  const int co0 = (pair / a.ptiles_n) * HCT, ci0 = (pair % a.ptiles_n) * HCT;
+  const int t_begin = range * a.tiles_per_block;
+  const int t_end = t_begin + a.tiles_per_block < a.ntiles ? t_begin + a.tiles_per_block : a.ntiles;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+
+  Vec<bf16_t> rx[X_LOADS], rd[D_LOADS];
+  bool xok[X_LOADS], dok[D_LOADS];
+  auto load_tile = [&](int t) {
+    const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * HTH, x0 = tx * HTW;
+#pragma unroll
+    for (int i = 0; i < X_LOADS; ++i) {
+      const int idx = tid + i * 256, p = idx >> 2, ch = ci0 + (idx & 3) * 8;
+      const int gy = y0 - 1 + p / (HTW + 2), gx = x0 - 1 + p % (HTW + 2);
+      xok[i] = idx < HHP * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ch < a.Cin;
+      rx[i].load(a.in + (xok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cin + ch : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      const int idx = tid + i * 256, p = idx >> 2, ch = co0 + (idx & 3) * 8;
+      const int gy = y0 + p / HTW, gx = x0 + p % HTW;
+      dok[i] = gy < a.H && gx < a.W && ch < a.Cout;
+      rd[i].load(a.dout + (dok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + ch : 0));
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < X_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      Vec<bf16_t> v = rx[i];
+      if (!xok[i]) v.raw = {0, 0, 0, 0};
+      if (idx < HHP * 4) v.store(XH + (idx >> 2) * HLD + (idx & 3) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      Vec<bf16_t> v = rd[i];
+      if (!dok[i]) v.raw = {0, 0, 0, 0};
+      v.store(DS + (idx >> 2) * HLD + (idx & 3) * 8);
+    }
+  };
+  // this lane's transpose-read base rows: dout tile row (pixel) / halo row of tap (0,0) for the 32-pixel k-step 0
+  const int i4 = l15 >> 2, c4 = (l15 & 3) * 4;
+  const bf16_t* dbase = DS + (grp * 8 + i4) * HLD + wm * 16 + c4;
+  const bf16_t* xbase = XH + (((grp >> 1) + 1) * (HTW + 2) + (grp & 1) * 8 + 1 + i4) * HLD + wn * 16 + c4;
+  auto tr8 = [&](const bf16_t* p) {          // 8 K values (two transpose reads 4 rows apart) of this lane's column
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * HLD));
+    union { struct { v4s a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+  };
+
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    store_tile();
+    __syncthreads();
+    if (t + 1 < t_end) load_tile(t + 1);
+#pragma unroll
+    for (int ks = 0; ks < HNPX / 32; ++ks) {                  // 32 pixels = image rows 2ks, 2ks+1 of the tile
+      const bf16x8 fa = tr8(dbase + ks * 32 * HLD);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const bf16x8 fb = tr8(xbase + ((2 * ks + a.dy[tap]) * (HTW + 2) + a.dx[tap]) * HLD);
+        acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[tap], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wm * 16 + grp * 4 + r, ci = ci0 + wn * 16 + l15;
+      if (co < a.Cout && ci < a.Cin) a.partial[(((int64_t)range * 9 + tap) * a.Cout + co) * a.Cin + ci] = acc[tap][r];
+    }
+}
+
+// spatial tiles per block: 8 when that still yields >= 256 blocks, fewer for small problems
+int halo_tiles_per_block(int64_t ntiles, int npairs) {
+  int tpb = 8;
+  while (tpb > 1 && ((ntiles + tpb - 1) / tpb) * npairs < 256) tpb >>= 1;
+  return tpb;
+}
+int halo_ksplit(int B, int H, int W, int Cout, int Cin) {
+  const int64_t ntiles = (int64_t)B * ((H + HTH - 1) / HTH) * ((W + HTW - 1) / HTW);
+  const int npairs = ((Cout + HCT - 1) / HCT) * ((Cin + HCT - 1) / HCT);
+  const int tpb = halo_tiles_per_block(ntiles, npairs);
+  return (int)((ntiles + tpb - 1) / tpb);
+}
+bool halo_wgrad_eligible(int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, int nsrc, const int* dy, const int* dx) {
+  if (stride != 1 || IH != OH || IW != OW || ntaps != 9 || nsrc != 1 || (Cin % 8) != 0 || (Cout % 8) != 0) return false;
+  for (int t = 0; t < 9; ++t)
+    if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1) return false;
+  return true;
+}
+
 // Tiling: 32x32 output tile with all 9 taps of a 3x3 in registers for the 32-channel layers (few FLOPs per pixel:
 // stage dout once per slab); 64x64 / 128x128 tiles with ONE tap per block for wider layers (light registers -> many
 // resident blocks hide the gather latency; 128x128 doubles the FLOPs per staged byte for the MLP's 128-channel convs).
@@ -321,7 +448,9 @@ int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
 }  // namespace
 
 extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Cin, int Cout, int ntaps) {
-  return (int64_t)pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW) * ntaps * Cout * Cin;
+  int ks = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
+  if (ntaps == 9) { const int hk = halo_ksplit(B, OH, OW, Cout, Cin); if (hk > ks) ks = hk; }   // either kernel may run
+  return (int64_t)ks * ntaps * Cout * Cin;
 }
 
 extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
@@ -344,6 +473,23 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
   a.partial = workspace; a.ntaps_total = ntaps;
   a.ksplit = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_BF16 && workspace && !dbias && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx)) {
+    WgradHaloArgs h;
+    h.dout = (const bf16_t*)dout; h.in = (const bf16_t*)in; h.partial = workspace;
+    h.B = B; h.H = IH; h.W = IW; h.Cin = Cin; h.Cout = Cout;
+    h.tiles_y = (IH + HTH - 1) / HTH; h.tiles_x = (IW + HTW - 1) / HTW; h.ntiles = B * h.tiles_y * h.tiles_x;
+    h.ptiles_n = (Cin + HCT - 1) / HCT; h.npairs = ((Cout + HCT - 1) / HCT) * h.ptiles_n;
+    h.tiles_per_block = halo_tiles_per_block(h.ntiles, h.npairs);
+    a.ksplit = (h.ntiles + h.tiles_per_block - 1) / h.tiles_per_block;
+    h.total = (int64_t)a.ksplit * h.npairs;
+    h.xcd_per = xcd_per(h.total);
+    for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
+    conv3x3_wgrad_halo_kernel<<<(unsigned)h.xcd_per * 8, 256, 0, st>>>(h);
+    if (int rc = check_launch("conv3x3_wgrad_halo")) return rc;
+    const int64_t per = (int64_t)ntaps * Cout * Cin;
+    wgrad_reduce_kernel<<<(unsigned)((per + RI - 1) / RI), 256, 0, st>>>(a);
+    return check_launch("conv_wgrad_reduce");
+  }
   if (dtype == RSSF_F32) return launch_all<float>(a, ntaps, st);
   if (dtype == RSSF_BF16) return launch_all<bf16_t>(a, ntaps, st);
   set_error("conv_wgrad: unsupported dtype %d", dtype);
