@@ -48,9 +48,13 @@ template <typename T> struct SlabFrag;
 template <> struct SlabFrag<bf16_t> {
   static __device__ __forceinline__ bf16x8 load(const bf16_t* slab, int ld, int k0, int c0, int lane) {
     const int grp = lane >> 4, i = lane & 15;
-    const bf16_t* p = slab + (k0 + grp * 8 + (i >> 2)) * ld + c0 + (i & 3) * 4;
+    // K-slot -> pixel-row map of a 32-row K-step: lane group g takes rows 4g..4g+3 (first read) and 16+4g..16+4g+3
+    // (second read).  Any bijection works as long as both operands use it; this one makes the 32 lanes an LDS cycle
+    // services touch rows 0..7 (resp. 16..23): eight consecutive 32-byte bank groups with the +32 B row pad.  (With rows
+    // 8g..8g+3 the two lane groups of a cycle sit 8 rows = 0 mod 256 B apart: a 2-way conflict on every read.)
+    const bf16_t* p = slab + (k0 + grp * 4 + (i >> 2)) * ld + c0 + (i & 3) * 4;
     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
-    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * ld));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 16 * ld));
     union { struct { v4s a, b; } s; bf16x8 v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
@@ -114,18 +118,34 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   int pb[CHUNKS], py[CHUNKS], px[CHUNKS];
   bool pv[CHUNKS], dok[CHUNKS], xok[CHUNKS];
 
-  auto set_slab = [&](int64_t k0) {   // pixel coordinates of this thread's rows of the slab starting at pixel k0 + its dout rows
+  // Pixel coordinates of this thread's slab rows are carried from slab to slab (+KP pixels with carries) instead of being
+  // re-derived by integer division: the index arithmetic was ~11 VALU instructions per MFMA (a third of the wave's cycles).
+  // Offsets are 32-bit (the host entry rejects tensors of >= 2^31 elements).
+  int pix[CHUNKS];
+  auto first_slab = [&](int64_t k0) {
 #pragma unroll
     for (int c = 0; c < CHUNKS; ++c) {
-      const int64_t p = k0 + srow[c];
-      pv[c] = srow[c] < KP && p < kend;
-      const int pp = pv[c] ? (int)p : 0;                  // M < 2^31 (checked by the host entry)
-      pb[c] = pp / (a.OH * a.OW);
-      const int rem = pp % (a.OH * a.OW);
+      pix[c] = (int)k0 + srow[c];
+      pb[c] = pix[c] / (a.OH * a.OW);
+      const int rem = pix[c] % (a.OH * a.OW);
       py[c] = rem / a.OW; px[c] = rem % a.OW;
+    }
+  };
+  auto next_slab = [&]() {
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      pix[c] += KP; px[c] += KP;
+      while (px[c] >= a.OW) { px[c] -= a.OW; ++py[c]; }
+      while (py[c] >= a.OH) { py[c] -= a.OH; ++pb[c]; }
+    }
+  };
+  auto load_d = [&]() {               // dout rows of the current slab
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      pv[c] = srow[c] < KP && pix[c] < (int)kend;
       const int ch = co0 + scol[c];
       dok[c] = pv[c] && ch < a.Cout;
-      const int64_t off = dok[c] ? (int64_t)pp * a.Cout + ch : 0;
+      const int off = dok[c] ? pix[c] * a.Cout + ch : 0;
       if constexpr (VOK) {
         rd[c].load(DO + off);
       } else {
@@ -142,7 +162,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
       const int sy = py[c] * a.stride + dy, sx = px[c] * a.stride + dx;
       const int ch = ci0 + scol[c];
       xok[c] = pv[c] && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW && ch < a.Cin;
-      const int64_t off = xok[c] ? (((int64_t)pb[c] * a.IH + sy) * a.IW + sx) * a.Cin + ch : 0;
+      const int off = xok[c] ? ((pb[c] * a.IH + sy) * a.IW + sx) * a.Cin + ch : 0;
       if constexpr (VOK) {
         rx[c].load(IN + off);
       } else {
@@ -156,7 +176,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   // Software pipeline over (slab, tap) steps: the operands of the NEXT step (next tap of this slab, or the dout rows and
   // first tap of the next slab) are requested right after the barrier that publishes the current step, so the global
   // latency runs under the MFMAs instead of in front of them.
-  if (kbeg < kend) { set_slab(kbeg); load_x(0); }
+  if (kbeg < kend) { first_slab(kbeg); load_d(); load_x(0); }
   for (int64_t k0 = kbeg; k0 < kend; k0 += KP) {
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
@@ -175,7 +195,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
           }
         __syncthreads();
         if (t + 1 < TG && t + 1 < a.ntap) load_x(t + 1);
-        else if (k0 + KP < kend) { set_slab(k0 + KP); load_x(0); }
+        else if (k0 + KP < kend) { next_slab(); load_d(); load_x(0); }
 #pragma unroll
         for (int ks = 0; ks < KP; ks += MK::KSTEP) {
           typename MK::frag fa[WI], fb[WI];
@@ -325,11 +345,12 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
   };
   // this lane's transpose-read base rows: dout tile row (pixel) / halo row of tap (0,0) for the 32-pixel k-step 0
   const int i4 = l15 >> 2, c4 = (l15 & 3) * 4;
-  const bf16_t* dbase = DS + (grp * 8 + i4) * HLD + wm * 16 + c4;
-  const bf16_t* xbase = XH + (((grp >> 1) + 1) * (HTW + 2) + (grp & 1) * 8 + 1 + i4) * HLD + wn * 16 + c4;
-  auto tr8 = [&](const bf16_t* p) {          // 8 K values (two transpose reads 4 rows apart) of this lane's column
+  // K-slot map of a 32-pixel step (see SlabFrag): first read = pixels 4g..4g+3 of image row 2ks, second = same of row 2ks+1
+  const bf16_t* dbase = DS + (grp * 4 + i4) * HLD + wm * 16 + c4;
+  const bf16_t* xbase = XH + ((HTW + 2) + grp * 4 + 1 + i4) * HLD + wn * 16 + c4;
+  auto tr8 = [&](const bf16_t* p, int hi_rows) {   // 8 K values of this lane's column: two transpose reads `hi_rows` rows apart
     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
-    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 4 * HLD));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + hi_rows * HLD));
     union { struct { v4s a, b; } s; bf16x8 v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
@@ -342,10 +363,10 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
     if (t + 1 < t_end) load_tile(t + 1);
 #pragma unroll
     for (int ks = 0; ks < HNPX / 32; ++ks) {                  // 32 pixels = image rows 2ks, 2ks+1 of the tile
-      const bf16x8 fa = tr8(dbase + ks * 32 * HLD);
+      const bf16x8 fa = tr8(dbase + ks * 32 * HLD, HTW);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const bf16x8 fb = tr8(xbase + ((2 * ks + a.dy[tap]) * (HTW + 2) + a.dx[tap]) * HLD);
+        const bf16x8 fb = tr8(xbase + ((2 * ks + a.dy[tap]) * (HTW + 2) + a.dx[tap]) * HLD, HTW + 2);
         acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[tap], 0, 0, 0);
       }
     }
@@ -460,7 +481,8 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
-  RSSF_REQUIRE((int64_t)B * OH * OW < (int64_t)1 << 31, "conv_wgrad: more than 2^31 output pixels");
+  RSSF_REQUIRE((int64_t)B * OH * OW * Cout < ((int64_t)1 << 31) && (int64_t)B * IH * IW * Cin < ((int64_t)1 << 31),
+               "conv_wgrad: activation tensors of 2^31 or more elements are not supported (32-bit offsets)");
   WgradArgs a;
   a.dout = dout; a.in = in; a.dw[0] = dw0; a.dw[1] = dw1; a.dw[2] = dw2; a.dbias = dbias;
   for (int i = 0; i < 3; ++i) a.ks[i] = i < nsrc ? ksizes[i] : 1;
