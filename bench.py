@@ -9,7 +9,8 @@ minibatch already resident in HBM: RSSFormer-Base (HRNetV2-W32 + 8 transformer b
 per-GPU batch 16 x 3 x 512 x 512 (BASELINE configs[1] / [2]), bf16 activations with fp32 master weights.  Prints ONE
 JSON line on rank 0.  `roofline` times the fused window cross-attention forward kernel (the kernel BASELINE's
 north_star names; HBM-bound) with HIP events on the launch stream; `cpu_baseline` times the CPU
-restatement (oracle/) of the same step on the host cores, rank 0, N=1 only.
+restatement (oracle/) of the same step on the host cores, rank 0, N=1 only.  `roofline_mfma` is the same measurement
+for the step's largest GEMM (the MlpDWBN 19-tap fused convolution), which is MFMA-bound.
 """
 import argparse
 import json
@@ -59,6 +60,36 @@ def measure_window_attention(B, S, iters=30):
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel="winattn_fwd_kernel<bf16,Dims<32,2>>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, us_per_launch=round(ms * 1e3, 2), algorithmic_bytes=alg_bytes)
+
+
+def measure_mlp_conv(B, S, iters=20):
+    """Average duration of the MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12} convolution (ONE 19-tap implicit-GEMM launch,
+    128 -> 128 channels on the (S/4)^2 map): the largest single GEMM of the step, MFMA-bound."""
+    from representationlearning_amd import nnf
+    H = W = S // 4
+    C = 128
+    dev = "cuda"
+    torch.manual_seed(0)
+    convs = [torch.nn.Conv2d(C, C, 1), torch.nn.Conv2d(C, C, 3, padding=6, dilation=6), torch.nn.Conv2d(C, C, 3, padding=12, dilation=12)]
+    convs = [c.to(dev) for c in convs]
+    spec = nnf.spec_of(convs)
+    x = torch.nn.functional.gelu(torch.randn(B, H, W, C, device=dev)).bfloat16()      # the distribution fc1 + GELU feeds it
+    ws = [c.weight for c in convs]
+    for _ in range(3):
+        nnf._conv_forward(spec, x, ws, None, None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        nnf._conv_forward(spec, x, ws, None, None)          # includes the (4 us) weight packing launch
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * H * W * C * C * spec.ntaps
+    tf = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel="conv_gather_kernel<bf16,128,128> (MlpDWBN 19-tap fused conv, 128->128 ch)", achieved=round(tf, 1),
+                peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s", frac=round(tf * 1e12 / MFMA_BF16_PEAK, 4), traffic=None,
+                us_per_launch=round(ms * 1e3, 2), algorithmic_flops=flops)
 
 
 def _cpu_baseline_child(threads, batch, max_steps):
@@ -186,6 +217,7 @@ def main():
         }
         if world == 1:
             line["roofline"] = measure_window_attention(args.batch, args.size)
+            line["roofline_mfma"] = measure_mlp_conv(args.batch, args.size)
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
