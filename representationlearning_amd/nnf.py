@@ -99,14 +99,15 @@ class ConvSpec:
         return self._out_hw(h, w)
 
 
-_SPEC_CACHE = {}
-
-
 def spec_of(convs):
-    key = tuple(id(c) for c in convs)
-    sp = _SPEC_CACHE.get(key)
+    """ConvSpec of a (tuple of) nn.Conv2d, cached ON the first module (a global dict keyed by id() would hand a stale
+    spec to a new module that happens to reuse the address of a freed one)."""
+    c0 = convs[0]
+    key = tuple(id(c) for c in convs[1:])
+    cache = c0.__dict__.setdefault("_rssf_specs", {})
+    sp = cache.get(key)
     if sp is None:
-        sp = _SPEC_CACHE[key] = ConvSpec(convs)
+        sp = cache[key] = ConvSpec(convs)
     return sp
 
 
@@ -271,7 +272,16 @@ def _pack(spec, weights, transpose, dtype, device):
     return out
 
 
+def _pad_channels(t):
+    """[B,H,W,C] -> channels zero-padded to the 16-byte vector width (C=3 stem input, C=6 head gradient, 18-channel Small):
+    the kernels then take their vector paths; the packed weight slabs are zero there anyway."""
+    v = 8 if t.dtype == torch.bfloat16 else 4
+    c = t.shape[-1]
+    return t if c % v == 0 else torch.nn.functional.pad(t, (0, v - c % v))
+
+
 def _conv_forward(spec, xh, weights, bias, stats):
+    xh = _pad_channels(xh)
     B, H, W, C = xh.shape
     OH, OW = spec.out_hw(H, W)
     wpk = _pack(spec, weights, False, xh.dtype, xh.device)
@@ -284,10 +294,11 @@ def _conv_forward(spec, xh, weights, bias, stats):
 
 def _conv_dgrad(spec, dout, weights, in_shape):
     B, H, W, C = in_shape
-    _, OH, OW, _ = dout.shape
+    dout = _pad_channels(dout)
+    _, OH, OW, cout_p = dout.shape
     wpk = _pack(spec, weights, True, dout.dtype, dout.device)
     dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype)
-    L.check(L.load().rssf_conv_gather(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, B, OH, OW, spec.cout, H, W, C, 1, spec.stride,
+    L.check(L.load().rssf_conv_gather(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, B, OH, OW, cout_p, H, W, C, 1, spec.stride,
                                       spec.ntaps, _ia([-v for v in spec.dy]), _ia([-v for v in spec.dx]), L.dtype_code(dout),
                                       L.stream()), "rssf_conv_gather(dgrad)")
     return dx
@@ -295,14 +306,25 @@ def _conv_dgrad(spec, dout, weights, in_shape):
 
 def _conv_wgrad(spec, dout, xh, dws, db):
     """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional)."""
+    xh, dout = _pad_channels(xh), _pad_channels(dout)
     B, H, W, C = xh.shape
-    _, OH, OW, _ = dout.shape
-    d = list(dws) + [None, None]
+    _, OH, OW, CO = dout.shape
+    padded = C != spec.cin or CO != spec.cout
+    tgt, tdb = list(dws), db
+    if padded:            # gradients of the padded problem, sliced back afterwards
+        tgt = [torch.zeros(CO, C, k, k, device=xh.device, dtype=torch.float32) for k in spec.ksizes]
+        tdb = torch.zeros(CO, device=xh.device, dtype=torch.float32) if db is not None else None
+    d = tgt + [None, None]
     lib = L.load()
-    ws = torch.empty(lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, spec.cout, spec.ntaps), device=xh.device, dtype=torch.float32)
+    ws = torch.empty(lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, CO, spec.ntaps), device=xh.device, dtype=torch.float32)
     L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), _ia(spec.ksizes), len(dws),
-                                     _ia(spec.src), _ia(spec.kpos), L.ptr(db), L.ptr(ws), B, H, W, C, OH, OW, spec.cout, spec.stride, spec.ntaps,
+                                     _ia(spec.src), _ia(spec.kpos), L.ptr(tdb), L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps,
                                      _ia(spec.dy), _ia(spec.dx), L.dtype_code(xh), L.stream()), "rssf_conv_wgrad")
+    if padded:
+        for g, t in zip(dws, tgt):
+            g += t[:spec.cout, :spec.cin]
+        if db is not None:
+            db += tdb[:spec.cout]
 
 
 class _ConvBNAct(torch.autograd.Function):

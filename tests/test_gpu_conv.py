@@ -40,6 +40,7 @@ CONVS = [  # ci, co, k, stride, pad, dil, bias, B, H, W
     (256, 256, 3, 1, 1, 1, False, 2, 4, 4),
     (48, 96, 3, 1, 1, 1, True, 3, 21, 37),          # halo kernel: ragged tiles, partial channel chunk, bias
     (64, 128, 3, 1, 1, 1, False, 4, 64, 128),       # halo kernel: 64-wide channel tile
+    (480, 6, 1, 1, 0, 1, True, 1, 16, 16),          # the head's shape: 6 output channels (gradient padded to 8)
 ]
 
 
