@@ -58,7 +58,9 @@ int rssf_gate_pool_fwd(const void* x, const void* y, const float* stats_x, const
 int rssf_gate_weights_fwd(const float* pooled, const float* k, const float* wl, const float* bl, float* gsig,
                           float* omega, float* logits, int B, int H, int W, void* stream);
 /* backward of gate_weights: domega [B][2][N] -> dpooled; dk, dwl, dbl accumulated (+=).
- * `dpooled` must hold [B][6][N] floats: the first B*4*N are the result ([B][4][N]), the tail [B][2][N] is scratch. */
+ * `dpooled` must hold B*6*N + RSSF_GATE_SLOTS*202 floats: the first B*4*N are the result ([B][4][N]), the rest is
+ * scratch ([B][2][N] pre-sigmoid gradients, then slotted partial sums of the 202 parameter gradients). */
+#define RSSF_GATE_SLOTS 16
 int rssf_gate_weights_bwd(const float* domega, const float* pooled, const float* gsig, const float* omega,
                           const float* k, const float* wl, float* dpooled, float* dk, float* dwl, float* dbl,
                           int B, int H, int W, void* stream);

@@ -38,35 +38,93 @@ __global__ void __launch_bounds__(256) gate_pool_fwd_kernel(const T* __restrict_
   argmax[((int64_t)b * 2 + s) * N + p] = am;
 }
 
+// Vector form (N and C multiples of the 16-byte vector): a thread owns VEC consecutive view-pixels; for each
+// view-channel its VEC elements are one 16-byte load that lies inside ONE token row (so one {mean, rstd} pair), and the
+// (token, channel) of the next view-channel follows by adding N/C and N%C with a carry - no division in the loop.
+template <typename T>
+__global__ void __launch_bounds__(256) gate_pool_fwd_vec_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                                const float* __restrict__ stx, const float* __restrict__ sty,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ pooled, int32_t* __restrict__ argmax,
+                                                                int B, int N, int C) {
+  constexpr int V = Vec<T>::N;
+  const int nv = N / V;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * 2 * nv) return;
+  const int p0 = (int)(gid % nv) * V;
+  const int s = (int)((gid / nv) % 2);
+  const int b = (int)(gid / (2 * (int64_t)nv));
+  const T* src = (s == 0 ? x : y) + (int64_t)b * N * C;
+  const float2* st = reinterpret_cast<const float2*>((s == 0 ? stx : sty) + (int64_t)b * N * 2);
+  const int qn = N / C, rn = N % C;
+  int n = p0 / C, c = p0 % C;
+  float sum[V], mx[V];
+  int am[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { sum[i] = 0.f; mx[i] = -INFINITY; am[i] = 0; }
+#pragma unroll 8
+  for (int cp = 0; cp < C; ++cp) {
+    Vec<T> v;
+    v.load(src + (int64_t)cp * N + p0);
+    const float2 ms = st[n];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float t = (v.get(i) - ms.x) * ms.y * gamma[c + i] + beta[c + i];
+      sum[i] += t;
+      if (t > mx[i]) { mx[i] = t; am[i] = cp; }
+    }
+    n += qn; c += rn;
+    if (c >= C) { c -= C; ++n; }
+  }
+  float* pb = pooled + (int64_t)b * 4 * N;
+  int32_t* ab = argmax + ((int64_t)b * 2 + s) * N;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    pb[(2 * s) * N + p0 + i] = sum[i] / C;
+    pb[(2 * s + 1) * N + p0 + i] = mx[i];
+    ab[p0 + i] = am[i];
+  }
+}
+
+// ---- the two 7x7 convolutions run on 16x16-pixel tiles staged (with a 3-pixel halo, zero outside the image) in LDS ---
+constexpr int GT = 16, GH = GT + 6, GLD = GH + 1;
+constexpr int GATE_SLOT_ELEMS = 196 + 6;            // dk [2][2][7][7], dwl [2][2], dbl [2]
+__device__ __forceinline__ void gate_load_tile(const float* __restrict__ plane, int H, int W, int h0, int w0, float* sm) {
+  for (int i = threadIdx.x; i < GH * GH; i += blockDim.x) {
+    const int r = i / GH, c = i % GH, hh = h0 + r - 3, ww = w0 + c - 3;
+    sm[r * GLD + c] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? plane[hh * W + ww] : 0.f;
+  }
+}
+
 // ---- weights: 7x7 conv (2->1, pad 3, no bias) + sigmoid per stream, 1x1 conv 2->2 + softmax over the 2 streams
 __global__ void __launch_bounds__(256) gate_weights_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ k,
                                                                const float* __restrict__ wl, const float* __restrict__ bl,
                                                                float* __restrict__ gsig, float* __restrict__ omega,
                                                                float* __restrict__ logits, int B, int H, int W) {
   __shared__ float sk[196];
-  for (int i = threadIdx.x; i < 196; i += blockDim.x) sk[i] = k[i];
-  __syncthreads();
+  __shared__ float sm[4][GH * GLD];
   const int N = H * W;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (int64_t)B * N) return;
-  const int p = (int)(gid % N), b = (int)(gid / N);
-  const int h = p / W, w = p % W;
+  const int tw = (W + GT - 1) / GT, th = (H + GT - 1) / GT;
+  const int b = blockIdx.x / (tw * th), t = blockIdx.x % (tw * th);
+  const int h0 = (t / tw) * GT, w0 = (t % tw) * GT;
+  for (int i = threadIdx.x; i < 196; i += blockDim.x) sk[i] = k[i];
+#pragma unroll
+  for (int pl = 0; pl < 4; ++pl) gate_load_tile(pooled + ((int64_t)b * 4 + pl) * N, H, W, h0, w0, sm[pl]);
+  __syncthreads();
+  const int lh = threadIdx.x / GT, lw = threadIdx.x % GT, h = h0 + lh, w = w0 + lw;
+  if (h >= H || w >= W) return;
   float g[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     float acc = 0.f;
+#pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-      const float* m = pooled + ((int64_t)b * 4 + 2 * s + ch) * N;
+      const float* m = sm[2 * s + ch] + lh * GLD + lw;
       const float* kk = sk + (s * 2 + ch) * 49;
-      for (int u = 0; u < 7; ++u) {
-        const int hh = h + u - 3;
-        if (hh < 0 || hh >= H) continue;
-        for (int v = 0; v < 7; ++v) {
-          const int ww = w + v - 3;
-          if (ww < 0 || ww >= W) continue;
-          acc += kk[u * 7 + v] * m[hh * W + ww];
-        }
-      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u)
+#pragma unroll
+        for (int v = 0; v < 7; ++v) acc += kk[u * 7 + v] * m[u * GLD + v];
     }
     g[s] = sigmoidf(acc);
   }
@@ -76,6 +134,7 @@ __global__ void __launch_bounds__(256) gate_weights_fwd_kernel(const float* __re
   const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
   const float inv = 1.f / (e0 + e1);
   const int64_t o = (int64_t)b * 2 * N;
+  const int p = h * W + w;
   gsig[o + p] = g[0]; gsig[o + N + p] = g[1];
   omega[o + p] = e0 * inv; omega[o + N + p] = e1 * inv;
   if (logits) { logits[o + p] = l0; logits[o + N + p] = l1; }
@@ -84,8 +143,8 @@ __global__ void __launch_bounds__(256) gate_weights_fwd_kernel(const float* __re
 // ---- weights backward, stage 1: domega -> dpre (gradient at the 7x7 conv outputs, pre-sigmoid); dwl/dbl --------
 __global__ void __launch_bounds__(256) gate_weights_bwd1_kernel(const float* __restrict__ domega, const float* __restrict__ gsig,
                                                                 const float* __restrict__ omega, const float* __restrict__ wl,
-                                                                float* __restrict__ dpre, float* __restrict__ dwl,
-                                                                float* __restrict__ dbl, int B, int N) {
+                                                                float* __restrict__ dpre, float* __restrict__ slots,
+                                                                int B, int N) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dwl[4], dbl[2]
   if (gid < (int64_t)B * N) {
@@ -111,47 +170,79 @@ __global__ void __launch_bounds__(256) gate_weights_bwd1_kernel(const float* __r
     for (int i = 0; i < 6; ++i) atomicAdd(&red[i], a[i]);
   }
   __syncthreads();
-  if (threadIdx.x < 4) atomicAdd(&dwl[threadIdx.x], red[threadIdx.x]);          // one global atomic per block
-  else if (threadIdx.x < 6) atomicAdd(&dbl[threadIdx.x - 4], red[threadIdx.x]);
+  // one global atomic per value per block, spread over RSSF_GATE_SLOTS copies (1024 blocks on one address cost ~40 us)
+  if (threadIdx.x < 6) atomicAdd(&slots[(blockIdx.x % RSSF_GATE_SLOTS) * GATE_SLOT_ELEMS + 196 + threadIdx.x], red[threadIdx.x]);
 }
 
-// stage 2: dpooled = conv^T(dpre, k) ; dk += sum_pixels dpre * shifted(pooled)
+// stage 2: dpooled = conv^T(dpre, k) ; dk += sum_pixels dpre * shifted(pooled).  Same 16x16 tiles: the dpre halo tile
+// serves the transposed convolution, the pooled halo tiles the kernel gradient; per-tap partial sums are folded over the
+// wave by shuffles and over the block through LDS, one global atomic per tap per block.
 __global__ void __launch_bounds__(256) gate_weights_bwd2_kernel(const float* __restrict__ dpre, const float* __restrict__ pooled,
                                                                 const float* __restrict__ k, float* __restrict__ dpooled,
-                                                                float* __restrict__ dk, int B, int H, int W) {
+                                                                float* __restrict__ slots, int B, int H, int W) {
   __shared__ float sk[196];
   __shared__ float sdk[196];
-  for (int i = threadIdx.x; i < 196; i += blockDim.x) { sk[i] = k[i]; sdk[i] = 0.f; }
-  __syncthreads();
+  __shared__ float sd[2][GH * GLD];
+  __shared__ float sm[4][GH * GLD];
+  __shared__ float red[49][65];                          // per-tap partial sums of the 64 lane quads of the block
   const int N = H * W;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool ok = gid < (int64_t)B * N;
-  const int p = ok ? (int)(gid % N) : 0, b = ok ? (int)(gid / N) : 0;
-  const int h = p / W, w = p % W;
+  const int tw = (W + GT - 1) / GT, th = (H + GT - 1) / GT;
+  const int b = blockIdx.x / (tw * th), t = blockIdx.x % (tw * th);
+  const int h0 = (t / tw) * GT, w0 = (t % tw) * GT;
+  for (int i = threadIdx.x; i < 196; i += blockDim.x) { sk[i] = k[i]; sdk[i] = 0.f; }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) gate_load_tile(dpre + ((int64_t)b * 2 + s) * N, H, W, h0, w0, sd[s]);
+#pragma unroll
+  for (int pl = 0; pl < 4; ++pl) gate_load_tile(pooled + ((int64_t)b * 4 + pl) * N, H, W, h0, w0, sm[pl]);
+  __syncthreads();
+  const int lh = threadIdx.x / GT, lw = threadIdx.x % GT, h = h0 + lh, w = w0 + lw;
+  const bool ok = h < H && w < W;
+#pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const float* dp = dpre + ((int64_t)b * 2 + s) * N;
-    const float mine = ok ? dp[p] : 0.f;
+    const float* dp = sd[s] + lh * GLD + lw;             // dp[(3+a)*GLD + 3+c] = dpre(h+a, w+c)
+    const float mine = ok ? dp[3 * GLD + 3] : 0.f;
+#pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-      const float* m = pooled + ((int64_t)b * 4 + 2 * s + ch) * N;
+      const float* m = sm[2 * s + ch] + lh * GLD + lw;
       const float* kk = sk + (s * 2 + ch) * 49;
       float acc = 0.f;
-      for (int u = 0; u < 7; ++u) {
+#pragma unroll
+      for (int u = 0; u < 7; ++u)
+#pragma unroll
         for (int v = 0; v < 7; ++v) {
-          // forward: out[h,w] += k[u,v] * in[h+u-3, w+v-3]
-          const int ho = h - (u - 3), wo = w - (v - 3);          // output pixel that read THIS input through tap (u,v)
-          if (ok && ho >= 0 && ho < H && wo >= 0 && wo < W) acc += kk[u * 7 + v] * dp[ho * W + wo];
-          const int hi = h + u - 3, wi = w + v - 3;              // input pixel THIS output read through tap (u,v)
-          float t = 0.f;
-          if (ok && hi >= 0 && hi < H && wi >= 0 && wi < W) t = mine * m[hi * W + wi];
-          t = wave_sum(t);
-          if ((threadIdx.x & 63) == 0) atomicAdd(&sdk[(s * 2 + ch) * 49 + u * 7 + v], t);
+          // forward: out[h,w] += k[u,v] * in[h+u-3, w+v-3]  ->  this input was read by output (h-(u-3), w-(v-3))
+          acc += kk[u * 7 + v] * dp[(6 - u) * GLD + (6 - v)];
+          // kernel-gradient partial: fold the lane quad with two DPP adds (no LDS traffic), one LDS write per quad
+          float tq = mine * m[u * GLD + v];
+          tq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tq), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+          tq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tq), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+          red[u * 7 + v][threadIdx.x >> 2] = tq;           // the four lanes of a quad store the same value
         }
+      if (ok) dpooled[((int64_t)b * 4 + 2 * s + ch) * N + h * W + w] = acc;
+      __syncthreads();
+      if (threadIdx.x < 245) {                            // 5 threads per tap, ~13 quads each
+        const int tap = threadIdx.x % 49, part = threadIdx.x / 49;
+        float sum = 0.f;
+        for (int q = part * 13; q < (part * 13 + 13 < 64 ? part * 13 + 13 : 64); ++q) sum += red[tap][q];
+        atomicAdd(&sdk[(s * 2 + ch) * 49 + tap], sum);
       }
-      if (ok) dpooled[((int64_t)b * 4 + 2 * s + ch) * N + p] = acc;
+      __syncthreads();
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 196; i += blockDim.x) atomicAdd(&dk[i], sdk[i]);
+  for (int i = threadIdx.x; i < 196; i += blockDim.x) atomicAdd(&slots[(blockIdx.x % RSSF_GATE_SLOTS) * GATE_SLOT_ELEMS + i], sdk[i]);
+}
+
+// folds the slot copies into the parameter gradients: dk [196], dwl [4], dbl [2]
+__global__ void __launch_bounds__(256) gate_weights_fold_kernel(const float* __restrict__ slots, float* __restrict__ dk,
+                                                               float* __restrict__ dwl, float* __restrict__ dbl) {
+  const int i = threadIdx.x;
+  if (i >= GATE_SLOT_ELEMS) return;
+  float s = 0.f;
+  for (int k = 0; k < RSSF_GATE_SLOTS; ++k) s += slots[k * GATE_SLOT_ELEMS + i];
+  if (i < 196) dk[i] += s;
+  else if (i < 200) dwl[i - 196] += s;
+  else dbl[i - 200] += s;
 }
 
 // ---- pool backward: add the gate-path gradient into d(LN1 output) ----------------------------------------------
@@ -172,6 +263,37 @@ __global__ void __launch_bounds__(256) gate_pool_bwd_kernel(const float* __restr
   stf(dst, ldf(dst) + g);
 }
 
+// Vector form: a thread owns V consecutive view-pixels of one stream, keeps their {d mean, d max, argmax} in registers and
+// walks the C view-channels (one 16-byte read-modify-write each): the [B][k][N] maps are read once, not C times.
+template <typename T>
+__global__ void __launch_bounds__(256) gate_pool_bwd_vec_kernel(const float* __restrict__ dpooled, const int32_t* __restrict__ argmax,
+                                                                T* __restrict__ dxhat, T* __restrict__ dyhat, int B, int N, int C) {
+  constexpr int V = Vec<T>::N;
+  const int nv = N / V;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * 2 * nv) return;
+  const int p0 = (int)(gid % nv) * V;
+  const int s = (int)((gid / nv) % 2);
+  const int b = (int)(gid / (2 * (int64_t)nv));
+  const float* dm = dpooled + ((int64_t)b * 4 + 2 * s) * N + p0;
+  const int32_t* am = argmax + ((int64_t)b * 2 + s) * N + p0;
+  float gmean[V], gmax[V];
+  int a[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { gmean[i] = dm[i] / C; gmax[i] = dm[N + i]; a[i] = am[i]; }
+  T* dst = (s == 0 ? dxhat : dyhat) + (int64_t)b * N * C + p0;
+#pragma unroll 8
+  for (int cp = 0; cp < C; ++cp) {
+    Vec<T> v;
+    v.load(dst + (int64_t)cp * N);
+    float o[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = v.get(i) + gmean[i] + (a[i] == cp ? gmax[i] : 0.f);
+    v.set_all(o);
+    v.store(dst + (int64_t)cp * N);
+  }
+}
+
 }  // namespace
 
 extern "C" int rssf_gate_pool_fwd(const void* x, const void* y, const float* stats_x, const float* stats_y,
@@ -182,7 +304,16 @@ extern "C" int rssf_gate_pool_fwd(const void* x, const void* y, const float* sta
   const int64_t total = (int64_t)B * 2 * N;
   dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RSSF_F32)
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  if ((dtype == RSSF_F32 || dtype == RSSF_BF16) && N % V == 0 && C % V == 0) {
+    dim3 gv((unsigned)((total / V + 255) / 256));
+    if (dtype == RSSF_F32)
+      gate_pool_fwd_vec_kernel<float><<<gv, 256, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta, pooled,
+                                                          argmax, B, N, C);
+    else
+      gate_pool_fwd_vec_kernel<bf16_t><<<gv, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, stats_x, stats_y, gamma, beta, pooled,
+                                                           argmax, B, N, C);
+  } else if (dtype == RSSF_F32)
     gate_pool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta,
                                                        pooled, argmax, B, N, C);
   else if (dtype == RSSF_BF16)
@@ -195,9 +326,8 @@ extern "C" int rssf_gate_pool_fwd(const void* x, const void* y, const float* sta
 extern "C" int rssf_gate_weights_fwd(const float* pooled, const float* k, const float* wl, const float* bl, float* gsig,
                                      float* omega, float* logits, int B, int H, int W, void* stream) {
   RSSF_REQUIRE(pooled && k && wl && bl && gsig && omega && B > 0 && H > 0 && W > 0, "gate_weights_fwd: bad arguments");
-  const int64_t total = (int64_t)B * H * W;
-  gate_weights_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
-      pooled, k, wl, bl, gsig, omega, logits, B, H, W);
+  const int tiles = ((H + GT - 1) / GT) * ((W + GT - 1) / GT);
+  gate_weights_fwd_kernel<<<dim3((unsigned)(B * tiles)), 256, 0, (hipStream_t)stream>>>(pooled, k, wl, bl, gsig, omega, logits, B, H, W);
   return check_launch("gate_weights_fwd");
 }
 
@@ -214,12 +344,21 @@ extern "C" int rssf_gate_weights_bwd(const float* domega, const float* pooled, c
   // writing dpooled, so it needs its own storage: reuse the tail of `dpooled` is unsafe -> use domega's sibling:
   // the caller passes dpooled sized [B][6][N]; planes 4..5 hold dpre.
   float* dpre = dpooled + (int64_t)B * 4 * N;
-  gate_weights_bwd1_kernel<<<grid, 256, 0, st>>>(domega, gsig, omega, wl, dpre, dwl, dbl, B, N);
+  float* slots = dpooled + (int64_t)B * 6 * N;
+  if (hipMemsetAsync(slots, 0, sizeof(float) * RSSF_GATE_SLOTS * GATE_SLOT_ELEMS, st) != hipSuccess) {
+    set_error("gate_weights_bwd: memset failed");
+    return RSSF_ERR_LAUNCH;
+  }
+  gate_weights_bwd1_kernel<<<grid, 256, 0, st>>>(domega, gsig, omega, wl, dpre, slots, B, N);
   int rc = check_launch("gate_weights_bwd1");
   if (rc) return rc;
   // note: dpre layout is [B][2][N] contiguous after the 4N planes of ALL batches
-  gate_weights_bwd2_kernel<<<grid, 256, 0, st>>>(dpre, pooled, k, dpooled, dk, B, H, W);
-  return check_launch("gate_weights_bwd2");
+  const int tiles = ((H + GT - 1) / GT) * ((W + GT - 1) / GT);
+  gate_weights_bwd2_kernel<<<dim3((unsigned)(B * tiles)), 256, 0, st>>>(dpre, pooled, k, dpooled, slots, B, H, W);
+  rc = check_launch("gate_weights_bwd2");
+  if (rc) return rc;
+  gate_weights_fold_kernel<<<1, 256, 0, st>>>(slots, dk, dwl, dbl);
+  return check_launch("gate_weights_fold");
 }
 
 extern "C" int rssf_gate_pool_bwd(const float* dpooled, const int32_t* argmax, void* dxhat, void* dyhat, int B, int N,
@@ -228,7 +367,12 @@ extern "C" int rssf_gate_pool_bwd(const float* dpooled, const int32_t* argmax, v
   const int64_t total = (int64_t)B * 2 * N * C;
   dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RSSF_F32)
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  if ((dtype == RSSF_F32 || dtype == RSSF_BF16) && N % V == 0) {
+    dim3 gv((unsigned)(((int64_t)B * 2 * (N / V) + 255) / 256));
+    if (dtype == RSSF_F32) gate_pool_bwd_vec_kernel<float><<<gv, 256, 0, st>>>(dpooled, argmax, (float*)dxhat, (float*)dyhat, B, N, C);
+    else gate_pool_bwd_vec_kernel<bf16_t><<<gv, 256, 0, st>>>(dpooled, argmax, (bf16_t*)dxhat, (bf16_t*)dyhat, B, N, C);
+  } else if (dtype == RSSF_F32)
     gate_pool_bwd_kernel<float><<<grid, 256, 0, st>>>(dpooled, argmax, (float*)dxhat, (float*)dyhat, B, N, C);
   else if (dtype == RSSF_BF16)
     gate_pool_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>(dpooled, argmax, (bf16_t*)dxhat, (bf16_t*)dyhat, B, N, C);

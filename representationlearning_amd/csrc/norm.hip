@@ -87,41 +87,54 @@ __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dy, cons
   for (int i = 0; i < VEC; ++i) { gam[i] = gamma[sub * VEC + i]; ag[i] = 0.f; ab[i] = 0.f; }
   const int64_t rows_per_pass = (int64_t)gridDim.x * (blockDim.x / G);
   const int64_t niter = (rows + rows_per_pass - 1) / rows_per_pass;
-  for (int64_t it = 0; it < niter; ++it) {
-    const int64_t row = it * rows_per_pass + (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
-    const bool ok = row < rows;
-    Vec<T> vx, vd;
-    float mean = 0.f, rstd = 0.f, s1 = 0.f, s2 = 0.f, xh[VEC], g[VEC];
-    if (ok) {
-      vx.load(x + row * C + sub * VEC);
-      vd.load(dy + row * C + sub * VEC);
-      mean = stats[row * 2]; rstd = stats[row * 2 + 1];
+  const int64_t row0 = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
+  // two rows in flight per lane group, loads issued unconditionally (a row past the end re-reads row 0 and is discarded)
+  auto one = [&](int64_t row, bool ok, const Vec<T>& vx, const Vec<T>& vd, const Vec<T>& va, float mean, float rstd) {
+    float s1 = 0.f, s2 = 0.f, xh[VEC], g[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        xh[i] = (vx.get(i) - mean) * rstd;
-        const float d = vd.get(i);
-        g[i] = d * gam[i];
-        s1 += g[i]; s2 += g[i] * xh[i];
-        ag[i] += d * xh[i]; ab[i] += d;
-      }
+    for (int i = 0; i < VEC; ++i) {
+      xh[i] = (vx.get(i) - mean) * rstd;
+      const float d = ok ? vd.get(i) : 0.f;
+      g[i] = d * gam[i];
+      s1 += g[i]; s2 += g[i] * xh[i];
+      ag[i] += d * xh[i]; ab[i] += d;
     }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if (ok) {
-      s1 /= C; s2 /= C;
-      Vec<T> o, va;
-      if (dx_add) va.load(dx_add + row * C + sub * VEC);
+    s1 /= C; s2 /= C;
+    float o[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float v = rstd * (g[i] - s1 - xh[i] * s2);
-        if (dx_add) v += va.get(i);
-        o.set(i, v);
-      }
-      o.store(dx + row * C + sub * VEC);
+    for (int i = 0; i < VEC; ++i) {
+      o[i] = rstd * (g[i] - s1 - xh[i] * s2);
+      if (dx_add) o[i] += va.get(i);
     }
+    if (ok) {
+      Vec<T> w;
+      w.set_all(o);
+      w.store(dx + row * C + sub * VEC);
+    }
+  };
+  for (int64_t it = 0; it < niter; it += 2) {
+    const int64_t ra = it * rows_per_pass + row0, rb = ra + rows_per_pass;
+    const bool oka = ra < rows, okb = (it + 1 < niter) && rb < rows;
+    const int64_t qa = oka ? ra : 0, qb = okb ? rb : 0;
+    Vec<T> xa, da, aa, xb, db, ab2;
+    xa.load(x + qa * C + sub * VEC); da.load(dy + qa * C + sub * VEC);
+    xb.load(x + qb * C + sub * VEC); db.load(dy + qb * C + sub * VEC);
+    if (dx_add) { aa.load(dx_add + qa * C + sub * VEC); ab2.load(dx_add + qb * C + sub * VEC); }
+    const float ma = stats[qa * 2], sa = stats[qa * 2 + 1], mb = stats[qb * 2], sb2 = stats[qb * 2 + 1];
+    one(ra, oka, xa, da, aa, ma, sa);
+    one(rb, okb, xb, db, ab2, mb, sb2);
   }
+  // lanes that own the same channels (same `sub`) inside a wave are folded by shuffles before the LDS atomics
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { atomicAdd(&sg[sub * VEC + i], ag[i]); atomicAdd(&sb[sub * VEC + i], ab[i]); }
+  for (int o = 32; o >= G; o >>= 1)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { ag[i] += __shfl_xor(ag[i], o, 64); ab[i] += __shfl_xor(ab[i], o, 64); }
+  if ((threadIdx.x & 63) < G) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { atomicAdd(&sg[sub * VEC + i], ag[i]); atomicAdd(&sb[sub * VEC + i], ab[i]); }
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < C; i += blockDim.x) { atomicAdd(&dgamma[i], sg[i]); atomicAdd(&dbeta[i], sb[i]); }
 }
@@ -173,7 +186,8 @@ int ln_bwd_launch(const void* dy, const void* x, const float* stats, const float
   const int G = (C % VEC == 0) ? C / VEC : 0;
   const size_t sh = 2 * C * sizeof(float);
   const T* a = (const T*)dy; const T* b = (const T*)x; const T* c = (const T*)dx_add; T* d = (T*)dx;
-  auto grid = [&](int g) { int64_t n = (rows * g + 255) / 256; return dim3((unsigned)(n > 1024 ? 1024 : n)); };
+  // 256 blocks: every block ends with 2C same-address global atomics (~40 ns each, serialised per address)
+  auto grid = [&](int g) { int64_t n = (rows * g + 255) / 256; return dim3((unsigned)(n > 256 ? 256 : n)); };
   switch (G) {
     case 1: ln_bwd_vec<T, 1><<<grid(1), 256, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
     case 2: ln_bwd_vec<T, 2><<<grid(2), 256, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;

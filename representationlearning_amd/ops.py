@@ -86,7 +86,7 @@ def gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W):
     """Returns dpooled [B,4,N]; accumulates dk [2,2,7,7], dwl [2,2], dbl [2]."""
     B = pooled.shape[0]
     N = H * W
-    buf = torch.empty(B * 6 * N, device=pooled.device, dtype=torch.float32)   # [B][4][N] dpooled + [B][2][N] scratch
+    buf = torch.empty(B * 6 * N + 16 * 202, device=pooled.device, dtype=torch.float32)   # [B][4][N] dpooled + scratch (rssf.h)
     L.check(L.load().rssf_gate_weights_bwd(L.ptr(domega), L.ptr(pooled), L.ptr(gsig), L.ptr(omega), L.ptr(_f32(k)),
                                            L.ptr(_f32(wl)), L.ptr(buf), L.ptr(_f32(dk)), L.ptr(_f32(dwl)), L.ptr(_f32(dbl)),
                                            B, H, W, L.stream()), "rssf_gate_weights_bwd")
