@@ -27,7 +27,7 @@ typedef enum { RSSF_F32 = 0, RSSF_BF16 = 1 } rssf_dtype;
 /* per-channel BatchNorm statistics are accumulated into this many interleaved copies (slot = block index mod slots) to
  * spread same-address atomics; every statistics buffer below is [RSSF_BN_SLOTS][2][C] fp32 and consumers sum the slots */
 #define RSSF_BN_SLOTS 16
-#define RSSF_BN_BWD_SLOTS 4
+#define RSSF_BN_BWD_SLOTS 8
 typedef enum {
   RSSF_OK = 0,
   RSSF_ERR_BAD_ARG = -1,

@@ -584,7 +584,7 @@ template <typename T, typename DM, bool ACC_LDS>
 int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) {
   using LY = BwdLayout<T, DM, ACC_LDS>;
   int blocks = (g.nWin + LY::WAVES - 1) / LY::WAVES;
-  if (blocks > 512) blocks = 512;           // persistent-ish: fewer weight-gradient flushes
+  if (blocks > 256) blocks = 256;           // one resident workgroup per CU (157 KB LDS): persistent, one gradient flush each
   auto kern = winattn_bwd_kernel<T, DM, ACC_LDS>;
   static bool attr_set = false;     // idempotent per instantiation; kept out of replayed hipGraph captures
   if (LY::BYTES > 64 * 1024 && !attr_set) {

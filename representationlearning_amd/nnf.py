@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import _lib as L
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-BN_SLOTS, BN_BWD_SLOTS = 16, 4            # RSSF_BN_SLOTS / RSSF_BN_BWD_SLOTS of include/rssf.h
+BN_SLOTS, BN_BWD_SLOTS = 16, 8            # RSSF_BN_SLOTS / RSSF_BN_BWD_SLOTS of include/rssf.h
 _SYNC_ALL_BN = False          # set by the trainer: configs/base/loveda.py:107 train.sync_bn
 
 

@@ -15,7 +15,7 @@ for rows, C, res in [(262144, 32, True), (262144, 32, False), (262144, 64, False
     dy = torch.randn(rows, C, device=dev).bfloat16(); raw = torch.randn(rows, C, device=dev).bfloat16()
     rp = torch.randn(rows, C, device=dev).bfloat16() if res else None
     ss = torch.randn(2, C, device=dev); mi = torch.rand(2, C, device=dev) + 0.5
-    sums = torch.zeros(4, 2, C, device=dev)
+    sums = torch.zeros(8, 2, C, device=dev)
     draw = torch.empty_like(raw); dres = torch.empty_like(raw) if res else None
     dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
     y = torch.empty_like(raw)
