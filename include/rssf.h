@@ -156,6 +156,11 @@ int rssf_bn_finalize(const float* stats, const float* gamma, const float* beta, 
 /* y = act(raw*scale + shift + res_pre) + res_post   (res_* optional, same shape as raw) */
 int rssf_bn_apply(const void* raw, const float* scale_shift, const void* res_pre, const void* res_post, void* y,
                   int64_t rows, int C, int act, int dtype, void* stream);
+/* rssf_bn_finalize followed by rssf_bn_apply as ONE launch (same arguments, same results) */
+int rssf_bn_finalize_apply(const void* raw, const float* stats, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* mean_invstd, float* scale_shift, const void* res_pre, const void* res_post,
+                           void* y, int64_t rows, int C, int act, double n, float momentum, float eps, int training, int dtype,
+                           void* stream);
 /* sums [RSSF_BN_BWD_SLOTS][2][C] fp32, zeroed by the caller: slot (block mod slots) += { sum dz, sum dz*raw },
  * dz = dy * act'(raw*scale + shift + res_pre).  rssf_bn_bwd_apply sums the slots (all-reduce the whole buffer for SyncBN) */
 int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, float* sums,

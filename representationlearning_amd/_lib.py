@@ -61,6 +61,7 @@ SIGNATURES = {
     "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),
     "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
+    "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_reduce": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_int, c_void_p]),
     "rssf_upsample_bilinear": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),

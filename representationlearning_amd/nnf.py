@@ -349,16 +349,15 @@ class _ConvBNAct(torch.autograd.Function):
         mi = torch.empty(2, C, device=dev, dtype=torch.float32)
         ss = torch.empty(2, C, device=dev, dtype=torch.float32)
         lib = L.load()
-        L.check(lib.rssf_bn_finalize(L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi), L.ptr(ss), C, n,
-                                     momentum, eps, int(training), L.stream()), "rssf_bn_finalize")
         rp = None if res_pre is None else _nhwc(res_pre)
         rq = None if res_post is None else _nhwc(res_post)
         for r in (rp, rq):
             if r is not None and (r.dtype != raw.dtype or r.shape != raw.shape):
                 raise RuntimeError("conv_bn_act: residual dtype/shape mismatch %s%s vs %s%s" % (r.dtype, tuple(r.shape), raw.dtype, tuple(raw.shape)))
         y = torch.empty_like(raw)
-        L.check(lib.rssf_bn_apply(L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, L.dtype_code(raw), L.stream()),
-                "rssf_bn_apply")
+        L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi), L.ptr(ss),
+                                           L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, n, momentum, eps, int(training), L.dtype_code(raw),
+                                           L.stream()), "rssf_bn_finalize_apply")
         ctx.save_for_backward(xh, raw, ss, mi, rp, *weights)
         ctx.meta = (spec, act, training, n, sync, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
         ctx.params = (gamma, beta, weights, biases)
