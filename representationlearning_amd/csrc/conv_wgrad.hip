@@ -290,10 +290,18 @@ struct WgradHaloArgs {
 };
 constexpr int HTH = 8, HTW = 16, HHP = (HTH + 2) * (HTW + 2), HNPX = HTH * HTW, HCT = 32, HLD = HCT + 16;
 
-__global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
-  constexpr int X_LOADS = (HHP * 4 + 255) / 256, D_LOADS = HNPX * 4 / 256;
-  __shared__ __attribute__((aligned(16))) bf16_t XH[HHP * HLD];
-  __shared__ __attribute__((aligned(16))) bf16_t DS[HNPX * HLD];
+// 8 waves: two groups of four split the four 32-pixel K-steps of every tile (twice the waves per CU on the same LDS
+// footprint - the block is latency-bound, one resident block per CU); group 1's accumulators are folded into group 0's
+// through LDS once, after the last tile.
+constexpr int HWG_THREADS = 512;
+__global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
+  constexpr int NT_ = HWG_THREADS;
+  constexpr int X_LOADS = (HHP * 4 + NT_ - 1) / NT_, D_LOADS = HNPX * 4 / NT_;
+  constexpr int STAGE_ELEMS = (HHP + HNPX) * HLD;
+  static_assert(STAGE_ELEMS * 2 >= 5 * 4 * 64 * 4 * 4, "fold buffer (5 taps x 4 waves x 64 lanes x f32x4) must fit the staging LDS");
+  __shared__ __attribute__((aligned(16))) bf16_t lds_raw[STAGE_ELEMS];
+  bf16_t* XH = lds_raw;
+  bf16_t* DS = lds_raw + HHP * HLD;
   const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);       // the (co, ci) tiles of one pixel range share an XCD's L2
   if (q >= a.total) return;
   const int pair = (int)(q % a.npairs), range = (int)(q / a.npairs);
@@ -301,7 +309,8 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
   const int t_begin = range * a.tiles_per_block;
   const int t_end = t_begin + a.tiles_per_block < a.ntiles ? t_begin + a.tiles_per_block : a.ntiles;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wg = wave >> 2, w4 = wave & 3;                  // wave group (K-steps 2wg, 2wg+1), wave inside the group
+  const int wm = w4 >> 1, wn = w4 & 1;
 
   f32x4 acc[9];
 #pragma unroll
@@ -314,14 +323,14 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
     const int y0 = ty * HTH, x0 = tx * HTW;
 #pragma unroll
     for (int i = 0; i < X_LOADS; ++i) {
-      const int idx = tid + i * 256, p = idx >> 2, ch = ci0 + (idx & 3) * 8;
+      const int idx = tid + i * NT_, p = idx >> 2, ch = ci0 + (idx & 3) * 8;
       const int gy = y0 - 1 + p / (HTW + 2), gx = x0 - 1 + p % (HTW + 2);
       xok[i] = idx < HHP * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ch < a.Cin;
       rx[i].load(a.in + (xok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cin + ch : 0));
     }
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i) {
-      const int idx = tid + i * 256, p = idx >> 2, ch = co0 + (idx & 3) * 8;
+      const int idx = tid + i * NT_, p = idx >> 2, ch = co0 + (idx & 3) * 8;
       const int gy = y0 + p / HTW, gx = x0 + p % HTW;
       dok[i] = gy < a.H && gx < a.W && ch < a.Cout;
       rd[i].load(a.dout + (dok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + ch : 0));
@@ -330,14 +339,14 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < X_LOADS; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT_;
       Vec<bf16_t> v = rx[i];
       if (!xok[i]) v.raw = {0, 0, 0, 0};
       if (idx < HHP * 4) v.store(XH + (idx >> 2) * HLD + (idx & 3) * 8);
     }
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT_;
       Vec<bf16_t> v = rd[i];
       if (!dok[i]) v.raw = {0, 0, 0, 0};
       v.store(DS + (idx >> 2) * HLD + (idx & 3) * 8);
@@ -362,7 +371,8 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
     __syncthreads();
     if (t + 1 < t_end) load_tile(t + 1);
 #pragma unroll
-    for (int ks = 0; ks < HNPX / 32; ++ks) {                  // 32 pixels = image rows 2ks, 2ks+1 of the tile
+    for (int kk = 0; kk < HNPX / 64; ++kk) {                  // 32 pixels = image rows 2ks, 2ks+1 of the tile
+      const int ks = 2 * wg + kk;
       const bf16x8 fa = tr8(dbase + ks * 32 * HLD, HTW);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -372,13 +382,31 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
     }
     __syncthreads();
   }
+  // fold group 1 into group 0 (two passes of <= 5 taps through the now idle staging LDS), then group 0 writes the partials
+  f32x4* fold = reinterpret_cast<f32x4*>(lds_raw);
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+  for (int pass = 0; pass < 2; ++pass) {
+    const int t0 = pass * 5, t1 = pass == 0 ? 5 : 9;
+    if (wg == 1)
+      for (int tap = t0; tap < t1; ++tap) fold[((tap - t0) * 4 + w4) * 64 + lane] = acc[tap];
+    __syncthreads();
+    if (wg == 0)
+      for (int tap = t0; tap < t1; ++tap) {
+        const f32x4 o = fold[((tap - t0) * 4 + w4) * 64 + lane];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co0 + wm * 16 + grp * 4 + r, ci = ci0 + wn * 16 + l15;
-      if (co < a.Cout && ci < a.Cin) a.partial[(((int64_t)range * 9 + tap) * a.Cout + co) * a.Cin + ci] = acc[tap][r];
-    }
+        for (int r = 0; r < 4; ++r) acc[tap][r] += o[r];
+      }
+    __syncthreads();
+  }
+  if (wg == 0) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wm * 16 + grp * 4 + r, ci = ci0 + wn * 16 + l15;
+        if (co < a.Cout && ci < a.Cin) a.partial[(((int64_t)range * 9 + tap) * a.Cout + co) * a.Cin + ci] = acc[tap][r];
+      }
+  }
 }
 
 // spatial tiles per block: 8 when that still yields >= 256 blocks, fewer for small problems
@@ -506,7 +534,7 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
     h.total = (int64_t)a.ksplit * h.npairs;
     h.xcd_per = xcd_per(h.total);
     for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
-    conv3x3_wgrad_halo_kernel<<<(unsigned)h.xcd_per * 8, 256, 0, st>>>(h);
+    conv3x3_wgrad_halo_kernel<<<(unsigned)h.xcd_per * 8, HWG_THREADS, 0, st>>>(h);
     if (int rc = check_launch("conv3x3_wgrad_halo")) return rc;
     const int64_t per = (int64_t)ntaps * Cout * Cin;
     wgrad_reduce_kernel<<<(unsigned)((per + RI - 1) / RI), 256, 0, st>>>(a);
