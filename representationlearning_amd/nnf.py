@@ -89,6 +89,10 @@ class ConvSpec:
                     self.dy.append(ky * d - p)
                     self.dx.append(kx * d - p)
         self.ntaps = len(self.src)
+        # ctypes views of the tap tables, built once (they are passed to every launch of this convolution)
+        self.c_ksizes, self.c_src, self.c_kpos = _ia(self.ksizes), _ia(self.src), _ia(self.kpos)
+        self.c_dy, self.c_dx = _ia(self.dy), _ia(self.dx)
+        self.c_ndy, self.c_ndx = _ia([-v for v in self.dy]), _ia([-v for v in self.dx])
         if self.ntaps > 19 or len(convs) > 3:
             raise NotImplementedError("librssf conv: at most 19 taps / 3 fused convolutions")
         c = c0
@@ -287,7 +291,7 @@ def _conv_forward(spec, xh, weights, bias, stats):
     wpk = _pack(spec, weights, False, xh.dtype, xh.device)
     out = torch.empty(B, OH, OW, spec.cout, device=xh.device, dtype=xh.dtype)
     L.check(L.load().rssf_conv_gather(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), B, H, W, C, OH, OW, spec.cout,
-                                      spec.stride, 1, spec.ntaps, _ia(spec.dy), _ia(spec.dx), L.dtype_code(xh), L.stream()),
+                                      spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
             "rssf_conv_gather")
     return out
 
@@ -299,7 +303,7 @@ def _conv_dgrad(spec, dout, weights, in_shape):
     wpk = _pack(spec, weights, True, dout.dtype, dout.device)
     dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype)
     L.check(L.load().rssf_conv_gather(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, B, OH, OW, cout_p, H, W, C, 1, spec.stride,
-                                      spec.ntaps, _ia([-v for v in spec.dy]), _ia([-v for v in spec.dx]), L.dtype_code(dout),
+                                      spec.ntaps, spec.c_ndy, spec.c_ndx, L.dtype_code(dout),
                                       L.stream()), "rssf_conv_gather(dgrad)")
     return dx
 
@@ -317,9 +321,9 @@ def _conv_wgrad(spec, dout, xh, dws, db):
     d = tgt + [None, None]
     lib = L.load()
     ws = torch.empty(lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, CO, spec.ntaps), device=xh.device, dtype=torch.float32)
-    L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), _ia(spec.ksizes), len(dws),
-                                     _ia(spec.src), _ia(spec.kpos), L.ptr(tdb), L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps,
-                                     _ia(spec.dy), _ia(spec.dx), L.dtype_code(xh), L.stream()), "rssf_conv_wgrad")
+    L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws),
+                                     spec.c_src, spec.c_kpos, L.ptr(tdb), L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps,
+                                     spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()), "rssf_conv_wgrad")
     if padded:
         for g, t in zip(dws, tgt):
             g += t[:spec.cout, :spec.cin]

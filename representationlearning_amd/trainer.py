@@ -150,7 +150,8 @@ class Trainer:
         self._side = None
 
     def _eager_step(self, img, target):
-        self.model.train()
+        if not self.model.training:          # Module.train() walks all 1 300 sub-modules: not once per step
+            self.model.train()
         self.flat.zero_grad()
         if self.buckets is not None:
             self.buckets.begin()
@@ -176,7 +177,9 @@ class Trainer:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
+            # thread_local: the NCCL watchdog thread keeps polling events of earlier collectives, which a global-mode
+            # capture forbids ("operation not permitted when stream is capturing")
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._static_loss = self._eager_step(*self._static)
         except Exception as e:       # fall back to eager launches, loudly
             print("[rssf] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), flush=True)

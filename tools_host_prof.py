@@ -1,0 +1,22 @@
+"""cProfile of eager training steps (host-side cost per step), run on the GPU box."""
+import cProfile, pstats, os, sys, torch
+os.environ["RSSF_GRAPH"] = "0"
+sys.path.insert(0, ".")
+from representationlearning_amd.configs import rssformer_config, synthetic_batch
+from representationlearning_amd.core import registry
+from representationlearning_amd.trainer import Trainer
+registry.register_all()
+torch.manual_seed(0)
+model = registry.MODEL["RSSFormer"](rssformer_config("base")).cuda()
+tr = Trainer(model, bf16=True, sync_bn=True)
+img, lab = synthetic_batch(16, 512, seed=1)
+tgt = dict(cls=lab)
+for _ in range(3): tr.step(img, tgt)
+torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(3): tr.step(img, tgt)
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
