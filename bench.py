@@ -211,7 +211,10 @@ def main():
             "config": {"workload": "RSSFormer-%s (HRNetV2 + 8 window-attention transformer blocks), %dx3x%dx%d per GPU, 6 classes, "
                                    "fwd+CGFL loss+bwd+clip+SGD, random-init weights" % (args.variant, args.batch, args.size, args.size),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                       "sync_bn": (not args.no_sync_bn) and world > 1},
+                       "sync_bn": (not args.no_sync_bn) and world > 1,
+                       "step_launch": "hipGraph replay" if trainer.graph is not None else "eager",
+                       "collectives": None if world == 1 else ("direct RCCL on the compute stream" if trainer.comm is not None
+                                                               else "torch.distributed (bucketed, hook-driven)")},
             "final_loss": round(final_loss, 5),
             "whole_step_mfma_frac": round(value * FLOP_PER_IMG / (world * MFMA_BF16_PEAK), 5),
         }
@@ -222,6 +225,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+        from representationlearning_amd import rccl
+        rccl.shutdown()
         dist.destroy_process_group()
 
 

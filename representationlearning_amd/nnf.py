@@ -60,6 +60,17 @@ def grad_result(p, buf, direct):
     return buf
 
 
+def _all_reduce(t):
+    """Sum over the data-parallel ranks: direct RCCL on the compute stream when the trainer set a communicator up
+    (graph-capturable, ~5 us of host time), else torch.distributed."""
+    from . import rccl
+    comm = rccl.get()
+    if comm is not None:
+        comm.all_reduce_(t)
+    else:
+        dist.all_reduce(t)
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -348,7 +359,7 @@ class _ConvBNAct(torch.autograd.Function):
         rows = raw.numel() // C
         n = float(rows)
         if training and sync and (_world() > 1 or _FORCE_COLLECTIVES):
-            dist.all_reduce(stats)
+            _all_reduce(stats)
             n *= _world()
         mi = torch.empty(2, C, device=dev, dtype=torch.float32)
         ss = torch.empty(2, C, device=dev, dtype=torch.float32)
@@ -382,7 +393,7 @@ class _ConvBNAct(torch.autograd.Function):
         L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.dtype_code(raw),
                                        L.stream()), "rssf_bn_bwd_reduce")
         if training and sync and (_world() > 1 or _FORCE_COLLECTIVES):
-            dist.all_reduce(sums)
+            _all_reduce(sums)
         draw = torch.empty_like(raw)
         dres = torch.empty_like(raw) if has_pre else None
         p_gamma, p_beta, p_weights, p_biases = ctx.params

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import nnf, ops
+from . import nnf, ops, rccl
 
 
 class FlatParams:
@@ -128,7 +128,11 @@ class Trainer:
         dp = self.world > 1 or (dist.is_initialized() and os.environ.get("RSSF_FORCE_DP") == "1")
         self.model = model
         self.flat = FlatParams(model)
-        self.buckets = GradBuckets(self.flat, nbuckets) if dp else None
+        # Data path of DP: a direct RCCL communicator when possible (collectives on the compute stream, so the whole step
+        # can still be one hipGraph; the 128 MB flat gradient is ONE all-reduce after backward, ~1 ms over xGMI), else
+        # torch.distributed with bucketed, hook-driven all-reduces overlapped with backward.
+        self.comm = rccl.init() if dp else None
+        self.buckets = GradBuckets(self.flat, nbuckets) if (dp and self.comm is None) else None
         nnf.set_sync_bn(sync_bn and dp, force=dp and self.world == 1)
         nnf.set_direct_grad(True, self.buckets.param_ready if self.buckets is not None else None)
         self.hp = dict(base_lr=base_lr, momentum=momentum, wd=weight_decay, max_norm=max_norm, power=power, max_iters=max_iters)
@@ -139,10 +143,10 @@ class Trainer:
         self.lr_dev = torch.zeros(1, device=dev, dtype=torch.float32)
         # Whole-step hipGraph: the step is ~3 k short launches and the Python/launch overhead (~65 ms) exceeds the GPU
         # time, so after `graph_warmup` eager steps the step (fwd + loss + bwd + clip + SGD) is captured once and
-        # replayed.  Single-GPU only by default: capturing RCCL collectives is left off until it can be validated on a
-        # multi-GPU box (RSSF_GRAPH=1 forces it, RSSF_GRAPH=0 disables graphs).
+        # replayed.  In DP this needs the direct RCCL communicator (collectives issued through torch.distributed cannot be
+        # captured: its watchdog thread polls their events).  RSSF_GRAPH=1 forces graphs, RSSF_GRAPH=0 disables them.
         env = os.environ.get("RSSF_GRAPH")
-        self.use_graph = (env == "1") or (env != "0" and use_graph and not dp)
+        self.use_graph = (env == "1") or (env != "0" and use_graph and (not dp or self.comm is not None))
         self.graph_warmup = 3
         self.pack_plan = nnf.PackPlan() if os.environ.get("RSSF_PACK_PLAN", "1") != "0" else None
         self.graph = None
@@ -166,6 +170,8 @@ class Trainer:
             nnf.step_end()
         if self.buckets is not None:
             self.buckets.finish()
+        elif self.comm is not None:
+            self.comm.all_reduce_(self.flat.grad)
         hp = self.hp
         ops.grad_sqnorm(self.flat.grad, self.sqnorm)
         ops.sgd_step_(self.flat.flat, self.flat.grad, self.flat.mom, self.sqnorm, 1.0 / self.world, hp["max_norm"], 0.0,

@@ -56,34 +56,47 @@ def test_training_steps_decrease_loss_fp32_and_bf16():
         assert all(l == l for l in losses) and min(losses[-3:]) < losses[0], losses
 
 
-def test_dp_plumbing_on_one_rank_matches_plain_path():
-    """Buckets + SyncBN all-reduces over RCCL (world 1) must reproduce the plain single-GPU step.  Training itself is
-    chaotic at this size (two plain runs already drift by 1 % after one update because of fp32 atomics order), so the
-    comparison is made on one step's loss and on the all-reduced flat gradient with the learning rate at 0."""
+@pytest.mark.parametrize("backend", ["torch", "rccl", "rccl+graph"])
+def test_dp_plumbing_on_one_rank_matches_plain_path(backend):
+    """SyncBN all-reduces + gradient all-reduce over RCCL (world 1) must reproduce the plain single-GPU step, through
+    torch.distributed (hook-driven buckets), through the direct RCCL communicator, and with that step captured into a
+    hipGraph.  Training itself is chaotic at this size (two plain runs already drift by 1 % after one update because of
+    fp32 atomics order), so the comparison is made on one step's loss and on the all-reduced flat gradient with the
+    learning rate at 0."""
     from representationlearning_amd.trainer import Trainer
-    from representationlearning_amd import nnf
+    from representationlearning_amd import nnf, rccl
     from tests.helpers import rel_err
-    t0 = Trainer(_mk(1), bf16=False, base_lr=0.0, weight_decay=0.0)
+    t0 = Trainer(_mk(1), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=False)
     plain = _run(t0, steps=2)
     g_plain = t0.flat.grad.clone()
     _run(t0, steps=1)
     # yardstick: the plain path against itself (fp32 atomics order in the BN statistics, amplified by 100 BN layers
     # normalising over a handful of samples at this test size)
     self_dist = rel_err(t0.flat.grad.cpu(), g_plain.cpu())
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RSSF_FORCE_DP="1")
+    graph = backend.endswith("+graph")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RSSF_FORCE_DP="1", RSSF_DP_BACKEND=backend.split("+")[0],
+                      RSSF_GRAPH="1" if graph else "0")
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         tr = Trainer(_mk(1), bf16=False, sync_bn=True, base_lr=0.0, weight_decay=0.0)
-        assert tr.buckets is not None and len(tr.buckets.bounds) >= 4
-        dp = _run(tr, steps=2)
-        assert all(tr.buckets.launched)
+        if backend == "torch":
+            assert tr.comm is None and tr.buckets is not None and len(tr.buckets.bounds) >= 4
+        else:
+            assert tr.comm is not None and tr.buckets is None
+        dp = _run(tr, steps=6 if graph else 2)
+        if backend == "torch":
+            assert all(tr.buckets.launched)
+        if graph:
+            assert tr.graph is not None and tr._replayed >= 2
         g_dp = tr.flat.grad.clone()
     finally:
+        rccl.shutdown()
         dist.destroy_process_group()
-        os.environ.pop("RSSF_FORCE_DP")
+        for k in ("RSSF_FORCE_DP", "RSSF_DP_BACKEND", "RSSF_GRAPH"):
+            os.environ.pop(k)
         nnf.set_sync_bn(False)
         nnf.set_direct_grad(False)
-    assert max(abs(a - b) for a, b in zip(plain, dp)) < 1e-5 * abs(plain[0]), (plain, dp)
+    assert max(abs(a - plain[0]) for a in dp) < 1e-5 * abs(plain[0]), (plain, dp)
     assert abs(plain[0] - plain[1]) < 1e-5 * abs(plain[0])          # lr = 0: the step is a fixed point
     assert rel_err(g_dp.cpu(), g_plain.cpu()) < 3 * self_dist + 1e-4, (rel_err(g_dp.cpu(), g_plain.cpu()), self_dist)
 
