@@ -303,7 +303,14 @@ int launch_fwd(const rssf_winattn_fwd_params* p, const Geom& g, hipStream_t st) 
   using LY = FwdLayout<T, DM>;
   static_assert(LY::BYTES <= 160 * 1024, "LDS budget");
   int blocks = (g.nWin + LY::WAVES - 1) / LY::WAVES;
-  if (blocks > 4096) blocks = 4096;
+  // persistent: 3 workgroups fit a CU's LDS; more blocks only re-stage the weights (measured 79.7 -> 71.9 us at 768 on 256 CUs)
+  static int cap = 0;
+  if (!cap) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    cap = 3 * cus;
+  }
+  if (blocks > cap) blocks = cap;
   auto kern = winattn_fwd_kernel<T, DM>;
   static bool attr_set = false;     // idempotent per instantiation; kept out of replayed hipGraph captures
   if (LY::BYTES > 64 * 1024 && !attr_set) {
