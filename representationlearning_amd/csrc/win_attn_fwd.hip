@@ -86,7 +86,7 @@ template <> struct Quad<float> {
 };
 
 template <typename T, typename DM>
-__global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) == 2 && DM::C <= 32) ? 3 : 1)) winattn_fwd_kernel(rssf_winattn_fwd_params p, Geom g) {
+__global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) == 2 && DM::C <= 32) ? 2 : 1)) winattn_fwd_kernel(rssf_winattn_fwd_params p, Geom g) {
   using LY = FwdLayout<T, DM>;
   constexpr int LDX = LY::LDX, LDW = LY::LDW, LDO = LY::LDO;
   constexpr int C = DM::C, CP = DM::CP, CV = DM::CV, MT = DM::MT, CT = DM::CT, TPH = DM::TPH, D = DM::D;
