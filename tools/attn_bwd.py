@@ -1,6 +1,6 @@
 """Times rssf_winattn_fwd / rssf_winattn_bwd at the benchmark geometry (run on the GPU box)."""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")   # run from the repository root: python tools/<script>.py
 from representationlearning_amd import ops
 B, H, W, C = 16, 128, 128, 32
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10

@@ -1,5 +1,6 @@
 """Micro-benchmark of the BatchNorm backward kernels (run on the GPU box)."""
 import torch, sys
+sys.path.insert(0, ".")   # run from the repository root: python tools/<script>.py
 from representationlearning_amd import _lib as L
 lib = L.load()
 dev = 'cuda'

@@ -3,7 +3,7 @@ import os, sys, time, torch
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 os.environ["RSSF_FORCE_DP"] = "1"
 import torch.distributed as dist
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")   # run from the repository root: python tools/<script>.py
 dist.init_process_group("nccl", rank=0, world_size=1)
 torch.cuda.set_device(0)
 from representationlearning_amd.configs import rssformer_config, synthetic_batch

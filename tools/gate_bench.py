@@ -1,6 +1,6 @@
 """Times the LayerNorm / gate kernels at the benchmark geometry (run on the GPU box)."""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")   # run from the repository root: python tools/<script>.py
 from representationlearning_amd import ops
 B, H, W, C = 16, 128, 128, 32
 N = H * W

@@ -1,7 +1,7 @@
 """cProfile of eager training steps (host-side cost per step), run on the GPU box."""
 import cProfile, pstats, os, sys, torch
 os.environ["RSSF_GRAPH"] = "0"
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")   # run from the repository root: python tools/<script>.py
 from representationlearning_amd.configs import rssformer_config, synthetic_batch
 from representationlearning_amd.core import registry
 from representationlearning_amd.trainer import Trainer

@@ -1,5 +1,5 @@
 import sys, torch, ctypes
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")   # run from the repository root: python tools/<script>.py
 from representationlearning_amd import _lib as L
 lib = L.load()
 def run(addr):

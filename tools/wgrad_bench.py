@@ -1,6 +1,6 @@
 """Micro-benchmark of conv kernels on the MlpDWBN 19-tap shape and HRNet 3x3 shapes (run on the GPU box)."""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")   # run from the repository root: python tools/<script>.py
 from representationlearning_amd import nnf, _lib as L
 which = sys.argv[1] if len(sys.argv) > 1 else "mlp"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
