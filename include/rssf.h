@@ -137,6 +137,11 @@ int rssf_conv_pack_batch(const rssf_pack_job* jobs, const int* block_map, int nb
 int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bias, float* stats, int B, int IH, int IW,
                      int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype,
                      void* stream);
+/* the same with `addend` [B][OH][OW][Cout] (optional) added to the result in the epilogue: the data-gradient launch of a
+ * residual block folds the skip-path gradient in instead of leaving a separate elementwise add to autograd */
+int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, int B,
+                         int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy,
+                         const int* dx, int dtype, void* stream);
 /* weight gradient, accumulated (+=) into the torch-layout fp32 gradients of the source convs; dbias optional (+=).
  * workspace: fp32 scratch of rssf_conv_wgrad_workspace_elems() elements for the split-K partials (two-stage
  * reduction); NULL selects the slower atomic path. */

@@ -49,6 +49,7 @@ struct HaloArgs {
   bf16_t* out;           // [B, H, W, Cout]
   const float* bias;
   float* stats;          // [RSSF_BN_SLOTS][2][Cout] or null
+  const bf16_t* addend;  // [B, H, W, Cout] added to the output (fused gradient accumulation) or null
   int B, H, W, Cin, Cout, CinP, CoutP;
   int tiles_y, tiles_x, ntiles_n, xcd_per;
   int64_t total;

@@ -22,6 +22,7 @@ struct ConvArgs {
   const void* wpk;       // [ntaps][CoutP][CinP]  (k = input channel contiguous, zero padded)
   void* out;             // [B, OH, OW, Cout]
   const float* bias;     // [Cout] or null
+  const void* addend;    // [B, OH, OW, Cout] added to the output (fused gradient accumulation) or null
   float* stats;          // [RSSF_BN_SLOTS][2][Cout] sum, sumsq (atomically accumulated, slot = block % slots) or null
   int B, IH, IW, Cin, OH, OW, Cout, CinP, CoutP;
   int ntiles_n, xcd_per;
@@ -222,12 +223,21 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
     const int col = n0 + cc;
     if (m >= M || col >= a.Cout) continue;
     T* dst = OUT + m * a.Cout + col;
+    const T* add = a.addend ? reinterpret_cast<const T*>(a.addend) + m * a.Cout + col : nullptr;
     if (ovec) {
       Vec<T> v;
       v.load(Cs + row * LDC + cc);
+      if (add) {
+        Vec<T> w;
+        w.load(add);
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = v.get(e) + w.get(e);
+        v.set_all(o);
+      }
       v.store(dst);
     } else {
-      for (int e = 0; e < V && col + e < a.Cout; ++e) dst[e] = Cs[row * LDC + cc + e];
+      for (int e = 0; e < V && col + e < a.Cout; ++e) stf(dst + e, ldf(Cs + row * LDC + cc + e) + (add ? ldf(add + e) : 0.f));
     }
   }
 }
@@ -373,13 +383,19 @@ extern "C" int64_t rssf_conv_packed_elems(int ntaps, int rows, int cols, int dty
 extern "C" int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bias, float* stats, int B, int IH,
                                 int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy,
                                 const int* dx, int dtype, void* stream) {
+  return rssf_conv_gather_add(in, wpk, out, bias, stats, nullptr, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype, stream);
+}
+
+extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend,
+                                    int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
+                                    const int* dy, const int* dx, int dtype, void* stream) {
   RSSF_REQUIRE(in && wpk && out && dy && dx && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 &&
                    ntaps >= 1 && ntaps <= MAX_TAPS && mul >= 1 && div >= 1,
                "conv_gather: bad arguments");
   RSSF_REQUIRE((int64_t)B * IH * IW * Cin < ((int64_t)1 << 31) && (int64_t)B * OH * OW < ((int64_t)1 << 31),
                "conv_gather: activation tensors of 2^31 or more elements are not supported (32-bit offsets)");
   ConvArgs a;
-  a.in = in; a.wpk = wpk; a.out = out; a.bias = bias; a.stats = stats;
+  a.in = in; a.wpk = wpk; a.out = out; a.bias = bias; a.stats = stats; a.addend = addend;
   a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
   a.mul = mul; a.div = div;
   a.taps.n = ntaps;
@@ -392,6 +408,7 @@ extern "C" int rssf_conv_gather(const void* in, const void* wpk, void* out, cons
   if (dtype == RSSF_BF16 && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx)) {
     HaloArgs h;
     h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats;
+    h.addend = (const bf16_t*)addend;
     h.B = B; h.H = IH; h.W = IW; h.Cin = Cin; h.Cout = Cout; h.CinP = a.CinP; h.CoutP = a.CoutP;
     for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
     return launch_halo(h, st);

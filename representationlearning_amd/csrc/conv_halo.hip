@@ -152,12 +152,21 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
     const int gy = y0 + pix / TW, gx = x0 + pix % TW, col = n0 + cc;
     if (gy >= a.H || gx >= a.W || col >= a.Cout) continue;
     bf16_t* dst = a.out + (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + col;
+    const bf16_t* add = a.addend ? a.addend + (dst - a.out) : nullptr;
     if (ovec) {
       Vec<bf16_t> v;
       v.load(Cs + pix * LDC + cc);
+      if (add) {
+        Vec<bf16_t> w;
+        w.load(add);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = v.get(e) + w.get(e);
+        v.set_all(o);
+      }
       v.store(dst);
     } else {
-      for (int e = 0; e < 8 && col + e < a.Cout; ++e) dst[e] = Cs[pix * LDC + cc + e];
+      for (int e = 0; e < 8 && col + e < a.Cout; ++e) stf(dst + e, ldf(Cs + pix * LDC + cc + e) + (add ? ldf(add + e) : 0.f));
     }
   }
 }

@@ -56,9 +56,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU)
         res = x if self.downsample is None else nnf.run_sequential(self.downsample, x)
-        return nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU, res_pre=res)
+        link = nnf.residual_link(x, res)          # the skip gradient rides on conv1's data-gradient launch
+        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, grad_sink=link)
+        return nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU, res_pre=res, grad_deposit=link)
 
 
 class Bottleneck(nn.Module):
@@ -77,10 +78,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU)
-        out = nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU)
         res = x if self.downsample is None else nnf.run_sequential(self.downsample, x)
-        return nnf.conv_bn_act(out, self.conv3, self.bn3, nnf.ACT_RELU, res_pre=res)
+        link = nnf.residual_link(x, res)
+        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, grad_sink=link)
+        out = nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU)
+        return nnf.conv_bn_act(out, self.conv3, self.bn3, nnf.ACT_RELU, res_pre=res, grad_deposit=link)
 
 
 blocks_dict = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}

@@ -307,13 +307,28 @@ def _conv_forward(spec, xh, weights, bias, stats):
     return out
 
 
-def _conv_dgrad(spec, dout, weights, in_shape):
+class GradLink:
+    """Fuses the skip-path gradient of a residual block into the data-gradient launch of the block's first convolution.
+
+    `y = act(bn(conv_b(act(bn(conv_a(x))))) + x)`: autograd would add the two gradients of x (through conv_a, and the skip)
+    with a separate elementwise kernel - 108 of them per step.  The node that owns the skip (`deposit=link`) hands its
+    residual gradient to the link and returns None for it; the node of conv_a (`sink=link`), which by construction runs
+    later in backward, adds it in the epilogue of its data-gradient convolution (`rssf_conv_gather_add`)."""
+
+    def __init__(self):
+        self.value = None
+
+
+def _conv_dgrad(spec, dout, weights, in_shape, addend=None):
     B, H, W, C = in_shape
     dout = _pad_channels(dout)
     _, OH, OW, cout_p = dout.shape
     wpk = _pack(spec, weights, True, dout.dtype, dout.device)
     dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype)
-    L.check(L.load().rssf_conv_gather(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, B, OH, OW, cout_p, H, W, C, 1, spec.stride,
+    if addend is not None and (addend.shape != dx.shape or addend.dtype != dx.dtype or not addend.is_contiguous()):
+        raise RuntimeError("conv dgrad: fused skip gradient has shape/dtype %s %s, expected %s %s"
+                           % (tuple(addend.shape), addend.dtype, tuple(dx.shape), dx.dtype))
+    L.check(L.load().rssf_conv_gather_add(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, L.ptr(addend), B, OH, OW, cout_p, H, W, C, 1, spec.stride,
                                       spec.ntaps, spec.c_ndy, spec.c_ndx, L.dtype_code(dout),
                                       L.stream()), "rssf_conv_gather(dgrad)")
     return dx
@@ -344,7 +359,7 @@ def _conv_wgrad(spec, dout, xh, dws, db):
 
 class _ConvBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res_pre, res_post, gamma, beta, rmean, rvar, spec, act, training, momentum, eps, sync, nbias, *wb):
+    def forward(ctx, x, res_pre, res_post, gamma, beta, rmean, rvar, spec, act, training, momentum, eps, sync, nbias, links, *wb):
         weights, biases = wb[:len(wb) - nbias], wb[len(wb) - nbias:]
         L.require_gpu(x)
         xh = _nhwc(x)
@@ -376,6 +391,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.save_for_backward(xh, raw, ss, mi, rp, *weights)
         ctx.meta = (spec, act, training, n, sync, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
         ctx.params = (gamma, beta, weights, biases)
+        ctx.links = links                 # (sink, deposit) GradLinks or (None, None)
         return _nchw(y)
 
     @staticmethod
@@ -402,7 +418,18 @@ class _ConvBNAct(torch.autograd.Function):
         L.check(lib.rssf_bn_bwd_apply(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres),
                                       L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), L.dtype_code(raw), L.stream()),
                 "rssf_bn_bwd_apply")
-        dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape)) if x_req else None
+        sink, deposit = ctx.links
+        if deposit is not None and dres is not None:
+            deposit.value, dres = dres, None              # the first conv of the block folds it into its data gradient
+        addend = None
+        if sink is not None:
+            addend, sink.value = sink.value, None
+        if x_req:
+            dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape, addend))
+        else:
+            if addend is not None:
+                raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
+            dx = None
         wt = [grad_target(w) for w in p_weights]
         db = _zeros(C, raw.device) if nbias else None
         _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db)
@@ -413,7 +440,7 @@ class _ConvBNAct(torch.autograd.Function):
             tb += db
             gbs.append(grad_result(b, tb, direct))
         return (dx, None if dres is None else _nchw(dres), dy if has_post else None, grad_result(p_gamma, dgamma, dg_direct),
-                grad_result(p_beta, dbeta, db_direct), None, None, None, None, None, None, None, None, None, *gws, *gbs)
+                grad_result(p_beta, dbeta, db_direct), None, None, None, None, None, None, None, None, None, None, *gws, *gbs)
 
 
 class _ConvBias(torch.autograd.Function):
@@ -535,8 +562,9 @@ def cgfl_loss(logits, labels, aux, ignore_index=-1):
     return _CGFLLoss.apply(logits, labels, aux, int(ignore_index))
 
 
-def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None):
-    """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm."""
+def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_sink=None, grad_deposit=None):
+    """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm.
+    grad_sink / grad_deposit: GradLink of a residual block (see GradLink)."""
     convs = convs if isinstance(convs, (list, tuple)) else [convs]
     spec = spec_of(convs)
     training = bn.training or not bn.track_running_stats
@@ -549,7 +577,12 @@ def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None):
         raise NotImplementedError("conv_bn_act: either all or none of the summed convs carry a bias")
     mom = 0.1 if bn.momentum is None else bn.momentum
     return _ConvBNAct.apply(x, res_pre, res_post, bn.weight, bn.bias, bn.running_mean, bn.running_var, spec, act, training, mom, bn.eps,
-                            sync, len(biases), *weights, *biases)
+                            sync, len(biases), (grad_sink, grad_deposit), *weights, *biases)
+
+
+def residual_link(x, res):
+    """GradLink for `conv_a(x) ... + res` when the skip IS the block input and gradients flow into it (else None)."""
+    return GradLink() if (res is x and torch.is_grad_enabled() and x.requires_grad) else None
 
 
 def conv_bias(x, conv):
