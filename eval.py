@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """eval.py — surface of the reference's RSSFormer-TIP2023/eval.py (:17-24, :32-81): `evaluate(ckpt_path, config_path,
 use_tta)`: load a checkpoint (DDP `module.` prefix stripped, :37-38), softmax -> argmax -> ignore(-1) mask -> confusion
-matrix -> mIoU.  TTA and the LoveDA loader are not part of this round: without a dataset the
-synthetic validation tiles are used."""
+matrix -> mIoU, optionally with the six-scale test-time augmentation (module/tta.py).  The LoveDA loader is not part of this round
+(SURVEY.md §8f rank 3): without a dataset the synthetic validation tiles are used."""
 import argparse
 import os
 import sys
@@ -23,8 +23,6 @@ def evaluate(ckpt_path, config_path="baseline.hrnetw32", use_tta=False, batches=
     from representationlearning_amd.core import registry
     from representationlearning_amd.core.config import AttrDict
     from train import evaluate_cls_fn
-    if use_tta:
-        raise NotImplementedError("eval.py: test-time augmentation (module/tta.py) is a later row (SURVEY.md §8f rank 2)")
     _lib.load()
     registry.register_all()
     cfg = AttrDict.wrap(config_by_name(config_path))
@@ -34,7 +32,9 @@ def evaluate(ckpt_path, config_path="baseline.hrnetw32", use_tta=False, batches=
     model = model.cuda().eval()
     if batches is None:
         batches = [synthetic_batch(4, 512, classes=cfg.model.params.classes, seed=7)]
-    return evaluate_cls_fn(model, batches, cfg.model.params.classes)
+    # eval.py:57-64 of the reference: six bilinear scales when --tta
+    scales = (0.5, 0.75, 1.0, 1.25, 1.5, 1.75) if use_tta else None
+    return evaluate_cls_fn(model, batches, cfg.model.params.classes, tta_scales=scales)
 
 
 if __name__ == "__main__":

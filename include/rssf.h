@@ -197,6 +197,12 @@ int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* a
 int rssf_cgfl_loss_bwd(const void* logits, const int64_t* labels, const float* out, const float* dloss, void* dlogits, int B, int HW,
                        int K, int ignore_index, int dtype, void* stream);
 
+/* ---- evaluation: eval.py:66-71 (`pred.argmax(dim=1)`, ignore(-1) mask, er.metric.PixelMetric.forward) ----------------
+ * scores [npix][K] channels-last class scores (logits or probabilities: same argmax), labels [npix] int64 (optional),
+ * pred [npix] int32 (optional), cm [K][K] int64 += bincount(label*K + pred) over pixels whose label != ignore_index. */
+int rssf_argmax_confusion(const void* scores, const int64_t* labels, int32_t* pred, int64_t* cm, int64_t npix, int K,
+                          int ignore_index, int dtype, void* stream);
+
 /* ---- optimizer over flat fp32 buffers: the external `ever` trainer's clip_grad_norm_(35) + SGD(momentum .9,
  *      wd 1e-4) of configs/base/loveda.py:68-77 as two launches over all parameters ----------------------- */
 /* out[0] = sum g^2 (zeroed inside, on the stream). */

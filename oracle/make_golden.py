@@ -225,6 +225,27 @@ def case_model(variant, B, S, tag):
     save(f"model_{tag}", **arrs)
 
 
+def case_eval():
+    """Eval path of the reference (eval.py:55-71): model.eval() -> softmax probabilities, test-time augmentation over
+    Scale transforms (module/tta.py:12-24,118-135), argmax, ignore(-1) mask, confusion matrix."""
+    from module.tta import tta, Scale
+    torch.manual_seed(0)
+    m = load_seeded(build_model("tiny")).eval()
+    x = seeded_input((2, 3, 64, 64), 11)
+    y = proc_labels(2, 64, 64, 6, 9)
+    with torch.no_grad():
+        probs = m(x)
+        scales = (0.5, 1.0, 1.5)
+        out = tta(m, x, tta_config=[Scale(scale_factor=s) for s in scales])
+    pred, pred_tta = probs.argmax(1), out.argmax(1)
+    keep = y != -1
+    k = 6
+    cm = torch.bincount(y[keep] * k + pred[keep], minlength=k * k).reshape(k, k)
+    cm_tta = torch.bincount(y[keep] * k + pred_tta[keep], minlength=k * k).reshape(k, k)
+    save("eval_tiny_2x64", probs=npy(probs), tta=npy(out), scales=np.array(scales), y=npy(y), pred=npy(pred), pred_tta=npy(pred_tta),
+         cm=npy(cm), cm_tta=npy(cm_tta))
+
+
 def case_state_keys():
     for variant in ("tiny", "base", "large"):
         m = build_model(variant)
@@ -236,7 +257,8 @@ def case_state_keys():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["mhca", "attention", "block", "mlp", "loss", "neck_head", "keys", "models"]
+    which = sys.argv[1:] or ["mhca", "attention", "block", "mlp", "loss", "neck_head", "keys", "models", "eval"]
+    if "eval" in which: case_eval()
     if "mhca" in which: case_mhca()
     if "attention" in which: case_attention()
     if "block" in which: case_block()

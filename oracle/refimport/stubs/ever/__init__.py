@@ -6,3 +6,4 @@ oracle/make_golden.py to import /root/reference and emit golden vectors.
 """
 from .interface import ERModule  # noqa: F401
 from .core import registry  # noqa: F401
+from .interface import MultiTransform  # noqa: F401  (er.MultiTransform, module/tta.py:13)

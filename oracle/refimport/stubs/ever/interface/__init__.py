@@ -44,3 +44,25 @@ class ERModule(nn.Module):
 
     def set_default_config(self):
         pass
+
+
+# ---- only for the eval/TTA golden case: `er.MultiTransform` and `ever.interface.transform_base.Transform` are used by
+# the reference's module/tta.py:12-24,52-136.  ever is un-vendored: semantics restated from the call sites in tta():
+# transform(image) -> one image per transform; inv_transform(outs) -> each output mapped back by ITS transform.
+class Transform:
+    def transform(self, inputs):
+        raise NotImplementedError
+
+    def inv_transform(self, transformed_inputs):
+        raise NotImplementedError
+
+
+class MultiTransform:
+    def __init__(self, *transforms):
+        self.transforms = list(transforms)
+
+    def transform(self, inputs):
+        return [t.transform(inputs) for t in self.transforms]
+
+    def inv_transform(self, outs):
+        return [t.inv_transform(o) for t, o in zip(self.transforms, outs)]

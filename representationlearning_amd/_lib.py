@@ -69,6 +69,7 @@ SIGNATURES = {
     "rssf_upsample_nearest_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rssf_cgfl_loss_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "rssf_cgfl_loss_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "rssf_argmax_confusion": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p, c_float, c_float,
                               c_float, c_int, c_void_p]),

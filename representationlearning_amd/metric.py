@@ -15,7 +15,21 @@ class PixelMetric:
         k = self.num_classes
         self.cm += torch.bincount(y_true * k + y_pred, minlength=k * k).reshape(k, k)
 
+    def forward_scores(self, y_true, scores, ignore_index=-1):
+        """Device path: class scores [B,K,H,W] (logits or probabilities) + labels [B,H,W] -> confusion matrix, in ONE
+        kernel (argmax, ignore mask, histogram: rssf_argmax_confusion); nothing but K*K counters leaves the GPU."""
+        from . import ops
+        if not hasattr(self, "_cm_dev") or self._cm_dev.device != scores.device:
+            self._cm_dev = torch.zeros(self.num_classes, self.num_classes, dtype=torch.int64, device=scores.device)
+        ops.argmax_confusion(scores, y_true, self._cm_dev, ignore_index, want_pred=False)
+
+    def _sync(self):
+        if hasattr(self, "_cm_dev"):
+            self.cm += self._cm_dev.cpu()
+            self._cm_dev.zero_()
+
     def iou(self):
+        self._sync()
         cm = self.cm.double()
         tp = cm.diag()
         denom = cm.sum(0) + cm.sum(1) - tp

@@ -141,6 +141,28 @@ def winattn_bwd(dout, x, y, stats_x, stats_y, omega, ln_g, ln_b, w, gw, H, W, he
     return dxhat, dyhat, domega
 
 
+def argmax_confusion(scores, labels=None, cm=None, ignore_index=-1, want_pred=True):
+    """scores: logical [B,K,H,W] channels-last (or [npix,K]) class scores; labels [B,H,W] int64.  Returns pred [B,H,W] int32
+    (if want_pred) and accumulates cm [K,K] int64 += confusion of the non-ignored pixels (eval.py:66-71 of the reference)."""
+    L.require_gpu(scores)
+    if scores.dim() == 4:
+        sh = scores.permute(0, 2, 3, 1)
+        sh = sh if sh.is_contiguous() else sh.contiguous()
+        out_shape = sh.shape[:3]
+    else:
+        sh, out_shape = scores.contiguous(), scores.shape[:1]
+    K = sh.shape[-1]
+    npix = sh.numel() // K
+    pred = torch.empty(out_shape, device=scores.device, dtype=torch.int32) if want_pred else None
+    if labels is not None:
+        labels = labels.to(device=scores.device, dtype=torch.int64).contiguous()
+        if labels.numel() != npix or cm is None or cm.dtype != torch.int64 or tuple(cm.shape) != (K, K) or not cm.is_cuda:
+            raise ValueError("argmax_confusion: labels must match the pixels and cm must be a [K,K] int64 device tensor")
+    L.check(L.load().rssf_argmax_confusion(L.ptr(sh), L.ptr(labels), L.ptr(pred), L.ptr(cm), npix, K, ignore_index, L.dtype_code(sh),
+                                           L.stream()), "rssf_argmax_confusion")
+    return pred
+
+
 def grad_sqnorm(flat_grad, out):
     """out[0] = ||flat_grad||^2 (fp32, on the current stream)."""
     L.require_gpu(flat_grad)

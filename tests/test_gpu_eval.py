@@ -1,0 +1,90 @@
+"""GPU parity of the evaluation path: eval-mode forward, six-transform TTA machinery with the
+bilinear `Scale`, argmax + ignore mask + confusion matrix kernel - against the golden vectors produced by the reference's
+own eval code (oracle/make_golden.py::case_eval) and against plain torch on the same inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.procedural import seeded_input
+from tests.helpers import golden, rel_err
+from tests.test_gpu_model import build
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,K,H,W", [(2, 6, 33, 47), (1, 7, 8, 8), (3, 19, 16, 5)])
+def test_argmax_confusion_kernel(B, K, H, W, dtype):
+    from representationlearning_amd import ops
+    torch.manual_seed(B * 100 + K)
+    s = torch.randn(B, K, H, W).to(dtype)
+    s[0, :, 0, 0] = 1.0                                           # a tie: the first maximum wins, as torch.argmax
+    y = torch.randint(-1, K, (B, H, W))
+    ref_pred = s.float().argmax(1)
+    keep = y != -1
+    ref_cm = torch.bincount(y[keep] * K + ref_pred[keep], minlength=K * K).reshape(K, K)
+    cm = torch.zeros(K, K, dtype=torch.int64, device=DEV)
+    sd = s.to(DEV).contiguous(memory_format=torch.channels_last)
+    pred = ops.argmax_confusion(sd, y.to(DEV), cm)
+    ops.argmax_confusion(sd, y.to(DEV), cm, want_pred=False)      # accumulates
+    assert torch.equal(pred.cpu().long(), ref_pred)
+    assert torch.equal(cm.cpu(), 2 * ref_cm)
+
+
+@pytest.mark.parametrize("factor", [0.5, 0.75, 1.25, 1.75])
+def test_scale_transform_matches_interpolate(factor):
+    from representationlearning_amd.module.tta import Scale
+    torch.manual_seed(3)
+    x = torch.randn(2, 5, 24, 40)
+    t = Scale(scale_factor=factor)
+    ref = F.interpolate(x, scale_factor=factor, mode="bilinear", align_corners=True)
+    got = t.transform(x.to(DEV))
+    assert got.shape == ref.shape and rel_err(got.cpu(), ref) < 1e-5
+    back_ref = F.interpolate(ref, size=(24, 40), mode="bilinear", align_corners=True)
+    assert rel_err(t.inv_transform(got).cpu(), back_ref) < 1e-5
+
+
+def test_flip_rotate_transforms_round_trip():
+    from representationlearning_amd.module.tta import Rotate90k, HorizontalFlip, VerticalFlip, Transpose, Identity, tta
+    x = torch.randn(1, 3, 6, 6, device=DEV)
+    for t in (Identity(), Rotate90k(1), Rotate90k(3), HorizontalFlip(), VerticalFlip(), Transpose()):
+        assert torch.equal(t.inv_transform(t.transform(x)), x)
+    # an equivariant "model" (identity) is a fixed point of the averaged TTA
+    assert rel_err(tta(lambda im: im, x, [Identity(), HorizontalFlip(), Rotate90k(2)]).cpu(), x.cpu()) < 1e-6
+
+
+def test_eval_probs_tta_confusion_vs_reference():
+    """Tiny 2x3x64x64, eval mode: probabilities, 3-scale TTA and confusion matrices of the reference's eval.py path."""
+    from representationlearning_amd.module.tta import tta, Scale
+    from representationlearning_amd.metric import PixelMetric
+    g = golden("eval_tiny_2x64")
+    m = build("tiny").eval()
+    x = seeded_input((2, 3, 64, 64), 11).to(DEV)
+    y = torch.from_numpy(g["y"])
+    with torch.no_grad():
+        probs = m(x)
+        out = tta(m, x, [Scale(scale_factor=float(s)) for s in g["scales"]])
+    assert rel_err(probs.cpu(), g["probs"]) < 1e-3
+    assert rel_err(out.cpu(), g["tta"]) < 1e-3
+    for scores, key in ((probs, "cm"), (out, "cm_tta")):
+        metric = PixelMetric(6)
+        metric.forward_scores(y.to(DEV), scores)
+        metric._sync()
+        # a handful of near-tie pixels may flip class between fp32 implementations: total count exact, cells within 0.2 %
+        assert int(metric.cm.sum()) == int(g[key].sum())
+        assert np.abs(metric.cm.numpy() - g[key]).sum() <= max(4, 0.002 * g[key].sum()), (metric.cm, g[key])
+    s = PixelMetric(6)
+    s.forward_scores(y.to(DEV), out)
+    assert 0.0 <= s.summary_all()["miou"] <= 1.0
+
+
+def test_evaluate_entry_point_with_tta():
+    """eval.evaluate(): checkpoint-less model, synthetic tile, with and without the six-scale TTA."""
+    import eval as ev
+    from representationlearning_amd.configs import synthetic_batch
+    batches = [synthetic_batch(1, 128, classes=6, seed=3)]
+    for use_tta in (False, True):
+        out = ev.evaluate(None, "baseline.hrnetw32", use_tta, batches=batches)
+        assert set(out) >= {"miou", "iou", "overall_accuracy"} and 0.0 <= out["overall_accuracy"] <= 1.0

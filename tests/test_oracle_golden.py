@@ -186,3 +186,21 @@ def test_full_model(variant, B, S, tag):
     assert rel_err(pr[:, :, ::st, ::st], g["eval_probs_sample"]) < 1e-4
     hist = np.bincount(pr.argmax(1).numpy().ravel(), minlength=6)
     assert np.abs(hist - g["eval_argmax_hist"]).sum() <= 0.002 * hist.sum()
+
+
+def test_eval_tta_confusion():
+    """Eval path (eval.py:55-71, module/tta.py): probabilities, 3-scale TTA, argmax, ignore mask, confusion matrix."""
+    g = golden("eval_tiny_2x64")
+    P = seeded_params(O.model_template("tiny"))
+    x = seeded_input((2, 3, 64, 64), 11)
+    y = torch.from_numpy(g["y"])
+    with torch.no_grad():
+        probs = O.model_forward(x, P, False)
+        out = O.tta_scales(lambda im: O.model_forward(im, P, False), x, g["scales"].tolist())
+    assert rel_err(probs, g["probs"]) < 1e-4
+    assert rel_err(out, g["tta"]) < 1e-4
+    agree = (out.argmax(1).numpy() == g["pred_tta"]).mean()
+    assert agree > 0.999, agree
+    cm = O.confusion_matrix(y, torch.from_numpy(g["pred_tta"]), 6)
+    assert np.array_equal(cm.numpy(), g["cm_tta"])
+    assert np.array_equal(O.confusion_matrix(y, torch.from_numpy(g["pred"]), 6).numpy(), g["cm"])

@@ -24,16 +24,17 @@ def seed_torch(seed=2333):
     torch.cuda.manual_seed_all(seed)
 
 
-def evaluate_cls_fn(model, batches, classes, logger=print):
-    """train.py:14-57 of the reference: argmax, drop ignore(-1), confusion-matrix metrics."""
+def evaluate_cls_fn(model, batches, classes, logger=print, tta_scales=None):
+    """train.py:14-57 / eval.py:55-71 of the reference: (optional test-time augmentation,) argmax, drop ignore(-1),
+    confusion-matrix metrics."""
     from representationlearning_amd.metric import PixelMetric
+    from representationlearning_amd.module.tta import tta, Scale
     metric = PixelMetric(classes)
     model.eval()
     with torch.no_grad():
         for img, lab in batches:
-            pred = model(img).argmax(dim=1)
-            keep = lab != -1
-            metric.forward(lab[keep], pred[keep])
+            scores = model(img) if tta_scales is None else tta(model, img, [Scale(scale_factor=s) for s in tta_scales])
+            metric.forward_scores(lab, scores)          # argmax + ignore(-1) mask + confusion matrix: one HIP kernel
     out = metric.summary_all()
     logger("mIoU %.4f  OA %.4f" % (out["miou"], out["overall_accuracy"]))
     return out
