@@ -110,13 +110,34 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
 
   const int kchunks = a.CinP / BK;
-  const int nsteps = a.taps.n * kchunks;
+  // Strided data gradient: a tap contributes to an output row only when (oy + dy) is divisible by the stride.  When the
+  // whole pixel tile lies in ONE output row (the usual case: OW is a multiple of the tile), the taps of the wrong row
+  // parity are dropped for the whole block (3 or 6 of a 3x3's 9 taps remain) instead of being staged as zeros.
+  __shared__ int s_tap[MAX_TAPS];
+  __shared__ int s_ntap;
+  int ntap_act = a.taps.n;
+  if constexpr (DIV) {
+    if (tid == 0) {
+      const int64_t mlast = (m0 + BM - 1 < M ? m0 + BM - 1 : M - 1);
+      const int64_t r0 = m0 / a.OW, r1 = mlast / a.OW;               // global output-row index (batch folded in)
+      int n = 0;
+      for (int t = 0; t < a.taps.n; ++t) {
+        bool any = r0 != r1;
+        if (!any) { const int sy = (int)(r0 % a.OH) * a.mul + a.taps.dy[t]; any = sy >= 0 && sy % a.div == 0 && sy / a.div < a.IH; }
+        if (any) s_tap[n++] = t;
+      }
+      s_ntap = n;
+    }
+    __syncthreads();
+    ntap_act = s_ntap;
+  }
+  const int nsteps = ntap_act * kchunks;
   Vec<T> ra[A_CHUNKS], rb[B_CHUNKS];
 
   bool rok[A_CHUNKS];
-  int lt = 0, lkc = 0;                                    // (tap, channel chunk) of the next step to load
+  int lt = 0, lkc = 0;                                    // (active tap index, channel chunk) of the next step to load
   auto load_step = [&]() {
-    const int t = lt, kc = lkc;
+    const int t = DIV ? s_tap[lt] : lt, kc = lkc;
     if (++lkc == kchunks) { lkc = 0; ++lt; }
     const int dy = a.taps.dy[t], dx = a.taps.dx[t];
     const int c0 = kc * BK + sub;
@@ -125,8 +146,13 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
       int sy = py[i] + dy, sx = px[i] + dx;
       bool ok = pv[i] && sy >= 0 && sx >= 0 && c0 < a.Cin;
       if constexpr (DIV) {
-        ok = ok && (sy % a.div == 0) && (sx % a.div == 0);
-        sy /= a.div; sx /= a.div;
+        if (a.div == 2) {                                  // the only stride on this path: no integer division
+          ok = ok && ((sy | sx) & 1) == 0;
+          sy >>= 1; sx >>= 1;
+        } else {
+          ok = ok && (sy % a.div == 0) && (sx % a.div == 0);
+          sy /= a.div; sx /= a.div;
+        }
       }
       ok = ok && sy < a.IH && sx < a.IW;
       const int off = ok ? pb[i] + (sy * a.IW + sx) * a.Cin + c0 : 0;
@@ -162,7 +188,7 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
     }
   };
 
-  load_step();
+  if (nsteps > 0) load_step();
   for (int step = 0; step < nsteps; ++step) {
     store_step();
     __syncthreads();
