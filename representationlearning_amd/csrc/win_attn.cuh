@@ -5,6 +5,7 @@
 namespace rssf {
 namespace wa {
 
+constexpr int WIN = 7;       // window side (multihead_isa_pool_attention.py: window_size=7)
 constexpr int LP = 64;      // window tokens padded to 4 MFMA tiles (49 live)
 constexpr int NT = LP / 16;
 constexpr int MAX_MT = 4;   // virtual channel tiles: heads * ceil16(d) / 16  (Base 2, Tiny 2, Large 4)
@@ -55,9 +56,10 @@ __device__ __forceinline__ int real_ch(int m) {
 
 // token index (within the image) of window slot t, or -1 if the slot lies in the zero padding / beyond 49
 __device__ __forceinline__ int slot_token(const Geom& g, int qh, int qw, int t) {
-  if (t >= g.L) return -1;
-  const int u = qh * g.win + t / g.win - g.padT;
-  const int v = qw * g.win + t % g.win - g.padL;
+  // the window is always 7x7 (checked by the entry points): compile-time divisors, no integer division per token
+  if (t >= WIN * WIN) return -1;
+  const int u = qh * WIN + t / WIN - g.padT;
+  const int v = qw * WIN + t % WIN - g.padL;
   return (u >= 0 && u < g.H && v >= 0 && v < g.W) ? u * g.W + v : -1;
 }
 
@@ -206,7 +208,7 @@ __device__ __forceinline__ void load_gated_tiles(const rssf_winattn_fwd_params& 
       vy[it].load(Y + img * DM::C + f);
       sx[it] = *reinterpret_cast<const float2*>(p.stats_x + (img + nn) * 2);
       sy[it] = *reinterpret_cast<const float2*>(p.stats_y + (img + nn) * 2);
-      pp[it] = (int)(f % g.N);
+      pp[it] = (int)((unsigned)f % (unsigned)g.N);          // N*C < 2^31 (checked by the entry points): 32-bit modulo
     }
     const bool contiguous = g.N % DM::C == 0;   // the V gate weights of a chunk are contiguous (no wrap inside a token row)
 #pragma unroll
@@ -250,7 +252,7 @@ __device__ __forceinline__ void load_gated_tiles(const rssf_winattn_fwd_params& 
       float vx = 0.f, vy = 0.f;
       if (n >= 0 && c < DM::C) {
         const int64_t f = (int64_t)n * DM::C + c;
-        const int pp = (int)(f % g.N);
+        const int pp = (int)((unsigned)f % (unsigned)g.N);
         const float* sx = p.stats_x + (img + n) * 2;
         const float* sy = p.stats_y + (img + n) * 2;
         vx = ((ldf(X + img * DM::C + f) - sx[0]) * sx[1] * sLn[c] + sLn[DM::CP + c]) * om0[pp];

@@ -486,7 +486,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           const int c0 = ct * 16 + grp * 4;
           const int cc = c0 < C ? c0 : 0;
           const int64_t f = (int64_t)nn * C + cc;
-          pp[ct] = (int)(f % g.N);
+          pp[ct] = (int)((unsigned)f % (unsigned)g.N);
           rx[ct] = Quad4<T>::load(X + img * C + f);
           ry[ct] = Quad4<T>::load(Y + img * C + f);
           w0[ct] = *reinterpret_cast<const f32x4*>(om0 + pp[ct]);
@@ -530,7 +530,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
             const int c = ct * 16 + grp * 4 + r;
             if (c >= C) continue;
             const int64_t f = (int64_t)n * C + c;
-            const int pp = (int)(f % g.N);
+            const int pp = (int)((unsigned)f % (unsigned)g.N);
             const int64_t off = img * C + f;
             const float xh = (ldf(X + off) - sx.x) * sx.y * sLn[c] + sLn[CP + c];
             const float yh = (ldf(Y + off) - sy.x) * sy.y * sLn[c] + sLn[CP + c];
@@ -628,6 +628,7 @@ extern "C" int rssf_winattn_bwd(const rssf_winattn_bwd_params* p, void* stream) 
                "winattn_bwd: null gradient pointer");
   RSSF_REQUIRE(f.B > 0 && f.H > 0 && f.W > 0 && f.C > 0 && f.heads > 0 && f.window == 7, "winattn_bwd: bad shape");
   RSSF_REQUIRE(f.C % f.heads == 0, "winattn_bwd: embed_dim must be divisible by num_heads");
+  RSSF_REQUIRE((int64_t)f.H * f.W * f.C < ((int64_t)1 << 31), "winattn_bwd: H*W*C must stay below 2^31");
   const Geom g = make_geom(f.B, f.H, f.W, f.window);
   hipStream_t st = (hipStream_t)stream;
   if (f.dtype == RSSF_F32) return dispatch_bwd<float>(p, g, st);

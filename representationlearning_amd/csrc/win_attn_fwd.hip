@@ -341,6 +341,7 @@ extern "C" int rssf_winattn_fwd(const rssf_winattn_fwd_params* p, void* stream) 
   RSSF_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->C > 0 && p->heads > 0 && p->window == 7,
                "winattn_fwd: bad shape B=%d H=%d W=%d C=%d heads=%d window=%d", p->B, p->H, p->W, p->C, p->heads, p->window);
   RSSF_REQUIRE(p->C % p->heads == 0, "winattn_fwd: embed_dim must be divisible by num_heads");   // DAL.py:700-702
+  RSSF_REQUIRE((int64_t)p->H * p->W * p->C < ((int64_t)1 << 31), "winattn_fwd: H*W*C must stay below 2^31");
   const Geom g = make_geom(p->B, p->H, p->W, p->window);
   hipStream_t st = (hipStream_t)stream;
   if (p->dtype == RSSF_F32) return dispatch_fwd<float>(p, g, st);
