@@ -159,7 +159,7 @@ class HighResolutionModule(nn.Module):
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        x = [self.branches[i](x[i]) for i in range(self.num_branches)]          # Sequential of BasicBlocks
+        x = nnf.parallel_map(list(self.branches), x[:self.num_branches])       # Sequentials of BasicBlocks, one stream each
         fused = []
         for i in range(len(self.fuse_layers)):
             low = None

@@ -60,6 +60,45 @@ def grad_result(p, buf, direct):
     return buf
 
 
+# ---- branch-level concurrency ---------------------------------------------------------------------------------------
+# The HRNet branches of a HighResolutionModule are independent chains of small kernels (a 32x32 or 16x16 map fills a fraction
+# of the 256 CUs and is latency-bound).  With this switch on, the mirror module runs them on side streams; autograd replays
+# the backward of every node on its forward stream, and a captured hipGraph keeps the fork/join as parallel graph branches.
+# Off in data-parallel runs: one RCCL communicator must not be driven from several streams at once.
+_BRANCH_STREAMS = False
+_SIDE_STREAMS = {}
+
+
+def set_branch_streams(flag):
+    global _BRANCH_STREAMS
+    _BRANCH_STREAMS = bool(flag)
+
+
+def parallel_map(fns, args):
+    """[f(a) for f, a in zip(fns, args)], items 1.. on side streams when branch streams are enabled (item 0 stays on the
+    current stream); joined before returning."""
+    n = len(fns)
+    if not (_BRANCH_STREAMS and n > 1 and args[0].is_cuda):
+        return [f(a) for f, a in zip(fns, args)]
+    dev = args[0].device
+    cur = torch.cuda.current_stream(dev)
+    pool = _SIDE_STREAMS.setdefault(dev, [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(dev))
+    outs = [None] * n
+    for i in range(1, n):
+        s = pool[i - 1]
+        s.wait_stream(cur)
+        args[i].record_stream(s)
+        with torch.cuda.stream(s):
+            outs[i] = fns[i](args[i])
+    outs[0] = fns[0](args[0])
+    for i in range(1, n):
+        cur.wait_stream(pool[i - 1])
+        outs[i].record_stream(cur)
+    return outs
+
+
 def _all_reduce(t):
     """Sum over the data-parallel ranks: direct RCCL on the compute stream when the trainer set a communicator up
     (graph-capturable, ~5 us of host time), else torch.distributed."""

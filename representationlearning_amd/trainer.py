@@ -148,6 +148,9 @@ class Trainer:
         env = os.environ.get("RSSF_GRAPH")
         self.use_graph = (env == "1") or (env != "0" and use_graph and (not dp or self.comm is not None))
         self.graph_warmup = 3
+        # HRNet branches on side streams: parallel branches of the captured graph (+1 % at B=16); eager launches are host-bound
+        # and DP drives one RCCL communicator, so both keep a single stream
+        nnf.set_branch_streams(self.use_graph and not dp and os.environ.get("RSSF_BRANCH_STREAMS", "1") != "0")
         self.pack_plan = nnf.PackPlan() if os.environ.get("RSSF_PACK_PLAN", "1") != "0" else None
         self.graph = None
         self._static = None
