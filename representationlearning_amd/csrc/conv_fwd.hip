@@ -62,7 +62,10 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   using MK = MmaK<T>;
   using SL = StageLay<T>;
   constexpr int BK = MK::BK, V = Vec<T>::N, CPR = BK / V;      // 16-byte chunks per staged row (= 4)
-  constexpr int WM = BM / 32, WN = 4 / WM;                       // wave grid: WM along pixels x WN along channels
+  // wave grid: WM along pixels x WN along channels.  The 128 x 128 tile uses 2 x 2 waves of 64 x 64 (8 fragment reads per 16
+  // MFMAs instead of 10 for 32 x 128 waves); narrower tiles keep 32-pixel waves.
+  constexpr int WM = (BM == 128 && BNT == 128) ? 2 : BM / 32, WN = 4 / WM;
+  constexpr int MI = BM / (16 * WM);                             // 16-row tiles per wave along the pixels
   constexpr int WCOLS = BNT / WN;                                // channels per wave
   constexpr int NI = WCOLS / 16;
   static_assert(NI >= 1, "tile too narrow for the wave grid");
@@ -103,9 +106,9 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   }
   const int sub = (tid % CPR) * V;
 
-  f32x4 acc[2][NI];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
 
@@ -195,13 +198,13 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
     if (step + 1 < nsteps) load_step();                  // global loads in flight under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < BK; ks += MK::KSTEP) {
-      typename MK::frag fa[2], fb[NI];
+      typename MK::frag fa[MI], fb[NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) fa[mi] = MK::load(As + SL::frag(wave_m * 32 + mi * 16 + l15, ks, grp, BM));
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = MK::load(As + SL::frag(wave_m * (16 * MI) + mi * 16 + l15, ks, grp, BM));
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) fb[ni] = MK::load(Bs + SL::frag(wave_n * WCOLS + ni * 16 + l15, ks, grp, BNT));
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MK::mma(fa[mi], fb[ni], acc[mi][ni]);
     }
@@ -220,10 +223,10 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
     const float bv = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = wave_m * 32 + mi * 16 + grp * 4 + r;
+        const int row = wave_m * (16 * MI) + mi * 16 + grp * 4 + r;
         const float v = acc[mi][ni][r] + bv;
         stf(Cs + row * LDC + lcol, v);
         if (m0 + row < M) { s1 += v; s2 += v * v; }
