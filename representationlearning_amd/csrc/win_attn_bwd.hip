@@ -44,13 +44,21 @@ __device__ __forceinline__ void load_plain_tile(const Geom& g, const T* src, int
   constexpr int V = Vec<T>::N;
   if constexpr (DM::C % V == 0) {
     constexpr int cpr = DM::CP / V;
-    for (int e = lane; e < LP * cpr; e += 64) {
-      const int t = e / cpr, c0 = (e % cpr) * V;
+    constexpr int ITERS = (LP * cpr + 63) / 64;
+    Vec<T> v[ITERS];
+    bool ok[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {          // branch-free: all loads in flight together, dead slots read token 0
+      const int e = lane + it * 64, t = e / cpr, c0 = (e % cpr) * V;
       const int n = slot_token(g, qh, qw, t);
-      Vec<T> o;
-      o.raw = {0, 0, 0, 0};
-      if (n >= 0 && c0 < DM::C) o.load(src + (img + n) * DM::C + c0);
-      o.store(dst + t * ldx + c0);
+      ok[it] = e < LP * cpr && n >= 0 && c0 < DM::C;
+      v[it].load(src + (img + (ok[it] ? n : 0)) * DM::C + (ok[it] ? c0 : 0));
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int e = lane + it * 64, t = e / cpr, c0 = (e % cpr) * V;
+      if (!ok[it]) v[it].raw = {0, 0, 0, 0};
+      if (e < LP * cpr) v[it].store(dst + t * ldx + c0);
     }
   } else {
     for (int e = lane; e < LP * DM::CP; e += 64) {
