@@ -93,8 +93,11 @@ typedef struct {
   const void* dout;            /* [B,N,C] gradient w.r.t. the attention term (the residual is the caller's) */
   void* dxhat;                 /* [B,N,C] grad w.r.t. LN1(x) through the attention path (gate applied) */
   void* dyhat;                 /* [B,N,C] */
-  float* domega;               /* [B][2][N], must be zeroed by the caller; accumulated with atomics */
+  float* domega;               /* [B][2][N].  With prod_ws: overwritten.  Without: must be zeroed by the caller, accumulated
+                                * with one fp32 atomic per activation element (18 M per Base launch: 43 % of the kernel) */
   float* dwq; float* dbq; float* dwk; float* dbk; float* dwv; float* dbv; float* dwo; float* dbo;  /* += */
+  float* prod_ws;              /* optional scratch [2][B][N][C] fp32: the per-element products d(x~)*LN(x), d(y~)*LN(y) are
+                                * stored there and a second launch sums the C elements that share a gate weight */
 } rssf_winattn_bwd_params;
 int rssf_winattn_bwd(const rssf_winattn_bwd_params* p, void* stream);
 

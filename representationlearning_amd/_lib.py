@@ -24,7 +24,7 @@ class WinAttnFwdParams(ctypes.Structure):
 
 class WinAttnBwdParams(ctypes.Structure):
     _fields_ = [("f", WinAttnFwdParams)] + [(n, c_void_p) for n in (
-        "dout", "dxhat", "dyhat", "domega", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv", "dwo", "dbo")]
+        "dout", "dxhat", "dyhat", "domega", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv", "dwo", "dbo", "prod_ws")]
 
 
 MAX_TAPS, PACK_CHUNK = 19, 1024      # RSSF_MAX_TAPS, RSSF_PACK_CHUNK

@@ -182,14 +182,16 @@ __device__ __forceinline__ f32x4 mma_row_row(const T* A, int lda, int ca, const 
 // Load the two 49xC tiles of one window, apply LayerNorm (precomputed {mean,rstd}) and the gate weight
 // omega[(n*C+c) mod N] (the reference's view-scramble), write them to LDS as T with
 // zero rows for padded / dead slots and zero columns C..Cp.  16-byte lane accesses when C % VEC == 0.
-template <typename T, typename DM>
+// NPARTS cooperating waves deal the 64-lane chunks of the tile round-robin (chunk index = part + NPARTS * j): same
+// branch-free code, a runtime chunk offset.
+template <typename T, typename DM, int NPARTS = 1>
 __device__ __forceinline__ void load_gated_tiles(const rssf_winattn_fwd_params& p, const Geom& g, const float* sLn,
                                                  const T* X, const T* Y, const float* om0, int64_t img, int qh, int qw,
-                                                 T* xs, T* ys, int ldx, int lane) {
+                                                 T* xs, T* ys, int ldx, int lane, int part = 0) {
   constexpr int V = Vec<T>::N;
   if constexpr (DM::C % V == 0) {
     constexpr int cpr = DM::CP / V;
-    constexpr int ITERS = (LP * cpr + 63) / 64;
+    constexpr int ITERS = ((LP * cpr + 63) / 64 + NPARTS - 1) / NPARTS;
     // branch-free: every lane issues all its global loads back to back (dead / padded slots read token 0 and are
     // zeroed afterwards), so the HBM latency is paid once per window instead of once per iteration.
     Vec<T> vx[ITERS], vy[ITERS];
@@ -198,7 +200,7 @@ __device__ __forceinline__ void load_gated_tiles(const rssf_winattn_fwd_params& 
     bool ok[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int e = lane + it * 64;
+      const int e = lane + (part + NPARTS * it) * 64;
       const int t = e / cpr, c0 = (e % cpr) * V;
       const int n = slot_token(g, qh, qw, t);
       ok[it] = n >= 0 && c0 < DM::C && e < LP * cpr;
@@ -213,7 +215,7 @@ __device__ __forceinline__ void load_gated_tiles(const rssf_winattn_fwd_params& 
     const bool contiguous = g.N % DM::C == 0;   // the V gate weights of a chunk are contiguous (no wrap inside a token row)
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int e = lane + it * 64;
+      const int e = lane + (part + NPARTS * it) * 64;
       if (e >= LP * cpr) break;
       const int t = e / cpr, c0 = (e % cpr) * V;
       float w0[V], w1[V];
@@ -246,7 +248,7 @@ __device__ __forceinline__ void load_gated_tiles(const rssf_winattn_fwd_params& 
       oy.store(ys + t * ldx + c0);
     }
   } else {
-    for (int e = lane; e < LP * DM::CP; e += 64) {
+    for (int e = lane + 64 * part; e < LP * DM::CP; e += 64 * NPARTS) {
       const int t = e / DM::CP, c = e % DM::CP;
       const int n = slot_token(g, qh, qw, t);
       float vx = 0.f, vy = 0.f;

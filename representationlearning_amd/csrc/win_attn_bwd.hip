@@ -2,13 +2,16 @@
 // torch autograd through InterlacedPoolAttention2.forward :164-188 and Mhca, modules/DAL.py:873-1020,
 // incl. the three gradient paths into q/k — softmax, mean(M), argmax-routed max(M) — SURVEY App. C).
 //
-// One wavefront per window.  The forward is recomputed from (x, y, LN stats, omega) so nothing but the
+// One PAIR of wavefronts per window, one attention head each (they share the six LDS tiles, stage the inputs together and
+// exchange their shares of the input gradient through LDS at the end; workgroup barriers separate those phases, so all
+// pairs of a workgroup walk their windows in lockstep).  The forward is recomputed from (x, y, LN stats, omega) so nothing but the
 // block inputs is saved; HBM traffic = read x, y, dout + write dxhat, dyhat.  Every operand is staged in LDS ONCE,
 // token-major; contractions over the token axis read it through the LDS transpose read (RowFrag, win_attn.cuh), which
 // keeps the per-wave footprint at 6 tiles (was 11 + transposed weight copies) so that 4 waves fit a CU instead of 2;
 // O and dU never touch LDS: they are formed in both register orientations by swapping MFMA operands.
 // Softmax / dS tiles stay in registers and are computed in both orientations instead of being transposed through LDS.
 // Weight gradients are accumulated in LDS per workgroup and flushed once.
+#include <type_traits>
 #include "win_attn.cuh"
 using namespace rssf;
 using namespace rssf::wa;
@@ -29,39 +32,45 @@ template <typename T, typename DM, bool ACC_LDS> struct BwdLayout {
   static constexpr int F_ELEMS = 3 * DM::CV + 2 * DM::CP;                       // bq bk bv, gamma beta
   static constexpr int A_ELEMS = ACC_LDS ? 4 * DM::CV * DM::CP + 3 * DM::CV + DM::CP : 0;
   static constexpr size_t SHARED_OFF = (sizeof(T) * W_ELEMS + sizeof(float) * (F_ELEMS + A_ELEMS) + 15) / 16 * 16;
-  static constexpr size_t WAVE_BYTES = sizeof(T) * (NREG * REGION + SCRATCH);
+  // A window is served by a PAIR of waves (one head each) that share the six tiles; each wave has its own dM scratch.
+  static_assert(DM::HEADS == 2, "the backward kernel maps one head to each wave of a pair");
+  static constexpr int PAIR_ELEMS = NREG * REGION + 2 * SCRATCH;
+  static constexpr size_t WAVE_BYTES = sizeof(T) * PAIR_ELEMS;            // per pair
   static constexpr size_t LIM = 160 * 1024;
-  static constexpr int WAVES = (SHARED_OFF + 4 * WAVE_BYTES <= LIM) ? 4 : (SHARED_OFF + 3 * WAVE_BYTES <= LIM) ? 3
+  static constexpr int PAIRS = (SHARED_OFF + 4 * WAVE_BYTES <= LIM) ? 4 : (SHARED_OFF + 3 * WAVE_BYTES <= LIM) ? 3
                              : (SHARED_OFF + 2 * WAVE_BYTES <= LIM) ? 2 : 1;
-  static constexpr size_t BYTES = SHARED_OFF + WAVE_BYTES * WAVES;
+  static constexpr int WAVES = 2 * PAIRS;
+  static constexpr size_t BYTES = SHARED_OFF + WAVE_BYTES * PAIRS;
   static constexpr bool FITS = BYTES <= LIM;
+  // head-sum exchange of the input-gradient tiles: CT x 2 token tiles x {x, y} f32x4 per lane, in two tile regions
+  static_assert(2 * REGION * sizeof(T) >= (size_t)DM::CT * 2 * 2 * 64 * 16, "exchange buffer does not fit two tile regions");
 };
 
 // plain (no LN / gate) token-major tile load, zero for pad / dead slots
 template <typename T, typename DM>
 __device__ __forceinline__ void load_plain_tile(const Geom& g, const T* src, int64_t img, int qh, int qw, T* dst, int ldx,
-                                                int lane) {
+                                                int lane, int part) {          // two cooperating waves: chunks part, part + 2, ..
   constexpr int V = Vec<T>::N;
   if constexpr (DM::C % V == 0) {
     constexpr int cpr = DM::CP / V;
-    constexpr int ITERS = (LP * cpr + 63) / 64;
+    constexpr int ITERS = ((LP * cpr + 63) / 64 + 1) / 2;
     Vec<T> v[ITERS];
     bool ok[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {          // branch-free: all loads in flight together, dead slots read token 0
-      const int e = lane + it * 64, t = e / cpr, c0 = (e % cpr) * V;
+      const int e = lane + (part + 2 * it) * 64, t = e / cpr, c0 = (e % cpr) * V;
       const int n = slot_token(g, qh, qw, t);
       ok[it] = e < LP * cpr && n >= 0 && c0 < DM::C;
       v[it].load(src + (img + (ok[it] ? n : 0)) * DM::C + (ok[it] ? c0 : 0));
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-      const int e = lane + it * 64, t = e / cpr, c0 = (e % cpr) * V;
+      const int e = lane + (part + 2 * it) * 64, t = e / cpr, c0 = (e % cpr) * V;
       if (!ok[it]) v[it].raw = {0, 0, 0, 0};
       if (e < LP * cpr) v[it].store(dst + t * ldx + c0);
     }
   } else {
-    for (int e = lane; e < LP * DM::CP; e += 64) {
+    for (int e = lane + 64 * part; e < LP * DM::CP; e += 128) {
       const int t = e / DM::CP, c = e % DM::CP;
       const int n = slot_token(g, qh, qw, t);
       stf(dst + t * ldx + c, (n >= 0 && c < DM::C) ? ldf(src + (img + n) * DM::C + c) : 0.f);
@@ -110,12 +119,13 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   float* sB = reinterpret_cast<float*>(sWoT + CV * LDW);   // bq bk bv [CV]
   float* sLn = sB + 3 * CV;                      // gamma, beta [CP]
   float* aW = sLn + 2 * CP;                      // accumulators: dWq dWk dWv [CV][CP], dWo^T [CV][CP], dbq dbk dbv [CV], dbo [CP]
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform: scalar branches on pair / hw
   const int l15 = lane & 15, grp = lane >> 4;
-  T* base = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)wave * (LY::NREG * LY::REGION + LY::SCRATCH);
+  const int pair = wave >> 1, hw = wave & 1;               // wave hw of a pair computes head hw of the pair's window
+  T* base = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)pair * LY::PAIR_ELEMS;
   T* XS = base;                 T* YS = XS + LY::REGION;   T* GS = YS + LY::REGION;
   T* QS = GS + LY::REGION;      T* KS = QS + LY::REGION;   T* VS = KS + LY::REGION;    // later dq, dk, dv (head by head)
-  T* dMs = VS + LY::REGION;     T* dMTs = dMs + DP * LDD;
+  T* dMs = VS + LY::REGION + hw * LY::SCRATCH;     T* dMTs = dMs + DP * LDD;
 
   for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
     const int m = i / LDW, k = i % LDW;
@@ -161,17 +171,18 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   const T* DOUT = reinterpret_cast<const T*>(bp.dout);
   T* DXH = reinterpret_cast<T*>(bp.dxhat);
   T* DYH = reinterpret_cast<T*>(bp.dyhat);
+  float* PW = bp.prod_ws;
   const int wpi = g.QH * g.QW;
 
   // Parameter gradients live in registers across ALL windows of this wave (the kernel is LDS-bound to one wave per
   // SIMD, so VGPRs are free) and are folded into the workgroup's LDS accumulators once at the end; measured before:
   // ~60 LDS float atomics per lane per window kept the LDS pipe busy 20x longer than all other LDS traffic together.
-  f32x4 gWq[MT][CT], gWk[MT][CT], gWv[MT][CT], gWo[MT][CT];
-  f32x4 gbq[MT], gbk[MT], gbv[MT];
+  f32x4 gWq[TPH][CT], gWk[TPH][CT], gWv[TPH][CT], gWo[TPH][CT];       // rows of THIS wave's head: virtual channel (hw*TPH + i)*16 ..
+  f32x4 gbq[TPH], gbk[TPH], gbv[TPH];
   float gbo = 0.f;
   const typename Packed<T>::type ones = Packed<T>::pack(f32x4{1.f, 1.f, 1.f, 1.f});
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = 0; mt < TPH; ++mt) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       gWq[mt][ct] = {0.f, 0.f, 0.f, 0.f}; gWk[mt][ct] = gWq[mt][ct]; gWv[mt][ct] = gWq[mt][ct]; gWo[mt][ct] = gWq[mt][ct];
@@ -179,21 +190,31 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
     gbq[mt] = {0.f, 0.f, 0.f, 0.f}; gbk[mt] = gbq[mt]; gbv[mt] = gbq[mt];
   }
 
-  for (int wi = blockIdx.x * LY::WAVES + wave; wi < g.nWin; wi += gridDim.x * LY::WAVES) {
+  // All pairs of the block run the same number of iterations: the phases are separated by workgroup barriers.
+  const int nslots = gridDim.x * LY::PAIRS;
+  const int iters = (g.nWin + nslots - 1) / nslots;
+  for (int iter = 0; iter < iters; ++iter) {
+    const int wi_raw = iter * nslots + blockIdx.x * LY::PAIRS + pair;
+    const bool active = wi_raw < g.nWin;
+    const int wi = active ? wi_raw : 0;
     const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;
     const int64_t img = (int64_t)b * g.N;
     const float* om0 = p.omega + (int64_t)b * 2 * g.N;
     float* dom0 = bp.domega + (int64_t)b * 2 * g.N;
 
-    // ---- S1: gated LN'ed inputs and dout tile, token-major -------------------------------------------------
-    wave_sync();
-    load_gated_tiles<T, DM>(p, g, sLn, X, Y, om0, img, qh, qw, XS, YS, LDX, lane);
-    load_plain_tile<T, DM>(g, DOUT, img, qh, qw, GS, LDX, lane);
-    wave_sync();
-
-    // ---- S2: projections; q,k,v staged token-major (K = tokens contractions read them through RowFrag) --------
+    f32x4 dxt[CT][NT], dyt[CT][NT];     // d(x~)^T, d(y~)^T accumulators (this head's share): rows = real channel, col = token
+    // ---- S1: gated LN'ed inputs and dout tile, token-major; the two waves of the pair stage half of the chunks each ----
+    __syncthreads();                    // the previous window's exchange buffers (which alias these tiles) have been read
+    if (active) {
+      load_gated_tiles<T, DM, 2>(p, g, sLn, X, Y, om0, img, qh, qw, XS, YS, LDX, lane, hw);
+      load_plain_tile<T, DM>(g, DOUT, img, qh, qw, GS, LDX, lane, hw);
+    }
+    __syncthreads();
+    if (active) {
+    // ---- S2: projections of THIS wave's head; q,k,v staged token-major (K = tokens contractions use RowFrag) -----------
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mi0 = 0; mi0 < TPH; ++mi0) {
+      const int mt = hw * TPH + mi0;
       const int mrow = mt * 16 + grp * 4;
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
@@ -216,17 +237,11 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
 
     // dbo += sum_tokens dout   (columns of GS)
     static_assert(CP <= 64, "dbo: one lane per padded channel");
-    if (lane < CP)
+    if (hw == 0 && lane < CP)
       for (int t = 0; t < g.L; ++t) gbo += ldf(GS + t * LDX + lane);
 
-    f32x4 dxt[CT][NT], dyt[CT][NT];     // d(x~)^T, d(y~)^T accumulators: rows = real channel, col = token
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int tt = 0; tt < NT; ++tt) { dxt[ct][tt] = {0.f, 0.f, 0.f, 0.f}; dyt[ct][tt] = {0.f, 0.f, 0.f, 0.f}; }
-
-#pragma unroll
-    for (int h = 0; h < DM::HEADS; ++h) {
+    {
+      const int h = hw;
       const int hoff = h * DP;
       // ---- S3: alpha = sigmoid(mean(M)+max(M)), M = q_h^T k_h, with its argmax ---------------------------------
       float msum = 0.f, mmax = -INFINITY;
@@ -276,6 +291,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
       float dalpha = 0.f;
 #pragma unroll
       for (int qt = 0; qt < NT; ++qt) {
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 s[NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
@@ -325,7 +341,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           const typename Packed<T>::type op = Packed<T>::pack(o);
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)      // dWo^T[m][c] += sum_q O[q][m] dout[q][c]   (dout rows of dead slots are zero)
-            gWo[h * TPH + mi][ct] = Packed<T>::mma(op, RowFrag<T>::load(GS, LDX, qt * 16, ct * 16), gWo[h * TPH + mi][ct]);
+            gWo[mi][ct] = Packed<T>::mma(op, RowFrag<T>::load(GS, LDX, qt * 16, ct * 16), gWo[mi][ct]);
         }
         // dP^T[key][query] = sum_m v[key][m] dU[query][m]
         f32x4 dp[NT];
@@ -360,6 +376,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
       // ---- S5: orientation 2 (rows = queries, col = key): dS -> dk, P -> dv ---------------------------------------
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 p2[NT], ds2[NT];
 #pragma unroll
         for (int qt = 0; qt < NT; ++qt) {
@@ -390,6 +407,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
         }
       }
 
+      __builtin_amdgcn_sched_barrier(0);
       // ---- S6: alpha path: dM = du * (1/d^2 + onehot(argmax)) -> dq += k dM^T, dk += q dM ---------------------------
       const float du = dalpha * alpha * (1.f - alpha);
 #pragma unroll
@@ -422,6 +440,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
         }
       wave_sync();   // every read of the QS/KS/VS columns of this head is done -> reuse them for dq, dk, dv
 
+      __builtin_amdgcn_sched_barrier(0);
       // ---- S7: stage gradients of the projection outputs; bias grads; input grads --------------------------------
 #pragma unroll
       for (int mi = 0; mi < TPH; ++mi) {
@@ -440,14 +459,17 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int tt = 0; tt < NT; ++tt) {
-            dxt[ct][tt] = mma_row_chain<T>(sWq, LDW, ct * 16, hoff + mi * 16, dq[mi][tt], dxt[ct][tt]);
-            dyt[ct][tt] = mma_row_chain<T>(sWk, LDW, ct * 16, hoff + mi * 16, dk[mi][tt], dyt[ct][tt]);
+            // first contribution starts from zero here: the 2 x CT x NT accumulators are not live during S3..S6
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            dxt[ct][tt] = mma_row_chain<T>(sWq, LDW, ct * 16, hoff + mi * 16, dq[mi][tt], mi == 0 ? z : dxt[ct][tt]);
+            dyt[ct][tt] = mma_row_chain<T>(sWk, LDW, ct * 16, hoff + mi * 16, dk[mi][tt], mi == 0 ? z : dyt[ct][tt]);
             dyt[ct][tt] = mma_row_chain<T>(sWv, LDW, ct * 16, hoff + mi * 16, dv[mi][tt], dyt[ct][tt]);
           }
       }
     }
     wave_sync();
 
+    __builtin_amdgcn_sched_barrier(0);
     // ---- S8: weight gradients dW[m][c] = sum_t d(proj)[t][m] * in[t][c]; bias gradients = the same contraction against
     //      a column of ones (every column of the gb* tiles holds the row sum; column 0 is flushed) ------------------------
 #pragma unroll
@@ -459,20 +481,54 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
         fy[ct] = RowFrag<T>::load(YS, LDX, tt * 16, ct * 16);
       }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const typename Packed<T>::type fq = RowFrag<T>::load(QS, LDV, tt * 16, mt * 16), fk = RowFrag<T>::load(KS, LDV, tt * 16, mt * 16),
-                                       fv = RowFrag<T>::load(VS, LDV, tt * 16, mt * 16);
-        gbq[mt] = Packed<T>::mma(fq, ones, gbq[mt]);
-        gbk[mt] = Packed<T>::mma(fk, ones, gbk[mt]);
-        gbv[mt] = Packed<T>::mma(fv, ones, gbv[mt]);
+      for (int mi = 0; mi < TPH; ++mi) {
+        const int mc = (hw * TPH + mi) * 16;
+        const typename Packed<T>::type fq = RowFrag<T>::load(QS, LDV, tt * 16, mc), fk = RowFrag<T>::load(KS, LDV, tt * 16, mc),
+                                       fv = RowFrag<T>::load(VS, LDV, tt * 16, mc);
+        gbq[mi] = Packed<T>::mma(fq, ones, gbq[mi]);
+        gbk[mi] = Packed<T>::mma(fk, ones, gbk[mi]);
+        gbv[mi] = Packed<T>::mma(fv, ones, gbv[mi]);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          gWq[mt][ct] = Packed<T>::mma(fq, fx[ct], gWq[mt][ct]);
-          gWk[mt][ct] = Packed<T>::mma(fk, fy[ct], gWk[mt][ct]);
-          gWv[mt][ct] = Packed<T>::mma(fv, fy[ct], gWv[mt][ct]);
+          gWq[mi][ct] = Packed<T>::mma(fq, fx[ct], gWq[mi][ct]);
+          gWk[mi][ct] = Packed<T>::mma(fk, fy[ct], gWk[mi][ct]);
+          gWv[mi][ct] = Packed<T>::mma(fv, fy[ct], gWv[mi][ct]);
         }
       }
     }
+    }   // active: S2 .. S8
+
+    // ---- head sum of d(x~), d(y~): wave hw keeps token tiles 2hw, 2hw+1 and receives the partner's share of them through
+    //      LDS (the six tiles are dead now): partner 0's inbox = {XS, YS}, partner 1's = {GS, QS} -------------------------
+    __syncthreads();
+    f32x4* inbox0 = reinterpret_cast<f32x4*>(XS);
+    f32x4* inbox1 = reinterpret_cast<f32x4*>(GS);
+    auto send = [&](auto TT0, f32x4* box) {               // TT0: first token tile of the RECEIVER
+      constexpr int t0 = decltype(TT0)::value;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          box[((ct * 2 + tl) * 2 + 0) * 64 + lane] = dxt[ct][t0 + tl];
+          box[((ct * 2 + tl) * 2 + 1) * 64 + lane] = dyt[ct][t0 + tl];
+        }
+    };
+    if (active) {
+      if (hw == 0) send(std::integral_constant<int, 2>{}, inbox1);
+      else send(std::integral_constant<int, 0>{}, inbox0);
+    }
+    __syncthreads();
+    if (active) {
+    auto finish = [&](auto TT0, const f32x4* box) {
+      constexpr int t0 = decltype(TT0)::value;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          const f32x4 ox = box[((ct * 2 + tl) * 2 + 0) * 64 + lane], oy = box[((ct * 2 + tl) * 2 + 1) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { dxt[ct][t0 + tl][r] += ox[r]; dyt[ct][t0 + tl][r] += oy[r]; }
+        }
 
     // ---- S9: dxhat = d(x~) * omega0, dyhat = d(y~) * omega1 ; domega += d(x~) * LN(x) ----------------------------------
     // A lane owns 4 consecutive channels (4g..4g+3 of tile ct) of token tt*16 + l15.  Vector path (C and N multiples of
@@ -481,7 +537,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
     // predicated.
     if ((C % 4 == 0) && (g.N % 4 == 0)) {
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
+      for (int tt = t0; tt < t0 + 2; ++tt) {
         const int n = slot_token(g, qh, qw, tt * 16 + l15);
         const int nn = n >= 0 ? n : 0;
         const float2 sx = *reinterpret_cast<const float2*>(p.stats_x + (img + nn) * 2);
@@ -517,16 +573,22 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           const int64_t off = img * C + (int64_t)n * C + c0;
           store4(DXH + off, ox);
           store4(DYH + off, oy);
+          if (PW) {                                       // products to scratch; domega_reduce_kernel sums them
+            const int64_t po = ((int64_t)b * g.N + n) * C + c0;
+            store4(PW + po, gx);
+            store4(PW + (int64_t)g.B * g.N * C + po, gy);
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            atomicAdd(dom0 + pp[ct] + r, gx[r]);
-            atomicAdd(dom0 + g.N + pp[ct] + r, gy[r]);
+            for (int r = 0; r < 4; ++r) {
+              atomicAdd(dom0 + pp[ct] + r, gx[r]);
+              atomicAdd(dom0 + g.N + pp[ct] + r, gy[r]);
+            }
           }
         }
       }
     } else {
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
+      for (int tt = t0; tt < t0 + 2; ++tt) {
         const int n = slot_token(g, qh, qw, tt * 16 + l15);
         if (n < 0) continue;
         const float2 sx = *reinterpret_cast<const float2*>(p.stats_x + (img + n) * 2);
@@ -544,32 +606,42 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
             const float yh = (ldf(Y + off) - sy.x) * sy.y * sLn[c] + sLn[CP + c];
             stf(DXH + off, dxt[ct][tt][r] * om0[pp]);
             stf(DYH + off, dyt[ct][tt][r] * om0[g.N + pp]);
-            atomicAdd(dom0 + pp, dxt[ct][tt][r] * xh);
-            atomicAdd(dom0 + g.N + pp, dyt[ct][tt][r] * yh);
+            if (PW) {
+              PW[off] = dxt[ct][tt][r] * xh;
+              PW[(int64_t)g.B * g.N * C + off] = dyt[ct][tt][r] * yh;
+            } else {
+              atomicAdd(dom0 + pp, dxt[ct][tt][r] * xh);
+              atomicAdd(dom0 + g.N + pp, dyt[ct][tt][r] * yh);
+            }
           }
       }
     }
+    };   // finish
+    static_assert(NT == 4, "two token tiles per wave of a pair");
+    if (hw == 0) finish(std::integral_constant<int, 0>{}, inbox0);
+    else finish(std::integral_constant<int, 2>{}, inbox1);
+    }   // active: exchange + S9
   }
 
   // ---- fold this wave's register accumulators into the workgroup accumulators (or straight into HBM) -------------------
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = 0; mt < TPH; ++mt) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = mt * 16 + grp * 4 + r, c = ct * 16 + l15;
+        const int m = (hw * TPH + mt) * 16 + grp * 4 + r, c = ct * 16 + l15;
         acc_w(0, m, c, gWq[mt][ct][r]); acc_w(1, m, c, gWk[mt][ct][r]); acc_w(2, m, c, gWv[mt][ct][r]);
         acc_w(3, m, c, gWo[mt][ct][r]);
       }
     if (l15 == 0)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = mt * 16 + grp * 4 + r;
+        const int m = (hw * TPH + mt) * 16 + grp * 4 + r;
         acc_b(0, m, gbq[mt][r]); acc_b(1, m, gbk[mt][r]); acc_b(2, m, gbv[mt][r]);
       }
   }
-  if (lane < CP) acc_b(3, lane, gbo);
+  if (hw == 0 && lane < CP) acc_b(3, lane, gbo);
 
   if (ACC_LDS) {
     __syncthreads();
@@ -588,10 +660,26 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   }
 }
 
+// domega[b][s][pp] = sum_j prod_s[b][pp + j*N], j = 0..C-1 : the C activation elements whose flat offset is pp modulo N
+// share gate weight pp (the reference's (B,N,C) -> view(B,C,H,W) scramble).  Coalesced over pp, C strided reads.
+__global__ void __launch_bounds__(256) domega_reduce_kernel(const float* __restrict__ prod, float* __restrict__ domega, int B, int N, int C) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * 2 * N) return;
+  const int pp = (int)(gid % N), s = (int)((gid / N) % 2), b = (int)(gid / (2 * (int64_t)N));
+  const float* src = prod + ((int64_t)s * B + b) * N * C + pp;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int j = 0;
+  for (; j + 3 < C; j += 4) {
+    a0 += src[(int64_t)j * N]; a1 += src[(int64_t)(j + 1) * N]; a2 += src[(int64_t)(j + 2) * N]; a3 += src[(int64_t)(j + 3) * N];
+  }
+  for (; j < C; ++j) a0 += src[(int64_t)j * N];
+  domega[gid] = (a0 + a1) + (a2 + a3);
+}
+
 template <typename T, typename DM, bool ACC_LDS>
 int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) {
   using LY = BwdLayout<T, DM, ACC_LDS>;
-  int blocks = (g.nWin + LY::WAVES - 1) / LY::WAVES;
+  int blocks = (g.nWin + LY::PAIRS - 1) / LY::PAIRS;
   if (blocks > 256) blocks = 256;           // one resident workgroup per CU (157 KB LDS): persistent, one gradient flush each
   auto kern = winattn_bwd_kernel<T, DM, ACC_LDS>;
   static bool attr_set = false;     // idempotent per instantiation; kept out of replayed hipGraph captures
@@ -601,7 +689,11 @@ int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) 
     if (e != hipSuccess) { set_error("winattn_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   }
   kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, g);
-  return check_launch("winattn_bwd");
+  int rc = check_launch("winattn_bwd");
+  if (rc || !p->prod_ws) return rc;
+  const int64_t n = (int64_t)g.B * 2 * g.N;
+  domega_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(p->prod_ws, p->domega, g.B, g.N, DM::C);
+  return check_launch("winattn_bwd(domega reduce)");
 }
 
 template <typename T, typename DM>

@@ -123,18 +123,25 @@ def winattn_fwd(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads=2):
     return out
 
 
-def winattn_bwd(dout, x, y, stats_x, stats_y, omega, ln_g, ln_b, w, gw, H, W, heads=2):
+def winattn_bwd(dout, x, y, stats_x, stats_y, omega, ln_g, ln_b, w, gw, H, W, heads=2, workspace=True):
     """Backward of the attention term.  gw: dict of fp32 grads (dwq..dbo) accumulated in place.
-    Returns dxhat, dyhat (grad w.r.t. LN1 outputs through the attention path) and domega [B,2,N]."""
+    Returns dxhat, dyhat (grad w.r.t. LN1 outputs through the attention path) and domega [B,2,N].
+    workspace=False takes the ABI's no-scratch route (domega accumulated with atomics into a zeroed buffer)."""
     L.require_gpu(dout, x, y)
     _tok(dout); _same(x, y, dout)
     B, N, C = x.shape
     dxhat = torch.empty_like(x)
     dyhat = torch.empty_like(y)
-    domega = torch.zeros(B, 2, N, device=x.device, dtype=torch.float32)
+    if workspace:
+        domega = torch.empty(B, 2, N, device=x.device, dtype=torch.float32)
+        prod_ws = torch.empty(2, B, N, C, device=x.device, dtype=torch.float32)    # per-element gate-gradient products (see rssf.h)
+    else:
+        domega = torch.zeros(B, 2, N, device=x.device, dtype=torch.float32)
+        prod_ws = None
     bp = L.WinAttnBwdParams()
     bp.f = _winattn_params(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads, None)
     bp.dout, bp.dxhat, bp.dyhat, bp.domega = dout.data_ptr(), dxhat.data_ptr(), dyhat.data_ptr(), domega.data_ptr()
+    bp.prod_ws = prod_ws.data_ptr() if workspace else None
     for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo"):
         setattr(bp, "d" + n, _f32(gw[n]).data_ptr())
     L.check(L.load().rssf_winattn_bwd(ctypes.byref(bp), L.stream()), "rssf_winattn_bwd")

@@ -164,3 +164,32 @@ def test_winattn_base_shape_properties():
     outp = ops.winattn_fwd(x[perm].contiguous(), y[perm].contiguous(), sx.view(B, -1, 2)[perm].reshape(-1, 2).contiguous(),
                            sy.view(B, -1, 2)[perm].reshape(-1, 2).contiguous(), omega, g, b, w, H, W, 2)
     assert torch.equal(outp, out[perm])
+
+
+@pytest.mark.parametrize("C,H,W,dtype", [(32, 16, 16, torch.bfloat16), (48, 14, 21, torch.bfloat16), (18, 7, 7, torch.float32)])
+def test_winattn_bwd_workspace_route_matches_atomic_route(C, H, W, dtype):
+    """rssf_winattn_bwd with prod_ws (products + reduce launch, domega overwritten) and without (atomics into a zeroed
+    domega) are the same sums in a different order: every other output is bit-identical, domega agrees to fp32 rounding."""
+    from representationlearning_amd import ops
+    B, N = 2, H * W
+    P, ln = _attn_params(C)
+    x = proc_input((B, N, C), 0.2).to(dtype).to(DEV)
+    y = proc_input((B, N, C), 0.8).to(dtype).to(DEV)
+    dout = proc_input((B, N, C), 1.7).to(dtype).to(DEV)
+    g, b = ln["norm1.weight"].to(DEV), ln["norm1.bias"].to(DEV)
+    _, sx = ops.layernorm_fwd(x, g, b, want_y=False)
+    _, sy = ops.layernorm_fwd(y, g, b, want_y=False)
+    omega = (proc_input((B, 2, N), 0.5).abs() + 0.25).to(DEV).contiguous()
+    w = _dev_weights(P)
+    res = []
+    for workspace in (True, False):
+        gw = {k: torch.zeros_like(v) for k, v in w.items()}
+        dxh, dyh, dom = ops.winattn_bwd(dout, x, y, sx, sy, omega, g, b, w, gw, H, W, 2, workspace=workspace)
+        torch.cuda.synchronize()
+        res.append((dxh, dyh, dom, gw))
+    (dx0, dy0, dom0, gw0), (dx1, dy1, dom1, gw1) = res
+    assert torch.equal(dx0, dx1) and torch.equal(dy0, dy1)
+    assert torch.isfinite(dom0).all() and dom0.abs().max() > 0
+    assert rel_err(dom0.cpu(), dom1.cpu()) < 1e-5
+    for k in gw0:
+        assert rel_err(gw0[k].cpu(), gw1[k].cpu()) < 1e-5, k
