@@ -92,11 +92,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) given e = exp(-u*u): one v_rcp + 6 FMA.
+// The library erff costs ~35 VALU instructions with two range branches and made the GELU BatchNorm passes (128 channels
+// at 1/4 resolution, 33 M elements) VALU-bound at 2.4 TB/s; the exponential is shared with the Gaussian of the gradient.
+__device__ __forceinline__ float erf_from_exp(float u, float e) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, fabsf(u), 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  return copysignf(fmaf(-poly, e, 1.f), u);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float u = x * 0.70710678118654752f;
+  return 0.5f * x * (1.0f + erf_from_exp(u, __expf(-u * u)));
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const float u = x * 0.70710678118654752f;
+  const float e = __expf(-u * u);                       // = exp(-x^2/2): also the Gaussian density's exponential
+  return 0.5f * (1.0f + erf_from_exp(u, e)) + x * 0.39894228040143268f * e;
 }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
