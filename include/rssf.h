@@ -117,7 +117,12 @@ int64_t rssf_conv_packed_elems(int ntaps, int rows, int cols, int dtype);
  * position kpos_of_tap[t] (= ky*k + kx) of source src_of_tap[t].  transpose = 0: rows = Cout (forward);
  * transpose = 1: rows = Cin (data gradient). */
 int rssf_conv_pack(const float* w0, const float* w1, const float* w2, const int* ksizes, int nsrc, const int* src_of_tap,
-                   const int* kpos_of_tap, int ntaps, int Cout, int Cin, int transpose, void* out, int dtype, void* stream);
+                   const int* kpos_of_tap, const int* alias_of_tap, int ntaps, int Cout, int Cin, int transpose, void* out,
+                   int dtype, void* stream);
+/* alias_of_tap (optional, [ntaps][4] = {src, kpos, src, kpos}, -1 = none): further kernel positions that sample the SAME
+ * input pixel as tap t (the centres of MlpDWBN's 1x1 + two dilated 3x3 convolutions, ffn_block.py:219-228).  Packing
+ * sums their weights into tap t's slab and the weight gradient writes tap t's gradient to each of them, so that a sum of
+ * convolutions runs with one tap per DISTINCT offset (17 instead of 19 for the MLP). */
 /* Batched packing: ONE launch re-packs every convolution of the model (both layouts) after an optimizer step.
  * `jobs` is a DEVICE array of rssf_pack_job; `block_map` a DEVICE array of nblocks {job index, chunk index} pairs, one
  * per 1024-element chunk of each job's output (chunks of a job: ceil(packed_elems / 1024)). */
@@ -130,6 +135,7 @@ typedef struct rssf_pack_job {
   int nsrc, ntaps, cout, cin, rows_p, cols_p, transpose;
   int src_of_tap[RSSF_MAX_TAPS];
   int kpos_of_tap[RSSF_MAX_TAPS];
+  int alias_of_tap[RSSF_MAX_TAPS][4];   /* see rssf_conv_pack; {-1,-1,-1,-1} when a tap has no aliases */
 } rssf_pack_job;
 /* rows_p / cols_p of the packed slabs for a (rows, cols) weight matrix (rows = cout, or cin when transposed) */
 int rssf_conv_packed_rows(int rows);
@@ -150,9 +156,9 @@ int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float
  * reduction); NULL selects the slower atomic path. */
 int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Cin, int Cout, int ntaps);
 int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes, int nsrc,
-                    const int* src_of_tap, const int* kpos_of_tap, float* dbias, float* workspace, int B, int IH, int IW,
-                    int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx, int dtype,
-                    void* stream);
+                    const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias, float* workspace,
+                    int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy,
+                    const int* dx, int dtype, void* stream);
 
 /* ---- BatchNorm2d (+ activation + residual adds), channels-last: nn.BatchNorm2d / nn.SyncBatchNorm call sites of
  *      _hrnet_rssformer.py, hrnet_aux.py:47 and ffn_block.py:222-234 (momentum 0.1, eps 1e-5) -------------------- */

@@ -33,7 +33,7 @@ MAX_TAPS, PACK_CHUNK = 19, 1024      # RSSF_MAX_TAPS, RSSF_PACK_CHUNK
 class PackJob(ctypes.Structure):       # rssf_pack_job
     _fields_ = [("w", c_void_p * 3), ("out", c_void_p), ("ks", c_int * 3)] + [
         (n, c_int) for n in ("nsrc", "ntaps", "cout", "cin", "rows_p", "cols_p", "transpose")] + [
-        ("src_of_tap", c_int * MAX_TAPS), ("kpos_of_tap", c_int * MAX_TAPS)]
+        ("src_of_tap", c_int * MAX_TAPS), ("kpos_of_tap", c_int * MAX_TAPS), ("alias_of_tap", (c_int * 4) * MAX_TAPS)]
 
 
 # name -> (restype, argtypes); every symbol include/rssf.h declares must appear here (tests check it)
@@ -54,12 +54,12 @@ SIGNATURES = {
     "rssf_conv_packed_rows": (c_int, [c_int]),
     "rssf_conv_packed_cols": (c_int, [c_int, c_int]),
     "rssf_conv_pack_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "rssf_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+    "rssf_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_void_p, c_int, c_void_p]),
     "rssf_conv_gather": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_gather_add": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_workspace_elems": (c_int64, [c_int] * 6),
-    "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),
     "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),

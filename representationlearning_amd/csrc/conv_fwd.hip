@@ -58,7 +58,7 @@ template <> struct StageLay<float> {
 // DIV: data gradient of a strided convolution (source pixel = (oy + dy) / div when divisible); a template parameter so
 // that the common case carries no integer division in the staging loop.
 template <typename T, int BM, int BNT, bool VOK, bool DIV>
-__global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BM == 128 && BNT == 128) ? 3 : 1, 8))) conv_gather_kernel(ConvArgs a) {
   using MK = MmaK<T>;
   using SL = StageLay<T>;
   constexpr int BK = MK::BK, V = Vec<T>::N, CPR = BK / V;      // 16-byte chunks per staged row (= 4)
@@ -72,13 +72,11 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
   constexpr int A_CHUNKS = BM * CPR / 256;                       // per thread
   constexpr int B_CHUNKS = (BNT * CPR + 255) / 256;
   constexpr int LDC = BNT + LdsPad<T>::X;
-  constexpr int STAGE_ELEMS = SL::elems(BM) + SL::elems(BNT);
+  constexpr int STAGE_ELEMS = SL::elems(BM) + SL::elems(BNT);        // one staging buffer (A tile + B tile); two of them
   constexpr int OUT_ELEMS = BM * LDC;
-  constexpr int LDS_ELEMS = STAGE_ELEMS > OUT_ELEMS ? STAGE_ELEMS : OUT_ELEMS;
+  constexpr int LDS_ELEMS = 2 * STAGE_ELEMS > OUT_ELEMS ? 2 * STAGE_ELEMS : OUT_ELEMS;
   __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
   __shared__ float sstat[2 * BNT];
-  T* As = lds;
-  T* Bs = lds + SL::elems(BM);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wave_m = wave % WM, wave_n = wave / WM;
@@ -105,6 +103,43 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
     px[i] = (rem % a.OW) * a.mul;
   }
   const int sub = (tid % CPR) * V;
+  // FAST (bf16, vector-aligned channels, no stride predicate): hardware-bounds-checked buffer loads.  Per thread and chunk
+  // the byte offset of (its pixel, tap (0,0), channel sub) and a bit mask of the taps whose source pixel lies inside the
+  // image are fixed; a step then costs one add (the tap's scalar byte offset) and one select (out-of-range sentinel ->
+  // the load returns zeros) per 16-byte chunk instead of ~25 VALU instructions of coordinate arithmetic and masking
+  // (measured before: 4.7 VALU per MFMA, the SIMD issue port saturated at 30 % MFMA utilisation).
+  constexpr bool FAST = VOK && !DIV && sizeof(T) == 2;
+  constexpr unsigned OOB = 0x80000000u;                 // >= num_records (the host keeps the tensors below 2^31 bytes)
+  unsigned abase[A_CHUNKS], amask[A_CHUNKS];
+  unsigned bbase[B_CHUNKS];
+  __amdgpu_buffer_rsrc_t rin, rw;
+  if constexpr (FAST) {
+    rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(IN), 0, (int)((int64_t)a.B * a.IH * a.IW * a.Cin * sizeof(T)), 0x00020000);
+    rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W), 0, (int)((int64_t)a.taps.n * a.CoutP * a.CinP * sizeof(T)), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+      abase[i] = (unsigned)(pb[i] + (py[i] * a.IW + px[i]) * a.Cin + sub) * (unsigned)sizeof(T);
+      unsigned m = 0;
+      for (int t = 0; t < a.taps.n; ++t) {
+        const int sy = py[i] + a.taps.dy[t], sx = px[i] + a.taps.dx[t];
+        if (pv[i] && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW) m |= 1u << t;
+      }
+      amask[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) {
+      const int c = tid + i * 256;
+      bbase[i] = (unsigned)((((c / CPR) % BNT) * a.CinP + (c % CPR) * V) * (int)sizeof(T));
+    }
+  }
+  // byte offset of every tap, read one step ahead of its use (a scalar load from the kernel arguments at the point of use
+  // put ~200 cycles of SMEM latency in front of every step's global loads)
+  __shared__ int s_toff[MAX_TAPS + 2];
+  if constexpr (FAST) {
+    if (tid < MAX_TAPS + 2) s_toff[tid] = tid < a.taps.n ? (a.taps.dy[tid] * a.IW + a.taps.dx[tid]) * a.Cin * (int)sizeof(T) : 0;
+    __syncthreads();
+  }
+  int toff_pref = FAST ? s_toff[0] : 0;
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -135,13 +170,35 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
     ntap_act = s_ntap;
   }
   const int nsteps = ntap_act * kchunks;
-  Vec<T> ra[A_CHUNKS], rb[B_CHUNKS];
-
-  bool rok[A_CHUNKS];
+  // Software pipeline, prefetch distance 2: the activations stream from HBM / the infinity cache (~1-2 us under load) and a
+  // step is only 16 MFMAs per wave, so with one step of lookahead every step waited out a full memory latency (measured:
+  // 2400 cycles per step with three resident blocks, 28 % MFMA utilisation at the MLP shape).  Two register sets hold the
+  // loads of steps s+1 and s+2 while step s computes; two LDS staging buffers leave one barrier per step.
+  struct StepRegs { Vec<T> ra[A_CHUNKS], rb[B_CHUNKS]; bool rok[A_CHUNKS]; };
+  StepRegs R0, R1;
   int lt = 0, lkc = 0;                                    // (active tap index, channel chunk) of the next step to load
-  auto load_step = [&]() {
+  auto load_step = [&](StepRegs& R) {
     const int t = DIV ? s_tap[lt] : lt, kc = lkc;
     if (++lkc == kchunks) { lkc = 0; ++lt; }
+    if constexpr (FAST) {
+      // steps past the end (the pipeline always runs an even number of steps and never branches around a load, so that the
+      // compiler can count the outstanding loads exactly: with conditional loads it drained vmcnt to 0 before every LDS
+      // store, i.e. it also waited for the step prefetched last) load from the out-of-range sentinel: zeros, never used.
+      const bool live = t < ntap_act;
+      const int toff = toff_pref + kc * BK * (int)sizeof(T);                                        // may be negative
+      const int crem = a.Cin - kc * BK;                                                              // channels left in this chunk
+#pragma unroll
+      for (int i = 0; i < A_CHUNKS; ++i) {
+        const bool ok = ((amask[i] >> t) & 1u) && sub < crem;                                        // mask has no bits >= ntaps
+        R.ra[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? abase[i] + (unsigned)toff : OOB, 0, 0));
+      }
+      const int woff = live ? (((t * a.CoutP + n0) * a.CinP) + kc * BK) * (int)sizeof(T) : 0;
+#pragma unroll
+      for (int i = 0; i < B_CHUNKS; ++i)
+        R.rb[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, live ? bbase[i] : OOB, woff, 0));
+      toff_pref = s_toff[lt < MAX_TAPS + 1 ? lt : MAX_TAPS + 1];                                   // next step's tap
+      return;
+    }
     const int dy = a.taps.dy[t], dx = a.taps.dx[t];
     const int c0 = kc * BK + sub;
 #pragma unroll
@@ -160,42 +217,37 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
       ok = ok && sy < a.IH && sx < a.IW;
       const int off = ok ? pb[i] + (sy * a.IW + sx) * a.Cin + c0 : 0;
       if constexpr (VOK) {
-        ra[i].load(IN + off);                             // unconditional; masked in store_step
-        rok[i] = ok;
+        R.ra[i].load(IN + off);                           // unconditional; masked in store_step
+        R.rok[i] = ok;
       } else {
-        ra[i].raw = {0, 0, 0, 0};
+        R.ra[i].raw = {0, 0, 0, 0};
         if (ok)
 #pragma unroll
-          for (int e = 0; e < V; ++e) if (c0 + e < a.Cin) ra[i].set(e, ldf(IN + off + e));
-        rok[i] = true;
+          for (int e = 0; e < V; ++e) if (c0 + e < a.Cin) R.ra[i].set(e, ldf(IN + off + e));
+        R.rok[i] = true;
       }
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
       const int c = tid + i * 256;
       const int row = (c / CPR) % BNT;                     // surplus threads re-read a valid row (not stored)
-      rb[i].load(W + ((int64_t)t * a.CoutP + n0 + row) * a.CinP + kc * BK + (c % CPR) * V);
+      R.rb[i].load(W + ((int64_t)t * a.CoutP + n0 + row) * a.CinP + kc * BK + (c % CPR) * V);
     }
   };
-  auto store_step = [&]() {
+  auto store_step = [&](const StepRegs& R, T* As, T* Bs) {
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
-      Vec<T> v = ra[i];
-      if (!rok[i]) v.raw = {0, 0, 0, 0};
+      Vec<T> v = R.ra[i];
+      if constexpr (!FAST) { if (!R.rok[i]) v.raw = {0, 0, 0, 0}; }     // FAST: the buffer load already returned zeros
       v.store(As + SL::off((tid + i * 256) / CPR, tid % CPR, BM));
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
       const int c = tid + i * 256;
-      if (c / CPR < BNT) rb[i].store(Bs + SL::off(c / CPR, c % CPR, BNT));
+      if ((BNT * CPR) % 256 == 0 || c / CPR < BNT) R.rb[i].store(Bs + SL::off(c / CPR, c % CPR, BNT));
     }
   };
-
-  if (nsteps > 0) load_step();
-  for (int step = 0; step < nsteps; ++step) {
-    store_step();
-    __syncthreads();
-    if (step + 1 < nsteps) load_step();                  // global loads in flight under the MFMAs below
+  auto compute_step = [&](const T* As, const T* Bs) {
 #pragma unroll
     for (int ks = 0; ks < BK; ks += MK::KSTEP) {
       typename MK::frag fa[MI], fb[NI];
@@ -208,8 +260,26 @@ __global__ void __launch_bounds__(256) conv_gather_kernel(ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = MK::mma(fa[mi], fb[ni], acc[mi][ni]);
     }
-    __syncthreads();
+  };
+  T* As0 = lds;                  T* Bs0 = As0 + SL::elems(BM);
+  T* As1 = lds + STAGE_ELEMS;    T* Bs1 = As1 + SL::elems(BM);
+
+  const int nrun = FAST ? (nsteps + 1) & ~1 : nsteps;
+  if (FAST || nsteps > 0) load_step(R0);
+  if (FAST || nsteps > 1) load_step(R1);
+  for (int step = 0; step < nrun; step += 2) {
+    store_step(R0, As0, Bs0);
+    __syncthreads();             // buffer 0 complete (and every wave is done reading buffer 1's previous contents)
+    if (FAST || step + 2 < nsteps) load_step(R0);
+    compute_step(As0, Bs0);
+    if (FAST || step + 1 < nsteps) {
+      store_step(R1, As1, Bs1);  // safe: all waves passed the barrier above, i.e. finished computing step-1 out of buffer 1
+      __syncthreads();
+      if (FAST || step + 3 < nsteps) load_step(R1);
+      compute_step(As1, Bs1);
+    }
   }
+  __syncthreads();               // the staging buffers become the output tile
 
   // ---- epilogue -------------------------------------------------------------------------------------------
   if (a.stats) {
@@ -280,6 +350,7 @@ struct PackArgs {
   int nsrc;
   int src_of_tap[MAX_TAPS];
   int kpos_of_tap[MAX_TAPS];
+  int alias[MAX_TAPS][4];      // {src, kpos} x 2 further kernel positions summed into the tap's slab (-1: none)
   int ntaps, Cout, Cin, RowsP, ColsP, transpose;
 };
 template <typename T>
@@ -292,6 +363,11 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a, T* out) {
     if (co < a.Cout && ci < a.Cin) {
       const int s = a.src_of_tap[t], kk = a.ks[s] * a.ks[s];
       v = a.w[s][((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[t]];
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const int s2 = a.alias[t][e];
+        if (s2 >= 0) v += a.w[s2][((int64_t)co * a.Cin + ci) * (a.ks[s2] * a.ks[s2]) + a.alias[t][e + 1]];
+      }
     }
     stf(out + i, v);
   }
@@ -313,6 +389,11 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const rssf_pack_job* __
     if (co < j.cout && ci < j.cin) {
       const int s = j.src_of_tap[t], kk = j.ks[s] * j.ks[s];
       v = j.w[s][((int64_t)co * j.cin + ci) * kk + j.kpos_of_tap[t]];
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const int s2 = j.alias_of_tap[t][e];
+        if (s2 >= 0) v += j.w[s2][((int64_t)co * j.cin + ci) * (j.ks[s2] * j.ks[s2]) + j.alias_of_tap[t][e + 1]];
+      }
     }
     stf(out + i, v);
   }
@@ -364,7 +445,7 @@ int launch_conv(ConvArgs a, hipStream_t st) {
 extern "C" int rssf_conv_tile_n(int cout) { return pick_bn(cout); }
 
 extern "C" int rssf_conv_pack(const float* w0, const float* w1, const float* w2, const int* ksizes, int nsrc,
-                              const int* src_of_tap, const int* kpos_of_tap, int ntaps, int Cout, int Cin, int transpose,
+                              const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, int ntaps, int Cout, int Cin, int transpose,
                               void* out, int dtype, void* stream) {
   RSSF_REQUIRE(w0 && ksizes && src_of_tap && kpos_of_tap && out && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 && ntaps <= MAX_TAPS,
                "conv_pack: bad arguments");
@@ -372,7 +453,13 @@ extern "C" int rssf_conv_pack(const float* w0, const float* w1, const float* w2,
   a.w[0] = w0; a.w[1] = w1; a.w[2] = w2;
   for (int i = 0; i < 3; ++i) a.ks[i] = i < nsrc ? ksizes[i] : 1;
   a.nsrc = nsrc;
-  for (int t = 0; t < ntaps; ++t) { a.src_of_tap[t] = src_of_tap[t]; a.kpos_of_tap[t] = kpos_of_tap[t]; }
+  for (int t = 0; t < ntaps; ++t) {
+    a.src_of_tap[t] = src_of_tap[t]; a.kpos_of_tap[t] = kpos_of_tap[t];
+    for (int e = 0; e < 4; ++e) {
+      a.alias[t][e] = alias_of_tap ? alias_of_tap[t * 4 + e] : -1;
+      RSSF_REQUIRE((e & 1) || a.alias[t][e] < nsrc, "conv_pack: alias source out of range");
+    }
+  }
   a.ntaps = ntaps; a.Cout = Cout; a.Cin = Cin; a.transpose = transpose;
   const int rows = transpose ? Cin : Cout, cols = transpose ? Cout : Cin;
   const int bk = dtype == RSSF_BF16 ? MmaK<bf16_t>::BK : MmaK<float>::BK;
@@ -421,8 +508,8 @@ extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, 
   RSSF_REQUIRE(in && wpk && out && dy && dx && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 &&
                    ntaps >= 1 && ntaps <= MAX_TAPS && mul >= 1 && div >= 1,
                "conv_gather: bad arguments");
-  RSSF_REQUIRE((int64_t)B * IH * IW * Cin < ((int64_t)1 << 31) && (int64_t)B * OH * OW < ((int64_t)1 << 31),
-               "conv_gather: activation tensors of 2^31 or more elements are not supported (32-bit offsets)");
+  RSSF_REQUIRE((int64_t)B * IH * IW * Cin < ((int64_t)1 << 30) && (int64_t)B * OH * OW < ((int64_t)1 << 31),
+               "conv_gather: input tensors of 2^30 or more elements are not supported (32-bit byte offsets, buffer bounds)");
   ConvArgs a;
   a.in = in; a.wpk = wpk; a.out = out; a.bias = bias; a.stats = stats; a.addend = addend;
   a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;

@@ -34,6 +34,7 @@ struct WgradArgs {
   int ntaps_total;
   int src_of_tap[MAX_TAPS];
   int kpos_of_tap[MAX_TAPS];
+  int alias[MAX_TAPS][4];      // further {src, kpos} x 2 that receive the tap's gradient (-1: none), see rssf_conv_pack
   int B, IH, IW, Cin, OH, OW, Cout, stride, ksplit, ctiles_m, ctiles_n, tap0, ntap, inner, xcd_per;
   Taps taps;
 };
@@ -235,7 +236,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
           const int co = co0 + (wm * WI + i) * 16 + grp * 4 + r, ci = ci0 + (wn * WI + j) * 16 + l15;
           if (co >= a.Cout || ci >= a.Cin) continue;
           if (a.partial) a.partial[(((int64_t)range * a.ntaps_total + tap) * a.Cout + co) * a.Cin + ci] = acc[t][i][j][r];
-          else atomicAdd(dw + ((int64_t)co * a.Cin + ci) * kk + kpos, acc[t][i][j][r]);
+          else {
+            atomicAdd(dw + ((int64_t)co * a.Cin + ci) * kk + kpos, acc[t][i][j][r]);
+            for (int e = 0; e < 4; e += 2) {
+              const int s2 = a.alias[tap][e];
+              if (s2 >= 0) atomicAdd(a.dw[s2] + ((int64_t)co * a.Cin + ci) * (a.ks[s2] * a.ks[s2]) + a.alias[tap][e + 1], acc[t][i][j][r]);
+            }
+          }
         }
   }
   if (do_bias && tid < TMN && co0 + tid < a.Cout) atomicAdd(a.dbias + co0 + tid, bsum);
@@ -269,6 +276,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
     const int ci = (int)(i % a.Cin), co = (int)((i / a.Cin) % a.Cout), tap = (int)(i / ((int64_t)a.Cin * a.Cout));
     const int sc = a.src_of_tap[tap], kk = a.ks[sc] * a.ks[sc];
     a.dw[sc][((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[tap]] += s;
+    for (int e = 0; e < 4; e += 2) {
+      const int s2 = a.alias[tap][e];
+      if (s2 >= 0) a.dw[s2][((int64_t)co * a.Cin + ci) * (a.ks[s2] * a.ks[s2]) + a.alias[tap][e + 1]] += s;
+    }
   }
 }
 
@@ -503,9 +514,9 @@ extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Ci
 }
 
 extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
-                               int nsrc, const int* src_of_tap, const int* kpos_of_tap, float* dbias, float* workspace, int B,
-                               int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy,
-                               const int* dx, int dtype, void* stream) {
+                               int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
+                               float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
+                               const int* dy, const int* dx, int dtype, void* stream) {
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
@@ -518,6 +529,10 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
   for (int t = 0; t < ntaps; ++t) {
     a.src_of_tap[t] = src_of_tap[t]; a.kpos_of_tap[t] = kpos_of_tap[t];
     a.taps.dy[t] = dy[t]; a.taps.dx[t] = dx[t];
+    for (int e = 0; e < 4; ++e) {
+      a.alias[t][e] = alias_of_tap ? alias_of_tap[t * 4 + e] : -1;
+      RSSF_REQUIRE((e & 1) || a.alias[t][e] < nsrc, "conv_wgrad: alias source out of range");
+    }
   }
   a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.stride = stride;
   a.partial = workspace; a.ntaps_total = ntaps;

@@ -126,6 +126,8 @@ class ConvSpec:
         self.cin, self.cout = c0.in_channels, c0.out_channels
         self.stride = c0.stride[0]
         self.ksizes, self.src, self.kpos, self.dy, self.dx = [], [], [], [], []
+        self.alias = []                                  # per tap: further (src, kpos) x 2 sampling the same pixel, -1 = none
+        slot = {}
         for s, c in enumerate(convs):
             k, d, p = c.kernel_size[0], c.dilation[0], c.padding[0]
             if (c.in_channels, c.out_channels, c.stride[0]) != (self.cin, self.cout, self.stride) or c.groups != 1 \
@@ -134,11 +136,20 @@ class ConvSpec:
             self.ksizes.append(k)
             for ky in range(k):
                 for kx in range(k):
+                    off = (ky * d - p, kx * d - p)
+                    u = slot.get(off)
+                    if u is not None and -1 in self.alias[u]:          # same source pixel as tap u: one tap, summed weights
+                        e = self.alias[u].index(-1)
+                        self.alias[u][e:e + 2] = [s, ky * k + kx]
+                        continue
+                    slot.setdefault(off, len(self.src))
                     self.src.append(s)
                     self.kpos.append(ky * k + kx)
-                    self.dy.append(ky * d - p)
-                    self.dx.append(kx * d - p)
+                    self.dy.append(off[0])
+                    self.dx.append(off[1])
+                    self.alias.append([-1, -1, -1, -1])
         self.ntaps = len(self.src)
+        self.c_alias = _ia([v for a4 in self.alias for v in a4])
         # ctypes views of the tap tables, built once (they are passed to every launch of this convolution)
         self.c_ksizes, self.c_src, self.c_kpos = _ia(self.ksizes), _ia(self.src), _ia(self.kpos)
         self.c_dy, self.c_dx = _ia(self.dy), _ia(self.dx)
@@ -254,6 +265,8 @@ class PackPlan:
                 j.rows_p, j.cols_p = lib.rssf_conv_packed_rows(rows), lib.rssf_conv_packed_cols(cols, code)
                 for t in range(spec.ntaps):
                     j.src_of_tap[t], j.kpos_of_tap[t] = spec.src[t], spec.kpos[t]
+                    for e in range(4):
+                        j.alias_of_tap[t][e] = spec.alias[t][e]
                 self.views[k] = flat[offs[i]:offs[i] + sizes[i]]
                 bmap += [(i, c) for c in range((sizes[i] + L.PACK_CHUNK - 1) // L.PACK_CHUNK)]
             jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
@@ -322,7 +335,7 @@ def _pack(spec, weights, transpose, dtype, device):
     out = torch.empty(n, device=device, dtype=dtype)
     w = [wt if wt.is_contiguous() else wt.contiguous() for wt in weights] + [None, None]
     L.check(lib.rssf_conv_pack(L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), _ia(spec.ksizes), len(weights), _ia(spec.src), _ia(spec.kpos),
-                               spec.ntaps, spec.cout, spec.cin, int(transpose), L.ptr(out), code, L.stream()), "rssf_conv_pack")
+                               spec.c_alias, spec.ntaps, spec.cout, spec.cin, int(transpose), L.ptr(out), code, L.stream()), "rssf_conv_pack")
     return out
 
 
@@ -387,7 +400,7 @@ def _conv_wgrad(spec, dout, xh, dws, db):
     lib = L.load()
     ws = torch.empty(lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, CO, spec.ntaps), device=xh.device, dtype=torch.float32)
     L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws),
-                                     spec.c_src, spec.c_kpos, L.ptr(tdb), L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps,
+                                     spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb), L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps,
                                      spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()), "rssf_conv_wgrad")
     if padded:
         for g, t in zip(dws, tgt):

@@ -52,7 +52,9 @@ def test_conv_spec_taps():
     s = ConvSpec([nn.Conv2d(8, 8, 3, 2, 1)])
     assert s.ntaps == 9 and s.dy[0] == -1 and s.dx[8] == 1 and s.out_hw(16, 15) == (8, 8)
     f = ConvSpec([nn.Conv2d(8, 8, 1), nn.Conv2d(8, 8, 3, 1, 6, 6), nn.Conv2d(8, 8, 3, 1, 12, 12)])
-    assert f.ntaps == 19 and sorted(set(f.dy)) == [-12, -6, 0, 6, 12] and f.src.count(0) == 1 and f.out_hw(10, 10) == (10, 10)
+    # the three centre positions sample the same pixel: ONE tap (the 1x1's) with the two 3x3 centres as weight aliases
+    assert f.ntaps == 17 and sorted(set(f.dy)) == [-12, -6, 0, 6, 12] and f.src.count(0) == 1 and f.out_hw(10, 10) == (10, 10)
+    assert f.alias[0] == [1, 4, 2, 4] and all(a == [-1] * 4 for a in f.alias[1:]) and len(set(zip(f.dy, f.dx))) == 17
     with pytest.raises(NotImplementedError):
         ConvSpec([nn.Conv2d(8, 8, 3, groups=2)])
 
