@@ -58,13 +58,13 @@ template <> struct StageLay<float> {
 // DIV: data gradient of a strided convolution (source pixel = (oy + dy) / div when divisible); a template parameter so
 // that the common case carries no integer division in the staging loop.
 template <typename T, int BM, int BNT, bool VOK, bool DIV>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BM == 128 && BNT == 128) ? 3 : 1, 8))) conv_gather_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 256 ? 2 : (BM == 128 && BNT == 128) ? 3 : 1, 8))) conv_gather_kernel(ConvArgs a) {
   using MK = MmaK<T>;
   using SL = StageLay<T>;
   constexpr int BK = MK::BK, V = Vec<T>::N, CPR = BK / V;      // 16-byte chunks per staged row (= 4)
   // wave grid: WM along pixels x WN along channels.  The 128 x 128 tile uses 2 x 2 waves of 64 x 64 (8 fragment reads per 16
   // MFMAs instead of 10 for 32 x 128 waves); narrower tiles keep 32-pixel waves.
-  constexpr int WM = (BM == 128 && BNT == 128) ? 2 : BM / 32, WN = 4 / WM;
+  constexpr int WM = (BM >= 128 && BNT == 128) ? 2 : BM / 32, WN = 4 / WM;     // 256 x 128: 2 x 2 waves of 128 x 64
   constexpr int MI = BM / (16 * WM);                             // 16-row tiles per wave along the pixels
   constexpr int WCOLS = BNT / WN;                                // channels per wave
   constexpr int NI = WCOLS / 16;
@@ -419,6 +419,11 @@ int launch_conv(ConvArgs a, hipStream_t st) {
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
   int bm, bnt;
   pick_tile(M, a.Cout, bm, bnt);
+  // many-tap 128-channel layers (the MLP's 17-tap sum): a 256-pixel tile halves the weight-slab traffic per MFMA and
+  // makes the wave tile 128 x 64 (LDS fragment reads per MFMA 0.375 instead of 0.5)
+  if (sizeof(T) == 2 && bm == 128 && bnt == 128 && a.taps.n * a.CinP >= 1024 && a.div == 1 && (a.Cin % Vec<T>::N) == 0 &&
+      (M + 255) / 256 * ((a.Cout + 127) / 128) >= 512)
+    bm = 256;
   a.ntiles_n = (a.Cout + bnt - 1) / bnt;
   a.total = ((M + bm - 1) / bm) * a.ntiles_n;
   a.xcd_per = xcd_per(a.total);
@@ -434,6 +439,10 @@ int launch_conv(ConvArgs a, hipStream_t st) {
       else conv_gather_kernel<T, BMv, BNv, false, false><<<grid, 256, 0, st>>>(a);      \
     }                                                                         \
   } while (0)
+  if (bm == 256) {                                    // deep-K 128-channel layers only (bf16, vector-aligned, unit stride)
+    if (vok && a.div == 1) conv_gather_kernel<T, 256, 128, true, false><<<grid, 256, 0, st>>>(a);
+    else { set_error("conv_gather: 256-pixel tile chosen for an unsupported layer"); return RSSF_ERR_LAUNCH; }
+  } else
   if (bm == 128) { if (bnt == 32) RSSF_CONV(128, 32); else if (bnt == 64) RSSF_CONV(128, 64); else RSSF_CONV(128, 128); }
   else           { if (bnt == 32) RSSF_CONV(64, 32);  else if (bnt == 64) RSSF_CONV(64, 64);  else RSSF_CONV(64, 128); }
 #undef RSSF_CONV

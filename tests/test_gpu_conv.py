@@ -115,6 +115,31 @@ def test_fused_mlp_conv(C, B, H, W, dtype):
         assert rel_err(a.weight.grad.cpu(), b.weight.grad) < (3e-4 if f32 else 7e-2)
 
 
+def test_fused_mlp_conv_wide_tile_vs_torch_fp32():
+    """B=8 x 128 ch x 128^2 (>= 512 tiles of 256 pixels): the MLP sum takes the 256 x 128 tile of the gather kernel, which
+    the small cases never reach.  Reference: torch fp32 convolutions on the same device over the bf16-rounded operands."""
+    from representationlearning_amd import nnf
+    C, B, H, W = 128, 8, 128, 128
+    torch.manual_seed(5)
+    convs = [nn.Conv2d(C, C, 1, 1).to(DEV), nn.Conv2d(C, C, 3, 1, padding=6, dilation=6).to(DEV),
+             nn.Conv2d(C, C, 3, 1, padding=12, dilation=12).to(DEV)]
+    bn = _mk_bn(C, sync=True).to(DEV).train()
+    bnr = _mk_bn(C, sync=False).to(DEV).train()
+    x = torch.randn(B, C, H, W, device=DEV).bfloat16()
+    gy = torch.randn(B, C, H, W, device=DEV).bfloat16()
+    xr = x.float().requires_grad_()
+    wr = [c.weight.detach().clone().requires_grad_() for c in convs]
+    yr = F.gelu(bnr(sum(F.conv2d(xr, w, c.bias.detach(), 1, c.padding, c.dilation) for w, c in zip(wr, convs))))
+    yr.backward(gy.float())
+    xd = x.contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = nnf.conv_bn_act(xd, convs, bn, 2)
+    y.backward(gy)
+    assert rel_err(y.detach().float().cpu(), yr.detach().cpu()) < 1.5e-2
+    assert rel_err(xd.grad.float().cpu(), xr.grad.cpu()) < 7e-2
+    for a, b in zip(convs, wr):
+        assert rel_err(a.weight.grad.cpu(), b.grad.cpu()) < 7e-2
+
+
 def test_conv_bias_head():
     from representationlearning_amd import nnf
     conv_r = _mk_conv(480, 6, 1, bias=True)
