@@ -190,6 +190,12 @@ int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift,
  * [B,OH,OW,C], `out` receives the input gradient [B,IH,IW,C] (gather form, no atomics). */
 int rssf_upsample_bilinear(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int backward, int dtype,
                            void* stream);
+/* The same with the full-resolution tensor addressed as a CHANNEL SLICE of a wider channels-last tensor (pixel stride
+ * ld_wide >= C elements, pointer already offset to the slice): forward writes straight into a concatenation buffer
+ * (SimpleFusion8's torch.cat, hrnet_aux.py:64), backward reads the slice of the concatenated gradient - no cat / split
+ * copies.  IH == OH, IW == OW is the identity (the un-resized branch 0). */
+int rssf_upsample_bilinear_slice(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int ld_wide, int backward,
+                                 int dtype, void* stream);
 /* nearest up-sampling by an integer factor fused with the running branch sum of the HRNet fuse layers
  * (_hrnet_rssformer.py:380, 424-427).  backward = 0: out [B,IH*s,IW*s,C] = (acc ? acc : 0) + up(in);
  * backward = 1: `in` is the output gradient, `out` [B,IH,IW,C] = its s x s block sums (acc ignored). */

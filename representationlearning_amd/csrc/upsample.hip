@@ -14,7 +14,7 @@ __device__ __forceinline__ float src_coord(int o, float scale) { return scale * 
 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bilinear_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int IH, int IW, int OH,
-                                                           int OW, int C, float sy, float sx) {
+                                                           int OW, int C, int ldw, float sy, float sx) {
   const int cols = C / VEC;
   const int64_t total = (int64_t)B * OH * OW * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) bilinear_fwd_kernel(const T* __restrict__
     const T* p01 = base + ((int64_t)y0 * IW + x1) * C;
     const T* p10 = base + ((int64_t)y1 * IW + x0) * C;
     const T* p11 = base + ((int64_t)y1 * IW + x1) * C;
-    T* dst = out + (((int64_t)b * OH + oy) * OW + ox) * C + cv * VEC;
+    T* dst = out + (((int64_t)b * OH + oy) * OW + ox) * ldw + cv * VEC;     // ldw: pixel stride of the full-resolution tensor
     const float w00 = (1.f - wy) * (1.f - wx), w01 = (1.f - wy) * wx, w10 = wy * (1.f - wx), w11 = wy * wx;
     if constexpr (VEC > 1) {
       Vec<T> a, bq, c, d, o;
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) bilinear_fwd_kernel(const T* __restrict__
 // din(iy,ix) = sum over output pixels (oy,ox) of coef_y(oy,iy) * coef_x(ox,ix) * dout(oy,ox)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int IH, int IW, int OH,
-                                                           int OW, int C, float sy, float sx) {
+                                                           int OW, int C, int ldw, float sy, float sx) {
   const int cols = C / VEC;
   const int64_t total = (int64_t)B * IH * IW * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const T* __restrict__
         const float wx = fx - x0;
         const float cx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
         if (cx == 0.f) continue;
-        const T* src = dout + (((int64_t)b * OH + oy) * OW + ox) * C + cv * VEC;
+        const T* src = dout + (((int64_t)b * OH + oy) * OW + ox) * ldw + cv * VEC;
         const float w = cy * cx;
         if constexpr (VEC > 1) {
           Vec<T> v;
@@ -179,18 +179,18 @@ int grid_for(int64_t total) {
 float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 template <typename T>
-int bilinear_launch(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int backward, hipStream_t st) {
+int bilinear_launch(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int ldw, int backward, hipStream_t st) {
   constexpr int V = Vec<T>::N;
   const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
   const bool vec = C % V == 0;
   const int64_t px = (int64_t)B * (backward ? IH * IW : OH * OW);
   const int g = grid_for(px * (vec ? C / V : C));
   if (!backward) {
-    if (vec) bilinear_fwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, sy, sx);
-    else bilinear_fwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, sy, sx);
+    if (vec) bilinear_fwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
+    else bilinear_fwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
   } else {
-    if (vec) bilinear_bwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, sy, sx);
-    else bilinear_bwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, sy, sx);
+    if (vec) bilinear_bwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
+    else bilinear_bwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
   }
   return check_launch(backward ? "upsample_bilinear_bwd" : "upsample_bilinear_fwd");
 }
@@ -212,14 +212,19 @@ int nearest_launch(const void* acc, const void* in, void* out, int B, int IH, in
 }
 }  // namespace
 
-extern "C" int rssf_upsample_bilinear(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int backward, int dtype,
-                                      void* stream) {
-  RSSF_REQUIRE(in && out && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0, "upsample_bilinear: bad arguments");
+extern "C" int rssf_upsample_bilinear_slice(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int ld_wide,
+                                            int backward, int dtype, void* stream) {
+  RSSF_REQUIRE(in && out && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && ld_wide >= C, "upsample_bilinear: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RSSF_F32) return bilinear_launch<float>(in, out, B, IH, IW, OH, OW, C, backward, st);
-  if (dtype == RSSF_BF16) return bilinear_launch<bf16_t>(in, out, B, IH, IW, OH, OW, C, backward, st);
+  if (dtype == RSSF_F32) return bilinear_launch<float>(in, out, B, IH, IW, OH, OW, C, ld_wide, backward, st);
+  if (dtype == RSSF_BF16) return bilinear_launch<bf16_t>(in, out, B, IH, IW, OH, OW, C, ld_wide, backward, st);
   set_error("upsample_bilinear: unsupported dtype %d", dtype);
   return RSSF_ERR_UNSUPPORTED;
+}
+
+extern "C" int rssf_upsample_bilinear(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int backward, int dtype,
+                                      void* stream) {
+  return rssf_upsample_bilinear_slice(in, out, B, IH, IW, OH, OW, C, C, backward, dtype, stream);
 }
 
 extern "C" int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B, int IH, int IW, int scale, int C, int backward,

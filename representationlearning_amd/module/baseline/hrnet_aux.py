@@ -19,8 +19,7 @@ class SimpleFusion8(nn.Module):
     def forward(self, feat_list):
         x0 = feat_list[0]
         size = x0.shape[2:]
-        ups = [x0] + [nnf.upsample_bilinear(f, size) for f in feat_list[1:]]
-        cat = torch.cat(ups, dim=1).contiguous(memory_format=torch.channels_last)
+        cat = nnf.upsample_bilinear_concat(list(feat_list), size)      # resize + concat (hrnet_aux.py:61-64) without the cat copy
         return nnf.run_sequential(self.fuse_conv, cat), x0
 
 

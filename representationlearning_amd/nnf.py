@@ -570,6 +570,50 @@ class _NearestAdd(torch.autograd.Function):
         return (dy if has_acc else None), _nchw(dx), None
 
 
+class _BilinearConcat(torch.autograd.Function):
+    """cat([F.interpolate(f, size, 'bilinear', align_corners=True) for f in feats], dim=1) written slice by slice into one
+    channels-last buffer (a feature map already at `size` is the identity case of the same kernel); the backward reads each
+    slice of the concatenated gradient in place."""
+
+    @staticmethod
+    def forward(ctx, OH, OW, *feats):
+        L.require_gpu(*feats)
+        fh = [_nhwc(f) for f in feats]
+        B = fh[0].shape[0]
+        ctot = sum(f.shape[3] for f in fh)
+        out = torch.empty(B, OH, OW, ctot, device=fh[0].device, dtype=fh[0].dtype)
+        lib, es, off, shapes = L.load(), out.element_size(), 0, []
+        for f in fh:
+            _, IH, IW, C = f.shape
+            L.check(lib.rssf_upsample_bilinear_slice(L.ptr(f), out.data_ptr() + off * es, B, IH, IW, OH, OW, C, ctot, 0, L.dtype_code(f),
+                                                     L.stream()), "rssf_upsample_bilinear_slice")
+            shapes.append((IH, IW, C))
+            off += C
+        ctx.meta = (B, OH, OW, ctot, shapes)
+        return _nchw(out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, OH, OW, ctot, shapes = ctx.meta
+        dyh = _nhwc(dy)
+        lib, es, off, grads = L.load(), dyh.element_size(), 0, []
+        for i, (IH, IW, C) in enumerate(shapes):
+            if ctx.needs_input_grad[2 + i]:
+                dx = torch.empty(B, IH, IW, C, device=dy.device, dtype=dy.dtype)
+                L.check(lib.rssf_upsample_bilinear_slice(dyh.data_ptr() + off * es, L.ptr(dx), B, IH, IW, OH, OW, C, ctot, 1,
+                                                         L.dtype_code(dyh), L.stream()), "rssf_upsample_bilinear_slice(bwd)")
+                grads.append(_nchw(dx))
+            else:
+                grads.append(None)
+            off += C
+        return (None, None, *grads)
+
+
+def upsample_bilinear_concat(feats, size):
+    """torch.cat([f resized to `size` (bilinear, align_corners=True) for f in feats], dim=1), channels-last, in one buffer."""
+    return _BilinearConcat.apply(int(size[0]), int(size[1]), *feats)
+
+
 def upsample_bilinear(x, size):
     """F.interpolate(x, size, mode='bilinear', align_corners=True)."""
     return _Bilinear.apply(x, int(size[0]), int(size[1]))

@@ -194,6 +194,28 @@ def test_upsample_bilinear(B, C, IH, IW, OH, OW, dtype):
     assert rel_err(xd.grad.float().cpu(), xr.grad) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_bilinear_concat(dtype):
+    """SimpleFusion8's resize + cat (hrnet_aux.py:61-64) written slice by slice into one buffer, gradient read in place."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(2)
+    shapes = [(2, 32, 12, 10), (2, 64, 6, 5), (2, 128, 3, 3), (2, 24, 2, 1)]
+    xs = [torch.randn(*sh).to(dtype).float() for sh in shapes]
+    xr = [x.clone().requires_grad_() for x in xs]
+    yr = torch.cat([xr[0]] + [F.interpolate(x, size=(12, 10), mode="bilinear", align_corners=True) for x in xr[1:]], dim=1)
+    gy = torch.randn_like(yr).to(dtype).float()
+    yr.backward(gy)
+    xd = [x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_() for x in xs]
+    y = nnf.upsample_bilinear_concat(xd, (12, 10))
+    assert y.shape == yr.shape and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(DEV).to(dtype))
+    f32 = dtype == torch.float32
+    assert rel_err(y.detach().float().cpu(), yr.detach()) < (1e-6 if f32 else 4e-3)
+    assert torch.equal(y.detach()[:, :32].float().cpu(), xs[0])                     # the un-resized branch is an exact copy
+    for a, b in zip(xd, xr):
+        assert rel_err(a.grad.float().cpu(), b.grad) < (1e-5 if f32 else 6e-3)
+
+
 @pytest.mark.parametrize("B,C,H,W,s", [(2, 32, 5, 7, 2), (1, 36, 3, 3, 4), (1, 64, 2, 2, 8)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upsample_nearest_add(B, C, H, W, s, dtype):
