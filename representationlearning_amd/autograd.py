@@ -43,16 +43,19 @@ class GatedWindowCrossAttention(torch.autograd.Function):
         tg = {n: nnf.grad_target(P[n]) for n in P}            # kernels accumulate straight into .grad when possible
         gw = {n: tg[n][0] for n in w}
         dxhat, dyhat, domega = ops.winattn_bwd(dout, x, y, sx, sy, omega, ln_g, ln_b, w, gw, H, W, heads)
-        dk = torch.zeros_like(kk)
-        dwl = torch.zeros_like(wl2)
-        dbl = torch.zeros(2, device=x.device, dtype=torch.float32)
+        zb = nnf._zeros(kk.numel() + 8, x.device)            # one slice of the step's pre-zeroed pool instead of three fills
+        dk, dwl, dbl = zb[:kk.numel()].view_as(kk), zb[kk.numel():kk.numel() + 4].view(2, 2), zb[kk.numel() + 4:kk.numel() + 6]
         dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, kk, wl2, dk, dwl, dbl, H, W)
         ops.gate_pool_bwd_(dpooled, argmax, dxhat, dyhat)
         dg, db = tg["ln_g"][0], tg["ln_b"][0]
         dx = ops.layernorm_bwd(dxhat, x, sx, ln_g, dg, db, dx_add=dout)      # + residual path
         dy = ops.layernorm_bwd(dyhat, y, sy, ln_g, dg, db)
         r = {n: nnf.grad_result(P[n], tg[n][0], tg[n][1]) for n in P}
-        return (dx, dy, r["ln_g"], r["ln_b"], dk[0:1].clone(), dk[1:2].clone(), dwl.reshape(2, 2, 1, 1), dbl,
+        nk = kk.numel()
+        gp = zb[:nk + 6].clone()                               # the pool slice is recycled next step: hand autograd a copy
+        h = nk // 2
+        return (dx, dy, r["ln_g"], r["ln_b"], gp[:h].view_as(kk[0:1]), gp[h:nk].view_as(kk[1:2]), gp[nk:nk + 4].view(2, 2, 1, 1),
+                gp[nk + 4:nk + 6],
                 r["wq"], r["bq"], r["wk"], r["bk"], r["wv"], r["bv"], r["wo"], r["bo"], None, None, None)
 
 

@@ -174,10 +174,10 @@ class HighResolutionModule(nn.Module):
                     t = nnf.run_sequential(self.fuse_layers[i][j], x[j])
                     low = t if low is None else low + t
             if i == 0:
-                y = self.transformer(low, x[0])        # residual comes from `low`; x[0] only feeds K/V (:430-431)
-            else:
-                y = nnf.run_sequential(self.fuse_layers[i][0], x[0]) + low
-            fused.append(self.relu(y))
+                y = self.relu(self.transformer(low, x[0]))        # residual comes from `low`; x[0] only feeds K/V (:430-431)
+            else:       # relu(fuse[i][0](x[0]) + low) (:432-435): sum and ReLU ride in the last down-sampling conv's BatchNorm pass
+                y = nnf.run_sequential(self.fuse_layers[i][0], x[0], res_pre=low, act_last=nnf.ACT_RELU)
+            fused.append(y)
         return fused
 
 

@@ -697,20 +697,29 @@ def flush_bn_counters(model, extra=0):
             m._rssf_steps = 0
 
 
-def run_sequential(seq, x):
+def run_sequential(seq, x, res_pre=None, act_last=None):
     """Execute an nn.Sequential of the reference's shape (Conv2d, BatchNorm2d[, ReLU][, Upsample] or nested
-    Sequentials thereof) through the fused ops."""
+    Sequentials thereof) through the fused ops.  res_pre / act_last: the sequence must END in a Conv2d + BatchNorm2d pair
+    (possibly inside a nested Sequential), which then computes act_last(bn(conv(.)) + res_pre) in its own epilogue - the
+    `fuse(x0) + low` -> ReLU of a HighResolutionModule output without separate add / clamp launches."""
     mods = list(seq)
+    tail = res_pre is not None or act_last is not None
     i = 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, nn.Sequential):
-            x = run_sequential(m, x)
+            last = tail and i + 1 == len(mods)
+            x = run_sequential(m, x, res_pre if last else None, act_last if last else None)
+            tail = tail and not last
             i += 1
         elif isinstance(m, nn.Conv2d):
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.modules.batchnorm._BatchNorm):
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
-                x = conv_bn_act(x, m, mods[i + 1], ACT_RELU if relu else ACT_NONE)
+                if tail and not relu and i + 2 == len(mods):
+                    x = conv_bn_act(x, m, mods[i + 1], ACT_NONE if act_last is None else act_last, res_pre=res_pre)
+                    tail = False
+                else:
+                    x = conv_bn_act(x, m, mods[i + 1], ACT_RELU if relu else ACT_NONE)
                 i += 3 if relu else 2
             else:
                 x = conv_bias(x, m)
@@ -724,4 +733,6 @@ def run_sequential(seq, x):
             i += 1
         else:
             raise NotImplementedError("run_sequential: no HIP kernel for %s on the RSSFormer path" % type(m).__name__)
+    if tail:
+        raise NotImplementedError("run_sequential: res_pre / act_last need a sequence that ends in Conv2d + BatchNorm2d")
     return x
