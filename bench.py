@@ -30,6 +30,18 @@ FLOP_PER_IMG = 528.07e9        # fwd+bwd matmul/conv FLOPs per 512x512 image, Ba
 MFMA_BF16_PEAK = 2.5e15
 
 
+def _profiled_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed counter pass (profiles/r01_hbm_traffic.json, written from
+    tools/hbm_traffic.sh: rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum in a run of its own, reads
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read inside this process: None if absent."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")) as f:
+            e = json.load(f)[kernel]
+        return int(e["read_bytes"] + e["write_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def measure_window_attention(B, S, iters=30):
     """Average duration of one rssf_winattn_fwd launch at the benchmark geometry (branch 0: C=32, (S/4)^2 tokens)."""
     from representationlearning_amd import ops
@@ -59,11 +71,12 @@ def measure_window_attention(B, S, iters=30):
     alg_bytes = 3 * B * H * W * C * 2                # read low, read high, write out (bf16)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel="winattn_fwd_kernel<bf16,Dims<32,2>>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None, us_per_launch=round(ms * 1e3, 2), algorithmic_bytes=alg_bytes)
+                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=_profiled_traffic("winattn_fwd_kernel") if (B, S) == (16, 512) else None,
+                us_per_launch=round(ms * 1e3, 2), algorithmic_bytes=alg_bytes)
 
 
 def measure_mlp_conv(B, S, iters=20):
-    """Average duration of the MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12} convolution (ONE 19-tap implicit-GEMM launch,
+    """Average duration of the MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12} convolution (ONE implicit-GEMM launch, 17 distinct taps,
     128 -> 128 channels on the (S/4)^2 map): the largest single GEMM of the step, MFMA-bound."""
     from representationlearning_amd import nnf
     H = W = S // 4
@@ -85,11 +98,12 @@ def measure_mlp_conv(B, S, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * B * H * W * C * C * spec.ntaps
+    flops = 2.0 * B * H * W * C * C * 19             # the reference's three convolutions: 1 + 9 + 9 kernel positions
     tf = flops / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="conv_gather_kernel<bf16,128,128> (MlpDWBN 19-tap fused conv, 128->128 ch)", achieved=round(tf, 1),
-                peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s", frac=round(tf * 1e12 / MFMA_BF16_PEAK, 4), traffic=None,
-                us_per_launch=round(ms * 1e3, 2), algorithmic_flops=flops)
+    return dict(bound="mfma", kernel="conv_gather_kernel<bf16,256,128> (MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12}, 128->128 ch)",
+                achieved=round(tf, 1), peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s", frac=round(tf * 1e12 / MFMA_BF16_PEAK, 4),
+                traffic=None, us_per_launch=round(ms * 1e3, 2), algorithmic_flops=flops,
+                executed_flops=2.0 * B * H * W * C * C * spec.ntaps)       # the three centre taps share one pixel: 17 taps run
 
 
 def _cpu_baseline_child(threads, batch, max_steps):
