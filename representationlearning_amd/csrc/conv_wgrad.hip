@@ -261,6 +261,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
   if (i < per) {
     const float* p = a.partial + i;
     int k = kg;
+    for (; k + 7 * RG < a.ksplit; k += 8 * RG) {           // eight planes in flight per thread: the walk is latency-bound
+      const float v0 = p[(int64_t)k * per], v1 = p[(int64_t)(k + RG) * per], v2 = p[(int64_t)(k + 2 * RG) * per],
+                  v3 = p[(int64_t)(k + 3 * RG) * per], v4 = p[(int64_t)(k + 4 * RG) * per], v5 = p[(int64_t)(k + 5 * RG) * per],
+                  v6 = p[(int64_t)(k + 6 * RG) * per], v7 = p[(int64_t)(k + 7 * RG) * per];
+      s0 += v0 + v4; s1 += v1 + v5; s2 += v2 + v6; s3 += v3 + v7;
+    }
     for (; k + 3 * RG < a.ksplit; k += 4 * RG) {
       s0 += p[(int64_t)k * per]; s1 += p[(int64_t)(k + RG) * per];
       s2 += p[(int64_t)(k + 2 * RG) * per]; s3 += p[(int64_t)(k + 3 * RG) * per];
