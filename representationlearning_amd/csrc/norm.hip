@@ -88,7 +88,6 @@ __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dy, cons
   const int64_t rows_per_pass = (int64_t)gridDim.x * (blockDim.x / G);
   const int64_t niter = (rows + rows_per_pass - 1) / rows_per_pass;
   const int64_t row0 = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
-  // two rows in flight per lane group, loads issued unconditionally (a row past the end re-reads row 0 and is discarded)
   auto one = [&](int64_t row, bool ok, const Vec<T>& vx, const Vec<T>& vd, const Vec<T>& va, float mean, float rstd) {
     float s1 = 0.f, s2 = 0.f, xh[VEC], g[VEC];
 #pragma unroll
@@ -114,17 +113,25 @@ __global__ void __launch_bounds__(256) ln_bwd_vec(const T* __restrict__ dy, cons
       w.store(dx + row * C + sub * VEC);
     }
   };
-  for (int64_t it = 0; it < niter; it += 2) {
-    const int64_t ra = it * rows_per_pass + row0, rb = ra + rows_per_pass;
-    const bool oka = ra < rows, okb = (it + 1 < niter) && rb < rows;
-    const int64_t qa = oka ? ra : 0, qb = okb ? rb : 0;
-    Vec<T> xa, da, aa, xb, db, ab2;
-    xa.load(x + qa * C + sub * VEC); da.load(dy + qa * C + sub * VEC);
-    xb.load(x + qb * C + sub * VEC); db.load(dy + qb * C + sub * VEC);
-    if (dx_add) { aa.load(dx_add + qa * C + sub * VEC); ab2.load(dx_add + qb * C + sub * VEC); }
-    const float ma = stats[qa * 2], sa = stats[qa * 2 + 1], mb = stats[qb * 2], sb2 = stats[qb * 2 + 1];
-    one(ra, oka, xa, da, aa, ma, sa);
-    one(rb, okb, xb, db, ab2, mb, sb2);
+  // RF rows in flight per lane group (the loop is a chain of memory round trips: 2 in flight left it latency-bound at
+  // 2.5 TB/s); loads issued unconditionally (a row past the end re-reads row 0 and is discarded)
+  constexpr int RF = 4;
+  for (int64_t it = 0; it < niter; it += RF) {
+    int64_t rr[RF], qq[RF];
+    bool ok[RF];
+    Vec<T> vx[RF], vd[RF], va[RF];
+    float mm[RF], ss[RF];
+#pragma unroll
+    for (int u = 0; u < RF; ++u) {
+      rr[u] = (it + u) * rows_per_pass + row0;
+      ok[u] = (it + u < niter) && rr[u] < rows;
+      qq[u] = ok[u] ? rr[u] : 0;
+      vx[u].load(x + qq[u] * C + sub * VEC); vd[u].load(dy + qq[u] * C + sub * VEC);
+      if (dx_add) va[u].load(dx_add + qq[u] * C + sub * VEC);
+      mm[u] = stats[qq[u] * 2]; ss[u] = stats[qq[u] * 2 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < RF; ++u) one(rr[u], ok[u], vx[u], vd[u], va[u], mm[u], ss[u]);
   }
   // lanes that own the same channels (same `sub`) inside a wave are folded by shuffles before the LDS atomics
 #pragma unroll
