@@ -103,3 +103,18 @@ def test_miou_metric():
     iou = m.iou()
     assert iou[0] == pytest.approx(1 / 3) and iou[1] == pytest.approx(2 / 3) and iou[2] == pytest.approx(1 / 2)
     assert m.miou() == pytest.approx((1 / 3 + 2 / 3 + 1 / 2) / 3)
+
+
+def test_palette_png_writer(tmp_path):
+    """module/viz.py (mirror of the reference's VisualizeSegmm, viz.py:6-23; byte-identical files were checked against the
+    imported reference class in the build container): palette PNG with the LoveDA colours; PIL stores the 7-colour image at
+    4 bits per pixel, so the ignore label (-1 -> uint8 255) reads back as 15 - the reference's files do the same."""
+    import numpy as np
+    from PIL import Image
+    from representationlearning_amd.module.viz import LOVEDA_PALETTE, VisualizeSegmm
+    y = np.array([[[0, 1, 2, 3], [4, 5, 6, -1]]], dtype=np.int64)
+    VisualizeSegmm(str(tmp_path / "vis"), LOVEDA_PALETTE)(y, "a.png")
+    im = Image.open(tmp_path / "vis" / "a.png")
+    assert im.mode == "P" and im.size == (4, 2)
+    assert np.array_equal(np.asarray(im), np.array([[0, 1, 2, 3], [4, 5, 6, 15]], dtype=np.uint8))
+    assert im.getpalette()[:21] == LOVEDA_PALETTE and im.convert("RGB").getpixel((1, 0)) == (255, 0, 0)

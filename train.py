@@ -24,17 +24,24 @@ def seed_torch(seed=2333):
     torch.cuda.manual_seed_all(seed)
 
 
-def evaluate_cls_fn(model, batches, classes, logger=print, tta_scales=None):
-    """train.py:14-57 / eval.py:55-71 of the reference: (optional test-time augmentation,) argmax, drop ignore(-1),
-    confusion-matrix metrics."""
+def evaluate_cls_fn(model, batches, classes, logger=print, tta_scales=None, viz_op=None):
+    """train.py:14-57 / eval.py:55-77 of the reference: (optional test-time augmentation,) argmax, drop ignore(-1),
+    confusion-matrix metrics; with a `viz_op` (module/viz.py) the label and prediction maps are also written as palette
+    PNGs, `gt<name>.png` / `<name>.png` (eval.py:73-77; names: batch index and position, the synthetic tiles have no file)."""
+    from representationlearning_amd import ops
     from representationlearning_amd.metric import PixelMetric
     from representationlearning_amd.module.tta import tta, Scale
     metric = PixelMetric(classes)
     model.eval()
     with torch.no_grad():
-        for img, lab in batches:
+        for bi, (img, lab) in enumerate(batches):
             scores = model(img) if tta_scales is None else tta(model, img, [Scale(scale_factor=s) for s in tta_scales])
             metric.forward_scores(lab, scores)          # argmax + ignore(-1) mask + confusion matrix: one HIP kernel
+            if viz_op is not None:
+                pred = ops.argmax_confusion(scores, want_pred=True).cpu().numpy()
+                for i in range(pred.shape[0]):
+                    viz_op(lab[i].cpu().numpy(), "gt%04d_%02d.png" % (bi, i))
+                    viz_op(pred[i], "%04d_%02d.png" % (bi, i))
     out = metric.summary_all()
     logger("mIoU %.4f  OA %.4f" % (out["miou"], out["overall_accuracy"]))
     return out
