@@ -184,6 +184,20 @@ int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift,
                       const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
                       double n, int training, int dtype, void* stream);
 
+/* ---- Device input pipeline: RandomCrop -> OneOf(HorizontalFlip, VerticalFlip, RandomRotate90) -> Normalize
+ *      -> ToTensor and the LoveDA `mask - 1` shift (configs/base/loveda.py:18-36, data/loveda.py:82-91) as one gather over a
+ *      device-resident uint8 dataset img [nsrc][SH][SW][3], mask [nsrc][SH][SW] (optional).  params [B][4] (device, int32) =
+ *      {source image, crop y0, crop x0, op}; out_img [B][OH][OW][3] channels-last of `dtype`; out_mask [B][OH][OW] int64.
+ *      Normalize as albumentations does it: (float32(v) - mean*max_pixel_value) * reciprocal(std*max_pixel_value).
+ *      The rot90 ops need a square crop.  ShiftScaleRotate is not implemented. ------------------------------------------------ */
+#define RSSF_AUG_NONE 0
+#define RSSF_AUG_HFLIP 1
+#define RSSF_AUG_VFLIP 2
+#define RSSF_AUG_ROT90 3        /* + k, k = 0..3 quarter turns counter-clockwise (np.rot90) */
+int rssf_input_pipeline(const uint8_t* img, const uint8_t* mask, const int* params, void* out_img, int64_t* out_mask, int B,
+                        int nsrc, int SH, int SW, int OH, int OW, const float* mean3, const float* std3, float max_pixel_value,
+                        int dtype, void* stream);
+
 /* ---- Up-sampling, channels-last ------------------------------------------------------------------------------
  * bilinear with align_corners=True: F.interpolate x3 in SimpleFusion8 (hrnet_aux.py:61-65), UpsamplingBilinear2d(x4)
  * of the head (:80).  backward = 0: in [B,IH,IW,C] -> out [B,OH,OW,C];  backward = 1: `in` is the gradient

@@ -65,6 +65,7 @@ SIGNATURES = {
     "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_reduce": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_int, c_void_p]),
+    "rssf_input_pipeline": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "rssf_upsample_bilinear": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "rssf_upsample_bilinear_slice": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "rssf_upsample_nearest_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

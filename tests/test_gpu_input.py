@@ -1,0 +1,63 @@
+"""Device input pipeline against the numpy restatement of the albumentations chain (oracle/input_cpu.py,
+parity unpinned: see its header).  Bit-exact: labels are integers, the fp32 image is the same two float32 roundings, the bf16
+image is that value rounded to nearest-even."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import input_cpu as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tiles(n, H, W, seed):
+    rng = np.random.RandomState(seed)
+    return rng.randint(0, 256, size=(n, H, W, 3)).astype(np.uint8), rng.randint(0, 8, size=(n, H, W)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_every_op_matches_oracle_bit_exact(dtype):
+    from representationlearning_amd.data import DeviceAugment, LOVEDA_MEAN, LOVEDA_STD
+    img, msk = _tiles(3, 40, 52, 1)
+    aug = DeviceAugment(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV), crop=32, dtype=dtype, seed=0)
+    params = np.array([[0, 0, 0, 0], [1, 8, 20, 1], [2, 3, 5, 2], [0, 8, 0, 3], [1, 0, 20, 4], [2, 7, 19, 5], [1, 4, 4, 6]], dtype=np.int32)
+    x, y = aug.apply(params)
+    ri, rl = O.pipeline(img, msk, params, 32, LOVEDA_MEAN, LOVEDA_STD)
+    assert x.shape == (7, 3, 32, 32) and x.is_contiguous(memory_format=torch.channels_last) and y.dtype == torch.int64
+    assert np.array_equal(y.cpu().numpy(), rl) and rl.min() == -1
+    ref = torch.from_numpy(ri).permute(0, 3, 1, 2)
+    if dtype == torch.bfloat16:
+        ref = ref.bfloat16()
+    assert torch.equal(x.cpu(), ref)
+
+
+def test_random_draws_in_range_and_reference_size_properties():
+    """1024 x 1024 tiles, 512 crops (the reference's sizes): draws stay inside the tile, all ops occur, flipping twice and four
+    quarter turns are the identity, and a crop of a crop equals the direct crop."""
+    from representationlearning_amd.data import DeviceAugment
+    img, msk = _tiles(2, 1024, 1024, 2)
+    aug = DeviceAugment(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV), crop=512, seed=3)
+    p = aug.draw(256)
+    assert p[:, 1].min() >= 0 and p[:, 1].max() <= 512 and p[:, 2].min() >= 0 and p[:, 2].max() <= 512 and set(p[:, 3]) == set(range(7))
+    assert 0.15 < (p[:, 3] == 0).mean() < 0.35          # OneOf(p=0.75): a quarter untouched
+    base = np.array([[1, 100, 200, 0]], dtype=np.int32)
+    x0, y0 = aug.apply(base)
+    for op, inv in ((1, lambda t: t.flip(-1)), (2, lambda t: t.flip(-2)), (4, lambda t: torch.rot90(t, -1, (-2, -1))),
+                    (5, lambda t: torch.rot90(t, -2, (-2, -1))), (6, lambda t: torch.rot90(t, -3, (-2, -1)))):
+        q = base.copy(); q[0, 3] = op
+        x, y = aug.apply(q)
+        assert torch.equal(inv(x), x0) and torch.equal(inv(y), y0)
+    xb, yb = aug(4)      # the __call__ path
+    assert xb.shape == (4, 3, 512, 512) and yb.shape == (4, 512, 512) and int(yb.min()) >= -1 and int(yb.max()) <= 6
+
+
+def test_bad_parameters_are_rejected():
+    from representationlearning_amd.data import DeviceAugment
+    img, msk = _tiles(1, 16, 16, 0)
+    aug = DeviceAugment(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV), crop=8)
+    for bad in ([[1, 0, 0, 0]], [[0, 9, 0, 0]], [[0, 0, 0, 7]], [[0, -1, 0, 0]]):
+        with pytest.raises(ValueError):
+            aug.apply(np.array(bad, dtype=np.int32))
+    with pytest.raises(ValueError):
+        DeviceAugment(torch.from_numpy(img).to(DEV), crop=32)
