@@ -204,3 +204,23 @@ def test_eval_tta_confusion():
     cm = O.confusion_matrix(y, torch.from_numpy(g["pred_tta"]), 6)
     assert np.array_equal(cm.numpy(), g["cm_tta"])
     assert np.array_equal(O.confusion_matrix(y, torch.from_numpy(g["pred"]), 6).numpy(), g["cm"])
+
+
+def test_input_pipeline_oracle_known_answers():
+    """oracle/input_cpu.py (parity unpinned - albumentations is not installed): hand-derived known answers for the index maps
+    and the two-rounding normalisation, so that the checker of tests/test_gpu_input.py is itself pinned to something."""
+    import numpy as np
+    from oracle import input_cpu as IC
+    a = np.arange(6, dtype=np.uint8).reshape(2, 3)                     # [[0 1 2] [3 4 5]]
+    assert IC.geometric(a, IC.AUG_HFLIP).tolist() == [[2, 1, 0], [5, 4, 3]]
+    assert IC.geometric(a, IC.AUG_VFLIP).tolist() == [[3, 4, 5], [0, 1, 2]]
+    assert IC.geometric(a, IC.AUG_ROT90 + 0).tolist() == a.tolist()
+    assert IC.geometric(a, IC.AUG_ROT90 + 1).tolist() == [[2, 5], [1, 4], [0, 3]]          # counter-clockwise quarter turn
+    assert IC.geometric(a, IC.AUG_ROT90 + 2).tolist() == [[5, 4, 3], [2, 1, 0]]
+    assert IC.geometric(a, IC.AUG_ROT90 + 3).tolist() == [[3, 0], [4, 1], [5, 2]]
+    img = np.array([[[[0, 128, 255]]]], dtype=np.uint8)                # one pixel
+    out, lab = IC.pipeline(img, np.array([[[0]]], dtype=np.uint8), [[0, 0, 0, 0]], 1, (123.675, 116.28, 103.53), (58.395, 57.12, 57.375))
+    exp = [(np.float32(v) - np.float32(m)) * (np.float32(1) / np.float32(s)) for v, m, s in zip((0, 128, 255), (123.675, 116.28, 103.53), (58.395, 57.12, 57.375))]
+    assert out.dtype == np.float32 and out[0, 0, 0].tolist() == [float(e) for e in exp]
+    assert abs(out[0, 0, 0, 0] + 2.117904) < 1e-5 and abs(out[0, 0, 0, 2] - 2.64) < 1e-5          # the familiar ImageNet range
+    assert lab.tolist() == [[[-1]]]                                    # LoveDA no-data 0 -> ignore -1
