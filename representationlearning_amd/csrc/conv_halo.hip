@@ -40,44 +40,50 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
   const int y0 = ty * TH, x0 = tx * TW, n0 = (int)(q % a.ntiles_n) * BN;
 
-  // fixed per-thread staging slots
-  const bf16_t* asrc[A_LOADS];
-  bool aok[A_LOADS];
+  // fixed per-thread staging slots.  All loads are hardware-bounds-checked buffer loads with 32-bit byte offsets: an
+  // out-of-image halo pixel or an out-of-range channel chunk gets the out-of-range sentinel and the load returns zeros (no
+  // 64-bit address arithmetic, no clamps, no zeroing at the LDS store).  The kernel is instruction-issue-bound (4 waves per
+  // SIMD, each issuing 35 % of its cycles: 727 VALU + 486 SALU around 36 MFMAs before this change), so instructions are time.
+  constexpr unsigned OOB = 0x80000000u;                   // >= num_records: the host keeps both tensors below 2^31 bytes
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.in), 0,
+                                                                         (int)((int64_t)a.B * a.H * a.W * a.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wpk), 0, 9 * a.CoutP * a.CinP * 2, 0x00020000);
+  unsigned aoff[A_LOADS], boff[B_LOADS];
+  int asub[A_LOADS];
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
     const int idx = tid + i * 256, p = idx >> 2;
-    const int gy = y0 - 1 + p / (TW + 2), gx = x0 - 1 + p % (TW + 2);
-    aok[i] = idx < HP * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    asrc[i] = a.in + (((int64_t)b * a.H + (aok[i] ? gy : 0)) * a.W + (aok[i] ? gx : 0)) * a.Cin + (idx & 3) * 8;
+    const int py = p / (TW + 2), gy = y0 - 1 + py, gx = x0 - 1 + (p - py * (TW + 2));
+    const bool ok = idx < HP * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    asub[i] = (idx & 3) * 8;
+    aoff[i] = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.Cin + asub[i]) * 2) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int idx = tid + i * 256, row = idx >> 2;                          // row = tap*BN + n
+    boff[i] = idx < 9 * BN * 4 ? (unsigned)((((row / BN) * a.CoutP + (row % BN)) * a.CinP + (idx & 3) * 8) * 2) : OOB;
   }
   Vec<bf16_t> ra[A_LOADS], rb[B_LOADS];
-  bool rok[A_LOADS];
-  // branch-free staging: every load is issued (from a clamped address), out-of-image / out-of-channel slots are zeroed
-  // when written to LDS, so the chunk's loads are all in flight together
   auto load_chunk = [&](int kc) {
+    const int crem = a.Cin - kc * KC;                                        // channels left in this chunk (scalar)
+    const int soff = kc * KC * 2, swoff = (n0 * a.CinP + kc * KC) * 2;
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      rok[i] = aok[i] && kc * KC + ((tid + i * 256) & 3) * 8 < a.Cin;
-      ra[i].load(rok[i] ? asrc[i] + kc * KC : a.in);
-    }
+    for (int i = 0; i < A_LOADS; ++i)
+      ra[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, asub[i] < crem ? aoff[i] : OOB, soff, 0));
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int idx = tid + i * 256, row = (idx >> 2) % (9 * BN);          // row = tap*BN + n
-      rb[i].load(a.wpk + ((int64_t)(row / BN) * a.CoutP + n0 + row % BN) * a.CinP + kc * KC + (idx & 3) * 8);
-    }
+    for (int i = 0; i < B_LOADS; ++i)
+      rb[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, boff[i], swoff, 0));
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int idx = tid + i * 256;
-      Vec<bf16_t> v = ra[i];
-      if (!rok[i]) v.raw = {0, 0, 0, 0};
-      if (idx < HP * 4) v.store(As + (idx >> 2) * LDK + (idx & 3) * 8);
+      if ((HP * 4) % 256 == 0 || idx < HP * 4) ra[i].store(As + (idx >> 2) * LDK + (idx & 3) * 8);
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
       const int idx = tid + i * 256;
-      if (idx < 9 * BN * 4) rb[i].store(Bs + (idx >> 2) * LDK + (idx & 3) * 8);
+      if ((9 * BN * 4) % 256 == 0 || idx < 9 * BN * 4) rb[i].store(Bs + (idx >> 2) * LDK + (idx & 3) * 8);
     }
   };
 
