@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
       if (res_pre) vp.load(res_pre + r * C + c0);
     }
   }
-  float sc[VEC], sh[VEC], mean[VEC], istd[VEC], k1[VEC], k2[VEC];
+  float sc[VEC], sh[VEC], mean[VEC], istd[VEC], k1[VEC], k2[VEC], cb[VEC], cc[VEC];
   if (active) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; mean[e] = mi[c0 + e]; istd[e] = mi[C + c0 + e]; }
@@ -321,6 +321,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     k1[e] = s1 / n;
     k2[e] = dot / n;
     if (dgamma && blockIdx.x == 0 && rlocal == 0) { dgamma[c] += dot; dbeta[c] += s1; }     // one writer per channel
+    // draw = sc*(dz - k1 - (x - mean)*istd*k2) = sc*dz + cb*x + cc : two FMAs per element instead of six operations (the pass
+    // runs 8 waves per SIMD at 22 % VALU-active each: instruction issue, not the fabric, was its limit)
+    cb[e] = -sc[e] * istd[e] * k2[e];
+    cc[e] = -sc[e] * k1[e] - cb[e] * mean[e];
   }
   if constexpr (VEC > 1) {
     while (have) {
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
         const float z = x * sc[e] + sh[e] + (res_pre ? vp.get(e) : 0.f);
         const float dz = vd.get(e) * act_bwd(z, act);
         o2[e] = dz;
-        o1[e] = training ? sc[e] * (dz - k1[e] - (x - mean[e]) * istd[e] * k2[e]) : sc[e] * dz;
+        o1[e] = training ? fmaf(sc[e], dz, fmaf(cb[e], x, cc[e])) : sc[e] * dz;
       }
       Vec<T> w1, w2;
       w1.set_all(o1); w2.set_all(o2);
