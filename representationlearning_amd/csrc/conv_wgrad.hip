@@ -99,6 +99,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   const T* DO = reinterpret_cast<const T*>(a.dout);
   const T* IN = reinterpret_cast<const T*>(a.in);
   const int wm = wave >> 1, wn = wave & 1;
+  // bf16 vector path: hardware-bounds-checked buffer loads (32-bit byte offsets; an invalid row gets the out-of-range sentinel
+  // and the load returns zeros: no zeroing at the LDS store), and for the one-tap-per-block tiles NO branch around the loads
+  // of the next slab, so that the compiler counts the outstanding loads exactly (see conv_fwd.hip)
+  constexpr bool FASTW = VOK && sizeof(T) == 2;
+  constexpr unsigned OOB = 0x80000000u;
+  __amdgpu_buffer_rsrc_t rdo, rin;
+  if constexpr (FASTW) {
+    rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(DO), 0, (int)((int64_t)a.B * a.OH * a.OW * a.Cout * sizeof(T)), 0x00020000);
+    rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(IN), 0, (int)((int64_t)a.B * a.IH * a.IW * a.Cin * sizeof(T)), 0x00020000);
+  }
 
   f32x4 acc[TG][WI][WI];
 #pragma unroll
@@ -147,7 +157,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
       const int ch = co0 + scol[c];
       dok[c] = pv[c] && ch < a.Cout;
       const int off = dok[c] ? pix[c] * a.Cout + ch : 0;
-      if constexpr (VOK) {
+      if constexpr (FASTW) {
+        rd[c].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, dok[c] ? (unsigned)off * 2u : OOB, 0, 0));
+      } else if constexpr (VOK) {
         rd[c].load(DO + off);
       } else {
         rd[c].raw = {0, 0, 0, 0};
@@ -164,7 +176,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
       const int ch = ci0 + scol[c];
       xok[c] = pv[c] && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW && ch < a.Cin;
       const int off = xok[c] ? ((pb[c] * a.IH + sy) * a.IW + sx) * a.Cin + ch : 0;
-      if constexpr (VOK) {
+      if constexpr (FASTW) {
+        rx[c].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xok[c] ? (unsigned)off * 2u : OOB, 0, 0));
+      } else if constexpr (VOK) {
         rx[c].load(IN + off);
       } else {
         rx[c].raw = {0, 0, 0, 0};
@@ -187,16 +201,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
           if (srow[c] < KP) {
             if (t == 0) {
               Vec<T> v = rd[c];
-              if (VOK && !dok[c]) v.raw = {0, 0, 0, 0};
+              if (VOK && !FASTW && !dok[c]) v.raw = {0, 0, 0, 0};
               v.store(DS + srow[c] * LD + scol[c]);
             }
             Vec<T> v = rx[c];
-            if (VOK && !xok[c]) v.raw = {0, 0, 0, 0};
+            if (VOK && !FASTW && !xok[c]) v.raw = {0, 0, 0, 0};
             v.store(XS + srow[c] * LD + scol[c]);
           }
         __syncthreads();
         if (t + 1 < TG && t + 1 < a.ntap) load_x(t + 1);
-        else if (k0 + KP < kend) { next_slab(); load_d(); load_x(0); }
+        else if ((FASTW && TG == 1) || k0 + KP < kend) { next_slab(); load_d(); load_x(0); }    // past the end: pv false -> zeros, unused
 #pragma unroll
         for (int ks = 0; ks < KP; ks += MK::KSTEP) {
           typename MK::frag fa[WI], fb[WI];
@@ -526,8 +540,8 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
-  RSSF_REQUIRE((int64_t)B * OH * OW * Cout < ((int64_t)1 << 31) && (int64_t)B * IH * IW * Cin < ((int64_t)1 << 31),
-               "conv_wgrad: activation tensors of 2^31 or more elements are not supported (32-bit offsets)");
+  RSSF_REQUIRE((int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && (int64_t)B * IH * IW * Cin < ((int64_t)1 << 30),
+               "conv_wgrad: activation tensors of 2^30 or more elements are not supported (32-bit byte offsets, buffer bounds)");
   WgradArgs a;
   a.dout = dout; a.in = in; a.dw[0] = dw0; a.dw[1] = dw1; a.dw[2] = dw2; a.dbias = dbias;
   for (int i = 0; i < 3; ++i) a.ks[i] = i < nsrc ? ksizes[i] : 1;
