@@ -122,6 +122,9 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
     for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
   bf16_t* Cs = lds;                                       // [TH*16][LDC]
   if (a.stats) __syncthreads();
+  // (the statistics are only wanted by the forward launches, and only edge tiles need the per-pixel validity test: both are
+  // block-uniform branches around ~40 VALU instructions of an issue-bound kernel)
+  const bool full = y0 + TH <= a.H && x0 + TW <= a.W;
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int lcol = ni * 16 + l15, col = n0 + lcol;
@@ -130,16 +133,29 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int py = wave * MI + mi;
-      const bool yok = y0 + py < a.H;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int px = grp * 4 + r;
-        const float v = acc[mi][ni][r] + bv;
-        stf(Cs + (py * TW + px) * LDC + lcol, v);
-        if (yok && x0 + px < a.W) { s1 += v; s2 += v * v; }
+        acc[mi][ni][r] += bv;
+        stf(Cs + (py * TW + grp * 4 + r) * LDC + lcol, acc[mi][ni][r]);
       }
     }
     if (a.stats) {
+      if (full) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = acc[mi][ni][r]; s1 += v; s2 += v * v; }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const bool yok = y0 + wave * MI + mi < a.H;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[mi][ni][r];
+            if (yok && x0 + grp * 4 + r < a.W) { s1 += v; s2 += v * v; }
+          }
+        }
+      }
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       if (grp == 0) { atomicAdd(&sstat[lcol], s1); atomicAdd(&sstat[BN + lcol], s2); }
