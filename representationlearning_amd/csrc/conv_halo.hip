@@ -21,7 +21,10 @@ namespace {
 
 constexpr int TW = 16, KC = 32, LDK = KC + 8;             // 80-byte LDS rows: conflict-free ds_read_b128
 
-template <int TH, int BN>
+// MIRROR: the nine taps in data-gradient order (offset of tap t = -(t/3 - 1, t%3 - 1)) instead of forward order; the offsets
+// are compile-time, so a tap only changes the IMMEDIATE offset of the A-operand LDS reads (with run-time dy/dx every tap cost
+// two scalar loads and ~6 VALU of address arithmetic per fragment in an issue-bound kernel).
+template <int TH, int BN, bool MIRROR>
 __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   constexpr int MI = TH / 4, NI = BN / 16, HP = (TH + 2) * (TW + 2), BMP = TH * TW;
   constexpr int A_ELEMS = HP * LDK, B_ELEMS = 9 * BN * LDK, LDC = BN + 8;
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
     if (kc + 1 < nchunks) load_chunk(kc + 1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int dy = a.dy[tap], dx = a.dx[tap];
+      const int dy = MIRROR ? 1 - tap / 3 : tap / 3 - 1, dx = MIRROR ? 1 - tap % 3 : tap % 3 - 1;
       bf16x8 fa[MI], fb[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -196,11 +199,20 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
 }  // namespace
 
 // true when the halo kernel covers this call (bf16 only; the caller checked the dtype)
+// +1: forward tap order, -1: mirrored (data-gradient) order, 0: neither
+static int tap_order(const int* dy, const int* dx) {
+  int sign = 0;
+  for (int s = 1; s >= -1 && !sign; s -= 2) {
+    bool ok = true;
+    for (int t = 0; t < 9; ++t) ok = ok && dy[t] == s * (t / 3 - 1) && dx[t] == s * (t % 3 - 1);
+    if (ok) sign = s;
+  }
+  return sign;
+}
+
 bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, int ntaps, const int* dy, const int* dx) {
   if (mul != 1 || div != 1 || IH != OH || IW != OW || ntaps != 9 || (Cin % 8) != 0) return false;
-  for (int t = 0; t < 9; ++t)
-    if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1) return false;
-  return true;
+  return tap_order(dy, dx) != 0;
 }
 
 int launch_halo(HaloArgs a, hipStream_t st) {
@@ -215,9 +227,16 @@ int launch_halo(HaloArgs a, hipStream_t st) {
   a.total = (int64_t)a.B * a.tiles_y * a.tiles_x * a.ntiles_n;
   a.xcd_per = xcd_per(a.total);
   dim3 grid((unsigned)a.xcd_per * 8);
-  if (th == 8 && bn == 64) conv3x3_halo_kernel<8, 64><<<grid, 256, 0, st>>>(a);
-  else if (th == 8) conv3x3_halo_kernel<8, 32><<<grid, 256, 0, st>>>(a);
-  else conv3x3_halo_kernel<4, 32><<<grid, 256, 0, st>>>(a);
+  const bool mirror = tap_order(a.dy, a.dx) < 0;
+#define RSSF_HALO(THv, BNv)                                                      \
+  do {                                                                           \
+    if (mirror) conv3x3_halo_kernel<THv, BNv, true><<<grid, 256, 0, st>>>(a);    \
+    else conv3x3_halo_kernel<THv, BNv, false><<<grid, 256, 0, st>>>(a);          \
+  } while (0)
+  if (th == 8 && bn == 64) RSSF_HALO(8, 64);
+  else if (th == 8) RSSF_HALO(8, 32);
+  else RSSF_HALO(4, 32);
+#undef RSSF_HALO
   return check_launch("conv3x3_halo");
 }
 
