@@ -61,10 +61,14 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
     asub[i] = (idx & 3) * 8;
     aoff[i] = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.Cin + asub[i]) * 2) : OOB;
   }
+  {
+    // row = tap*BN + n; chunk i of a thread is 64 rows = 64/BN taps further on, same n: one multiply for all of them
+    static_assert(64 % BN == 0, "a thread's weight chunks must keep their column");
+    const int row0 = tid >> 2;
+    const unsigned b0 = (unsigned)((((row0 / BN) * a.CoutP + (row0 % BN)) * a.CinP + (tid & 3) * 8) * 2);
+    const unsigned bstep = (unsigned)((64 / BN) * a.CoutP * a.CinP * 2);
 #pragma unroll
-  for (int i = 0; i < B_LOADS; ++i) {
-    const int idx = tid + i * 256, row = idx >> 2;                          // row = tap*BN + n
-    boff[i] = idx < 9 * BN * 4 ? (unsigned)((((row / BN) * a.CoutP + (row % BN)) * a.CinP + (idx & 3) * 8) * 2) : OOB;
+    for (int i = 0; i < B_LOADS; ++i) boff[i] = ((9 * BN * 4) % 256 == 0 || tid + i * 256 < 9 * BN * 4) ? b0 + i * bstep : OOB;
   }
   Vec<bf16_t> ra[A_LOADS], rb[B_LOADS];
   auto load_chunk = [&](int kc) {
