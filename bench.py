@@ -15,7 +15,6 @@ for the step's largest GEMM (the MlpDWBN 19-tap fused convolution), which is MFM
 import argparse
 import json
 import os
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # fresh boxes have no MIOpen find-db: skip the exhaustive per-shape search
 import sys
 import time
 
@@ -239,8 +238,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
-        from representationlearning_amd import rccl
-        rccl.shutdown()
+        trainer.close()
         dist.destroy_process_group()
 
 

@@ -17,15 +17,15 @@ def remove_module_prefix(state):
     return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
 
 
-def evaluate(ckpt_path, config_path="baseline.hrnetw32", use_tta=False, batches=None, vis_dir=None):
+def evaluate(ckpt_path, config_path="baseline.hrnetw32", use_tta=False, batches=None, vis_dir=None, overrides=()):
     from representationlearning_amd import _lib
     from representationlearning_amd.configs import config_by_name, synthetic_batch
     from representationlearning_amd.core import registry
-    from representationlearning_amd.core.config import AttrDict
+    from representationlearning_amd.core.config import AttrDict, apply_overrides
     from train import evaluate_cls_fn
     _lib.load()
     registry.register_all()
-    cfg = AttrDict.wrap(config_by_name(config_path))
+    cfg = apply_overrides(AttrDict.wrap(config_by_name(config_path)), list(overrides))       # e.g. model.params.classes 6
     model = registry.MODEL[cfg.model.type](cfg.model.params)
     if ckpt_path:
         model.load_state_dict(remove_module_prefix(torch.load(ckpt_path, map_location="cpu")))
@@ -50,5 +50,6 @@ if __name__ == "__main__":
     ap.add_argument("--config_path", type=str, default="baseline.hrnetw32")
     ap.add_argument("--tta", type=bool, default=False)
     ap.add_argument("--vis_dir", type=str, default=None, help="where the palette PNGs go (default: vis-<ckpt> next to the checkpoint)")
+    ap.add_argument("overrides", nargs="*", help="`a.b.c value` config overrides, as train.py takes them")
     a = ap.parse_args()
-    evaluate(a.ckpt_path, a.config_path, a.tta, vis_dir=a.vis_dir)
+    evaluate(a.ckpt_path, a.config_path, a.tta, vis_dir=a.vis_dir, overrides=a.overrides)

@@ -36,7 +36,8 @@ typedef enum {
 } rssf_status;
 
 const char* rssf_version(void);
-const char* rssf_arch(void);        /* always "gfx950" */
+const char* rssf_arch(void);        /* gcnArchName of the current device ("gfx950" is the only one the kernels exist for);
+                                     * the compiled-for architecture when no device is present */
 const char* rssf_last_error(void);  /* thread-local */
 
 /* ---- LayerNorm over C (eps 1e-6): modules/MTFM.py:64,80-81,107,109 ------------------------------ */
@@ -179,10 +180,13 @@ int rssf_bn_finalize_apply(const void* raw, const float* stats, const float* gam
  * dz = dy * act'(raw*scale + shift + res_pre).  rssf_bn_bwd_apply sums the slots (all-reduce the whole buffer for SyncBN) */
 int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, float* sums,
                        int64_t rows, int C, int act, int dtype, void* stream);
-/* draw = d(loss)/d(raw); dres (optional) = dz = gradient of res_pre; dgamma/dbeta (optional) accumulated */
+/* draw = d(loss)/d(raw); dres (optional) = dz = gradient of res_pre; dgamma/dbeta (optional) accumulated:
+ * dgamma += param_grad_scale * sum(dz*xhat), dbeta += param_grad_scale * sum(dz).  param_grad_scale is 1, or 1/world when
+ * `sums` were all-reduced for SyncBN: the data-parallel mean of the LOCAL parameter gradients (torch SyncBatchNorm + DDP
+ * semantics, configs/base/loveda.py:106-108) equals the global sums / world. */
 int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift, const float* mean_invstd, const float* sums,
                       const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
-                      double n, int training, int dtype, void* stream);
+                      double n, int training, float param_grad_scale, int dtype, void* stream);
 
 /* ---- Device input pipeline: RandomCrop -> OneOf(HorizontalFlip, VerticalFlip, RandomRotate90) -> Normalize
  *      -> ToTensor and the LoveDA `mask - 1` shift (configs/base/loveda.py:18-36, data/loveda.py:82-91) as one gather over a
@@ -218,8 +222,9 @@ int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B,
 
 /* ---- CGFL loss: SegmentationLossaux.forward (module/CGFL.py:201-227) -> MCTransAuxLoss (losses/auxloss.py:257-305)
  *      -> softmax_focalloss (module/CGFL.py:72-101), on channels-last logits [B, HW, K] and int64 labels [B, HW] ---- */
-/* acc: fp32 scratch [B][5] (zeroed inside); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);
- * out[0] = loss, out[1] = backward coefficient (detached modulating bracket / n_valid). */
+/* acc: fp32 scratch [B][6] (zeroed inside); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);
+ * out[0] = loss, out[1] = backward coefficient (detached modulating bracket / n_valid).  A label outside [0, K) that is not
+ * ignore_index (F.cross_entropy asserts on it) makes both NaN: the failure is loud, no out-of-range read happens. */
 int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* aux, float* acc, float* out, int B, int HW, int K,
                        int KA, int ignore_index, int dtype, void* stream);
 /* dlogits = dloss * out[1] * (softmax(logits) - onehot(label)) on valid pixels, 0 on ignored ones; dloss may be NULL (=1) */
@@ -242,6 +247,24 @@ int rssf_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
 int rssf_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, const float* sqnorm, float grad_scale,
                   float max_norm, const float* lr_dev, float lr, float momentum, float weight_decay, int first_step,
                   void* stream);
+
+/* ---- data-parallel exchange: what the reference gets from DistributedDataParallel + nn.SyncBatchNorm
+ *      (`ever` th_amp_ddp trainer, train.py:79; configs/base/loveda.py:106-108 sync_bn; modules/ffn_block.py:222-234) as
+ *      RCCL collectives enqueued on the CALLER's stream (capturable into the step's hipGraph).  RCCL is bound at run time:
+ *      rccl_path names the library to dlopen (the process's existing RCCL, e.g. <torch>/lib/librccl.so), NULL = default
+ *      search.  One process per GPU; the 128-byte id comes from rank 0 (rssf_comm_unique_id) over the caller's rendezvous. -- */
+typedef struct rssf_comm rssf_comm;
+int rssf_comm_unique_id(void* id128, const char* rccl_path);
+int rssf_comm_init(rssf_comm** comm, int rank, int world, const void* id128, const char* rccl_path);
+int rssf_comm_rank(const rssf_comm* comm);
+int rssf_comm_world(const rssf_comm* comm);
+/* in-place sum over ranks of one flat gradient bucket (`count` elements of `dtype`); the 1/world factor of the mean is
+ * folded into rssf_sgd_step's grad_scale */
+int rssf_allreduce_bucket(void* buf, int64_t count, int dtype, rssf_comm* comm, void* stream);
+/* in-place sum over ranks of a BatchNorm statistics buffer ([slots][2][C] fp32: forward {sum, sumsq}, backward
+ * {sum dz, sum dz*raw}); the caller multiplies the sample count by rssf_comm_world() */
+int rssf_syncbn_exchange(float* stats, int64_t count, rssf_comm* comm, void* stream);
+int rssf_comm_destroy(rssf_comm* comm);
 
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 /* D[16][16] = A[16][K] * B[16][K]^T through the library's MFMA tile helper (layout self-check). */

@@ -64,7 +64,7 @@ SIGNATURES = {
     "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_reduce": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
-    "rssf_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_int, c_void_p]),
+    "rssf_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_float, c_int, c_void_p]),
     "rssf_input_pipeline": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "rssf_upsample_bilinear": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "rssf_upsample_bilinear_slice": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
@@ -75,6 +75,13 @@ SIGNATURES = {
     "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p, c_float, c_float,
                               c_float, c_int, c_void_p]),
+    "rssf_comm_unique_id": (c_int, [c_void_p, ctypes.c_char_p]),
+    "rssf_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, ctypes.c_char_p]),
+    "rssf_comm_rank": (c_int, [c_void_p]),
+    "rssf_comm_world": (c_int, [c_void_p]),
+    "rssf_allreduce_bucket": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "rssf_syncbn_exchange": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "rssf_comm_destroy": (c_int, [c_void_p]),
     "rssf_debug_trread": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_mma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
@@ -96,8 +103,9 @@ def load():
         fn = getattr(lib, name)       # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.rssf_arch() != b"gfx950":
-        raise RuntimeError("librssf.so was not built for gfx950")
+    arch = lib.rssf_arch()
+    if arch != b"gfx950":
+        raise RuntimeError("librssf.so holds gfx950 code objects only; the current device reports %r" % arch.decode())
     _lib = lib
     return lib
 

@@ -31,6 +31,7 @@ class GatedWindowCrossAttention(torch.autograd.Function):
         ctx.save_for_backward(x, y, sx, sy, pooled, argmax, gsig, omega, kk, wl2, ln_g, ln_b, wq, bq, wk, bk, wv, bv, wo, bo)
         ctx.dims = (H, W, heads)
         ctx.params = dict(ln_g=ln_g, ln_b=ln_b, wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+        ctx.rt = nnf.current()
         return out
 
     @staticmethod
@@ -39,18 +40,18 @@ class GatedWindowCrossAttention(torch.autograd.Function):
         H, W, heads = ctx.dims
         dout = dout.contiguous()
         w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
-        P = ctx.params
-        tg = {n: nnf.grad_target(P[n]) for n in P}            # kernels accumulate straight into .grad when possible
+        P, rt = ctx.params, ctx.rt
+        tg = {n: nnf.grad_target(P[n], rt) for n in P}            # kernels accumulate straight into .grad when possible
         gw = {n: tg[n][0] for n in w}
         dxhat, dyhat, domega = ops.winattn_bwd(dout, x, y, sx, sy, omega, ln_g, ln_b, w, gw, H, W, heads)
-        zb = nnf._zeros(kk.numel() + 8, x.device)            # one slice of the step's pre-zeroed pool instead of three fills
+        zb = nnf._zeros(kk.numel() + 8, x.device, rt)            # one slice of the step's pre-zeroed pool instead of three fills
         dk, dwl, dbl = zb[:kk.numel()].view_as(kk), zb[kk.numel():kk.numel() + 4].view(2, 2), zb[kk.numel() + 4:kk.numel() + 6]
         dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, kk, wl2, dk, dwl, dbl, H, W)
         ops.gate_pool_bwd_(dpooled, argmax, dxhat, dyhat)
         dg, db = tg["ln_g"][0], tg["ln_b"][0]
         dx = ops.layernorm_bwd(dxhat, x, sx, ln_g, dg, db, dx_add=dout)      # + residual path
         dy = ops.layernorm_bwd(dyhat, y, sy, ln_g, dg, db)
-        r = {n: nnf.grad_result(P[n], tg[n][0], tg[n][1]) for n in P}
+        r = {n: nnf.grad_result(P[n], tg[n][0], tg[n][1], rt) for n in P}
         nk = kk.numel()
         gp = zb[:nk + 6].clone()                               # the pool slice is recycled next step: hand autograd a copy
         h = nk // 2
@@ -68,15 +69,17 @@ class LayerNormTokens(torch.autograd.Function):
         y, st = ops.layernorm_fwd(x, g, b)
         ctx.save_for_backward(x, st, g)
         ctx.params = (g, b)
+        ctx.rt = nnf.current()
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, st, g = ctx.saved_tensors
         pg, pb = ctx.params
-        (dg, gd), (db, bd) = nnf.grad_target(pg), nnf.grad_target(pb)
+        rt = ctx.rt
+        (dg, gd), (db, bd) = nnf.grad_target(pg, rt), nnf.grad_target(pb, rt)
         dx = ops.layernorm_bwd(dy.contiguous(), x, st, g, dg, db)
-        return dx, nnf.grad_result(pg, dg, gd), nnf.grad_result(pb, db, bd)
+        return dx, nnf.grad_result(pg, dg, gd, rt), nnf.grad_result(pb, db, bd, rt)
 
 
 def _identity_ln(x):

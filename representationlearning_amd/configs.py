@@ -21,13 +21,14 @@ def synthetic_batch(B, S, classes=6, seed=2333, device="cuda"):
 
 def config_by_name(name):
     """Dotted config names of the reference (configs/baseline/hrnetw32.py + configs/base/loveda.py): model params +
-    the optimizer / LR / train sections the trainer reads.  `classes` follows BASELINE (6); the reference's LoveDA
-    config uses 7 (configs/baseline/hrnetw32.py:19) — override with `model.params.classes 7`."""
+    the optimizer / LR / train sections the trainer reads.  `classes` = 7 as in the reference's LoveDA config
+    (configs/baseline/hrnetw32.py:19: LoveDA masks reach 6 after the `mask - 1` shift), so a reference checkpoint loads;
+    BASELINE's synthetic 6-class tiles (bench.py) use rssformer_config() directly — or override `model.params.classes 6`."""
     variants = {"baseline.hrnetw32": "base", "baseline.hrnetw18": "tiny", "baseline.hrnetw48": "large"}
     if name not in variants:
         raise KeyError("unknown config '%s' (built: %s)" % (name, ", ".join(sorted(variants))))
     return dict(
-        model=dict(type="RSSFormer", params=rssformer_config(variants[name])),
+        model=dict(type="RSSFormer", params=rssformer_config(variants[name], classes=7)),
         optimizer=dict(type="sgd", params=dict(momentum=0.9, weight_decay=0.0001), grad_clip=dict(max_norm=35, norm_type=2)),
         learning_rate=dict(type="poly", params=dict(base_lr=0.01, power=0.9, max_iters=30000)),
         train=dict(forward_times=1, num_iters=30000, eval_per_epoch=True, summary_grads=False, summary_weights=False,

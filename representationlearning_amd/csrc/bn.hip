@@ -9,7 +9,7 @@
 //   reduce: s1 = sum dz, s2 = sum dz*raw   (dz = dy * act'(z))                            (one pass)
 //   apply : draw = scale * (dz - s1/n - xhat * sum(dz*xhat)/n),  dres_pre = dz            (one pass)
 // Cross-rank SyncBN = all-reduce of the tiny [2][C] buffers between the two launches (host side, RCCL).
-#include "common.cuh"
+#include "common.hip.h"
 using namespace rssf;
 
 namespace {
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mi, const float* __restrict__ sums,
                                                            const T* __restrict__ res_pre, T* __restrict__ draw, T* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
-                                                           int act, float n, int training) {
+                                                           int act, float n, int training, float pscale) {
   const int allcols = C / VEC;
   const int colbase = blockIdx.y * 256;
   const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
@@ -320,7 +320,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     const float dot = (s2 - mean[e] * s1) * istd[e];        // sum dz*xhat
     k1[e] = s1 / n;
     k2[e] = dot / n;
-    if (dgamma && blockIdx.x == 0 && rlocal == 0) { dgamma[c] += dot; dbeta[c] += s1; }     // one writer per channel
+    // one writer per channel.  pscale = 1/world under SyncBN: `sums` are then the GLOBAL totals, while DDP averages the LOCAL
+    // parameter gradients (torch SyncBatchNorm takes grad_weight/grad_bias from the local sums) - global/world == that mean
+    if (dgamma && blockIdx.x == 0 && rlocal == 0) { dgamma[c] += dot * pscale; dbeta[c] += s1 * pscale; }
     // draw = sc*(dz - k1 - (x - mean)*istd*k2) = sc*dz + cb*x + cc : two FMAs per element instead of six operations (the pass
     // runs 8 waves per SIMD at 22 % VALU-active each: instruction issue, not the fabric, was its limit)
     cb[e] = -sc[e] * istd[e] * k2[e];
@@ -419,16 +421,17 @@ int reduce_launch(const void* dy, const void* raw, const float* ss, const void* 
 
 template <typename T>
 int bwd_apply_launch(const void* dy, const void* raw, const float* ss, const float* mi, const float* sums, const void* rp, void* draw,
-                     void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act, float n, int training, hipStream_t st) {
+                     void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act, float n, int training, float pscale,
+                     hipStream_t st) {
   constexpr int V = Vec<T>::N;
   const dim3 grid = grid2d(rows, C, (C % V == 0) ? V : 1);
   const size_t sh = 2 * sizeof(float) * (C < 256 * V ? C : 256 * V);
   if (C % V == 0)
     bn_bwd_apply_kernel<T, V><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, dgamma,
-                                                    dbeta, rows, C, act, n, training);
+                                                    dbeta, rows, C, act, n, training, pscale);
   else
     bn_bwd_apply_kernel<T, 1><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, dgamma,
-                                                    dbeta, rows, C, act, n, training);
+                                                    dbeta, rows, C, act, n, training, pscale);
   return check_launch("bn_bwd_apply");
 }
 }  // namespace
@@ -483,16 +486,16 @@ extern "C" int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* 
 
 extern "C" int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift, const float* mean_invstd, const float* sums,
                                  const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
-                                 double n, int training, int dtype, void* stream) {
+                                 double n, int training, float param_grad_scale, int dtype, void* stream) {
   RSSF_REQUIRE(dy && raw && scale_shift && mean_invstd && sums && draw && rows > 0 && C > 0, "bn_bwd_apply: bad arguments");
   RSSF_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_apply: dgamma and dbeta go together");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RSSF_F32)
     return bwd_apply_launch<float>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, dgamma, dbeta, rows, C, act, (float)n,
-                                   training, st);
+                                   training, param_grad_scale, st);
   if (dtype == RSSF_BF16)
     return bwd_apply_launch<bf16_t>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, dgamma, dbeta, rows, C, act, (float)n,
-                                    training, st);
+                                    training, param_grad_scale, st);
   set_error("bn_bwd_apply: unsupported dtype %d", dtype);
   return RSSF_ERR_UNSUPPORTED;
 }

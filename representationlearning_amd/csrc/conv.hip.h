@@ -1,6 +1,6 @@
 // Implicit-GEMM convolution on channels-last activations (gfx950 MFMA), shared definitions.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace rssf {
 namespace cv {

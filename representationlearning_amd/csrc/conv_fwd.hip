@@ -11,7 +11,7 @@
 // chunk's global loads issued before the MFMAs of the current one (register double buffering).  Epilogue:
 // + bias, per-channel sum / sum-of-squares partials for the following BatchNorm (fused statistics: the
 // activation is not re-read for the mean/var pass), tile transposed through LDS for 16-byte coalesced stores.
-#include "conv.cuh"
+#include "conv.hip.h"
 using namespace rssf;
 using namespace rssf::cv;
 

@@ -10,7 +10,7 @@
 //
 // Epilogue identical to the gather kernel: + bias, fused BatchNorm statistics (slotted atomics), LDS transpose
 // for 16-byte coalesced stores.
-#include "conv.cuh"
+#include "conv.hip.h"
 using namespace rssf;
 using namespace rssf::cv;
 

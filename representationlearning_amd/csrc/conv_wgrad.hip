@@ -18,7 +18,7 @@
 // scatters to its three source convs); measured: per-element atomics from ~1000 blocks cost 300-470 us per call,
 // ~10x the GEMM itself.  (Without a workspace the kernel falls back to atomics.)
 // Optional bias gradient (sum_p dout) for convolutions without a following BatchNorm.
-#include "conv.cuh"
+#include "conv.hip.h"
 using namespace rssf;
 using namespace rssf::cv;
 

@@ -1,6 +1,6 @@
 // Test hooks: exercise the MFMA tile helpers in isolation so layout mistakes show up as a unit-test failure
 // rather than inside a fused kernel.
-#include "win_attn.cuh"
+#include "win_attn.hip.h"
 using namespace rssf;
 
 namespace {

@@ -3,7 +3,7 @@
 // reinterpretation: for flat offset f = n*C + c inside one image, view-pixel p = f mod N, view-channel
 // c' = f div N.  All maps are tiny ([B][k][N] fp32) and stay L2 resident;
 // the only full-tensor traffic is one read of x and y (pool) and one read-modify-write (pool backward).
-#include "common.cuh"
+#include "common.hip.h"
 using namespace rssf;
 
 namespace {

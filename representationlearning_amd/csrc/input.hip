@@ -7,7 +7,7 @@
 // The random draws stay on the host (a handful of integers per image).  ShiftScaleRotate (p=0.2, an OpenCV affine warp with
 // fixed-point bilinear taps) is NOT covered - see DESIGN.md §7.
 // HBM-bound by construction: 4 B read (3 + 1), 3 x sizeof(T) + 8 B written per output pixel.
-#include "common.cuh"
+#include "common.hip.h"
 using namespace rssf;
 
 namespace {

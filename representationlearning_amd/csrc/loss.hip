@@ -8,18 +8,19 @@
 //     loss    = CE * [ sum_{all pixels} (1 - p[max(y,0)]) * (1 - l1_b/7) / (n_valid + B) ]        (bracket detached)
 // One pass over the logits for the forward (per-sample partial sums via block reduction + atomics), a 1-block
 // finalize, one pass for the backward (softmax recomputed: nothing but the logits is kept).  HBM-bound.
-#include "common.cuh"
+#include "common.hip.h"
 using namespace rssf;
 
 namespace {
 constexpr int MAXK = 32;
 
-// acc[b] = { ce_sum, n_valid, sum(1-p_y), any_fg, any_nonfg }
+// acc[b] = { ce_sum, n_valid, sum(1-p_y), any_fg, any_nonfg, n_bad }   n_bad: labels outside [0, K) that are not ignore_index.
+// F.cross_entropy asserts on those; a kernel cannot raise, so the loss (and with it every gradient) becomes NaN instead.
 template <typename T>
 __global__ void __launch_bounds__(256) loss_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ acc,
                                                        int HW, int K, int ignore_index) {
   const int b = blockIdx.y;
-  float ce = 0.f, nv = 0.f, sm = 0.f, fg = 0.f, bg = 0.f;
+  float ce = 0.f, nv = 0.f, sm = 0.f, fg = 0.f, bg = 0.f, bad = 0.f;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
     const int64_t pix = (int64_t)b * HW + p;
     const T* lg = logits + pix * K;
@@ -29,33 +30,37 @@ __global__ void __launch_bounds__(256) loss_fwd_kernel(const T* __restrict__ log
     for (int k = 0; k < K; ++k) { v[k] = ldf(lg + k); mx = fmaxf(mx, v[k]); }
     float se = 0.f;
     for (int k = 0; k < K; ++k) se += __expf(v[k] - mx);
-    const int yy = valid ? y : 0;
+    const bool oob = valid && (y < 0 || y >= K);
+    if (oob) bad += 1.f;
+    const int yy = (valid && !oob) ? y : 0;
     const float logp = v[yy] - mx - __logf(se);
     if (valid) { ce -= logp; nv += 1.f; }
     sm += 1.f - __expf(logp);
     if (valid && y > 0) fg = 1.f; else bg = 1.f;
   }
-  ce = wave_sum(ce); nv = wave_sum(nv); sm = wave_sum(sm); fg = wave_max(fg); bg = wave_max(bg);
-  __shared__ float red[4][5];
+  ce = wave_sum(ce); nv = wave_sum(nv); sm = wave_sum(sm); fg = wave_max(fg); bg = wave_max(bg); bad = wave_max(bad);
+  __shared__ float red[4][6];
   const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[w][0] = ce; red[w][1] = nv; red[w][2] = sm; red[w][3] = fg; red[w][4] = bg; }
+  if ((threadIdx.x & 63) == 0) { red[w][0] = ce; red[w][1] = nv; red[w][2] = sm; red[w][3] = fg; red[w][4] = bg; red[w][5] = bad; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float* a = acc + b * 5;
+    float* a = acc + b * 6;
     atomicAdd(a + 0, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
     atomicAdd(a + 1, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
     atomicAdd(a + 2, red[0][2] + red[1][2] + red[2][2] + red[3][2]);
     if (fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])) > 0.f) atomicMax((int*)(a + 3), __float_as_int(1.f));
     if (fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])) > 0.f) atomicMax((int*)(a + 4), __float_as_int(1.f));
+    if (fmaxf(fmaxf(red[0][5], red[1][5]), fmaxf(red[2][5], red[3][5])) > 0.f) atomicMax((int*)(a + 5), __float_as_int(1.f));
   }
 }
 
 // out[0] = loss, out[1] = gradient coefficient = bracket / n_valid  (d loss / d logit = coef * (p - onehot) on valid pixels)
 __global__ void loss_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ aux, float* __restrict__ out, int B, int KA) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float ce = 0.f, nv = 0.f, mf = 0.f;
+  float ce = 0.f, nv = 0.f, mf = 0.f, bad = 0.f;
   for (int b = 0; b < B; ++b) {
-    const float* a = acc + b * 5;
+    const float* a = acc + b * 6;
+    bad += a[5];
     float l1 = 0.f;
     for (int c = 0; c < KA; ++c) {
       const float lab = c == 0 ? a[4] : (c == 1 ? a[3] : 0.f);
@@ -66,8 +71,8 @@ __global__ void loss_finalize_kernel(const float* __restrict__ acc, const float*
     mf += a[2] * (1.f - l1 / 7.f);
   }
   const float bracket = mf / (nv + (float)B);
-  out[0] = (ce / nv) * bracket;
-  out[1] = bracket / nv;
+  out[0] = bad > 0.f ? NAN : (ce / nv) * bracket;
+  out[1] = bad > 0.f ? NAN : bracket / nv;
 }
 
 template <typename T>
@@ -97,7 +102,7 @@ extern "C" int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, con
                                   int KA, int ignore_index, int dtype, void* stream) {
   RSSF_REQUIRE(logits && labels && aux && acc && out && B > 0 && HW > 0 && K > 0 && K <= MAXK && KA >= 2, "cgfl_loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * 5 * B, st);
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * 6 * B, st);
   if (e != hipSuccess) { set_error("cgfl_loss_fwd: memset failed: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   int bx = (HW + 255) / 256;
   if (bx > 128) bx = 128;

@@ -3,7 +3,7 @@
 // the in-tree confusion-matrix recipe SCD-AAAI2023/utils/evaluate.py:9-35 (bincount of true * K + pred).
 // argmax(softmax(z)) == argmax(z), so the scores may be logits or probabilities.  First maximum wins (torch.argmax).
 // HBM-bound: one read of [B, HW, K] scores + [B, HW] labels; K*K int64 counters accumulated through an LDS histogram.
-#include "common.cuh"
+#include "common.hip.h"
 using namespace rssf;
 
 namespace {

@@ -1,7 +1,7 @@
 // LayerNorm over the channel axis of channels-last tokens [rows, C] (eps 1e-6).
 // Reference: modules/MTFM.py:64,80-81 (nn.LayerNorm(C, eps=1e-6)), applied at :107 (norm1 on both
 // streams) and :109 (norm2).  HBM-bound: one read (+ one write); 16-byte lane accesses, G lanes per row.
-#include "common.cuh"
+#include "common.hip.h"
 using namespace rssf;
 
 namespace {

@@ -2,7 +2,7 @@
 // update} SGD step (reference recipe: configs/base/loveda.py:68-99 — SGD lr 0.01 poly 0.9, momentum 0.9,
 // wd 1e-4, clip_grad_norm 35; the external `ever` trainer applies torch.optim.SGD semantics).
 // One launch over all 32 M parameters instead of ~1.1 k per-tensor launches; HBM-bound (16 B/param read+write).
-#include "common.cuh"
+#include "common.hip.h"
 using namespace rssf;
 
 namespace {

@@ -5,7 +5,7 @@
 //                                   layers (_hrnet_rssformer.py:380) followed by `low = low + ...` (:424-427)
 // Both backward passes are written as GATHERS (each input pixel sums the output pixels that read it), so there
 // are no atomics: the ATen scatter-add backward costs 13 ms per call in bf16 on this shape, this one is HBM-bound.
-#include "common.cuh"
+#include "common.hip.h"
 using namespace rssf;
 
 namespace {

@@ -1,6 +1,6 @@
 // Shared pieces of the fused 7x7-window cross-attention kernels (forward and backward).
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace rssf {
 namespace wa {

@@ -6,13 +6,13 @@
 // exchange their shares of the input gradient through LDS at the end; workgroup barriers separate those phases, so all
 // pairs of a workgroup walk their windows in lockstep).  The forward is recomputed from (x, y, LN stats, omega) so nothing but the
 // block inputs is saved; HBM traffic = read x, y, dout + write dxhat, dyhat.  Every operand is staged in LDS ONCE,
-// token-major; contractions over the token axis read it through the LDS transpose read (RowFrag, win_attn.cuh), which
+// token-major; contractions over the token axis read it through the LDS transpose read (RowFrag, win_attn.hip.h), which
 // keeps the per-wave footprint at 6 tiles (was 11 + transposed weight copies) so that 4 waves fit a CU instead of 2;
 // O and dU never touch LDS: they are formed in both register orientations by swapping MFMA operands.
 // Softmax / dS tiles stay in registers and are computed in both orientations instead of being transposed through LDS.
 // Weight gradients are accumulated in LDS per workgroup and flushed once.
 #include <type_traits>
-#include "win_attn.cuh"
+#include "win_attn.hip.h"
 using namespace rssf;
 using namespace rssf::wa;
 

@@ -15,7 +15,7 @@
 // tile load: LDS holds only the two gated input tiles and the weights.
 // The kernel is HBM-bound (0.27 GFLOP vs 3.1 MB per image-block); MFMA just keeps the
 // arithmetic out of the way.
-#include "win_attn.cuh"
+#include "win_attn.hip.h"
 using namespace rssf;
 using namespace rssf::wa;
 

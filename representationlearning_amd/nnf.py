@@ -10,79 +10,153 @@ forward/backward are short sequences of C-ABI launches (no arithmetic in Python)
 [2][C] statistics between two launches.
 """
 import ctypes
+import os
+import threading
 
 import torch
-import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib as L
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 BN_SLOTS, BN_BWD_SLOTS = 16, 8            # RSSF_BN_SLOTS / RSSF_BN_BWD_SLOTS of include/rssf.h
-_SYNC_ALL_BN = False          # set by the trainer: configs/base/loveda.py:107 train.sync_bn
 
 
-_FORCE_COLLECTIVES = False    # issue the SyncBN all-reduces even on a 1-rank group (plumbing tests)
+# ---- per-step scratch: one zero-fill and one weight re-pack per training step ----------------------------------------
+# A training step needs ~700 small zeroed fp32 buffers (BatchNorm statistics, bias-gradient sums) and re-packs the
+# weights of ~330 convolutions twice (forward and data-gradient layouts).  Done per call that is ~1400 tiny launches
+# (4.7 ms of GPU time and as much host time per step on MI355X).  The trainer brackets a step with step_begin():
+#   * ZeroPool: one flat fp32 buffer, zeroed by ONE memset, handed out in 16-byte-aligned slices (sized from the
+#     previous step's demand; a request that does not fit falls back to torch.zeros),
+#   * PackPlan: every (ConvSpec, layout) packed during the first step is recorded; from then on ONE
+#     rssf_conv_pack_batch launch per step refreshes all of them (parameters live in the trainer's flat buffer, so
+#     their addresses are stable) and _pack() returns views of the plan's buffer.
+class ZeroPool:
+    def __init__(self):
+        self.buf, self.off, self.need, self.last_need, self.active = None, 0, 0, 0, False
+
+    def begin(self, device):
+        if self.last_need and (self.buf is None or self.buf.numel() < self.last_need or self.buf.device != device):
+            self.buf = torch.zeros(self.last_need, device=device, dtype=torch.float32)
+        elif self.buf is not None and self.off:
+            self.buf[:self.off].zero_()                   # only what the previous step handed out
+        self.off, self.need, self.active = 0, 0, True
+
+    def end(self):
+        self.last_need = max(self.last_need, self.need)
+        self.active = False
+
+    def zeros(self, n, device):
+        n4 = (n + 3) // 4 * 4
+        self.need += n4
+        if not self.active or self.buf is None or self.off + n4 > self.buf.numel() or self.buf.device != device:
+            return torch.zeros(n, device=device, dtype=torch.float32)
+        out = self.buf[self.off:self.off + n]
+        self.off += n4
+        return out
+
+
+class Runtime:
+    """Everything a step of the path needs besides the model: the data-parallel communicator and SyncBN policy, where
+    parameter gradients go, the per-step scratch pools, stream policy.  One per Trainer (two trainers in one process do not
+    share state); `current()` is the active one of the calling thread, the module-level default otherwise.  Autograd nodes
+    capture the runtime in forward and use THAT in backward (backward runs on the autograd engine's own thread)."""
+
+    def __init__(self):
+        self.comm = None                 # rccl.Communicator / rccl.TorchComm used for the SyncBN exchanges
+        self.sync_all_bn = False         # configs/base/loveda.py:107 train.sync_bn (MlpDWBN's nn.SyncBatchNorm always sync)
+        self.force_collectives = False   # issue the exchanges even on a 1-rank group (plumbing tests)
+        # direct gradient accumulation: with the trainer's flat gradient buffer every parameter already owns a zeroed fp32
+        # `.grad` view, and every librssf backward kernel ACCUMULATES (+=) its parameter gradients.  So the kernels write
+        # straight into `.grad` (no per-tensor zero-fill, no AccumulateGrad add: ~2 k tiny launches per step) and the autograd
+        # node returns None for them; the trainer's bucket hook is invoked by hand instead.
+        self.direct = False
+        self.param_ready = None
+        # HRNet branches of a HighResolutionModule on side streams (parallel branches of a captured hipGraph); off in
+        # data-parallel runs, where the branches' SyncBN exchanges must reach the communicator in one fixed order
+        self.branch_streams = False
+        self.side_streams = {}
+        self.zero_pool = ZeroPool()
+        self.pack_plan = None
+        # fixed-order reductions for the BatchNorm statistics (bit-identical runs): RSSF_DETERMINISTIC=1 or set by the caller
+        self.deterministic = os.environ.get("RSSF_DETERMINISTIC", "0") == "1"
+
+    @property
+    def world(self):
+        return self.comm.world if self.comm is not None else 1
+
+    def exchanging(self):
+        return self.comm is not None and (self.comm.world > 1 or self.force_collectives)
+
+
+_DEFAULT = Runtime()
+_TLS = threading.local()
+
+
+def current():
+    return getattr(_TLS, "rt", None) or _DEFAULT
+
+
+class use:
+    """`with nnf.use(rt):` - make rt the calling thread's runtime."""
+
+    def __init__(self, rt):
+        self.rt = rt
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "rt", None)
+        _TLS.rt = self.rt
+        return self.rt
+
+    def __exit__(self, *exc):
+        _TLS.rt = self.prev
+        return False
 
 
 def set_sync_bn(flag, force=False):
-    global _SYNC_ALL_BN, _FORCE_COLLECTIVES
-    _SYNC_ALL_BN, _FORCE_COLLECTIVES = bool(flag), bool(force)
-
-
-# ---- direct gradient accumulation ---------------------------------------------------------------------------------
-# With the trainer's flat gradient buffer every parameter already owns a zeroed fp32 `.grad` view, and every librssf
-# backward kernel ACCUMULATES (+=) its parameter gradients.  So the kernels write straight into `.grad` (no per-tensor
-# zero-fill, no AccumulateGrad add: ~2 k tiny launches per step) and the autograd node returns None for them; the
-# trainer's bucket hook is invoked by hand instead.
-_DIRECT = False
-_PARAM_READY = None
+    rt = current()
+    rt.sync_all_bn, rt.force_collectives = bool(flag), bool(force)
 
 
 def set_direct_grad(flag, on_ready=None):
-    global _DIRECT, _PARAM_READY
-    _DIRECT, _PARAM_READY = bool(flag), on_ready
+    rt = current()
+    rt.direct, rt.param_ready = bool(flag), on_ready
 
 
-def grad_target(p):
+def set_branch_streams(flag):
+    current().branch_streams = bool(flag)
+
+
+def grad_target(p, rt=None):
     """(buffer the kernels accumulate into, True if that buffer IS p.grad)."""
-    if _DIRECT and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous():
+    rt = rt or current()
+    if rt.direct and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous():
         return p.grad, True
     return torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format), False
 
 
-def grad_result(p, buf, direct):
+def grad_result(p, buf, direct, rt=None):
     """What the autograd node returns for parameter p."""
     if direct:
-        if _PARAM_READY is not None:
-            _PARAM_READY(p)
+        rt = rt or current()
+        if rt.param_ready is not None:
+            rt.param_ready(p)
         return None
     return buf
 
 
-# ---- branch-level concurrency ---------------------------------------------------------------------------------------
-# The HRNet branches of a HighResolutionModule are independent chains of small kernels (a 32x32 or 16x16 map fills a fraction
-# of the 256 CUs and is latency-bound).  With this switch on, the mirror module runs them on side streams; autograd replays
-# the backward of every node on its forward stream, and a captured hipGraph keeps the fork/join as parallel graph branches.
-# Off in data-parallel runs: one RCCL communicator must not be driven from several streams at once.
-_BRANCH_STREAMS = False
-_SIDE_STREAMS = {}
-
-
-def set_branch_streams(flag):
-    global _BRANCH_STREAMS
-    _BRANCH_STREAMS = bool(flag)
-
-
 def parallel_map(fns, args):
     """[f(a) for f, a in zip(fns, args)], items 1.. on side streams when branch streams are enabled (item 0 stays on the
-    current stream); joined before returning."""
+    current stream); joined before returning.  A small (32x32 or 16x16) map fills a fraction of the 256 CUs and its chain of
+    kernels is latency-bound; autograd replays the backward of every node on its forward stream, and a captured hipGraph keeps
+    the fork/join as parallel graph branches."""
     n = len(fns)
-    if not (_BRANCH_STREAMS and n > 1 and args[0].is_cuda):
+    rt = current()
+    if not (rt.branch_streams and n > 1 and args[0].is_cuda):
         return [f(a) for f, a in zip(fns, args)]
     dev = args[0].device
     cur = torch.cuda.current_stream(dev)
-    pool = _SIDE_STREAMS.setdefault(dev, [])
+    pool = rt.side_streams.setdefault(dev, [])
     while len(pool) < n - 1:
         pool.append(torch.cuda.Stream(dev))
     outs = [None] * n
@@ -97,21 +171,6 @@ def parallel_map(fns, args):
         cur.wait_stream(pool[i - 1])
         outs[i].record_stream(cur)
     return outs
-
-
-def _all_reduce(t):
-    """Sum over the data-parallel ranks: direct RCCL on the compute stream when the trainer set a communicator up
-    (graph-capturable, ~5 us of host time), else torch.distributed."""
-    from . import rccl
-    comm = rccl.get()
-    if comm is not None:
-        comm.all_reduce_(t)
-    else:
-        dist.all_reduce(t)
-
-
-def _world():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def _ia(vals):
@@ -186,40 +245,6 @@ def _nchw(t):
     return t.permute(0, 3, 1, 2)
 
 
-# ---- per-step scratch: one zero-fill and one weight re-pack per training step ----------------------------------------
-# A training step needs ~700 small zeroed fp32 buffers (BatchNorm statistics, bias-gradient sums) and re-packs the
-# weights of ~330 convolutions twice (forward and data-gradient layouts).  Done per call that is ~1400 tiny launches
-# (4.7 ms of GPU time and as much host time per step on MI355X).  The trainer brackets a step with step_begin():
-#   * ZeroPool: one flat fp32 buffer, zeroed by ONE memset, handed out in 16-byte-aligned slices (sized from the
-#     previous step's demand; a request that does not fit falls back to torch.zeros),
-#   * PackPlan: every (ConvSpec, layout) packed during the first step is recorded; from then on ONE
-#     rssf_conv_pack_batch launch per step refreshes all of them (parameters live in the trainer's flat buffer, so
-#     their addresses are stable) and _pack() returns views of the plan's buffer.
-class ZeroPool:
-    def __init__(self):
-        self.buf, self.off, self.need, self.last_need, self.active = None, 0, 0, 0, False
-
-    def begin(self, device):
-        if self.last_need and (self.buf is None or self.buf.numel() < self.last_need or self.buf.device != device):
-            self.buf = torch.zeros(self.last_need, device=device, dtype=torch.float32)
-        elif self.buf is not None and self.off:
-            self.buf[:self.off].zero_()                   # only what the previous step handed out
-        self.off, self.need, self.active = 0, 0, True
-
-    def end(self):
-        self.last_need = max(self.last_need, self.need)
-        self.active = False
-
-    def zeros(self, n, device):
-        n4 = (n + 3) // 4 * 4
-        self.need += n4
-        if not self.active or self.buf is None or self.off + n4 > self.buf.numel() or self.buf.device != device:
-            return torch.zeros(n, device=device, dtype=torch.float32)
-        out = self.buf[self.off:self.off + n]
-        self.off += n4
-        return out
-
-
 class PackPlan:
     def __init__(self):
         self.jobs, self.views, self.fresh, self.built = {}, {}, False, False
@@ -288,15 +313,11 @@ class PackPlan:
         return self.views.get(key) if (self.built and self.fresh) else None
 
 
-_ZERO_POOL = ZeroPool()
-_PACK_PLAN = None
-
-
-def step_begin(device, plan=None):
+def step_begin(device, plan=None, rt=None):
     """Trainer hook: start of a training step (zero pool reset + batched weight packing)."""
-    global _PACK_PLAN
-    _ZERO_POOL.begin(device)
-    _PACK_PLAN = plan
+    rt = rt or current()
+    rt.zero_pool.begin(device)
+    rt.pack_plan = plan
     if plan is not None:
         if plan.built:
             plan.refresh()
@@ -304,30 +325,31 @@ def step_begin(device, plan=None):
             plan.recording = True
 
 
-def step_end():
+def step_end(rt=None):
     """Trainer hook: end of a training step (the parameters are about to change / have changed)."""
-    global _PACK_PLAN
-    _ZERO_POOL.end()
-    if _PACK_PLAN is not None:
-        plan = _PACK_PLAN
+    rt = rt or current()
+    rt.zero_pool.end()
+    if rt.pack_plan is not None:
+        plan = rt.pack_plan
         if plan.recording and not plan.built:
             plan.recording = False
             plan.build()
         plan.fresh = False
-    _PACK_PLAN = None
+    rt.pack_plan = None
 
 
-def _zeros(n, device):
-    return _ZERO_POOL.zeros(n, device)
+def _zeros(n, device, rt=None):
+    return (rt or current()).zero_pool.zeros(n, device)
 
 
-def _pack(spec, weights, transpose, dtype, device):
+def _pack(spec, weights, transpose, dtype, device, rt=None):
     key = (id(spec), bool(transpose), dtype)
-    if _PACK_PLAN is not None:
-        v = _PACK_PLAN.lookup(key)
+    plan = (rt or current()).pack_plan
+    if plan is not None:
+        v = plan.lookup(key)
         if v is not None:
             return v
-        _PACK_PLAN.record(key, spec, weights, transpose, dtype)
+        plan.record(key, spec, weights, transpose, dtype)
     lib = L.load()
     code = L.RSSF_BF16 if dtype == torch.bfloat16 else L.RSSF_F32
     rows, cols = (spec.cin, spec.cout) if transpose else (spec.cout, spec.cin)
@@ -347,11 +369,11 @@ def _pad_channels(t):
     return t if c % v == 0 else torch.nn.functional.pad(t, (0, v - c % v))
 
 
-def _conv_forward(spec, xh, weights, bias, stats):
+def _conv_forward(spec, xh, weights, bias, stats, rt=None):
     xh = _pad_channels(xh)
     B, H, W, C = xh.shape
     OH, OW = spec.out_hw(H, W)
-    wpk = _pack(spec, weights, False, xh.dtype, xh.device)
+    wpk = _pack(spec, weights, False, xh.dtype, xh.device, rt)
     out = torch.empty(B, OH, OW, spec.cout, device=xh.device, dtype=xh.dtype)
     L.check(L.load().rssf_conv_gather(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), B, H, W, C, OH, OW, spec.cout,
                                       spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
@@ -371,11 +393,11 @@ class GradLink:
         self.value = None
 
 
-def _conv_dgrad(spec, dout, weights, in_shape, addend=None):
+def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None):
     B, H, W, C = in_shape
     dout = _pad_channels(dout)
     _, OH, OW, cout_p = dout.shape
-    wpk = _pack(spec, weights, True, dout.dtype, dout.device)
+    wpk = _pack(spec, weights, True, dout.dtype, dout.device, rt)
     dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype)
     if addend is not None and (addend.shape != dx.shape or addend.dtype != dx.dtype or not addend.is_contiguous()):
         raise RuntimeError("conv dgrad: fused skip gradient has shape/dtype %s %s, expected %s %s"
@@ -421,13 +443,15 @@ class _ConvBNAct(torch.autograd.Function):
             bias = biases[0] if nbias == 1 else torch.stack(biases).sum(0)      # summed convs: biases add
             bias = bias.float().contiguous()
         C = spec.cout
-        stats = _zeros(BN_SLOTS * 2 * C, dev) if training else None
-        raw = _conv_forward(spec, xh, weights, bias, stats)
+        rt = current()
+        stats = _zeros(BN_SLOTS * 2 * C, dev, rt) if training else None
+        raw = _conv_forward(spec, xh, weights, bias, stats, rt)
         rows = raw.numel() // C
         n = float(rows)
-        if training and sync and (_world() > 1 or _FORCE_COLLECTIVES):
-            _all_reduce(stats)
-            n *= _world()
+        exchanged = training and sync and rt.exchanging()
+        if exchanged:                  # SyncBN: pooled {sum, sumsq} and sample count over the data-parallel ranks
+            rt.comm.syncbn_exchange_(stats)
+            n *= rt.world
         mi = torch.empty(2, C, device=dev, dtype=torch.float32)
         ss = torch.empty(2, C, device=dev, dtype=torch.float32)
         lib = L.load()
@@ -441,14 +465,16 @@ class _ConvBNAct(torch.autograd.Function):
                                            L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, n, momentum, eps, int(training), L.dtype_code(raw),
                                            L.stream()), "rssf_bn_finalize_apply")
         ctx.save_for_backward(xh, raw, ss, mi, rp, *weights)
-        ctx.meta = (spec, act, training, n, sync, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
+        ctx.meta = (spec, act, training, n, exchanged, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
+        ctx.rt = rt
         ctx.params = (gamma, beta, weights, biases)
         ctx.links = links                 # (sink, deposit) GradLinks or (None, None)
         return _nchw(y)
 
     @staticmethod
     def backward(ctx, dy):
-        spec, act, training, n, sync, nbias, nw, has_pre, has_post, x_req = ctx.meta
+        spec, act, training, n, exchanged, nbias, nw, has_pre, has_post, x_req = ctx.meta
+        rt = ctx.rt
         xh, raw, ss, mi, rp = ctx.saved_tensors[:5]
         weights = ctx.saved_tensors[5:]
         dyh = _nhwc(dy)
@@ -457,18 +483,22 @@ class _ConvBNAct(torch.autograd.Function):
         C = spec.cout
         rows = raw.numel() // C
         lib = L.load()
-        sums = _zeros(BN_BWD_SLOTS * 2 * C, raw.device)
+        sums = _zeros(BN_BWD_SLOTS * 2 * C, raw.device, rt)
         L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.dtype_code(raw),
                                        L.stream()), "rssf_bn_bwd_reduce")
-        if training and sync and (_world() > 1 or _FORCE_COLLECTIVES):
-            _all_reduce(sums)
+        pscale = 1.0
+        if exchanged:
+            # the input gradient needs the GLOBAL {sum dz, sum dz*raw}; gamma/beta take the data-parallel MEAN of the local
+            # sums (torch SyncBatchNorm + DDP), which is the global total / world
+            rt.comm.syncbn_exchange_(sums)
+            pscale = 1.0 / rt.world
         draw = torch.empty_like(raw)
         dres = torch.empty_like(raw) if has_pre else None
         p_gamma, p_beta, p_weights, p_biases = ctx.params
-        dgamma, dg_direct = grad_target(p_gamma)
-        dbeta, db_direct = grad_target(p_beta)
+        dgamma, dg_direct = grad_target(p_gamma, rt)
+        dbeta, db_direct = grad_target(p_beta, rt)
         L.check(lib.rssf_bn_bwd_apply(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres),
-                                      L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), L.dtype_code(raw), L.stream()),
+                                      L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), pscale, L.dtype_code(raw), L.stream()),
                 "rssf_bn_bwd_apply")
         sink, deposit = ctx.links
         if deposit is not None and dres is not None:
@@ -477,22 +507,22 @@ class _ConvBNAct(torch.autograd.Function):
         if sink is not None:
             addend, sink.value = sink.value, None
         if x_req:
-            dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape, addend))
+            dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape, addend, rt))
         else:
             if addend is not None:
                 raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
             dx = None
-        wt = [grad_target(w) for w in p_weights]
-        db = _zeros(C, raw.device) if nbias else None
+        wt = [grad_target(w, rt) for w in p_weights]
+        db = _zeros(C, raw.device, rt) if nbias else None
         _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db)
-        gws = [grad_result(w, t[0], t[1]) for w, t in zip(p_weights, wt)]
+        gws = [grad_result(w, t[0], t[1], rt) for w, t in zip(p_weights, wt)]
         gbs = []
         for b in p_biases:      # every summed conv's bias sees the same gradient
-            tb, direct = grad_target(b)
+            tb, direct = grad_target(b, rt)
             tb += db
-            gbs.append(grad_result(b, tb, direct))
-        return (dx, None if dres is None else _nchw(dres), dy if has_post else None, grad_result(p_gamma, dgamma, dg_direct),
-                grad_result(p_beta, dbeta, db_direct), None, None, None, None, None, None, None, None, None, None, *gws, *gbs)
+            gbs.append(grad_result(b, tb, direct, rt))
+        return (dx, None if dres is None else _nchw(dres), dy if has_post else None, grad_result(p_gamma, dgamma, dg_direct, rt),
+                grad_result(p_beta, dbeta, db_direct, rt), None, None, None, None, None, None, None, None, None, None, *gws, *gbs)
 
 
 class _ConvBias(torch.autograd.Function):
@@ -500,8 +530,10 @@ class _ConvBias(torch.autograd.Function):
     def forward(ctx, x, spec, weight, bias):
         L.require_gpu(x)
         xh = _nhwc(x)
-        out = _conv_forward(spec, xh, [weight], None if bias is None else bias.float().contiguous(), None)
+        rt = current()
+        out = _conv_forward(spec, xh, [weight], None if bias is None else bias.float().contiguous(), None, rt)
         ctx.save_for_backward(xh, weight)
+        ctx.rt = rt
         ctx.meta = (spec, bias is not None, x.requires_grad)
         ctx.params = (weight, bias)
         return _nchw(out)
@@ -513,12 +545,13 @@ class _ConvBias(torch.autograd.Function):
         dyh = _nhwc(dy)
         if dyh.dtype != xh.dtype:
             dyh = dyh.to(xh.dtype)
-        dx = _nchw(_conv_dgrad(spec, dyh, [weight], xh.shape)) if x_req else None
+        rt = ctx.rt
+        dx = _nchw(_conv_dgrad(spec, dyh, [weight], xh.shape, None, rt)) if x_req else None
         p_w, p_b = ctx.params
-        tw, wd = grad_target(p_w)
-        tb, bd = grad_target(p_b) if has_bias else (None, False)
+        tw, wd = grad_target(p_w, rt)
+        tb, bd = grad_target(p_b, rt) if has_bias else (None, False)
         _conv_wgrad(spec, dyh, xh, [tw], tb)
-        return dx, None, grad_result(p_w, tw, wd), (grad_result(p_b, tb, bd) if has_bias else None)
+        return dx, None, grad_result(p_w, tw, wd, rt), (grad_result(p_b, tb, bd, rt) if has_bias else None)
 
 
 class _Bilinear(torch.autograd.Function):
@@ -634,7 +667,7 @@ class _CGFLLoss(torch.autograd.Function):
         if labels.dtype != torch.int64 or labels.shape != (B, H, W):
             raise RuntimeError("cgfl_loss: labels must be int64 [B,H,W]")
         auxf = aux.detach().float().contiguous()
-        acc = torch.empty(B, 5, device=lh.device, dtype=torch.float32)
+        acc = torch.empty(B, 6, device=lh.device, dtype=torch.float32)
         out = torch.empty(2, device=lh.device, dtype=torch.float32)
         L.check(L.load().rssf_cgfl_loss_fwd(L.ptr(lh), L.ptr(labels), L.ptr(auxf), L.ptr(acc), L.ptr(out), B, H * W, K, auxf.shape[1],
                                             ignore_index, L.dtype_code(lh), L.stream()), "rssf_cgfl_loss_fwd")
@@ -664,7 +697,7 @@ def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_si
     convs = convs if isinstance(convs, (list, tuple)) else [convs]
     spec = spec_of(convs)
     training = bn.training or not bn.track_running_stats
-    sync = isinstance(bn, nn.SyncBatchNorm) or _SYNC_ALL_BN
+    sync = isinstance(bn, nn.SyncBatchNorm) or current().sync_all_bn
     if training and bn.track_running_stats:
         bn._rssf_steps = getattr(bn, "_rssf_steps", 0) + 1      # num_batches_tracked, flushed by flush_bn_counters()
     weights = [c.weight for c in convs]

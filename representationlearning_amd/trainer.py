@@ -2,18 +2,16 @@
 train.py:79 + configs/base/loveda.py:68-113 of the reference): bf16 compute with fp32 master weights, sum of
 `*loss` entries, gradient all-reduce over RCCL overlapped with backward, global-norm clip (35) + SGD(0.9, wd 1e-4)
 with poly LR.  Trainer internals of `ever` are un-vendored => "parity unpinned" (SURVEY.md §8c); the semantics
-implemented here are torch.optim.SGD / clip_grad_norm_ / DDP-mean-of-shard-gradients.
+implemented here are torch.optim.SGD / clip_grad_norm_ / DDP-mean-of-shard-gradients / nn.SyncBatchNorm.
 
 MI355X-first layout: all parameters live in ONE flat fp32 buffer (and one flat gradient buffer + one momentum
 buffer), so gradient exchange is a handful of large flat buckets (xGMI is per-link bound: few big collectives),
 the clip norm is one reduction and the optimizer is one fused HIP launch (csrc/optim.hip).
 """
-import math
 import os
 
 import torch
 import torch.distributed as dist
-import torch.nn as nn
 
 from . import nnf, ops, rccl
 
@@ -45,13 +43,27 @@ class FlatParams:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
 
+    def ranges_of(self, keep):
+        """Merged [start, end) ranges of the flat buffer covered by the parameters whose index is in `keep`."""
+        out = []
+        for i in sorted(keep):
+            s, e = self.offsets[i], self.offsets[i + 1]
+            if out and out[-1][1] == s:
+                out[-1][1] = e
+            else:
+                out.append([s, e])
+        return [tuple(r) for r in out]
+
 
 class GradBuckets:
     """Flat gradient buckets all-reduced (sum) as soon as every parameter in them has its gradient, i.e. in
-    reverse-registration (= roughly reverse-autograd) order on the communicator's own stream."""
+    reverse-registration (= roughly reverse-autograd: head/neck first, stem last) order, overlapped with the rest of backward:
+    * direct RCCL communicator: on a side stream forked from the compute stream at the moment the bucket completes and
+      joined before the clip (inside a captured step these are parallel branches of the hipGraph),
+    * torch.distributed: async_op work handles on the process group's own stream."""
 
-    def __init__(self, flat, nbuckets=6, group=None):
-        self.flat, self.group = flat, group
+    def __init__(self, flat, comm, nbuckets=6):
+        self.flat, self.comm = flat, comm
         n = flat.numel
         target = max(1, n // nbuckets)
         self.bounds = []          # (start, end) over the flat buffer, built from the END (last layers first)
@@ -71,6 +83,7 @@ class GradBuckets:
         self.handles = []
         self.launched = [False] * len(self.members)
         self.index_of = {id(p): i for i, p in enumerate(flat.params)}
+        self.side = torch.cuda.Stream() if comm.direct else None
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -93,7 +106,14 @@ class GradBuckets:
             return
         self.launched[b] = True
         s, e = self.bounds[b]
-        self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        g = self.flat.grad[s:e]
+        if self.comm.direct:
+            # the kernels that produced this bucket's gradients are already enqueued on the current (compute) stream
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.comm.allreduce_bucket_(g)
+        else:
+            self.handles.append(self.comm.allreduce_bucket_async(g))
 
     def begin(self):
         self.pending = [len(m) for m in self.members]
@@ -106,6 +126,8 @@ class GradBuckets:
             self._launch(b)
         for h in self.handles:
             h.wait()
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
 
 def flush_bn_counters(trainer):
@@ -118,43 +140,87 @@ def poly_lr(base_lr, power, max_iters, it):
     return base_lr * (1.0 - min(it, max_iters - 1) / max_iters) ** power     # configs/base/loveda.py:93-99
 
 
+def reachable_parameters(loss):
+    """ids of the leaf tensors the autograd graph of `loss` reaches - the parameters torch.optim.SGD would see a gradient
+    for (`p.grad is not None`).  RSSFormer's `headaux` is not among them: the loss uses its output under no_grad only
+    (module/CGFL.py:75-97)."""
+    seen, stack, leaves = set(), [loss.grad_fn], set()
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        v = getattr(fn, "variable", None)
+        if v is not None:
+            leaves.add(id(v))
+        stack.extend(f for f, _ in fn.next_functions)
+    return leaves
+
+
 class Trainer:
     def __init__(self, model, base_lr=0.01, momentum=0.9, weight_decay=1e-4, max_norm=35.0, power=0.9, max_iters=30000,
-                 bf16=True, sync_bn=True, nbuckets=6, use_graph=True):
+                 bf16=True, sync_bn=True, nbuckets=6, use_graph=True, deterministic=None):
         self._replayed = 0
         self._replayed_flushed = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        # RSSF_FORCE_DP=1 exercises the collective plumbing (buckets, SyncBN all-reduces) even on one rank (tests)
+        # RSSF_FORCE_DP=1 exercises the collective plumbing (buckets, SyncBN exchanges) even on one rank (tests)
         dp = self.world > 1 or (dist.is_initialized() and os.environ.get("RSSF_FORCE_DP") == "1")
         self.model = model
         self.flat = FlatParams(model)
-        # Data path of DP: a direct RCCL communicator when possible (collectives on the compute stream, so the whole step
-        # can still be one hipGraph; the 128 MB flat gradient is ONE all-reduce after backward, ~1 ms over xGMI), else
-        # torch.distributed with bucketed, hook-driven all-reduces overlapped with backward.
-        self.comm = rccl.init() if dp else None
-        self.buckets = GradBuckets(self.flat, nbuckets) if (dp and self.comm is None) else None
-        nnf.set_sync_bn(sync_bn and dp, force=dp and self.world == 1)
-        nnf.set_direct_grad(True, self.buckets.param_ready if self.buckets is not None else None)
+        self.rt = nnf.Runtime()
+        if deterministic is not None:
+            self.rt.deterministic = bool(deterministic)
+        # Data path of DP: direct RCCL communicators when possible (collectives enqueued like kernels, so the whole step can
+        # still be one hipGraph): one for the SyncBN exchanges on the compute stream, one for the gradient buckets on a side
+        # stream.  Else torch.distributed (eager launches; buckets as async work on the process group's stream).
+        self.comm = self.grad_comm = None
+        if dp:
+            comms = rccl.create(2)
+            self.comm, self.grad_comm = comms if comms is not None else (rccl.TorchComm(), rccl.TorchComm())
+            self._broadcast_initial_state()
+        overlap = os.environ.get("RSSF_GRAD_OVERLAP", "1") != "0"
+        self.buckets = GradBuckets(self.flat, self.grad_comm, nbuckets) if (dp and overlap) else None
+        self.rt.comm = self.comm
+        self.rt.sync_all_bn = bool(sync_bn and dp)
+        self.rt.force_collectives = dp and self.world == 1
+        self.rt.direct, self.rt.param_ready = True, (self.buckets.param_ready if self.buckets is not None else None)
         self.hp = dict(base_lr=base_lr, momentum=momentum, wd=weight_decay, max_norm=max_norm, power=power, max_iters=max_iters)
         self.bf16 = bf16
         self.it = 0
         dev = self.flat.flat.device
         self.sqnorm = torch.zeros(1, device=dev, dtype=torch.float32)
         self.lr_dev = torch.zeros(1, device=dev, dtype=torch.float32)
+        # torch.optim.SGD skips parameters whose gradient is None (no weight decay, no momentum): the flat update covers only
+        # the ranges of parameters the loss reaches, found from the autograd graph of the first step
+        self.sgd_ranges = None
         # Whole-step hipGraph: the step is ~3 k short launches and the Python/launch overhead (~65 ms) exceeds the GPU
-        # time, so after `graph_warmup` eager steps the step (fwd + loss + bwd + clip + SGD) is captured once and
-        # replayed.  In DP this needs the direct RCCL communicator (collectives issued through torch.distributed cannot be
+        # time, so after `graph_warmup` eager steps the step (fwd + loss + bwd + exchange + clip + SGD) is captured once and
+        # replayed.  In DP this needs the direct RCCL communicators (collectives issued through torch.distributed cannot be
         # captured: its watchdog thread polls their events).  RSSF_GRAPH=1 forces graphs, RSSF_GRAPH=0 disables them.
         env = os.environ.get("RSSF_GRAPH")
-        self.use_graph = (env == "1") or (env != "0" and use_graph and (not dp or self.comm is not None))
+        self.use_graph = (env == "1") or (env != "0" and use_graph and (not dp or self.comm.direct))
         self.graph_warmup = 3
         # HRNet branches on side streams: parallel branches of the captured graph (+1 % at B=16); eager launches are host-bound
-        # and DP drives one RCCL communicator, so both keep a single stream
-        nnf.set_branch_streams(self.use_graph and not dp and os.environ.get("RSSF_BRANCH_STREAMS", "1") != "0")
+        # and the SyncBN exchanges of a DP step must reach the communicator in one fixed order, so both keep a single stream
+        self.rt.branch_streams = self.use_graph and not dp and os.environ.get("RSSF_BRANCH_STREAMS", "1") != "0"
         self.pack_plan = nnf.PackPlan() if os.environ.get("RSSF_PACK_PLAN", "1") != "0" else None
         self.graph = None
         self._static = None
         self._side = None
+
+    def _broadcast_initial_state(self):
+        """What DistributedDataParallel does at construction: rank 0's parameters and buffers everywhere."""
+        if self.world == 1:
+            return
+        dist.broadcast(self.flat.flat, src=0)
+        bufs = [b for b in self.model.buffers() if b.is_floating_point()]
+        if bufs:
+            packed = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+            dist.broadcast(packed, src=0)
+            o = 0
+            for b in bufs:
+                b.copy_(packed[o:o + b.numel()].view_as(b))
+                o += b.numel()
 
     def _eager_step(self, img, target):
         if not self.model.training:          # Module.train() walks all 1 300 sub-modules: not once per step
@@ -162,29 +228,37 @@ class Trainer:
         self.flat.zero_grad()
         if self.buckets is not None:
             self.buckets.begin()
-        # one zero-fill and one weight re-pack for the whole step (nnf.ZeroPool / nnf.PackPlan)
-        nnf.step_begin(self.flat.flat.device, self.pack_plan)
-        try:
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
-                out = self.model(img, target)
-            loss = sum(v for k, v in out.items() if k.endswith("loss"))
-            loss.backward()
-        finally:
-            nnf.step_end()
+        with nnf.use(self.rt):
+            # one zero-fill and one weight re-pack for the whole step (nnf.ZeroPool / nnf.PackPlan)
+            nnf.step_begin(self.flat.flat.device, self.pack_plan)
+            try:
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
+                    out = self.model(img, target)
+                loss = sum(v for k, v in out.items() if k.endswith("loss"))
+                if self.sgd_ranges is None:
+                    live = reachable_parameters(loss)
+                    self.sgd_ranges = self.flat.ranges_of([i for i, p in enumerate(self.flat.params) if id(p) in live])
+                loss.backward()
+            finally:
+                nnf.step_end()
         if self.buckets is not None:
             self.buckets.finish()
-        elif self.comm is not None:
-            self.comm.all_reduce_(self.flat.grad)
+        elif self.grad_comm is not None:
+            self.grad_comm.allreduce_bucket_(self.flat.grad)
         hp = self.hp
-        ops.grad_sqnorm(self.flat.grad, self.sqnorm)
-        ops.sgd_step_(self.flat.flat, self.flat.grad, self.flat.mom, self.sqnorm, 1.0 / self.world, hp["max_norm"], 0.0,
-                      hp["momentum"], hp["wd"], False, lr_dev=self.lr_dev)
+        ops.grad_sqnorm(self.flat.grad, self.sqnorm)       # unreached parameters hold zeros: same norm as clip_grad_norm_
+        for s, e in self.sgd_ranges:
+            ops.sgd_step_(self.flat.flat[s:e], self.flat.grad[s:e], self.flat.mom[s:e], self.sqnorm, 1.0 / self.world, hp["max_norm"],
+                          0.0, hp["momentum"], hp["wd"], False, lr_dev=self.lr_dev)
         return loss.detach()
 
     def _capture(self, img, target):
         self._static = (img.clone(), {k: v.clone() for k, v in target.items()})
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        # Python runs the step once while capturing (no kernel executes): undo its num_batches_tracked bookkeeping, the
+        # replay that follows is what counts
+        counters = [(m, m._rssf_steps) for m in self.model.modules() if hasattr(m, "_rssf_steps")]
         try:
             # thread_local: the NCCL watchdog thread keeps polling events of earlier collectives, which a global-mode
             # capture forbids ("operation not permitted when stream is capturing")
@@ -195,8 +269,16 @@ class Trainer:
             self.use_graph = False
             torch.cuda.synchronize()
             return False
+        finally:
+            for m, k in counters:
+                m._rssf_steps = k
         self.graph = g
         return True
+
+    def _fits_static(self, img, target):
+        s_img, s_tgt = self._static
+        return (img.shape == s_img.shape and img.dtype == s_img.dtype and set(target) == set(s_tgt)
+                and all(v.shape == s_tgt[k].shape and v.dtype == s_tgt[k].dtype for k, v in target.items()))
 
     def step(self, img, target):
         """One optimisation step; returns the (detached, on-device) loss."""
@@ -205,6 +287,8 @@ class Trainer:
         if self.use_graph and self.it >= self.graph_warmup:
             if self.graph is None and not self._capture(img, target):
                 loss = self._eager_step(img, target)
+            elif not self._fits_static(img, target):
+                loss = self._eager_step(img, target)       # e.g. a last partial batch: the captured step has fixed shapes
             else:
                 s_img, s_tgt = self._static
                 if img.data_ptr() != s_img.data_ptr():
@@ -214,7 +298,7 @@ class Trainer:
                         s_tgt[k].copy_(v)
                 self.graph.replay()
                 self._replayed += 1
-                loss = self._static_loss
+                loss = self._static_loss.clone()           # the static tensor is overwritten by the next replay
         elif self.use_graph:
             # warm-up steps run on a side stream, as hipGraph capture requires (the autograd threads and lazily
             # initialised library state must have seen a non-default stream before the capture starts)
@@ -229,6 +313,12 @@ class Trainer:
         self.it += 1
         return loss
 
+    def close(self):
+        """Destroy the RCCL communicators (before torch.distributed's process group goes away)."""
+        for c in {id(c): c for c in (self.comm, self.grad_comm) if c is not None}.values():
+            c.destroy()
+        self.comm = self.grad_comm = self.rt.comm = None
+
 
 def init_distributed():
     """One process per GPU; rendezvous from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
@@ -242,3 +332,10 @@ def init_distributed():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
     return rank, local, world
+
+
+def shutdown_distributed(trainer=None):
+    if trainer is not None:
+        trainer.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -1,5 +1,4 @@
 import os
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # fresh boxes have no MIOpen find-db: skip the exhaustive per-shape search
 import sys
 
 import pytest

@@ -35,9 +35,10 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from representationlearning_amd.trainer import FlatParams, GradBuckets
+    from representationlearning_amd.rccl import TorchComm
     net = Net()
     flat = FlatParams(net)
-    buckets = GradBuckets(flat, nbuckets=3)
+    buckets = GradBuckets(flat, TorchComm(), nbuckets=3)
     assert len(buckets.bounds) >= 2 and buckets.bounds[0][1] == flat.numel and buckets.bounds[-1][0] == 0
     torch.manual_seed(100 + rank)
     x = torch.randn(5, 8)

@@ -64,7 +64,6 @@ def test_dp_plumbing_on_one_rank_matches_plain_path(backend):
     fp32 atomics order), so the comparison is made on one step's loss and on the all-reduced flat gradient with the
     learning rate at 0."""
     from representationlearning_amd.trainer import Trainer
-    from representationlearning_amd import nnf, rccl
     from tests.helpers import rel_err
     t0 = Trainer(_mk(1), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=False)
     plain = _run(t0, steps=2)
@@ -77,6 +76,7 @@ def test_dp_plumbing_on_one_rank_matches_plain_path(backend):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RSSF_FORCE_DP="1", RSSF_DP_BACKEND=backend.split("+")[0],
                       RSSF_GRAPH="1" if graph else "0")
     dist.init_process_group("nccl", rank=0, world_size=1)
+    tr = None
     try:
         tr = Trainer(_mk(1), bf16=False, sync_bn=True, base_lr=0.0, weight_decay=0.0)
         if backend == "torch":
@@ -90,12 +90,11 @@ def test_dp_plumbing_on_one_rank_matches_plain_path(backend):
             assert tr.graph is not None and tr._replayed >= 2
         g_dp = tr.flat.grad.clone()
     finally:
-        rccl.shutdown()
+        if tr is not None:
+            tr.close()
         dist.destroy_process_group()
         for k in ("RSSF_FORCE_DP", "RSSF_DP_BACKEND", "RSSF_GRAPH"):
             os.environ.pop(k)
-        nnf.set_sync_bn(False)
-        nnf.set_direct_grad(False)
     assert max(abs(a - plain[0]) for a in dp) < 1e-5 * abs(plain[0]), (plain, dp)
     assert abs(plain[0] - plain[1]) < 1e-5 * abs(plain[0])          # lr = 0: the step is a fixed point
     assert rel_err(g_dp.cpu(), g_plain.cpu()) < 3 * self_dist + 1e-4, (rel_err(g_dp.cpu(), g_plain.cpu()), self_dist)

@@ -24,6 +24,5 @@ for i in range(12):
 torch.cuda.synchronize()
 print("ms/step %.1f" % ((time.perf_counter() - t0) / 6 * 1e3), "graph captured:", tr.graph is not None)
 print("losses", [round(l, 4) for l in losses])
-from representationlearning_amd import rccl
-rccl.shutdown()
+tr.close()
 dist.destroy_process_group()

@@ -62,7 +62,7 @@ def main():
     from representationlearning_amd.configs import config_by_name, synthetic_batch
     from representationlearning_amd.core import registry
     from representationlearning_amd.core.config import AttrDict, apply_overrides
-    from representationlearning_amd.trainer import Trainer, init_distributed
+    from representationlearning_amd.trainer import Trainer, init_distributed, shutdown_distributed
     _lib.load()
     rank, local, world = init_distributed()
     seed_torch(2333)
@@ -87,6 +87,7 @@ def main():
         torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)   # reference-compatible keys
         print("saved", path)
         evaluate_cls_fn(model, [(img, lab)], cfg.model.params.classes)
+    shutdown_distributed(trainer)
 
 
 if __name__ == "__main__":
