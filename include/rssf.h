@@ -149,9 +149,14 @@ int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bi
                      void* stream);
 /* the same with `addend` [B][OH][OW][Cout] (optional) added to the result in the epilogue: the data-gradient launch of a
  * residual block folds the skip-path gradient in instead of leaving a separate elementwise add to autograd */
-int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, int B,
-                         int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy,
-                         const int* dx, int dtype, void* stream);
+/* stats_ws (optional, needs `stats`): DETERMINISTIC statistics (the reference trains with cuDNN off for the same
+ * reason, train.py:71-73) - instead of slotted atomics every pixel tile stores its partial {sum, sumsq} into
+ * stats_ws[tile][2][Cout] and a second launch adds the tiles in a fixed order into slot 0 of `stats` (which the caller zeroed):
+ * two runs are bit-identical.  Size it with rssf_conv_stats_workspace_elems(). */
+int64_t rssf_conv_stats_workspace_elems(int B, int OH, int OW, int Cout);
+int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend,
+                         float* stats_ws, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
+                         const int* dy, const int* dx, int dtype, void* stream);
 /* weight gradient, accumulated (+=) into the torch-layout fp32 gradients of the source convs; dbias optional (+=).
  * workspace: fp32 scratch of rssf_conv_wgrad_workspace_elems() elements for the split-K partials (two-stage
  * reduction); NULL selects the slower atomic path. */
@@ -178,8 +183,11 @@ int rssf_bn_finalize_apply(const void* raw, const float* stats, const float* gam
                            void* stream);
 /* sums [RSSF_BN_BWD_SLOTS][2][C] fp32, zeroed by the caller: slot (block mod slots) += { sum dz, sum dz*raw },
  * dz = dy * act'(raw*scale + shift + res_pre).  rssf_bn_bwd_apply sums the slots (all-reduce the whole buffer for SyncBN) */
+/* det_ws (optional): deterministic mode - per-block partials [blocks][2][C] (rssf_bn_bwd_reduce_workspace_elems() floats),
+ * added in block order into slot 0 of `sums` by a second launch; NULL: slotted atomics */
+int64_t rssf_bn_bwd_reduce_workspace_elems(int64_t rows, int C);
 int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, float* sums,
-                       int64_t rows, int C, int act, int dtype, void* stream);
+                       int64_t rows, int C, int act, float* det_ws, int dtype, void* stream);
 /* draw = d(loss)/d(raw); dres (optional) = dz = gradient of res_pre; dgamma/dbeta (optional) accumulated:
  * dgamma += param_grad_scale * sum(dz*xhat), dbeta += param_grad_scale * sum(dz).  param_grad_scale is 1, or 1/world when
  * `sums` were all-reduced for SyncBN: the data-parallel mean of the LOCAL parameter gradients (torch SyncBatchNorm + DDP
@@ -225,8 +233,9 @@ int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B,
 /* acc: fp32 scratch [B][6] (zeroed inside); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);
  * out[0] = loss, out[1] = backward coefficient (detached modulating bracket / n_valid).  A label outside [0, K) that is not
  * ignore_index (F.cross_entropy asserts on it) makes both NaN: the failure is loud, no out-of-range read happens. */
+/* deterministic != 0: one block per sample instead of up to 128 (no cross-block float atomics): bit-identical loss */
 int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* aux, float* acc, float* out, int B, int HW, int K,
-                       int KA, int ignore_index, int dtype, void* stream);
+                       int KA, int ignore_index, int deterministic, int dtype, void* stream);
 /* dlogits = dloss * out[1] * (softmax(logits) - onehot(label)) on valid pixels, 0 on ignored ones; dloss may be NULL (=1) */
 int rssf_cgfl_loss_bwd(const void* logits, const int64_t* labels, const float* out, const float* dloss, void* dlogits, int B, int HW,
                        int K, int ignore_index, int dtype, void* stream);

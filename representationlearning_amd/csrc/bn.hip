@@ -12,6 +12,9 @@
 #include "common.hip.h"
 using namespace rssf;
 
+// fixed-order second level of the deterministic statistics (conv_fwd.hip)
+namespace rssf { namespace cv { int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st); } }
+
 namespace {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
@@ -191,13 +194,18 @@ __global__ void __launch_bounds__(256) bn_finapply_kernel(const T* __restrict__ 
 }
 
 // s[0][c] += sum dz ; s[1][c] += sum dz*raw ; thread owns a fixed vector column and strides over rows.
-template <typename T, int VEC>
+// DET (deterministic mode): no shuffle/atomic folding - every thread parks its partials in LDS ([row group][2][channels of
+// this column block]), they are summed in row-group order and the block's totals go to det_ws[block][2][C] with plain stores;
+// cv::stats_fold_kernel then adds the blocks in order into slot 0 of `sums`.
+template <typename T, int VEC, bool DET>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
                                                             const T* __restrict__ res_pre, float* __restrict__ sums, int64_t rows, int C,
-                                                            int act) {
-  extern __shared__ float sacc[];                         // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sacc[i] = 0.f;
-  __syncthreads();
+                                                            int act, float* __restrict__ det_ws) {
+  extern __shared__ float sacc[];                         // [2][C]  (DET: [256 / cols][2][cols * VEC])
+  if constexpr (!DET) {
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sacc[i] = 0.f;
+    __syncthreads();
+  }
   const int allcols = C / VEC;
   const int colbase = blockIdx.y * 256;                   // column blocks of <= 256 vector columns
   const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
@@ -249,6 +257,22 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
         a1[0] += dz; a2[0] += dz * x;
       }
     }
+  }
+  if constexpr (DET) {
+    const int nch = cols * VEC;
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { sacc[(rlocal * 2) * nch + col * VEC + e] = a1[e]; sacc[(rlocal * 2 + 1) * nch + col * VEC + e] = a2[e]; }
+    }
+    __syncthreads();
+    float* part = det_ws + (size_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * nch; i += blockDim.x) {
+      const int half = i / nch, ch = i % nch;
+      float t = 0.f;
+      for (int g = 0; g < rpb; ++g) t += sacc[(g * 2 + half) * nch + ch];
+      part[half * C + colbase * VEC + ch] = t;
+    }
+    return;
   }
   // lanes that share a column inside a wave (cols divides 64) are folded with shuffles before touching LDS
   const bool fold = (64 % cols) == 0;
@@ -401,8 +425,11 @@ int finapply_launch(const void* raw, const float* stats, const float* gamma, con
   return check_launch("bn_finalize_apply");
 }
 
+constexpr int REDUCE_MAX_BLOCKS = 512;
+
 template <typename T>
-int reduce_launch(const void* dy, const void* raw, const float* ss, const void* rp, float* sums, int64_t rows, int C, int act, hipStream_t st) {
+int reduce_launch(const void* dy, const void* raw, const float* ss, const void* rp, float* sums, int64_t rows, int C, int act, float* det_ws,
+                  hipStream_t st) {
   constexpr int V = Vec<T>::N;
   const size_t sh = 2 * C * sizeof(float);
   const int vec = (C % V == 0) ? V : 1;
@@ -410,14 +437,24 @@ int reduce_launch(const void* dy, const void* raw, const float* ss, const void* 
   const int cblocks = (cols + 255) / 256;
   const int rpb = 256 / (cols < 256 ? cols : 256);
   int64_t blocks = (rows + 4 * rpb - 1) / (4 * rpb);      // >= 4 rows per thread; measured best cap on MI355X: 512
-  if (blocks > 512) blocks = 512;        // every block ends with 2C global atomics, spread over RSSF_BN_BWD_SLOTS copies
+  if (blocks > REDUCE_MAX_BLOCKS) blocks = REDUCE_MAX_BLOCKS;        // every block ends with 2C global atomics, spread over RSSF_BN_BWD_SLOTS copies
   dim3 grid((unsigned)blocks, (unsigned)cblocks);
+  if (det_ws) {
+    const size_t shd = (size_t)rpb * 2 * (cols < 256 ? cols : 256) * vec * sizeof(float);
+    if (vec == V)
+      bn_bwd_reduce_kernel<T, V, true><<<grid, 256, shd, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, det_ws);
+    else
+      bn_bwd_reduce_kernel<T, 1, true><<<grid, 256, shd, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, det_ws);
+    const int rc = check_launch("bn_bwd_reduce(det)");
+    return rc ? rc : rssf::cv::launch_stats_fold(det_ws, blocks, C, sums, st);
+  }
   if (vec == V)
-    bn_bwd_reduce_kernel<T, V><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
+    bn_bwd_reduce_kernel<T, V, false><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, nullptr);
   else
-    bn_bwd_reduce_kernel<T, 1><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act);
+    bn_bwd_reduce_kernel<T, 1, false><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, nullptr);
   return check_launch("bn_bwd_reduce");
 }
+
 
 template <typename T>
 int bwd_apply_launch(const void* dy, const void* raw, const float* ss, const float* mi, const float* sums, const void* rp, void* draw,
@@ -474,12 +511,14 @@ extern "C" int rssf_bn_finalize_apply(const void* raw, const float* stats, const
   return RSSF_ERR_UNSUPPORTED;
 }
 
+extern "C" int64_t rssf_bn_bwd_reduce_workspace_elems(int64_t rows, int C) { return (int64_t)REDUCE_MAX_BLOCKS * 2 * C; }
+
 extern "C" int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, float* sums,
-                                  int64_t rows, int C, int act, int dtype, void* stream) {
+                                  int64_t rows, int C, int act, float* det_ws, int dtype, void* stream) {
   RSSF_REQUIRE(dy && raw && scale_shift && sums && rows > 0 && C > 0, "bn_bwd_reduce: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RSSF_F32) return reduce_launch<float>(dy, raw, scale_shift, res_pre, sums, rows, C, act, st);
-  if (dtype == RSSF_BF16) return reduce_launch<bf16_t>(dy, raw, scale_shift, res_pre, sums, rows, C, act, st);
+  if (dtype == RSSF_F32) return reduce_launch<float>(dy, raw, scale_shift, res_pre, sums, rows, C, act, det_ws, st);
+  if (dtype == RSSF_BF16) return reduce_launch<bf16_t>(dy, raw, scale_shift, res_pre, sums, rows, C, act, det_ws, st);
   set_error("bn_bwd_reduce: unsupported dtype %d", dtype);
   return RSSF_ERR_UNSUPPORTED;
 }

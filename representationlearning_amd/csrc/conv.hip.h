@@ -49,6 +49,7 @@ struct HaloArgs {
   bf16_t* out;           // [B, H, W, Cout]
   const float* bias;
   float* stats;          // [RSSF_BN_SLOTS][2][Cout] or null
+  float* stats_ws;       // deterministic mode: per-tile partials [tiles][2][Cout] or null (see ConvArgs in conv_fwd.hip)
   const bf16_t* addend;  // [B, H, W, Cout] added to the output (fused gradient accumulation) or null
   int B, H, W, Cin, Cout, CinP, CoutP;
   int tiles_y, tiles_x, ntiles_n, xcd_per;
@@ -58,6 +59,7 @@ struct HaloArgs {
 
 bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_halo(HaloArgs a, hipStream_t st);
+int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st);
 
 template <typename T> struct LdsPad;
 template <> struct LdsPad<bf16_t> { static constexpr int X = 8; };   // +16 B per row: conflict-free ds_read_b128

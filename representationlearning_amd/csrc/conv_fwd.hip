@@ -24,6 +24,8 @@ struct ConvArgs {
   const float* bias;     // [Cout] or null
   const void* addend;    // [B, OH, OW, Cout] added to the output (fused gradient accumulation) or null
   float* stats;          // [RSSF_BN_SLOTS][2][Cout] sum, sumsq (atomically accumulated, slot = block % slots) or null
+  float* stats_ws;       // deterministic mode: per-pixel-tile partials [tiles_m][2][Cout] (plain stores; folded in tile order by
+                         // stats_fold_kernel into slot 0 of `stats`) or null
   int B, IH, IW, Cin, OH, OW, Cout, CinP, CoutP;
   int ntiles_n, xcd_per;
   int64_t total;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 
   constexpr int OUT_ELEMS = BM * LDC;
   constexpr int LDS_ELEMS = 2 * STAGE_ELEMS > OUT_ELEMS ? 2 * STAGE_ELEMS : OUT_ELEMS;
   __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
-  __shared__ float sstat[2 * BNT];
+  __shared__ float sstat[WM * 2 * BNT];                  // one row of partials per wave row: summed in a fixed order, no LDS atomics
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wave_m = wave % WM, wave_n = wave / WM;
@@ -282,9 +284,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 
   __syncthreads();               // the staging buffers become the output tile
 
   // ---- epilogue -------------------------------------------------------------------------------------------
-  if (a.stats) {
-    for (int i = tid; i < 2 * BNT; i += 256) sstat[i] = 0.f;
-  }
   T* Cs = lds;                                            // [BM][LDC]
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -304,14 +303,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 
     if (a.stats) {
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (grp == 0) { atomicAdd(&sstat[lcol], s1); atomicAdd(&sstat[BNT + lcol], s2); }
+      if (grp == 0) { sstat[wave_m * 2 * BNT + lcol] = s1; sstat[(wave_m * 2 + 1) * BNT + lcol] = s2; }     // one writer per entry
     }
   }
   __syncthreads();
   if (a.stats) {
     float* slot = a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * a.Cout;      // spread the same-address atomics
-    for (int i = tid; i < BNT; i += 256)
-      if (n0 + i < a.Cout) { atomicAdd(slot + n0 + i, sstat[i]); atomicAdd(slot + a.Cout + n0 + i, sstat[BNT + i]); }
+    float* part = a.stats_ws ? a.stats_ws + (size_t)(q / a.ntiles_n) * 2 * a.Cout : nullptr;
+    for (int i = tid; i < BNT; i += 256) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += sstat[w * 2 * BNT + i]; t2 += sstat[(w * 2 + 1) * BNT + i]; }
+      if (n0 + i < a.Cout) {
+        if (part) { part[n0 + i] = t1; part[a.Cout + n0 + i] = t2; }
+        else { atomicAdd(slot + n0 + i, t1); atomicAdd(slot + a.Cout + n0 + i, t2); }
+      }
+    }
   }
   T* OUT = reinterpret_cast<T*>(a.out);
   constexpr int OCPR = BNT / V;                          // 16-byte chunks per output row of the tile
@@ -400,6 +407,36 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const rssf_pack_job* __
 }
 
 int pick_bn(int cout) { return cout <= 32 ? 32 : cout <= 64 ? 64 : 128; }
+}  // namespace
+
+// Deterministic statistics, second level: out[col] = sum over the `tiles` rows of ws[tiles][ncol] in a fixed order (each
+// thread walks its rows in sequence, the 8 row groups are combined in sequence).  ncol = 2*C; out = slot 0 of a zeroed
+// slotted statistics buffer, so the consumers (which sum the slots) are unchanged.
+namespace rssf {
+namespace cv {
+__global__ void __launch_bounds__(256) stats_fold_kernel(const float* __restrict__ ws, int tiles, int ncol, float* __restrict__ out) {
+  __shared__ float part[8][32];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  float acc = 0.f;
+  if (col < ncol)
+    for (int t = rg; t < tiles; t += 8) acc += ws[(size_t)t * ncol + col];
+  part[rg][threadIdx.x & 31] = acc;
+  __syncthreads();
+  if (rg == 0 && col < ncol) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
+    out[col] = t;
+  }
+}
+int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st) {
+  stats_fold_kernel<<<(2 * C + 31) / 32, 256, 0, st>>>(ws, (int)tiles, 2 * C, stats);
+  return check_launch("stats_fold");
+}
+}  // namespace cv
+}  // namespace rssf
+
+namespace {
 
 // Tile choice: the widest tile that still gives the chip >= 2 blocks per CU; small feature maps (32x32, 16x16 at
 // B=16) otherwise run on a quarter of the CUs.
@@ -446,7 +483,9 @@ int launch_conv(ConvArgs a, hipStream_t st) {
   if (bm == 128) { if (bnt == 32) RSSF_CONV(128, 32); else if (bnt == 64) RSSF_CONV(128, 64); else RSSF_CONV(128, 128); }
   else           { if (bnt == 32) RSSF_CONV(64, 32);  else if (bnt == 64) RSSF_CONV(64, 64);  else RSSF_CONV(64, 128); }
 #undef RSSF_CONV
-  return check_launch("conv_gather");
+  const int rc = check_launch("conv_gather");
+  if (rc || !(a.stats && a.stats_ws)) return rc;
+  return launch_stats_fold(a.stats_ws, a.total / a.ntiles_n, a.Cout, a.stats, st);
 }
 
 }  // namespace
@@ -508,11 +547,19 @@ extern "C" int64_t rssf_conv_packed_elems(int ntaps, int rows, int cols, int dty
 extern "C" int rssf_conv_gather(const void* in, const void* wpk, void* out, const float* bias, float* stats, int B, int IH,
                                 int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy,
                                 const int* dx, int dtype, void* stream) {
-  return rssf_conv_gather_add(in, wpk, out, bias, stats, nullptr, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype, stream);
+  return rssf_conv_gather_add(in, wpk, out, bias, stats, nullptr, nullptr, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype,
+                              stream);
+}
+
+// upper bound over every tile shape the launchers may choose: 64-pixel GEMM tiles, 4 x 16-pixel halo tiles
+extern "C" int64_t rssf_conv_stats_workspace_elems(int B, int OH, int OW, int Cout) {
+  const int64_t gemm_tiles = ((int64_t)B * OH * OW + 63) / 64;
+  const int64_t halo_tiles = (int64_t)B * ((OH + 3) / 4) * ((OW + 15) / 16);
+  return (gemm_tiles > halo_tiles ? gemm_tiles : halo_tiles) * 2 * Cout;
 }
 
 extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend,
-                                    int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
+                                    float* stats_ws, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
                                     const int* dy, const int* dx, int dtype, void* stream) {
   RSSF_REQUIRE(in && wpk && out && dy && dx && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 &&
                    ntaps >= 1 && ntaps <= MAX_TAPS && mul >= 1 && div >= 1,
@@ -520,7 +567,7 @@ extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, 
   RSSF_REQUIRE((int64_t)B * IH * IW * Cin < ((int64_t)1 << 30) && (int64_t)B * OH * OW < ((int64_t)1 << 31),
                "conv_gather: input tensors of 2^30 or more elements are not supported (32-bit byte offsets, buffer bounds)");
   ConvArgs a;
-  a.in = in; a.wpk = wpk; a.out = out; a.bias = bias; a.stats = stats; a.addend = addend;
+  a.in = in; a.wpk = wpk; a.out = out; a.bias = bias; a.stats = stats; a.addend = addend; a.stats_ws = stats ? stats_ws : nullptr;
   a.B = B; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout;
   a.mul = mul; a.div = div;
   a.taps.n = ntaps;
@@ -532,7 +579,7 @@ extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RSSF_BF16 && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx)) {
     HaloArgs h;
-    h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats;
+    h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats; h.stats_ws = a.stats_ws;
     h.addend = (const bf16_t*)addend;
     h.B = B; h.H = IH; h.W = IW; h.Cin = Cin; h.Cout = Cout; h.CinP = a.CinP; h.CoutP = a.CoutP;
     for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }

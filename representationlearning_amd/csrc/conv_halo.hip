@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   constexpr int A_LOADS = (HP * 4 + 255) / 256, B_LOADS = (9 * BN * 4 + 255) / 256;
   constexpr int LDS_ELEMS = (A_ELEMS + B_ELEMS) > BMP * LDC ? (A_ELEMS + B_ELEMS) : BMP * LDC;
   __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
-  __shared__ float sstat[2 * BN];
+  __shared__ float sstat[4 * 2 * BN];                    // one row of partials per wave: summed in a fixed order, no LDS atomics
   bf16_t* As = lds;
   bf16_t* Bs = lds + A_ELEMS;
 
@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);
   if (q >= a.total) return;
   int t = (int)(q / a.ntiles_n);
+  const int tile_id = t;
   const int tx = t % a.tiles_x; t /= a.tiles_x;
   const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
   const int y0 = ty * TH, x0 = tx * TW, n0 = (int)(q % a.ntiles_n) * BN;
@@ -125,10 +126,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   }
 
   // ---- epilogue: bias, BatchNorm partial statistics, transposed store ------------------------------------------------
-  if (a.stats)
-    for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
   bf16_t* Cs = lds;                                       // [TH*16][LDC]
-  if (a.stats) __syncthreads();
   // (the statistics are only wanted by the forward launches, and only edge tiles need the per-pixel validity test: both are
   // block-uniform branches around ~40 VALU instructions of an issue-bound kernel)
   const bool full = y0 + TH <= a.H && x0 + TW <= a.W;
@@ -165,14 +163,22 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
       }
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (grp == 0) { atomicAdd(&sstat[lcol], s1); atomicAdd(&sstat[BN + lcol], s2); }
+      if (grp == 0) { sstat[wave * 2 * BN + lcol] = s1; sstat[(wave * 2 + 1) * BN + lcol] = s2; }
     }
   }
   __syncthreads();
   if (a.stats) {
     float* slot = a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * a.Cout;
-    for (int i = tid; i < BN; i += 256)
-      if (n0 + i < a.Cout) { atomicAdd(slot + n0 + i, sstat[i]); atomicAdd(slot + a.Cout + n0 + i, sstat[BN + i]); }
+    float* part = a.stats_ws ? a.stats_ws + (size_t)tile_id * 2 * a.Cout : nullptr;
+    for (int i = tid; i < BN; i += 256) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += sstat[w * 2 * BN + i]; t2 += sstat[(w * 2 + 1) * BN + i]; }
+      if (n0 + i < a.Cout) {
+        if (part) { part[n0 + i] = t1; part[a.Cout + n0 + i] = t2; }
+        else { atomicAdd(slot + n0 + i, t1); atomicAdd(slot + a.Cout + n0 + i, t2); }
+      }
+    }
   }
   constexpr int OCPR = BN / 8;
   const bool ovec = (a.Cout % 8) == 0;
@@ -241,7 +247,9 @@ int launch_halo(HaloArgs a, hipStream_t st) {
   else if (th == 8) RSSF_HALO(8, 32);
   else RSSF_HALO(4, 32);
 #undef RSSF_HALO
-  return check_launch("conv3x3_halo");
+  const int rc = check_launch("conv3x3_halo");
+  if (rc || !(a.stats && a.stats_ws)) return rc;
+  return launch_stats_fold(a.stats_ws, a.total / a.ntiles_n, a.Cout, a.stats, st);
 }
 
 }  // namespace cv

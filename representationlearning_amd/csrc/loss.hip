@@ -99,13 +99,14 @@ __global__ void __launch_bounds__(256) loss_bwd_kernel(const T* __restrict__ log
 }  // namespace
 
 extern "C" int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* aux, float* acc, float* out, int B, int HW, int K,
-                                  int KA, int ignore_index, int dtype, void* stream) {
+                                  int KA, int ignore_index, int deterministic, int dtype, void* stream) {
   RSSF_REQUIRE(logits && labels && aux && acc && out && B > 0 && HW > 0 && K > 0 && K <= MAXK && KA >= 2, "cgfl_loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * 6 * B, st);
   if (e != hipSuccess) { set_error("cgfl_loss_fwd: memset failed: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   int bx = (HW + 255) / 256;
   if (bx > 128) bx = 128;
+  if (deterministic) bx = 1;           // one block per sample: wave shuffles + an ordered 4-way sum, a single add into the zeroed acc
   dim3 grid((unsigned)bx, (unsigned)B);
   if (dtype == RSSF_F32) loss_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)logits, labels, acc, HW, K, ignore_index);
   else if (dtype == RSSF_BF16) loss_fwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)logits, labels, acc, HW, K, ignore_index);

@@ -375,8 +375,12 @@ def _conv_forward(spec, xh, weights, bias, stats, rt=None):
     OH, OW = spec.out_hw(H, W)
     wpk = _pack(spec, weights, False, xh.dtype, xh.device, rt)
     out = torch.empty(B, OH, OW, spec.cout, device=xh.device, dtype=xh.dtype)
-    L.check(L.load().rssf_conv_gather(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), B, H, W, C, OH, OW, spec.cout,
-                                      spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
+    lib = L.load()
+    ws = None
+    if stats is not None and (rt or current()).deterministic:       # fixed-order statistics: per-tile partials + ordered fold
+        ws = torch.empty(lib.rssf_conv_stats_workspace_elems(B, OH, OW, spec.cout), device=xh.device, dtype=torch.float32)
+    L.check(lib.rssf_conv_gather_add(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), None, L.ptr(ws), B, H, W, C, OH, OW,
+                                     spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
             "rssf_conv_gather")
     return out
 
@@ -402,7 +406,7 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None):
     if addend is not None and (addend.shape != dx.shape or addend.dtype != dx.dtype or not addend.is_contiguous()):
         raise RuntimeError("conv dgrad: fused skip gradient has shape/dtype %s %s, expected %s %s"
                            % (tuple(addend.shape), addend.dtype, tuple(dx.shape), dx.dtype))
-    L.check(L.load().rssf_conv_gather_add(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, L.ptr(addend), B, OH, OW, cout_p, H, W, C, 1, spec.stride,
+    L.check(L.load().rssf_conv_gather_add(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, L.ptr(addend), None, B, OH, OW, cout_p, H, W, C, 1, spec.stride,
                                       spec.ntaps, spec.c_ndy, spec.c_ndx, L.dtype_code(dout),
                                       L.stream()), "rssf_conv_gather(dgrad)")
     return dx
@@ -484,7 +488,10 @@ class _ConvBNAct(torch.autograd.Function):
         rows = raw.numel() // C
         lib = L.load()
         sums = _zeros(BN_BWD_SLOTS * 2 * C, raw.device, rt)
-        L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.dtype_code(raw),
+        dws = None
+        if rt.deterministic:
+            dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=raw.device, dtype=torch.float32)
+        L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.ptr(dws), L.dtype_code(raw),
                                        L.stream()), "rssf_bn_bwd_reduce")
         pscale = 1.0
         if exchanged:
@@ -670,7 +677,7 @@ class _CGFLLoss(torch.autograd.Function):
         acc = torch.empty(B, 6, device=lh.device, dtype=torch.float32)
         out = torch.empty(2, device=lh.device, dtype=torch.float32)
         L.check(L.load().rssf_cgfl_loss_fwd(L.ptr(lh), L.ptr(labels), L.ptr(auxf), L.ptr(acc), L.ptr(out), B, H * W, K, auxf.shape[1],
-                                            ignore_index, L.dtype_code(lh), L.stream()), "rssf_cgfl_loss_fwd")
+                                            ignore_index, int(current().deterministic), L.dtype_code(lh), L.stream()), "rssf_cgfl_loss_fwd")
         ctx.save_for_backward(lh, labels, out)
         ctx.ignore_index = ignore_index
         return out[0]

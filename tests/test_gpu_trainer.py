@@ -56,35 +56,50 @@ def test_training_steps_decrease_loss_fp32_and_bf16():
         assert all(l == l for l in losses) and min(losses[-3:]) < losses[0], losses
 
 
-@pytest.mark.parametrize("backend", ["torch", "rccl", "rccl+graph"])
-def test_dp_plumbing_on_one_rank_matches_plain_path(backend):
-    """SyncBN all-reduces + gradient all-reduce over RCCL (world 1) must reproduce the plain single-GPU step, through
-    torch.distributed (hook-driven buckets), through the direct RCCL communicator, and with that step captured into a
-    hipGraph.  Training itself is chaotic at this size (two plain runs already drift by 1 % after one update because of
-    fp32 atomics order), so the comparison is made on one step's loss and on the all-reduced flat gradient with the
-    learning rate at 0."""
+@pytest.mark.parametrize("bf16", [False, True])
+def test_deterministic_mode_is_bit_identical(bf16):
+    """RSSF_DETERMINISTIC / Trainer(deterministic=True): fixed-order BatchNorm statistics (conv epilogue partials + ordered
+    fold, backward reduce likewise) and a one-block-per-sample loss reduction.  Two independent runs give the SAME bits for the
+    loss and every BatchNorm running statistic; parameter gradients agree to fp32 rounding (a few of their reductions still
+    use float atomics: LayerNorm / attention / gate parameter sums - they do not feed back into the step)."""
     from representationlearning_amd.trainer import Trainer
     from tests.helpers import rel_err
-    t0 = Trainer(_mk(1), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=False)
+    runs = []
+    for _ in range(2):
+        t = Trainer(_mk(3), bf16=bf16, base_lr=0.0, weight_decay=0.0, use_graph=False, deterministic=True)
+        losses = _run(t, steps=2)
+        bufs = torch.cat([b.detach().flatten().float() for b in t.model.buffers() if b.is_floating_point()])
+        runs.append((losses, t.flat.grad.clone(), bufs))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][2], runs[1][2])
+    assert rel_err(runs[0][1].cpu(), runs[1][1].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("backend", ["torch", "rccl", "rccl+graph"])
+def test_dp_plumbing_on_one_rank_matches_plain_path(backend):
+    """SyncBN exchanges + bucketed gradient all-reduce over RCCL (world 1) must reproduce the plain single-GPU step, through
+    torch.distributed (hook-driven async buckets), through the direct rssf_comm_* communicators (buckets on a side stream),
+    and with that step captured into a hipGraph.  Deterministic statistics, lr = 0: the loss must agree to fp32 rounding and
+    the all-reduced flat gradient to 1e-5."""
+    from representationlearning_amd.trainer import Trainer
+    from tests.helpers import rel_err
+    t0 = Trainer(_mk(1), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=False, deterministic=True)
     plain = _run(t0, steps=2)
     g_plain = t0.flat.grad.clone()
-    _run(t0, steps=1)
-    # yardstick: the plain path against itself (fp32 atomics order in the BN statistics, amplified by 100 BN layers
-    # normalising over a handful of samples at this test size)
-    self_dist = rel_err(t0.flat.grad.cpu(), g_plain.cpu())
     graph = backend.endswith("+graph")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RSSF_FORCE_DP="1", RSSF_DP_BACKEND=backend.split("+")[0],
                       RSSF_GRAPH="1" if graph else "0")
     dist.init_process_group("nccl", rank=0, world_size=1)
     tr = None
     try:
-        tr = Trainer(_mk(1), bf16=False, sync_bn=True, base_lr=0.0, weight_decay=0.0)
+        tr = Trainer(_mk(1), bf16=False, sync_bn=True, base_lr=0.0, weight_decay=0.0, deterministic=True)
+        assert tr.buckets is not None and len(tr.buckets.bounds) >= 4
         if backend == "torch":
-            assert tr.comm is None and tr.buckets is not None and len(tr.buckets.bounds) >= 4
+            assert not tr.comm.direct
         else:
-            assert tr.comm is not None and tr.buckets is None
+            assert tr.comm.direct and tr.grad_comm.direct and tr.grad_comm is not tr.comm and tr.buckets.side is not None
         dp = _run(tr, steps=6 if graph else 2)
-        if backend == "torch":
+        if not graph:
             assert all(tr.buckets.launched)
         if graph:
             assert tr.graph is not None and tr._replayed >= 2
@@ -95,26 +110,51 @@ def test_dp_plumbing_on_one_rank_matches_plain_path(backend):
         dist.destroy_process_group()
         for k in ("RSSF_FORCE_DP", "RSSF_DP_BACKEND", "RSSF_GRAPH"):
             os.environ.pop(k)
-    assert max(abs(a - plain[0]) for a in dp) < 1e-5 * abs(plain[0]), (plain, dp)
-    assert abs(plain[0] - plain[1]) < 1e-5 * abs(plain[0])          # lr = 0: the step is a fixed point
-    assert rel_err(g_dp.cpu(), g_plain.cpu()) < 3 * self_dist + 1e-4, (rel_err(g_dp.cpu(), g_plain.cpu()), self_dist)
+    assert max(abs(a - plain[0]) for a in dp) < 1e-6 * abs(plain[0]), (plain, dp)
+    assert plain[0] == plain[1]                                     # lr = 0, deterministic: the step is a fixed point
+    assert rel_err(g_dp.cpu(), g_plain.cpu()) < 1e-5, rel_err(g_dp.cpu(), g_plain.cpu())
 
 
 def test_graph_replay_matches_eager():
-    """The captured whole-step hipGraph reproduces the eager step (lr = 0 so every step sees the same parameters)."""
-    from representationlearning_amd.trainer import Trainer
+    """The captured whole-step hipGraph reproduces the eager step (lr = 0 so every step sees the same parameters;
+    deterministic statistics so the comparison is not blurred by atomics order)."""
+    from representationlearning_amd.trainer import Trainer, flush_bn_counters
     from representationlearning_amd.configs import synthetic_batch
     from tests.helpers import rel_err
     img, lab = synthetic_batch(2, 128, seed=5)
-    te = Trainer(_mk(2), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=False)
+    te = Trainer(_mk(2), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=False, deterministic=True)
     le = [float(te.step(img, dict(cls=lab))) for _ in range(2)]
     ge = te.flat.grad.clone()
-    tg = Trainer(_mk(2), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=True)
-    lg = [float(tg.step(img, dict(cls=lab))) for _ in range(6)]       # 3 eager warm-up + capture + 2 replays
+    tg = Trainer(_mk(2), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=True, deterministic=True)
+    lg = [tg.step(img, dict(cls=lab)) for _ in range(6)]       # 3 eager warm-up + capture + 2 replays
     assert tg.graph is not None and tg._replayed >= 2
-    assert abs(lg[-1] - le[0]) < 1e-4 * abs(le[0]), (lg, le)
-    assert rel_err(tg.flat.grad.cpu(), ge.cpu()) < 0.1       # atomics-order noise at this tiny size (see the DP test)
+    assert lg[-1].data_ptr() != lg[-2].data_ptr()              # replays hand out copies, not the static loss tensor
+    lg = [float(l) for l in lg]
+    assert abs(lg[-1] - le[0]) < 1e-6 * abs(le[0]), (lg, le)
+    assert rel_err(tg.flat.grad.cpu(), ge.cpu()) < 1e-5
+    # num_batches_tracked counts executed steps only: the Python pass that records the graph does not count
+    flush_bn_counters(tg)
+    assert int(tg.model.backbone.hrnet.bn1.num_batches_tracked) == 6
     # a different batch through the replayed graph gives a different loss (static input buffers are refreshed)
     img2, lab2 = synthetic_batch(2, 128, seed=6)
     l2 = float(tg.step(img2, dict(cls=lab2)))
     assert abs(l2 - lg[-1]) > 1e-4
+    # a batch of another shape cannot go through the captured step: it runs eagerly instead of broadcasting into the buffers
+    img3, lab3 = synthetic_batch(1, 128, seed=7)
+    l3 = float(tg.step(img3, dict(cls=lab3)))
+    assert l3 == l3 and tg._replayed == 4
+
+
+def test_sgd_skips_parameters_without_gradient():
+    """torch.optim.SGD leaves a parameter whose .grad is None untouched (no weight decay, no momentum): `headaux` never
+    receives a gradient (the loss uses it under no_grad, module/CGFL.py:75-97), so it must keep its initial values."""
+    from representationlearning_amd.trainer import Trainer
+    m = _mk(4)
+    w0 = m.headaux[0].weight.detach().clone()
+    c0 = m.backbone.hrnet.conv1.weight.detach().clone()
+    t = Trainer(m, bf16=False, base_lr=0.01, weight_decay=0.1, use_graph=False)
+    _run(t, steps=2)
+    assert torch.equal(m.headaux[0].weight.detach(), w0)
+    assert not torch.equal(m.backbone.hrnet.conv1.weight.detach(), c0)
+    covered = sum(e - s for s, e in t.sgd_ranges)
+    assert covered == t.flat.numel - (t.flat.offsets[-1] - t.flat.offsets[-3])       # everything but headaux.0.{weight,bias}

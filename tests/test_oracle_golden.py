@@ -224,3 +224,24 @@ def test_input_pipeline_oracle_known_answers():
     assert out.dtype == np.float32 and out[0, 0, 0].tolist() == [float(e) for e in exp]
     assert abs(out[0, 0, 0, 0] + 2.117904) < 1e-5 and abs(out[0, 0, 0, 2] - 2.64) < 1e-5          # the familiar ImageNet range
     assert lab.tolist() == [[[-1]]]                                    # LoveDA no-data 0 -> ignore -1
+
+
+def test_dp_emulation_oracle_consistency():
+    """model_forward_dp: one shard == the plain path; two shards pool the BatchNorm statistics but keep the
+    loss normalisers local, so the mean of shard losses differs from ONE forward over the concatenated batch."""
+    from oracle.procedural import proc_labels, seeded_input
+    from tests.helpers import seeded_params
+    x = seeded_input((2, 3, 32, 32), 3)
+    y = proc_labels(2, 32, 32, 6, 4)
+    P1 = seeded_params(O.model_template("tiny"), requires_grad=False)
+    P2 = seeded_params(O.model_template("tiny"), requires_grad=False)
+    one, _ = O.model_forward_dp([x], [y], P1)
+    plain = O.model_forward(x, P2, True, y)
+    assert abs(float(one) - float(plain)) < 1e-6 * abs(float(plain))
+    P3 = seeded_params(O.model_template("tiny"), requires_grad=False)
+    two, parts = O.model_forward_dp([x[:1], x[1:]], [y[:1], y[1:]], P3)
+    assert abs(float(two) - 0.5 * (float(parts[0]) + float(parts[1]))) < 1e-6
+    assert abs(float(two) - float(plain)) > 1e-4 * abs(float(plain))
+    # pooled statistics: running buffers equal those of the full-batch forward
+    k = "backbone.hrnet.bn1.running_var"
+    assert torch.allclose(P3[k], P2[k], rtol=1e-6, atol=1e-7)

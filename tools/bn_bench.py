@@ -21,8 +21,8 @@ for rows, C, res in [(262144, 32, True), (262144, 32, False), (262144, 64, False
     dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
     y = torch.empty_like(raw)
     st = L.stream()
-    t_r = bench(lambda: lib.rssf_bn_bwd_reduce(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, 1, 1, st))
-    t_a = bench(lambda: lib.rssf_bn_bwd_apply(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres), L.ptr(dg), L.ptr(db), rows, C, 1, float(rows), 1, 1, st))
+    t_r = bench(lambda: lib.rssf_bn_bwd_reduce(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, 1, None, 1, st))
+    t_a = bench(lambda: lib.rssf_bn_bwd_apply(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres), L.ptr(dg), L.ptr(db), rows, C, 1, float(rows), 1, 1.0, 1, st))
     t_f = bench(lambda: lib.rssf_bn_apply(L.ptr(raw), L.ptr(ss), L.ptr(rp), None, L.ptr(y), rows, C, 1, 1, st))
     nb = rows * C * 2
     nr = 3 if res else 2
