@@ -248,7 +248,9 @@ int rssf_argmax_confusion(const void* scores, const int64_t* labels, int32_t* pr
 
 /* ---- optimizer over flat fp32 buffers: the external `ever` trainer's clip_grad_norm_(35) + SGD(momentum .9,
  *      wd 1e-4) of configs/base/loveda.py:68-77 as two launches over all parameters ----------------------- */
-/* out[0] = sum g^2 (zeroed inside, on the stream). */
+/* out[0] = sum g^2; `out` holds 1 + RSSF_SQNORM_BLOCKS floats (out[1..] = per-block partials, added in a fixed order:
+ * bit-identical on every data-parallel replica, no float atomics). */
+#define RSSF_SQNORM_BLOCKS 2048
 int rssf_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
 /* g' = grad_scale*g*clip + wd*p ; buf = first_step ? g' : mu*buf + g' ; p -= lr*buf
  * clip = max_norm > 0 ? min(1, max_norm / (grad_scale*sqrt(*sqnorm) + 1e-6)) : 1   (device-side, no host sync). */

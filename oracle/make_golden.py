@@ -270,3 +270,5 @@ if __name__ == "__main__":
         case_model("tiny", 2, 256, "tiny_2x256")      # BASELINE config 1
         case_model("base", 2, 64, "base_2x64")
         case_model("large", 1, 64, "large_1x64")
+    if "models" in which or "large256" in which:
+        case_model("large", 1, 256, "large_1x256")    # C = 48 window attention over 10 x 10 windows (pad 64 -> 70), all four branches live

@@ -7,6 +7,9 @@ using namespace rssf;
 
 namespace {
 
+// Two levels, fixed order (no float atomics): block partials into out[1 .. blocks], then one block adds them in sequence into
+// out[0].  Data-parallel replicas hold bit-identical gradients after the all-reduce and must take bit-identical clip
+// coefficients from them, or the replicas drift apart by an ulp per step (tests/test_gpu_dp.py).
 __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
   float acc = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
@@ -22,7 +25,20 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
   __shared__ float part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) out[1 + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ void __launch_bounds__(256) sqnorm_fold_kernel(float* __restrict__ out, int blocks) {
+  __shared__ float part[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < blocks; i += 256) acc += out[1 + i];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t += part[i];
+    out[0] = t;
+  }
 }
 
 // torch.optim.SGD semantics (dampening 0, nesterov off):  g' = s*g*clip + wd*p ; buf = mu*buf + g' ; p -= lr*buf
@@ -67,13 +83,14 @@ __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const f
 extern "C" int rssf_grad_sqnorm(const float* g, int64_t n, float* out, void* stream) {
   RSSF_REQUIRE(g && out && n > 0, "grad_sqnorm: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
-  if (e != hipSuccess) { set_error("grad_sqnorm: memset failed: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   int64_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > RSSF_SQNORM_BLOCKS) blocks = RSSF_SQNORM_BLOCKS;
   if (blocks < 1) blocks = 1;
   sqnorm_kernel<<<(unsigned)blocks, 256, 0, st>>>(g, n, out);
-  return check_launch("grad_sqnorm");
+  int rc = check_launch("grad_sqnorm");
+  if (rc) return rc;
+  sqnorm_fold_kernel<<<1, 256, 0, st>>>(out, (int)blocks);
+  return check_launch("grad_sqnorm(fold)");
 }
 
 extern "C" int rssf_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, const float* sqnorm, float grad_scale,

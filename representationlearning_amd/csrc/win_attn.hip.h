@@ -168,6 +168,12 @@ template <> struct RowFrag<float> {
     return f32x4{p[0], p[ld], p[2 * ld], p[3 * ld]};
   }
 };
+// operand fragment in CHAIN slot order (slot 4g + r) straight from a k-contiguous LDS tile: row l15, elements k0 + 4g .. + 3
+template <typename T>
+__device__ __forceinline__ typename Packed<T>::type chain_frag_lds(const T* buf, int ld, int k0) {
+  const int lane = threadIdx.x & 63;
+  return *reinterpret_cast<const typename Packed<T>::type*>(buf + (lane & 15) * ld + k0 + (lane >> 4) * 4);
+}
 // D += A^T-view * chain:  A operand = columns c0.. of buf with K = rows k0..k0+15, B operand chained from registers
 template <typename T>
 __device__ __forceinline__ f32x4 mma_row_chain(const T* buf, int ld, int c0, int k0, const f32x4& b, f32x4 acc) {

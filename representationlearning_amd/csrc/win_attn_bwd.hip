@@ -16,6 +16,10 @@
 using namespace rssf;
 using namespace rssf::wa;
 
+#ifndef RSSF_BWD_COMPACT_BF16
+#define RSSF_BWD_COMPACT_BF16 0
+#endif
+
 namespace {
 
 template <typename T, typename DM, bool ACC_LDS> struct BwdLayout {
@@ -25,16 +29,22 @@ template <typename T, typename DM, bool ACC_LDS> struct BwdLayout {
   static constexpr int LDW = DM::CP + P;     // Wq/Wk/Wv/WoT rows = virtual channel, k = real channel
   static constexpr int LDD = DM::DP + P;     // dM / dM^T scratch
   static constexpr int max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
-  static constexpr int REGION = (max3(LP * LDX, LP * LDV, 0) + 7) / 8 * 8;
-  static constexpr int NREG = 6;             // XS YS GS | QS KS VS (later dq dk dv)   - all token-major
-  static constexpr int SCRATCH = (2 * DM::DP * LDD + 7) / 8 * 8;
+  // fp32 (parity mode) must squeeze C = 48 into 160 KiB: tile regions sized per kind and ONE dM scratch read both ways
+  // (straight, and through the transposing fragment read as dM^T).  bf16 keeps the uniform regions and the two dM / dM^T
+  // copies of round 1: its C = 48 instantiation (512 VGPRs + ~80 spilled under divergent pair/head branches) is sensitive to
+  // code changes - the compact form produced garbage there on hardware while C = 32 / 18 and fp32 C = 48 were fine.
+  static constexpr bool COMPACT = RSSF_BWD_COMPACT_BF16 || sizeof(T) == 4;
+  static constexpr int REGU = (max3(LP * LDX, LP * LDV, 0) + 7) / 8 * 8;
+  static constexpr int REGX = COMPACT ? (LP * LDX + 7) / 8 * 8 : REGU;       // XS YS GS          [token][in channel]
+  static constexpr int REGV = COMPACT ? (LP * LDV + 7) / 8 * 8 : REGU;       // QS KS VS (later dq dk dv)   [token][virtual channel]
+  static constexpr int SCRATCH = ((COMPACT ? 1 : 2) * DM::DP * LDD + 7) / 8 * 8;
   static constexpr int W_ELEMS = 4 * DM::CV * LDW;
   static constexpr int F_ELEMS = 3 * DM::CV + 2 * DM::CP;                       // bq bk bv, gamma beta
   static constexpr int A_ELEMS = ACC_LDS ? 4 * DM::CV * DM::CP + 3 * DM::CV + DM::CP : 0;
   static constexpr size_t SHARED_OFF = (sizeof(T) * W_ELEMS + sizeof(float) * (F_ELEMS + A_ELEMS) + 15) / 16 * 16;
   // A window is served by a PAIR of waves (one head each) that share the six tiles; each wave has its own dM scratch.
   static_assert(DM::HEADS == 2, "the backward kernel maps one head to each wave of a pair");
-  static constexpr int PAIR_ELEMS = NREG * REGION + 2 * SCRATCH;
+  static constexpr int PAIR_ELEMS = 3 * REGX + 3 * REGV + 2 * SCRATCH;
   static constexpr size_t WAVE_BYTES = sizeof(T) * PAIR_ELEMS;            // per pair
   static constexpr size_t LIM = 160 * 1024;
   static constexpr int PAIRS = (SHARED_OFF + 4 * WAVE_BYTES <= LIM) ? 4 : (SHARED_OFF + 3 * WAVE_BYTES <= LIM) ? 3
@@ -43,7 +53,7 @@ template <typename T, typename DM, bool ACC_LDS> struct BwdLayout {
   static constexpr size_t BYTES = SHARED_OFF + WAVE_BYTES * PAIRS;
   static constexpr bool FITS = BYTES <= LIM;
   // head-sum exchange of the input-gradient tiles: CT x 2 token tiles x {x, y} f32x4 per lane, in two tile regions
-  static_assert(2 * REGION * sizeof(T) >= (size_t)DM::CT * 2 * 2 * 64 * 16, "exchange buffer does not fit two tile regions");
+  static_assert(2 * REGX * sizeof(T) >= (size_t)DM::CT * 2 * 2 * 64 * 16, "exchange buffer does not fit two tile regions");
 };
 
 // plain (no LN / gate) token-major tile load, zero for pad / dead slots
@@ -123,9 +133,9 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   const int l15 = lane & 15, grp = lane >> 4;
   const int pair = wave >> 1, hw = wave & 1;               // wave hw of a pair computes head hw of the pair's window
   T* base = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)pair * LY::PAIR_ELEMS;
-  T* XS = base;                 T* YS = XS + LY::REGION;   T* GS = YS + LY::REGION;
-  T* QS = GS + LY::REGION;      T* KS = QS + LY::REGION;   T* VS = KS + LY::REGION;    // later dq, dk, dv (head by head)
-  T* dMs = VS + LY::REGION + hw * LY::SCRATCH;     T* dMTs = dMs + DP * LDD;
+  T* XS = base;                 T* YS = XS + LY::REGX;     T* GS = YS + LY::REGX;
+  T* QS = GS + LY::REGX;        T* KS = QS + LY::REGV;     T* VS = KS + LY::REGV;      // later dq, dk, dv (head by head)
+  T* dMs = VS + LY::REGV + hw * LY::SCRATCH;
 
   for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
     const int m = i / LDW, k = i % LDW;
@@ -420,7 +430,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
             float v = 0.f;
             if (i < D && j < D) v = du / (float)(D * D) + ((i * DP + j) == marg ? du : 0.f);
             stf(dMs + i * LDD + j, v);
-            stf(dMTs + j * LDD + i, v);
+            if constexpr (!LY::COMPACT) stf(dMs + DP * LDD + j * LDD + i, v);
           }
       wave_sync();
 #pragma unroll
@@ -430,9 +440,13 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           f32x4 aq = dq[mi][tt], ak = dk[mi][tt];
 #pragma unroll
           for (int mj = 0; mj < TPH; ++mj) {
-            // dq^T += dM k^T, dk^T += dM^T q^T: both operands k-contiguous in LDS (K = head channels mj*16..)
+            // dq^T += dM k^T (both operands k-contiguous in LDS, K = head channels mj*16..), dk^T += dM^T q^T (dM^T rows =
+            // columns of the one dM buffer, through the transposing fragment read)
             aq = mma_tile<T>(dMs + mi * 16 * LDD + mj * 16, LDD, KS + tt * 16 * LDV + hoff + mj * 16, LDV, 16, aq);
-            ak = mma_tile<T>(dMTs + mi * 16 * LDD + mj * 16, LDD, QS + tt * 16 * LDV + hoff + mj * 16, LDV, 16, ak);
+            if constexpr (LY::COMPACT)
+              ak = Packed<T>::mma(RowFrag<T>::load(dMs, LDD, mj * 16, mi * 16), chain_frag_lds<T>(QS + tt * 16 * LDV, LDV, hoff + mj * 16), ak);
+            else
+              ak = mma_tile<T>(dMs + DP * LDD + mi * 16 * LDD + mj * 16, LDD, QS + tt * 16 * LDV + hoff + mj * 16, LDV, 16, ak);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) aq[r] *= scale;       // q = (W x + b) * scale
@@ -696,10 +710,15 @@ int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) 
   return check_launch("winattn_bwd(domega reduce)");
 }
 
+// LDS-resident gradient accumulators (one flush per workgroup) when they do not cost a pair of waves; else straight atomics
 template <typename T, typename DM>
 int pick_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) {
-  if constexpr (BwdLayout<T, DM, true>::FITS) return launch_bwd<T, DM, true>(p, g, st);
-  else if constexpr (BwdLayout<T, DM, false>::FITS) return launch_bwd<T, DM, false>(p, g, st);
+  using LA = BwdLayout<T, DM, true>;
+  using LN = BwdLayout<T, DM, false>;
+  // (C = 48 bf16: the LDS accumulators leave room for one pair only; the two-pair global-atomics variant aborted on
+  // hardware - 512 VGPRs + 90 spilled under divergent pair/head branches - so the validated one-pair form stays)
+  if constexpr (LA::FITS) return launch_bwd<T, DM, true>(p, g, st);
+  else if constexpr (LN::FITS) return launch_bwd<T, DM, false>(p, g, st);
   else {
     set_error("winattn_bwd: C=%d in this dtype exceeds the 160 KiB LDS of a CU (use bf16 activations)", DM::C);
     return RSSF_ERR_UNSUPPORTED;

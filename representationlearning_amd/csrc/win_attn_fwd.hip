@@ -15,9 +15,18 @@
 // tile load: LDS holds only the two gated input tiles and the weights.
 // The kernel is HBM-bound (0.27 GFLOP vs 3.1 MB per image-block); MFMA just keeps the
 // arithmetic out of the way.
+#include <mutex>
 #include "win_attn.hip.h"
 using namespace rssf;
 using namespace rssf::wa;
+
+// tuning knobs (defaults = the measured best on MI355X; tools/attn_variants.sh builds the alternatives)
+#ifndef RSSF_FWD_OCC
+#define RSSF_FWD_OCC 2             // waves per SIMD the register allocator makes room for (bf16)
+#endif
+#ifndef RSSF_FWD_PREFETCH_STATS
+#define RSSF_FWD_PREFETCH_STATS 1  // LayerNorm statistics travel with the prefetched tiles (1) or are fetched at use (0)
+#endif
 
 namespace {
 
@@ -85,11 +94,130 @@ template <> struct Quad<float> {
   static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 };
 
+// Global-load stage of one window's two 49xC tiles (vector path): issued one window AHEAD of its use, so that the HBM
+// latency of window i+1 is paid under the MFMA/softmax work of window i (the kernel used to park ~half of its wave cycles on
+// s_waitcnt: one wave per window is one long dependency chain, and 2-3 waves per SIMD do not cover an HBM round trip).
+template <typename T, typename DM> struct TileRegs {
+  static constexpr int V = Vec<T>::N, CPR = DM::CP / V, ITERS = (LP * CPR + 63) / 64;
+  Vec<T> vx[ITERS], vy[ITERS];
+#if RSSF_FWD_PREFETCH_STATS
+  float2 sx[ITERS], sy[ITERS];
+#else
+  int tok[ITERS];                    // LN statistics are fetched when the tile is finished (L2-resident: written by the pass before)
+#endif
+  int pp[ITERS];                     // gate-weight index of the chunk's first element, -1: dead slot / padding chunk
+};
+
 template <typename T, typename DM>
-__global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) == 2 && DM::C <= 32) ? 2 : 1)) winattn_fwd_kernel(rssf_winattn_fwd_params p, Geom g) {
+__device__ __forceinline__ void tiles_issue(TileRegs<T, DM>& R, const rssf_winattn_fwd_params& p, const Geom& g, const T* X, const T* Y,
+                                            int wi, int lane) {
+  using TR = TileRegs<T, DM>;
+  const int wpi = g.QH * g.QW;
+  const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;
+  const int64_t img = (int64_t)b * g.N;
+#pragma unroll
+  for (int it = 0; it < TR::ITERS; ++it) {          // branch-free: dead / padded slots read token 0 and are zeroed later
+    const int e = lane + it * 64;
+    const int t = e / TR::CPR, c0 = (e % TR::CPR) * TR::V;
+    const int n = slot_token(g, qh, qw, t);
+    const bool ok = n >= 0 && c0 < DM::C && e < LP * TR::CPR;
+    const int nn = ok ? n : 0, cc = ok ? c0 : 0;
+    const int64_t f = (int64_t)nn * DM::C + cc;
+    R.vx[it].load(X + img * DM::C + f);
+    R.vy[it].load(Y + img * DM::C + f);
+#if RSSF_FWD_PREFETCH_STATS
+    R.sx[it] = *reinterpret_cast<const float2*>(p.stats_x + (img + nn) * 2);
+    R.sy[it] = *reinterpret_cast<const float2*>(p.stats_y + (img + nn) * 2);
+#else
+    R.tok[it] = nn;
+#endif
+    R.pp[it] = ok ? (int)((unsigned)f % (unsigned)g.N) : -1;          // N*C < 2^31 (checked by the entry points)
+  }
+}
+
+// LayerNorm (given stats) * gate weight omega[(n*C+c) mod N] -> LDS as T, zero rows for padded / dead slots
+template <typename T, typename DM>
+__device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rssf_winattn_fwd_params& p, int64_t img, const Geom& g,
+                                             const float* sLn, const float* om0, T* xs, T* ys, int ldx, int lane) {
+  using TR = TileRegs<T, DM>;
+  constexpr int V = TR::V;
+#if !RSSF_FWD_PREFETCH_STATS
+  float2 sxv[TR::ITERS], syv[TR::ITERS];
+#pragma unroll
+  for (int it = 0; it < TR::ITERS; ++it) {
+    sxv[it] = *reinterpret_cast<const float2*>(p.stats_x + (img + R.tok[it]) * 2);
+    syv[it] = *reinterpret_cast<const float2*>(p.stats_y + (img + R.tok[it]) * 2);
+  }
+#endif
+  const bool contiguous = g.N % DM::C == 0;   // the V gate weights of a chunk are contiguous (no wrap inside a token row)
+  // gate weights: L2-resident (128 KB per image, every token row of a 512-token stripe reads the same 2 x C floats); fetched
+  // one iteration ahead of their use instead of all up front (64 registers for 4 iterations kept the kernel at 2 waves/SIMD)
+  float4 wa[2][V / 4], wb[2][V / 4];
+  auto fetch = [&](int it, int slot) {
+    const int q = R.pp[it] < 0 ? 0 : R.pp[it];
+#pragma unroll
+    for (int i = 0; i < V / 4; ++i) {
+      wa[slot][i] = *reinterpret_cast<const float4*>(om0 + q + 4 * i);
+      wb[slot][i] = *reinterpret_cast<const float4*>(om0 + g.N + q + 4 * i);
+    }
+  };
+  if (contiguous) fetch(0, 0);
+#pragma unroll
+  for (int it = 0; it < TR::ITERS; ++it) {
+    const int e = lane + it * 64;
+    if (e >= LP * TR::CPR) break;
+    const int t = e / TR::CPR, c0 = (e % TR::CPR) * V;
+    const bool ok = R.pp[it] >= 0;
+    float w0[V], w1[V];
+    if (contiguous) {
+      if (it + 1 < TR::ITERS) fetch(it + 1, (it + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < V / 4; ++i) {
+        const float4 a4 = wa[it & 1][i], b4 = wb[it & 1][i];
+        w0[4 * i] = a4.x; w0[4 * i + 1] = a4.y; w0[4 * i + 2] = a4.z; w0[4 * i + 3] = a4.w;
+        w1[4 * i] = b4.x; w1[4 * i + 1] = b4.y; w1[4 * i + 2] = b4.z; w1[4 * i + 3] = b4.w;
+      }
+    } else {
+      int q = ok ? R.pp[it] : 0;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        w0[i] = om0[q]; w1[i] = om0[g.N + q];
+        if (++q == g.N) q = 0;
+      }
+    }
+    float fx[V], fy[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float ga = sLn[c0 + i], be = sLn[DM::CP + c0 + i];
+#if RSSF_FWD_PREFETCH_STATS
+      const float2 sx = R.sx[it], sy = R.sy[it];
+#else
+      const float2 sx = sxv[it], sy = syv[it];
+#endif
+      fx[i] = ok ? ((R.vx[it].get(i) - sx.x) * sx.y * ga + be) * w0[i] : 0.f;
+      fy[i] = ok ? ((R.vy[it].get(i) - sy.x) * sy.y * ga + be) * w1[i] : 0.f;
+    }
+    Vec<T> ox, oy;
+    ox.set_all(fx); oy.set_all(fy);
+    ox.store(xs + t * ldx + c0);
+    oy.store(ys + t * ldx + c0);
+  }
+}
+
+template <typename T, typename DM> struct FwdOcc {
+  // waves per SIMD the register allocator is asked to make room for: what the LDS footprint allows anyway
+  static constexpr int WG_PER_CU = (int)((160 * 1024) / FwdLayout<T, DM>::BYTES);
+  static constexpr int WAVES_PER_SIMD = (WG_PER_CU * FwdLayout<T, DM>::WAVES + 3) / 4;
+  static constexpr int VALUE = sizeof(T) == 2 ? (WAVES_PER_SIMD > RSSF_FWD_OCC ? RSSF_FWD_OCC : (WAVES_PER_SIMD < 1 ? 1 : WAVES_PER_SIMD)) : 1;
+};
+
+template <typename T, typename DM>
+__global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>::VALUE)) winattn_fwd_kernel(rssf_winattn_fwd_params p, Geom g) {
   using LY = FwdLayout<T, DM>;
   constexpr int LDX = LY::LDX, LDW = LY::LDW, LDO = LY::LDO;
   constexpr int C = DM::C, CP = DM::CP, CV = DM::CV, MT = DM::MT, CT = DM::CT, TPH = DM::TPH, D = DM::D;
+  constexpr int LW = WIN * WIN;                      // live tokens of a window (the entry point checked window == 7)
+  constexpr bool PIPE = sizeof(T) == 2 && (C % Vec<T>::N) == 0;      // next window's global loads issued one window ahead
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // ---- workgroup-shared: weights as T (MFMA operands), biases / LN affine fp32 ---------------------------------
   T* sWq = reinterpret_cast<T*>(smem_raw);           // [CV][LDW]  virtual rows, k = real input channel
@@ -102,6 +230,15 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) ==
   const int l15 = lane & 15, grp = lane >> 4;
   T* xs = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)wave * 2 * LY::REGION;   // [LP][LDX] gated LN(x)
   T* ys = xs + LY::REGION;                                                                    // [LP][LDX] gated LN(y)
+
+  const T* X = reinterpret_cast<const T*>(p.x);
+  const T* Y = reinterpret_cast<const T*>(p.y);
+  T* OUT = reinterpret_cast<T*>(p.out);
+  const int wpi = g.QH * g.QW;
+  const int stride = gridDim.x * LY::WAVES;
+  int wi = blockIdx.x * LY::WAVES + wave;
+  TileRegs<T, DM> R;
+  if constexpr (PIPE) tiles_issue<T, DM>(R, p, g, X, Y, wi < g.nWin ? wi : g.nWin - 1, lane);   // under the weight staging below
 
   for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
     const int m = i / LDW, k = i % LDW;
@@ -129,85 +266,75 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) ==
   }
   __syncthreads();
 
+  // softmax in base 2: log2(e) rides on the q scale of the S operand (v_exp_f32 is a base-2 exponential; one multiply per
+  // score less).  The q that enters M = q^T k keeps the plain 1/sqrt(d) scale.
   const float scale = rsqrtf((float)D);
-  const T* X = reinterpret_cast<const T*>(p.x);
-  const T* Y = reinterpret_cast<const T*>(p.y);
-  T* OUT = reinterpret_cast<T*>(p.out);
-  const int wpi = g.QH * g.QW;
+  const float scale2 = scale * 1.4426950408889634f;
 
-  for (int wi = blockIdx.x * LY::WAVES + wave; wi < g.nWin; wi += gridDim.x * LY::WAVES) {
+  for (; wi < g.nWin; wi += stride) {
     const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;
     const int64_t img = (int64_t)b * g.N;
     const float* om0 = p.omega + (int64_t)b * 2 * g.N;
 
-    // ---- 1. load both 49xC tiles, LayerNorm (given stats) * gate weight -> LDS as T, zero padded ------
+    // ---- 1. both 49xC tiles: LayerNorm (given stats) * gate weight -> LDS as T, zero padded ------------------------------
     wave_sync();
-    load_gated_tiles<T, DM>(p, g, sLn, X, Y, om0, img, qh, qw, xs, ys, LDX, lane);
-    // residual values of the tokens / channels this lane will store (issued now, consumed in step 4)
-    typename Quad<T>::raw xres[NT][CT];
+    if constexpr (PIPE) {
+      tiles_finish<T, DM>(R, p, img, g, sLn, om0, xs, ys, LDX, lane);
+      const int nx = wi + stride < g.nWin ? wi + stride : g.nWin - 1;     // clamped, never branched around: a conditional load
+      tiles_issue<T, DM>(R, p, g, X, Y, nx, lane);                         // makes every later s_waitcnt drain to zero
+    } else {
+      load_gated_tiles<T, DM>(p, g, sLn, X, Y, om0, img, qh, qw, xs, ys, LDX, lane);
+    }
     int ntok[NT];
 #pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      ntok[qt] = slot_token(g, qh, qw, qt * 16 + l15);
-      if constexpr (C % 4 == 0) {
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const int c0 = ct * 16 + grp * 4;
-          const int64_t off = (img + (ntok[qt] >= 0 ? ntok[qt] : 0)) * C + (c0 < C ? c0 : 0);
-          xres[qt][ct] = Quad<T>::load_raw(X + off);
-        }
-      }
-    }
+    for (int qt = 0; qt < NT; ++qt) ntok[qt] = slot_token(g, qh, qw, qt * 16 + l15);
     wave_sync();
 
-    // ---- 2. projections.  Everything downstream is register-chained, so q and k are produced in BOTH orientations:
+    // ---- 2./3. head by head (only ONE head's q, k, v tiles are live at a time).  Everything downstream of the projections is
+    //      register-chained, so q and k are produced in BOTH orientations:
     //         transposed  q^T,k^T [channel][token] (k-slot = channel)  -> operands of S^T = k q^T
     //         straight    q,k,v   [token][channel] (k-slot = token)    -> operands of M = q^T k and of O^T = v^T P^T
     using PK = Packed<T>;
-    typename PK::type qT[MT][NT], kT[MT][NT], vN[NT][MT];
-    f32x4 Macc[DM::HEADS][TPH][TPH];
-#pragma unroll
-    for (int h = 0; h < DM::HEADS; ++h)
-#pragma unroll
-      for (int i = 0; i < TPH; ++i)
-#pragma unroll
-        for (int j = 0; j < TPH; ++j) Macc[h][i][j] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-      typename PK::type qN[MT], kN[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int mrow = mt * 16 + grp * 4, mcol = mt * 16 + l15;
-        f32x4 aq = proj_tile<T>(sWq + mt * 16 * LDW, LDW, xs + tt * 16 * LDX, LDX, CP);
-        f32x4 ak = proj_tile<T>(sWk + mt * 16 * LDW, LDW, ys + tt * 16 * LDX, LDX, CP);
-        f32x4 nq = proj_tile<T>(xs + tt * 16 * LDX, LDX, sWq + mt * 16 * LDW, LDW, CP);
-        f32x4 nk = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWk + mt * 16 * LDW, LDW, CP);
-        f32x4 nv = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWv + mt * 16 * LDW, LDW, CP);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          aq[r] = (aq[r] + sB[mrow + r]) * scale;
-          ak[r] += sB[CV + mrow + r];
-          const bool live = tt * 16 + grp * 4 + r < g.L;          // tokens >= 49 must not enter M (DAL.py:1003)
-          nq[r] = live ? (nq[r] + sB[mcol]) * scale : 0.f;
-          nk[r] += sB[CV + mcol];
-          nv[r] += sB[2 * CV + mcol];
-        }
-        qT[mt][tt] = PK::pack(aq); kT[mt][tt] = PK::pack(ak); qN[mt] = PK::pack(nq); kN[mt] = PK::pack(nk);
-        vN[tt][mt] = PK::pack(nv);
-      }
-      // M_h += q_h^T k_h over this token tile (k-slot = token: both operands are C-layout rows)
-#pragma unroll
-      for (int h = 0; h < DM::HEADS; ++h)
-#pragma unroll
-        for (int i = 0; i < TPH; ++i)
-#pragma unroll
-          for (int j = 0; j < TPH; ++j) Macc[h][i][j] = PK::mma(qN[h * TPH + i], kN[h * TPH + j], Macc[h][i][j]);
-    }
-
-    // ---- 3. per head: alpha from M; per query tile: S^T = k q^T, softmax over keys, O^T = v^T P^T ------------------------
     typename PK::type o[MT][NT];
 #pragma unroll
     for (int h = 0; h < DM::HEADS; ++h) {
+      typename PK::type qT[TPH][NT], kT[TPH][NT], vN[NT][TPH];
+      f32x4 Macc[TPH][TPH];
+#pragma unroll
+      for (int i = 0; i < TPH; ++i)
+#pragma unroll
+        for (int j = 0; j < TPH; ++j) Macc[i][j] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        typename PK::type qN[TPH], kN[TPH];
+#pragma unroll
+        for (int mi = 0; mi < TPH; ++mi) {
+          const int mt = h * TPH + mi;
+          const int mrow = mt * 16 + grp * 4, mcol = mt * 16 + l15;
+          f32x4 aq = proj_tile<T>(sWq + mt * 16 * LDW, LDW, xs + tt * 16 * LDX, LDX, CP);
+          f32x4 ak = proj_tile<T>(sWk + mt * 16 * LDW, LDW, ys + tt * 16 * LDX, LDX, CP);
+          f32x4 nq = proj_tile<T>(xs + tt * 16 * LDX, LDX, sWq + mt * 16 * LDW, LDW, CP);
+          f32x4 nk = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWk + mt * 16 * LDW, LDW, CP);
+          f32x4 nv = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWv + mt * 16 * LDW, LDW, CP);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            aq[r] = (aq[r] + sB[mrow + r]) * scale2;
+            ak[r] += sB[CV + mrow + r];
+            const bool live = tt * 16 + grp * 4 + r < LW;           // tokens >= 49 must not enter M (DAL.py:1003)
+            nq[r] = live ? (nq[r] + sB[mcol]) * scale : 0.f;
+            nk[r] += sB[CV + mcol];
+            nv[r] += sB[2 * CV + mcol];
+          }
+          qT[mi][tt] = PK::pack(aq); kT[mi][tt] = PK::pack(ak); qN[mi] = PK::pack(nq); kN[mi] = PK::pack(nk);
+          vN[tt][mi] = PK::pack(nv);
+        }
+        // M_h += q_h^T k_h over this token tile (k-slot = token: both operands are C-layout rows)
+#pragma unroll
+        for (int i = 0; i < TPH; ++i)
+#pragma unroll
+          for (int j = 0; j < TPH; ++j) Macc[i][j] = PK::mma(qN[i], kN[j], Macc[i][j]);
+      }
+
       // channel alpha = sigmoid(mean(M) + max(M)),  M = q_h^T k_h  (d x d)   (DAL.py:1003-1010)
       float msum = 0.f, mmax = -INFINITY;
 #pragma unroll
@@ -217,29 +344,30 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) ==
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = it * 16 + grp * 4 + r, j = jt * 16 + l15;
-            if (i < D && j < D) { msum += Macc[h][it][jt][r]; mmax = fmaxf(mmax, Macc[h][it][jt][r]); }
+            if (i < D && j < D) { msum += Macc[it][jt][r]; mmax = fmaxf(mmax, Macc[it][jt][r]); }
           }
       msum = wave_sum(msum);
       mmax = wave_max(mmax);
       const float alpha = sigmoidf(msum / (float)(D * D) + mmax);
 
+      // per query tile: S^T = k q^T, softmax over keys, O^T = v^T P^T
 #pragma unroll
       for (int qt = 0; qt < NT; ++qt) {
-        f32x4 s[NT];              // [key tile]: lane holds key kt*16+4*grp+r for query qt*16+l15
+        f32x4 s[NT];              // [key tile]: lane holds key kt*16+4*grp+r for query qt*16+l15   (base-2 logits)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int mt = h * TPH; mt < (h + 1) * TPH; ++mt) acc = PK::mma(kT[mt][kt], qT[mt][qt], acc);
+          for (int mi = 0; mi < TPH; ++mi) acc = PK::mma(kT[mi][kt], qT[mi][qt], acc);
           s[kt] = acc;
         }
-        // softmax over the 49 live keys (no mask, no bias: DAL.py:959,996)
+        // softmax over the 49 live keys (no mask, no bias: DAL.py:959,996); LW is a constant: only key tile 3 has dead rows
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (kt * 16 + grp * 4 + r >= g.L) s[kt][r] = -INFINITY;
+            if (kt * 16 + grp * 4 + r >= LW) s[kt][r] = -INFINITY;
             mx = fmaxf(mx, s[kt][r]);
           }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -248,7 +376,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) ==
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - mx); sum += s[kt][r]; }
+          for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); sum += s[kt][r]; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = alpha / sum;      // fold alpha into the normalisation: o = alpha * (P v)
@@ -261,16 +389,28 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) ==
         }
         // O^T[dcol][query] = sum_key v[key][dcol] P^T[key][query]   (A = straight v tile: row index = dcol lane, k-slot = key)
 #pragma unroll
-        for (int mt = h * TPH; mt < (h + 1) * TPH; ++mt) {
+        for (int mi = 0; mi < TPH; ++mi) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kt = 0; kt < NT; ++kt) acc = PK::mma(vN[kt][mt], pk[kt], acc);
-          o[mt][qt] = PK::pack(acc);
+          for (int kt = 0; kt < NT; ++kt) acc = PK::mma(vN[kt][mi], pk[kt], acc);
+          o[h * TPH + mi][qt] = PK::pack(acc);
         }
       }
     }
 
     // ---- 4. out-projection (transposed) + bias + residual; each lane stores 4 consecutive channels of one token ----------
+    // residual values: re-read from the lines this wave fetched a moment ago (L2 / infinity-cache hits), issued before the
+    // out-projection MFMAs that cover their latency - not carried in registers across steps 2-3
+    typename Quad<T>::raw xres[NT][CT];
+    if constexpr (C % 4 == 0) {
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c0 = ct * 16 + grp * 4;
+          xres[qt][ct] = Quad<T>::load_raw(X + (img + (ntok[qt] >= 0 ? ntok[qt] : 0)) * C + (c0 < C ? c0 : 0));
+        }
+    }
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
       const int n = ntok[qt];
@@ -298,24 +438,39 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), ((sizeof(T) ==
   }
 }
 
+// device properties / per-kernel attributes are looked up once per device and cached in immutable-after-publication slots
+// (no first-device-wins statics: one entry per device ordinal, written under a once_flag)
+constexpr int MAX_DEVICES = 32;
+int device_cus() {
+  static std::once_flag once[MAX_DEVICES];
+  static int cus[MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 256;
+  std::call_once(once[dev], [dev] {
+    int v = 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev] = v;
+  });
+  return cus[dev];
+}
+
 template <typename T, typename DM>
 int launch_fwd(const rssf_winattn_fwd_params* p, const Geom& g, hipStream_t st) {
   using LY = FwdLayout<T, DM>;
   static_assert(LY::BYTES <= 160 * 1024, "LDS budget");
   int blocks = (g.nWin + LY::WAVES - 1) / LY::WAVES;
-  // persistent: 3 workgroups fit a CU's LDS; more blocks only re-stage the weights (measured 79.7 -> 71.9 us at 768 on 256 CUs)
-  static int cap = 0;
-  if (!cap) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    cap = 3 * cus;
-  }
+  // persistent: as many workgroups as the LDS footprint lets a CU hold; more blocks only re-stage the weights
+  // (measured 79.7 -> 71.9 us at 768 blocks on 256 CUs)
+  const int cap = FwdOcc<T, DM>::WG_PER_CU * device_cus();
   if (blocks > cap) blocks = cap;
   auto kern = winattn_fwd_kernel<T, DM>;
-  static bool attr_set = false;     // idempotent per instantiation; kept out of replayed hipGraph captures
-  if (LY::BYTES > 64 * 1024 && !attr_set) {
-    attr_set = true;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES);
+  if (LY::BYTES > 64 * 1024) {      // once per (instantiation, device); never inside a replayed hipGraph capture
+    static std::once_flag once[MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipError_t e = hipSuccess;
+    std::call_once(once[dev < 0 || dev >= MAX_DEVICES ? 0 : dev],
+                   [&] { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES); });
     if (e != hipSuccess) { set_error("winattn_fwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   }
   kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, g);

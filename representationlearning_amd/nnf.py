@@ -695,7 +695,9 @@ class _CGFLLoss(torch.autograd.Function):
 
 def cgfl_loss(logits, labels, aux, ignore_index=-1):
     """SegmentationLossaux 'ce' branch: logits logical NCHW (channels-last), labels int64 [B,H,W], aux [B,7]."""
-    return _CGFLLoss.apply(logits, labels, aux, int(ignore_index))
+    # detached HERE, not inside the node: the reference's loss only uses the aux scores under no_grad (CGFL.py:75-97), so the
+    # aux head is not part of the autograd graph at all (its parameters keep grad None; torch.optim.SGD skips them)
+    return _CGFLLoss.apply(logits, labels, aux.detach(), int(ignore_index))
 
 
 def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_sink=None, grad_deposit=None):

@@ -170,9 +170,14 @@ def argmax_confusion(scores, labels=None, cm=None, ignore_index=-1, want_pred=Tr
     return pred
 
 
+SQNORM_ELEMS = 1 + 2048          # 1 + RSSF_SQNORM_BLOCKS
+
+
 def grad_sqnorm(flat_grad, out):
-    """out[0] = ||flat_grad||^2 (fp32, on the current stream)."""
+    """out[0] = ||flat_grad||^2 (fp32, on the current stream); out: fp32 [SQNORM_ELEMS] (result + per-block partials)."""
     L.require_gpu(flat_grad)
+    if out.numel() < SQNORM_ELEMS:
+        raise ValueError("grad_sqnorm: `out` must hold %d floats (include/rssf.h)" % SQNORM_ELEMS)
     L.check(L.load().rssf_grad_sqnorm(L.ptr(_f32(flat_grad)), flat_grad.numel(), L.ptr(out), L.stream()), "rssf_grad_sqnorm")
     return out
 

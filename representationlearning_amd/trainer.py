@@ -84,14 +84,13 @@ class GradBuckets:
         self.launched = [False] * len(self.members)
         self.index_of = {id(p): i for i, p in enumerate(flat.params)}
         self.side = torch.cuda.Stream() if comm.direct else None
+        # The post-accumulate-grad hook fires once per parameter and backward pass, after the LAST node that uses the parameter
+        # has run - also when that node returned None because its kernels accumulated straight into p.grad (nnf's direct
+        # gradient accumulation): AccumulateGrad is scheduled for undefined gradients too (tests/test_dp_gloo.py pins this).
+        # So the hook alone is the "gradient complete, kernels enqueued" signal; signalling by hand as well counted every
+        # parameter twice and launched buckets half-way (caught by tests/test_gpu_dp.py at world 2).
         for i, p in enumerate(flat.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
-
-    def param_ready(self, p):
-        """Called by the fused backward nodes that accumulate straight into p.grad (no AccumulateGrad hook fires)."""
-        i = self.index_of.get(id(p))
-        if i is not None:
-            self._make_hook(i)(p)
 
     def _make_hook(self, i):
         def hook(param):
@@ -183,12 +182,12 @@ class Trainer:
         self.rt.comm = self.comm
         self.rt.sync_all_bn = bool(sync_bn and dp)
         self.rt.force_collectives = dp and self.world == 1
-        self.rt.direct, self.rt.param_ready = True, (self.buckets.param_ready if self.buckets is not None else None)
+        self.rt.direct = True
         self.hp = dict(base_lr=base_lr, momentum=momentum, wd=weight_decay, max_norm=max_norm, power=power, max_iters=max_iters)
         self.bf16 = bf16
         self.it = 0
         dev = self.flat.flat.device
-        self.sqnorm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.sqnorm = torch.zeros(ops.SQNORM_ELEMS, device=dev, dtype=torch.float32)
         self.lr_dev = torch.zeros(1, device=dev, dtype=torch.float32)
         # torch.optim.SGD skips parameters whose gradient is None (no weight decay, no momentum): the flat update covers only
         # the ranges of parameters the loss reaches, found from the autograd graph of the first step

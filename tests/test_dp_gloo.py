@@ -18,17 +18,37 @@ def _free_port():
     return p
 
 
+class _DirectLinear(torch.autograd.Function):
+    """x @ w.T whose backward ACCUMULATES the weight gradient straight into w.grad and returns None for it - what every
+    librssf backward node does under the trainer's flat gradient buffer (representationlearning_amd.nnf.grad_target)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        w.grad += g.t() @ x
+        return g @ w, None
+
+
 class Net(nn.Module):
-    def __init__(self):
+    def __init__(self, direct=False):
         super().__init__()
         torch.manual_seed(0)
         self.a = nn.Linear(8, 16)
         self.b = nn.Linear(16, 16)
         self.c = nn.Linear(16, 4)
+        self.d = nn.Parameter(torch.randn(4, 4) * 0.3)      # used through the direct-accumulation node when `direct`
         self.unused = nn.Linear(3, 7)          # never in the graph (cf. headaux: SURVEY §2.2)
+        self.direct = direct
 
     def forward(self, x):
-        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+        h = self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+        # the parameter is used TWICE: its bucket may only go out after the second use has run backward
+        return _DirectLinear.apply(_DirectLinear.apply(h, self.d), self.d) if self.direct else (h @ self.d.t()) @ self.d.t()
 
 
 def _worker(rank, world, port, q):
@@ -36,7 +56,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from representationlearning_amd.trainer import FlatParams, GradBuckets
     from representationlearning_amd.rccl import TorchComm
-    net = Net()
+    net = Net(direct=True)
     flat = FlatParams(net)
     buckets = GradBuckets(flat, TorchComm(), nbuckets=3)
     assert len(buckets.bounds) >= 2 and buckets.bounds[0][1] == flat.numel and buckets.bounds[-1][0] == 0

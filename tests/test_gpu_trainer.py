@@ -31,7 +31,7 @@ def test_sgd_kernel_matches_torch_sgd():
     p = torch.randn(n, device="cuda"); g = [torch.randn(n, device="cuda") * s for s in (0.05, 3.0, 0.5)]
     ref = p.clone().requires_grad_()
     opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9, weight_decay=1e-4)
-    mom = torch.zeros_like(p); sq = torch.zeros(1, device="cuda")
+    mom = torch.zeros_like(p); sq = torch.zeros(ops.SQNORM_ELEMS, device="cuda")
     for i, gi in enumerate(g):
         ref.grad = gi.clone() * 0.5
         torch.nn.utils.clip_grad_norm_([ref], 35.0)

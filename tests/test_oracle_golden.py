@@ -147,7 +147,7 @@ def test_state_dict_keys(variant):
 
 
 @pytest.mark.parametrize("variant,B,S,tag", [("tiny", 2, 256, "tiny_2x256"), ("base", 2, 64, "base_2x64"),
-                                             ("large", 1, 64, "large_1x64")])
+                                             ("large", 1, 64, "large_1x64"), ("large", 1, 256, "large_1x256")])
 def test_full_model(variant, B, S, tag):
     """BASELINE config 1 (Tiny 2x3x256x256, one CPU train step) + small Base/Large."""
     g = golden(f"model_{tag}")
