@@ -29,16 +29,112 @@ FLOP_PER_IMG = 528.07e9        # fwd+bwd matmul/conv FLOPs per 512x512 image, Ba
 MFMA_BF16_PEAK = 2.5e15
 
 
+def _source_sha16(*rel):
+    import hashlib
+    h = hashlib.sha256()
+    for r in rel:
+        with open(os.path.join(ROOT, r), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+ATTN_SOURCES = ("representationlearning_amd/csrc/win_attn_fwd.hip", "representationlearning_amd/csrc/win_attn.hip.h",
+                "representationlearning_amd/csrc/common.hip.h")
+
+
 def _profiled_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed counter pass (profiles/r01_hbm_traffic.json, written from
-    tools/hbm_traffic.sh: rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum in a run of its own, reads
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read inside this process: None if absent."""
+    """HBM-side bytes per launch of `kernel` from the committed counter pass (profiles/r02_hbm_traffic.json, written by
+    tools/hbm_traffic.sh + tools/hbm_traffic_json.py: rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum in a
+    run of its own, reads doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read inside this process.
+    The file is stamped with the hash of the kernel's sources: a number measured on OTHER code is reported as null, not stale."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")) as f:
-            e = json.load(f)[kernel]
+        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
+            d = json.load(f)
+        if d.get("source_sha16") != _source_sha16(*ATTN_SOURCES):
+            return None
+        e = d[kernel]
         return int(e["read_bytes"] + e["write_bytes"])
     except (OSError, KeyError, ValueError):
         return None
+
+
+def _time_us(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def measure_dominant_kernels(B, S, iters=30):
+    """In-run HIP-event timings of the kernels that dominate the step BY TIME (profiles/r02_step_census.txt), at the benchmark
+    geometry of branch 0 (C = 32, (S/4)^2 map), each against the roofline that bounds it: the BatchNorm passes and the 3x3 halo
+    convolution / its weight gradient (HBM: arithmetic intensity 144 FLOP/B at C = 32), the attention backward (HBM)."""
+    from representationlearning_amd import _lib as L, nnf, ops
+    lib = L.load()
+    H = W = S // 4
+    C, dev = 32, "cuda"
+    rows = B * H * W
+    torch.manual_seed(1)
+    raw = torch.randn(B, H, W, C, device=dev).bfloat16()
+    dy = torch.randn(B, H, W, C, device=dev).bfloat16()
+    y = torch.empty_like(raw)
+    draw = torch.empty_like(raw)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mi, ss = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
+    stats = torch.zeros(nnf.BN_SLOTS * 2 * C, device=dev)
+    stats[:C] = raw.float().sum((0, 1, 2)); stats[C:2 * C] = raw.float().square().sum((0, 1, 2))
+    sums = torch.zeros(nnf.BN_BWD_SLOTS * 2 * C, device=dev)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    code, st = L.RSSF_BF16, L.stream
+    tensor_bytes = rows * C * 2
+    out = []
+
+    def entry(kernel, us, alg_bytes, what, flops=None):
+        gbs = alg_bytes / (us * 1e-6) / 1e9
+        d = dict(kernel=kernel, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                 us_per_launch=round(us, 2), algorithmic_bytes=alg_bytes, what=what)
+        if flops:
+            d["tflops"] = round(flops / (us * 1e-6) / 1e12, 1)
+        out.append(d)
+
+    us = _time_us(lambda: L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(mi),
+                                                             L.ptr(ss), None, None, L.ptr(y), rows, C, 1, float(rows), 0.1, 1e-5, 1, code, st()), "bn"), iters)
+    entry("bn_finapply_kernel<bf16,8>", us, 2 * tensor_bytes, "BatchNorm finalize+apply+ReLU, C=32: read raw, write y")
+    us = _time_us(lambda: (sums.zero_(), L.check(lib.rssf_bn_bwd_reduce(L.ptr(dy), L.ptr(raw), L.ptr(ss), None, L.ptr(sums), rows, C, 1, None, code, st()), "bn")), iters)
+    entry("bn_bwd_reduce_kernel<bf16,8> (+ 2 KB memset)", us, 2 * tensor_bytes, "BatchNorm backward statistics, C=32: read dy, raw")
+    us = _time_us(lambda: L.check(lib.rssf_bn_bwd_apply(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), None, L.ptr(draw), None, L.ptr(dg),
+                                                        L.ptr(db), rows, C, 1, float(rows), 1, 1.0, code, st()), "bn"), iters)
+    entry("bn_bwd_apply_kernel<bf16,8>", us, 3 * tensor_bytes, "BatchNorm backward apply, C=32: read dy, raw, write draw")
+    conv = torch.nn.Conv2d(C, C, 3, padding=1, bias=False).to(dev)
+    spec = nnf.spec_of([conv])
+    x = torch.relu(torch.randn(B, H, W, C, device=dev)).bfloat16()
+    cstats = torch.zeros(nnf.BN_SLOTS * 2 * C, device=dev)
+    flops = 2.0 * rows * C * C * 9
+    us = _time_us(lambda: nnf._conv_forward(spec, x, [conv.weight], None, cstats), iters)
+    entry("conv3x3_halo_kernel<8,32> (+ 4 us weight pack)", us, 2 * tensor_bytes, "3x3 conv 32->32 with fused BN statistics: read in, write out", flops)
+    dw = torch.zeros_like(conv.weight)
+    us = _time_us(lambda: nnf._conv_wgrad(spec, dy, x, [dw], None), iters)
+    entry("conv3x3_wgrad_halo_kernel + wgrad_reduce_kernel", us, 2 * tensor_bytes, "3x3 weight gradient 32x32: read dout, in", flops)
+    # attention backward (the kernel furthest below its roofline in round 1)
+    N = H * W
+    xa = torch.randn(B, N, C, device=dev).bfloat16(); ya = torch.randn(B, N, C, device=dev).bfloat16(); da = torch.randn(B, N, C, device=dev).bfloat16()
+    g1, b1 = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    _, sx = ops.layernorm_fwd(xa, g1, b1, want_y=False); _, sy = ops.layernorm_fwd(ya, g1, b1, want_y=False)
+    omega = torch.full((B, 2, N), 0.5, device=dev)
+    w = {}
+    for n in "qkvo":
+        w["w" + n] = (torch.randn(C, C, device=dev) / C ** 0.5).contiguous(); w["b" + n] = torch.zeros(C, device=dev)
+    gw = {k: torch.zeros_like(v) for k, v in w.items()}
+    us = _time_us(lambda: ops.winattn_bwd(da, xa, ya, sx, sy, omega, g1, b1, w, gw, H, W, 2), max(5, iters // 3))
+    entry("winattn_bwd_kernel<bf16,Dims<32,2>> + domega_reduce_kernel", us, 5 * B * N * C * 2, "read x, y, dout; write dxhat, dyhat")
+    return out
 
 
 def measure_window_attention(B, S, iters=30):
@@ -59,17 +155,10 @@ def measure_window_attention(B, S, iters=30):
         w["b" + n] = torch.zeros(C, device=dev)
     for _ in range(5):
         ops.winattn_fwd(x, y, sx, sy, omega, g, b, w, H, W, 2)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        ops.winattn_fwd(x, y, sx, sy, omega, g, b, w, H, W, 2)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = _time_us(lambda: ops.winattn_fwd(x, y, sx, sy, omega, g, b, w, H, W, 2), iters, warm=0) / 1e3
     alg_bytes = 3 * B * H * W * C * 2                # read low, read high, write out (bf16)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return dict(bound="hbm", kernel="winattn_fwd_kernel<bf16,Dims<32,2>>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    return dict(bound="hbm", kernel="winattn_fwd_kernel<bf16,Dims<32,2>,contiguous>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(gbs / HBM_PEAK_GBS, 4), traffic=_profiled_traffic("winattn_fwd_kernel") if (B, S) == (16, 512) else None,
                 us_per_launch=round(ms * 1e3, 2), algorithmic_bytes=alg_bytes)
 
@@ -129,9 +218,22 @@ def _cpu_baseline_child(threads, batch, max_steps):
         print("CPU_STEP %d %.4f" % (i, time.time() - t), flush=True)
 
 
-def cpu_baseline(budget_s=90.0, batch=2, max_steps=3):
-    """CPU restatement of the same training step (oracle/, plain PyTorch fp32) on the host cores: Base, 512x512.
-    Bounded: a subprocess is given `budget_s` seconds; step 0 is warm-up, the finished timed steps are averaged."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=150.0, batch=2, warm=3, timed=5):
+    """CPU restatement of the same training step (oracle/, plain PyTorch fp32) on the host cores: Base, 512x512, B = 2, 3 warm-up +
+    5 timed steps (SURVEY §8d / BASELINE.md §3).  Bounded: a subprocess is given `budget_s` seconds; the timed steps that finished
+    by then are averaged (the sample string says how many)."""
+    max_steps = warm + timed - 1
     import subprocess
     threads = min(os.cpu_count() or 1, 32)      # oneDNN does not scale past a few dozen threads at this size
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(threads), str(batch), str(max_steps)]
@@ -146,19 +248,20 @@ def cpu_baseline(budget_s=90.0, batch=2, max_steps=3):
                 break
             if line.startswith("CPU_STEP"):
                 _, i, dt = line.split()
-                if int(i) > 0:
+                if int(i) >= warm:
                     times.append(float(dt))
         elif proc.poll() is not None:
             break
     if proc.poll() is None:
         proc.kill()
+    cpu = "%s, %d logical cores" % (_cpu_model(), os.cpu_count() or 0)
     if not times:
-        return dict(value=None, unit="images/s", cores=threads, kind="port",
+        return dict(value=None, unit="images/s", cores=threads, kind="port", cpu=cpu,
                     sample="no timed step of the CPU oracle (fp32, B=%d, 3x512x512) finished within %.0f s" % (batch, budget_s))
     dt = sum(times) / len(times)
-    return dict(value=round(batch / dt, 4), unit="images/s", cores=threads, kind="port",
-                sample="1 warm-up + %d timed steps of the CPU oracle (fp32, B=%d, 3x512x512, fwd+loss+bwd+clip+SGD), %d threads"
-                       % (len(times), batch, threads))
+    return dict(value=round(batch / dt, 4), unit="images/s", cores=threads, kind="port", cpu=cpu,
+                sample="%d warm-up + %d timed steps of the CPU oracle (fp32, B=%d, 3x512x512, fwd+loss+bwd+clip+SGD), %d threads"
+                       % (warm, len(times), batch, threads))
 
 
 def main():
@@ -167,8 +270,8 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE: 16)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--variant", default="base")
@@ -234,6 +337,7 @@ def main():
         if world == 1:
             line["roofline"] = measure_window_attention(args.batch, args.size)
             line["roofline_mfma"] = measure_mlp_conv(args.batch, args.size)
+            line["roofline_kernels"] = measure_dominant_kernels(args.batch, args.size)
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -97,9 +97,11 @@ typedef struct {
   float* domega;               /* [B][2][N].  With prod_ws: overwritten.  Without: must be zeroed by the caller, accumulated
                                 * with one fp32 atomic per activation element (18 M per Base launch: 43 % of the kernel) */
   float* dwq; float* dbq; float* dwk; float* dbk; float* dwv; float* dbv; float* dwo; float* dbo;  /* += */
-  float* prod_ws;              /* optional scratch [2][B][N][C] fp32: the per-element products d(x~)*LN(x), d(y~)*LN(y) are
-                                * stored there and a second launch sums the C elements that share a gate weight */
+  void* prod_ws;               /* optional scratch [2][B][N][C] of the ACTIVATION dtype (rssf_winattn_bwd_workspace_elems()): the
+                                * per-element products d(x~)*LN(x), d(y~)*LN(y) are stored there and a second launch sums, in
+                                * fp32, the C elements that share a gate weight */
 } rssf_winattn_bwd_params;
+int64_t rssf_winattn_bwd_workspace_elems(int B, int H, int W, int C);      /* elements of prod_ws */
 int rssf_winattn_bwd(const rssf_winattn_bwd_params* p, void* stream);
 
 /* ---- Convolution (implicit GEMM, MFMA) on channels-last activations ------------------------------------------
@@ -280,6 +282,9 @@ int rssf_comm_destroy(rssf_comm* comm);
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 /* D[16][16] = A[16][K] * B[16][K]^T through the library's MFMA tile helper (layout self-check). */
 int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, void* stream);
+/* probe of the DPP / v_permlane{16,32}_swap lane reductions: in[64] -> out[6][64] = per lane {xor-16 pair sum, xor-32 pair sum,
+ * 4-row sum, 4-row max, wave sum, wave max} */
+int rssf_debug_lane_reduce(const float* in, float* out, void* stream);
 /* probe of the LDS transpose read (ds_read_b64_tr_b16): lds[i] = i, lane l reads at element address addr[l] */
 int rssf_debug_trread(const int* addr, short* out, void* stream);
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "rssf_gate_weights_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),
     "rssf_gate_pool_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_winattn_fwd": (c_int, [ctypes.POINTER(WinAttnFwdParams), c_void_p]),
+    "rssf_winattn_bwd_workspace_elems": (c_int64, [c_int] * 4),
     "rssf_winattn_bwd": (c_int, [ctypes.POINTER(WinAttnBwdParams), c_void_p]),
     "rssf_conv_tile_n": (c_int, [c_int]),
     "rssf_conv_packed_elems": (c_int64, [c_int, c_int, c_int, c_int]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "rssf_allreduce_bucket": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "rssf_syncbn_exchange": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_comm_destroy": (c_int, [c_void_p]),
+    "rssf_debug_lane_reduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_trread": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_mma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }

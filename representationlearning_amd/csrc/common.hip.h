@@ -92,6 +92,42 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// The same reductions without LDS traffic: ds_bpermute (what __shfl_xor lowers to) is an LDS instruction with ~100 cycles of
+// latency, and these reductions sit on the dependency chain of every softmax row.  Within a 16-lane row: DPP (quad_perm,
+// row_half_mirror, row_mirror); across rows: the gfx950 lane-swap instructions.  v_permlane16_swap(a, b) exchanges the odd
+// rows of a with the even rows of b, v_permlane32_swap(a, b) the upper half of a with the lower half of b; called with a = b = v
+// the two results hold, in every lane, the two values of the lane's xor-16 (xor-32) pair.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+struct OpSum { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+// Measured (tests/test_gpu_conv.py::test_lane_reductions_without_lds): swap16(a, b) -> a = [a.row0, b.row0, a.row2, b.row2],
+// b = [a.row1, b.row1, a.row3, b.row3]; swap32(a, b) -> a = [a.lo, b.lo], b = [a.hi, b.hi].  Issued through inline asm with two
+// read-write operands (two distinct registers by construction): handed the SAME value twice, the compiler merges the two results
+// of the __builtin_amdgcn_permlane*_swap builtins into one (observed in the ISA: v_add_f32 v7, v7, v7 after the swap).  The
+// s_nop covers the VALU-write -> lane-swap-read hazard the compiler would otherwise schedule for.
+template <typename OP> __device__ __forceinline__ float xor16_reduce(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return OP::f(a, b);
+}
+template <typename OP> __device__ __forceinline__ float xor32_reduce(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return OP::f(a, b);
+}
+// all four rows (lanes l, l^16, l^32, l^48)
+template <typename OP> __device__ __forceinline__ float rows_reduce(float v) { return xor32_reduce<OP>(xor16_reduce<OP>(v)); }
+// the whole wave
+template <typename OP> __device__ __forceinline__ float wave_reduce_dpp(float v) {
+  v = OP::f(v, dpp_mov<0xB1>(v));       // quad_perm [1,0,3,2]
+  v = OP::f(v, dpp_mov<0x4E>(v));       // quad_perm [2,3,0,1]
+  v = OP::f(v, dpp_mov<0x141>(v));      // row_half_mirror: quad q <-> quad q^1
+  v = OP::f(v, dpp_mov<0x140>(v));      // row_mirror: half <-> half
+  return rows_reduce<OP>(v);
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) given e = exp(-u*u): one v_rcp + 6 FMA.
 // The library erff costs ~35 VALU instructions with two range branches and made the GELU BatchNorm passes (128 channels
 // at 1/4 resolution, 33 M elements) VALU-bound at 2.4 TB/s; the exponential is shared with the Gaussian of the gradient.
@@ -149,7 +185,11 @@ __device__ __forceinline__ f32x4 mma_tile(const T* A, int lda, const T* B, int l
 // Pack 4 accumulator values (k-slots (l>>4)*4 + r of a 16-wide K tile) into a B/A fragment for the NEXT
 // mma whose K axis is this tile's row axis (register chaining, no LDS).  bf16: one frag; f32: 4 frags.
 __device__ __forceinline__ s16x4 pack_bf16x4(f32x4 v) {
-  return __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4_t));      // 2 x v_cvt_pk_bf16_f32
+  // two v_cvt_pk_bf16_f32.  (The 4-wide __builtin_convertvector lowers to four single conversions + two v_perm_b32 on gfx950:
+  // 6 instructions per packed tile, 13 % of the window-attention forward's VALU stream.)
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+  const u32x2_t r = {f2bf2(v[0], v[1]), f2bf2(v[2], v[3])};
+  return __builtin_bit_cast(s16x4, r);
 }
 
 }  // namespace rssf

@@ -47,6 +47,31 @@ extern "C" int rssf_debug_trread(const int* addr, short* out, void* stream) {
   return check_launch("debug_trread");
 }
 
+namespace {
+// probe of the LDS-free lane reductions of common.hip.h: out[0..5][lane] = xor16 sum, xor32 sum, 4-row sum, 4-row max, wave sum, wave max
+__global__ void debug_lane_reduce_kernel(const float* in, float* out) {
+  const int lane = threadIdx.x;
+  const float v = in[lane];
+  out[0 * 64 + lane] = xor16_reduce<OpSum>(v);
+  out[1 * 64 + lane] = xor32_reduce<OpSum>(v);
+  out[2 * 64 + lane] = rows_reduce<OpSum>(v);
+  out[3 * 64 + lane] = rows_reduce<OpMax>(v);
+  out[4 * 64 + lane] = wave_reduce_dpp<OpSum>(v);
+  out[5 * 64 + lane] = wave_reduce_dpp<OpMax>(v);
+  // raw semantics probe: a = 1000 + lane, b = 2000 + lane
+  const auto r16 = __builtin_amdgcn_permlane16_swap(1000u + lane, 2000u + lane, false, false);
+  const auto r32 = __builtin_amdgcn_permlane32_swap(1000u + lane, 2000u + lane, false, false);
+  out[6 * 64 + lane] = (float)r16[0]; out[7 * 64 + lane] = (float)r16[1];
+  out[8 * 64 + lane] = (float)r32[0]; out[9 * 64 + lane] = (float)r32[1];
+}
+}  // namespace
+
+extern "C" int rssf_debug_lane_reduce(const float* in, float* out, void* stream) {
+  RSSF_REQUIRE(in && out, "debug_lane_reduce: bad arguments");
+  debug_lane_reduce_kernel<<<1, 64, 0, (hipStream_t)stream>>>(in, out);
+  return check_launch("debug_lane_reduce");
+}
+
 extern "C" int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, void* stream) {
   RSSF_REQUIRE(a && b && d && K >= 16 && K % 16 == 0, "debug_mma: bad arguments");
   hipStream_t st = (hipStream_t)stream;

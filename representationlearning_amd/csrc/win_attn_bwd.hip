@@ -181,7 +181,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   const T* DOUT = reinterpret_cast<const T*>(bp.dout);
   T* DXH = reinterpret_cast<T*>(bp.dxhat);
   T* DYH = reinterpret_cast<T*>(bp.dyhat);
-  float* PW = bp.prod_ws;
+  T* PW = reinterpret_cast<T*>(bp.prod_ws);          // products in the activation dtype (bf16 mode: half the scratch traffic)
   const int wpi = g.QH * g.QW;
 
   // Parameter gradients live in registers across ALL windows of this wave (the kernel is LDS-bound to one wave per
@@ -621,8 +621,8 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
             stf(DXH + off, dxt[ct][tt][r] * om0[pp]);
             stf(DYH + off, dyt[ct][tt][r] * om0[g.N + pp]);
             if (PW) {
-              PW[off] = dxt[ct][tt][r] * xh;
-              PW[(int64_t)g.B * g.N * C + off] = dyt[ct][tt][r] * yh;
+              stf(PW + off, dxt[ct][tt][r] * xh);
+              stf(PW + (int64_t)g.B * g.N * C + off, dyt[ct][tt][r] * yh);
             } else {
               atomicAdd(dom0 + pp, dxt[ct][tt][r] * xh);
               atomicAdd(dom0 + g.N + pp, dyt[ct][tt][r] * yh);
@@ -676,17 +676,18 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
 
 // domega[b][s][pp] = sum_j prod_s[b][pp + j*N], j = 0..C-1 : the C activation elements whose flat offset is pp modulo N
 // share gate weight pp (the reference's (B,N,C) -> view(B,C,H,W) scramble).  Coalesced over pp, C strided reads.
-__global__ void __launch_bounds__(256) domega_reduce_kernel(const float* __restrict__ prod, float* __restrict__ domega, int B, int N, int C) {
+template <typename T>
+__global__ void __launch_bounds__(256) domega_reduce_kernel(const T* __restrict__ prod, float* __restrict__ domega, int B, int N, int C) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)B * 2 * N) return;
   const int pp = (int)(gid % N), s = (int)((gid / N) % 2), b = (int)(gid / (2 * (int64_t)N));
-  const float* src = prod + ((int64_t)s * B + b) * N * C + pp;
+  const T* src = prod + ((int64_t)s * B + b) * N * C + pp;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int j = 0;
   for (; j + 3 < C; j += 4) {
-    a0 += src[(int64_t)j * N]; a1 += src[(int64_t)(j + 1) * N]; a2 += src[(int64_t)(j + 2) * N]; a3 += src[(int64_t)(j + 3) * N];
+    a0 += ldf(src + (int64_t)j * N); a1 += ldf(src + (int64_t)(j + 1) * N); a2 += ldf(src + (int64_t)(j + 2) * N); a3 += ldf(src + (int64_t)(j + 3) * N);
   }
-  for (; j < C; ++j) a0 += src[(int64_t)j * N];
+  for (; j < C; ++j) a0 += ldf(src + (int64_t)j * N);
   domega[gid] = (a0 + a1) + (a2 + a3);
 }
 
@@ -706,7 +707,7 @@ int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) 
   int rc = check_launch("winattn_bwd");
   if (rc || !p->prod_ws) return rc;
   const int64_t n = (int64_t)g.B * 2 * g.N;
-  domega_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(p->prod_ws, p->domega, g.B, g.N, DM::C);
+  domega_reduce_kernel<T><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(reinterpret_cast<const T*>(p->prod_ws), p->domega, g.B, g.N, DM::C);
   return check_launch("winattn_bwd(domega reduce)");
 }
 
@@ -735,6 +736,8 @@ int dispatch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st
 }
 
 }  // namespace
+
+extern "C" int64_t rssf_winattn_bwd_workspace_elems(int B, int H, int W, int C) { return (int64_t)2 * B * H * W * C; }
 
 extern "C" int rssf_winattn_bwd(const rssf_winattn_bwd_params* p, void* stream) {
   RSSF_REQUIRE(p, "winattn_bwd: null params");

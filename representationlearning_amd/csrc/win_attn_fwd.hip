@@ -108,35 +108,56 @@ template <typename T, typename DM> struct TileRegs {
   int pp[ITERS];                     // gate-weight index of the chunk's first element, -1: dead slot / padding chunk
 };
 
+// n mod d for 0 <= n < 2^24 with a precomputed float reciprocal: one multiply, a truncation and one correction step (the
+// compiler's 32-bit integer division is ~20 instructions and sits behind a branch)
+__device__ __forceinline__ int fast_mod(int n, int d, float rcp) {
+  int r = n - (int)((float)n * rcp) * d;
+  r = r < 0 ? r + d : r;
+  return r >= d ? r - d : r;
+}
+
+// window-dependent SCALARS of the tile addressing; everything per lane is 32-bit arithmetic against them
+struct WinBase {
+  int uq, vq;          // image row / column of window slot 0 (may be negative: the centre padding)
+  int nc;              // N / C when N % C == 0 (gate weights of a token row are contiguous), else 0
+  float rcp_nc;
+};
+
 template <typename T, typename DM>
 __device__ __forceinline__ void tiles_issue(TileRegs<T, DM>& R, const rssf_winattn_fwd_params& p, const Geom& g, const T* X, const T* Y,
-                                            int wi, int lane) {
+                                            int wi, int lane, int nc, float rcp_nc) {
   using TR = TileRegs<T, DM>;
   const int wpi = g.QH * g.QW;
-  const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;
-  const int64_t img = (int64_t)b * g.N;
+  const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;           // scalar (wi is wave-uniform)
+  const int uq = qh * WIN - g.padT, vq = qw * WIN - g.padL;
+  const T* Xi = X + (int64_t)b * g.N * DM::C;                                // uniform bases: saddr + 32-bit lane offsets
+  const T* Yi = Y + (int64_t)b * g.N * DM::C;
+  const float* Sx = p.stats_x + (int64_t)b * g.N * 2;
+  const float* Sy = p.stats_y + (int64_t)b * g.N * 2;
 #pragma unroll
   for (int it = 0; it < TR::ITERS; ++it) {          // branch-free: dead / padded slots read token 0 and are zeroed later
     const int e = lane + it * 64;
     const int t = e / TR::CPR, c0 = (e % TR::CPR) * TR::V;
-    const int n = slot_token(g, qh, qw, t);
-    const bool ok = n >= 0 && c0 < DM::C && e < LP * TR::CPR;
-    const int nn = ok ? n : 0, cc = ok ? c0 : 0;
-    const int64_t f = (int64_t)nn * DM::C + cc;
-    R.vx[it].load(X + img * DM::C + f);
-    R.vy[it].load(Y + img * DM::C + f);
+    const int u = uq + t / WIN, v = vq + t % WIN;
+    const bool ok = t < WIN * WIN && (unsigned)u < (unsigned)g.H && (unsigned)v < (unsigned)g.W && c0 < DM::C && e < LP * TR::CPR;
+    const int nn = ok ? u * g.W + v : 0;
+    const unsigned f = (unsigned)(nn * DM::C + (ok ? c0 : 0));                // N*C < 2^31 (checked by the entry points); unsigned:
+    R.vx[it].load(Xi + f);                                                    // scalar base + 32-bit lane offset, no 64-bit VALU
+    R.vy[it].load(Yi + f);
 #if RSSF_FWD_PREFETCH_STATS
-    R.sx[it] = *reinterpret_cast<const float2*>(p.stats_x + (img + nn) * 2);
-    R.sy[it] = *reinterpret_cast<const float2*>(p.stats_y + (img + nn) * 2);
+    R.sx[it] = *reinterpret_cast<const float2*>(Sx + (unsigned)(nn * 2));
+    R.sy[it] = *reinterpret_cast<const float2*>(Sy + (unsigned)(nn * 2));
 #else
     R.tok[it] = nn;
 #endif
-    R.pp[it] = ok ? (int)((unsigned)f % (unsigned)g.N) : -1;          // N*C < 2^31 (checked by the entry points)
+    // gate-weight index (n*C + c) mod N: with N = nc*C it is (n mod nc)*C + c
+    const int pp = nc ? fast_mod(nn, nc, rcp_nc) * DM::C + c0 : (int)(f % (unsigned)g.N);
+    R.pp[it] = ok ? pp : -1;
   }
 }
 
 // LayerNorm (given stats) * gate weight omega[(n*C+c) mod N] -> LDS as T, zero rows for padded / dead slots
-template <typename T, typename DM>
+template <typename T, typename DM, bool CONTIG>
 __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rssf_winattn_fwd_params& p, int64_t img, const Geom& g,
                                              const float* sLn, const float* om0, T* xs, T* ys, int ldx, int lane) {
   using TR = TileRegs<T, DM>;
@@ -145,23 +166,24 @@ __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rss
   float2 sxv[TR::ITERS], syv[TR::ITERS];
 #pragma unroll
   for (int it = 0; it < TR::ITERS; ++it) {
-    sxv[it] = *reinterpret_cast<const float2*>(p.stats_x + (img + R.tok[it]) * 2);
-    syv[it] = *reinterpret_cast<const float2*>(p.stats_y + (img + R.tok[it]) * 2);
+    sxv[it] = *reinterpret_cast<const float2*>(p.stats_x + img * 2 + (unsigned)(R.tok[it] * 2));
+    syv[it] = *reinterpret_cast<const float2*>(p.stats_y + img * 2 + (unsigned)(R.tok[it] * 2));
   }
 #endif
-  const bool contiguous = g.N % DM::C == 0;   // the V gate weights of a chunk are contiguous (no wrap inside a token row)
+  constexpr bool contiguous = CONTIG;        // N % C == 0: the V gate weights of a chunk are contiguous (no wrap inside a token row)
+  const float* om1 = om0 + g.N;
   // gate weights: L2-resident (128 KB per image, every token row of a 512-token stripe reads the same 2 x C floats); fetched
   // one iteration ahead of their use instead of all up front (64 registers for 4 iterations kept the kernel at 2 waves/SIMD)
   float4 wa[2][V / 4], wb[2][V / 4];
   auto fetch = [&](int it, int slot) {
-    const int q = R.pp[it] < 0 ? 0 : R.pp[it];
+    const unsigned q = R.pp[it] < 0 ? 0u : (unsigned)R.pp[it];
 #pragma unroll
     for (int i = 0; i < V / 4; ++i) {
-      wa[slot][i] = *reinterpret_cast<const float4*>(om0 + q + 4 * i);
-      wb[slot][i] = *reinterpret_cast<const float4*>(om0 + g.N + q + 4 * i);
+      wa[slot][i] = *reinterpret_cast<const float4*>(om0 + (q + 4 * i));
+      wb[slot][i] = *reinterpret_cast<const float4*>(om1 + (q + 4 * i));
     }
   };
-  if (contiguous) fetch(0, 0);
+  if constexpr (contiguous) fetch(0, 0);
 #pragma unroll
   for (int it = 0; it < TR::ITERS; ++it) {
     const int e = lane + it * 64;
@@ -169,7 +191,7 @@ __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rss
     const int t = e / TR::CPR, c0 = (e % TR::CPR) * V;
     const bool ok = R.pp[it] >= 0;
     float w0[V], w1[V];
-    if (contiguous) {
+    if constexpr (contiguous) {
       if (it + 1 < TR::ITERS) fetch(it + 1, (it + 1) & 1);
 #pragma unroll
       for (int i = 0; i < V / 4; ++i) {
@@ -211,13 +233,15 @@ template <typename T, typename DM> struct FwdOcc {
   static constexpr int VALUE = sizeof(T) == 2 ? (WAVES_PER_SIMD > RSSF_FWD_OCC ? RSSF_FWD_OCC : (WAVES_PER_SIMD < 1 ? 1 : WAVES_PER_SIMD)) : 1;
 };
 
-template <typename T, typename DM>
+// CONTIG: N % C == 0 (every HRNet geometry of the path: the gate weights of a token row are contiguous).  A compile-time flag so
+// that the general-geometry gather (one scalar gate weight per element) is not carried as dead code through the hot variant.
+template <typename T, typename DM, bool CONTIG>
 __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>::VALUE)) winattn_fwd_kernel(rssf_winattn_fwd_params p, Geom g) {
   using LY = FwdLayout<T, DM>;
   constexpr int LDX = LY::LDX, LDW = LY::LDW, LDO = LY::LDO;
   constexpr int C = DM::C, CP = DM::CP, CV = DM::CV, MT = DM::MT, CT = DM::CT, TPH = DM::TPH, D = DM::D;
   constexpr int LW = WIN * WIN;                      // live tokens of a window (the entry point checked window == 7)
-  constexpr bool PIPE = sizeof(T) == 2 && (C % Vec<T>::N) == 0;      // next window's global loads issued one window ahead
+  constexpr bool PIPE = CONTIG && sizeof(T) == 2 && (C % Vec<T>::N) == 0;      // next window's global loads issued one window ahead
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // ---- workgroup-shared: weights as T (MFMA operands), biases / LN affine fp32 ---------------------------------
   T* sWq = reinterpret_cast<T*>(smem_raw);           // [CV][LDW]  virtual rows, k = real input channel
@@ -238,7 +262,9 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
   const int stride = gridDim.x * LY::WAVES;
   int wi = blockIdx.x * LY::WAVES + wave;
   TileRegs<T, DM> R;
-  if constexpr (PIPE) tiles_issue<T, DM>(R, p, g, X, Y, wi < g.nWin ? wi : g.nWin - 1, lane);   // under the weight staging below
+  const int nc = CONTIG ? g.N / C : 0;
+  const float rcp_nc = nc ? 1.0f / (float)nc : 0.f;
+  if constexpr (PIPE) tiles_issue<T, DM>(R, p, g, X, Y, wi < g.nWin ? wi : g.nWin - 1, lane, nc, rcp_nc);   // under the weight staging below
 
   for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
     const int m = i / LDW, k = i % LDW;
@@ -275,13 +301,15 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
     const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;
     const int64_t img = (int64_t)b * g.N;
     const float* om0 = p.omega + (int64_t)b * 2 * g.N;
+    const T* Ximg = X + img * C;
+    T* OUTimg = OUT + img * C;
 
     // ---- 1. both 49xC tiles: LayerNorm (given stats) * gate weight -> LDS as T, zero padded ------------------------------
     wave_sync();
     if constexpr (PIPE) {
-      tiles_finish<T, DM>(R, p, img, g, sLn, om0, xs, ys, LDX, lane);
+      tiles_finish<T, DM, CONTIG>(R, p, img, g, sLn, om0, xs, ys, LDX, lane);
       const int nx = wi + stride < g.nWin ? wi + stride : g.nWin - 1;     // clamped, never branched around: a conditional load
-      tiles_issue<T, DM>(R, p, g, X, Y, nx, lane);                         // makes every later s_waitcnt drain to zero
+      tiles_issue<T, DM>(R, p, g, X, Y, nx, lane, nc, rcp_nc);                         // makes every later s_waitcnt drain to zero
     } else {
       load_gated_tiles<T, DM>(p, g, sLn, X, Y, om0, img, qh, qw, xs, ys, LDX, lane);
     }
@@ -346,9 +374,9 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
             const int i = it * 16 + grp * 4 + r, j = jt * 16 + l15;
             if (i < D && j < D) { msum += Macc[it][jt][r]; mmax = fmaxf(mmax, Macc[it][jt][r]); }
           }
-      msum = wave_sum(msum);
-      mmax = wave_max(mmax);
-      const float alpha = sigmoidf(msum / (float)(D * D) + mmax);
+      msum = wave_reduce_dpp<OpSum>(msum);
+      mmax = wave_reduce_dpp<OpMax>(mmax);
+      const float alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-(msum * (1.0f / (float)(D * D)) + mmax)));   // sigmoid, v_rcp_f32 (1 ulp)
 
       // per query tile: S^T = k q^T, softmax over keys, O^T = v^T P^T
 #pragma unroll
@@ -370,16 +398,14 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
             if (kt * 16 + grp * 4 + r >= LW) s[kt][r] = -INFINITY;
             mx = fmaxf(mx, s[kt][r]);
           }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_reduce<OpMax>(mx);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); sum += s[kt][r]; }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = alpha / sum;      // fold alpha into the normalisation: o = alpha * (P v)
+        sum = rows_reduce<OpSum>(sum);
+        const float inv = alpha * __builtin_amdgcn_rcpf(sum);      // fold alpha into the normalisation: o = alpha * (P v)
         typename PK::type pk[NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
@@ -408,7 +434,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int c0 = ct * 16 + grp * 4;
-          xres[qt][ct] = Quad<T>::load_raw(X + (img + (ntok[qt] >= 0 ? ntok[qt] : 0)) * C + (c0 < C ? c0 : 0));
+          xres[qt][ct] = Quad<T>::load_raw(Ximg + (unsigned)((ntok[qt] >= 0 ? ntok[qt] : 0) * C + (c0 < C ? c0 : 0)));
         }
     }
 #pragma unroll
@@ -420,18 +446,18 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc = PK::mma_lds_a(sWo + ct * 16 * LDO, LDO, mt * 16, o[mt][qt], acc);
         const int c0 = ct * 16 + grp * 4;
-        const int64_t off = (img + n) * C + c0;
+        const unsigned off = (unsigned)(n * C + c0);                     // 32-bit, against the image's uniform base pointer
         if constexpr (C % 4 == 0) {
           float xr[4];
           Quad<T>::unpack(xres[qt][ct], xr);
 #pragma unroll
           for (int r = 0; r < 4; ++r) xr[r] += acc[r] + sB[3 * CV + (c0 < C ? c0 : 0) + r];
-          if (n >= 0 && c0 < C) Quad<T>::store(OUT + off, xr);
+          if (n >= 0 && c0 < C) Quad<T>::store(OUTimg + off, xr);
         } else {
           if (n < 0) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (c0 + r < C) stf(OUT + off + r, ldf(X + off + r) + acc[r] + sB[3 * CV + c0 + r]);
+            if (c0 + r < C) stf(OUTimg + off + r, ldf(Ximg + off + r) + acc[r] + sB[3 * CV + c0 + r]);
         }
       }
     }
@@ -459,20 +485,32 @@ int launch_fwd(const rssf_winattn_fwd_params* p, const Geom& g, hipStream_t st) 
   using LY = FwdLayout<T, DM>;
   static_assert(LY::BYTES <= 160 * 1024, "LDS budget");
   int blocks = (g.nWin + LY::WAVES - 1) / LY::WAVES;
-  // persistent: as many workgroups as the LDS footprint lets a CU hold; more blocks only re-stage the weights
-  // (measured 79.7 -> 71.9 us at 768 blocks on 256 CUs)
-  const int cap = FwdOcc<T, DM>::WG_PER_CU * device_cus();
-  if (blocks > cap) blocks = cap;
-  auto kern = winattn_fwd_kernel<T, DM>;
-  if (LY::BYTES > 64 * 1024) {      // once per (instantiation, device); never inside a replayed hipGraph capture
-    static std::once_flag once[MAX_DEVICES];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    hipError_t e = hipSuccess;
-    std::call_once(once[dev < 0 || dev >= MAX_DEVICES ? 0 : dev],
-                   [&] { e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES); });
-    if (e != hipSuccess) { set_error("winattn_fwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
-  }
+  const bool contig = g.N % DM::C == 0 && g.N < (1 << 24);
+  auto kern = contig ? winattn_fwd_kernel<T, DM, true> : winattn_fwd_kernel<T, DM, false>;
+  // once per (instantiation, device): raise the dynamic-LDS limit, then ask the runtime how many workgroups a CU really holds
+  // (registers AND LDS).  Persistent grid = exactly that many: a larger grid leaves a second, half-empty round of workgroups
+  // (the LDS-only estimate of 3 per CU against the 2 the registers allow cost a third of the machine in the tail).
+  static std::once_flag once[MAX_DEVICES];
+  static int resident[MAX_DEVICES];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  hipError_t e = hipSuccess;
+  std::call_once(once[dev], [&] {
+    if (LY::BYTES > 64 * 1024) {
+      e = hipFuncSetAttribute((const void*)winattn_fwd_kernel<T, DM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)winattn_fwd_kernel<T, DM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES);
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)winattn_fwd_kernel<T, DM, true>, LY::WAVES * 64, LY::BYTES) != hipSuccess ||
+        per_cu < 1)
+      per_cu = 1;
+    (void)hipGetLastError();
+    resident[dev] = per_cu * device_cus();
+  });
+  if (e != hipSuccess) { set_error("winattn_fwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
+  if (blocks > resident[dev]) blocks = resident[dev];
   kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, g);
   return check_launch("winattn_fwd");
 }

@@ -134,7 +134,7 @@ def winattn_bwd(dout, x, y, stats_x, stats_y, omega, ln_g, ln_b, w, gw, H, W, he
     dyhat = torch.empty_like(y)
     if workspace:
         domega = torch.empty(B, 2, N, device=x.device, dtype=torch.float32)
-        prod_ws = torch.empty(2, B, N, C, device=x.device, dtype=torch.float32)    # per-element gate-gradient products (see rssf.h)
+        prod_ws = torch.empty(L.load().rssf_winattn_bwd_workspace_elems(B, H, W, C), device=x.device, dtype=x.dtype)   # gate-gradient products (rssf.h)
     else:
         domega = torch.zeros(B, 2, N, device=x.device, dtype=torch.float32)
         prod_ws = None

@@ -169,7 +169,8 @@ def test_winattn_base_shape_properties():
 @pytest.mark.parametrize("C,H,W,dtype", [(32, 16, 16, torch.bfloat16), (48, 14, 21, torch.bfloat16), (18, 7, 7, torch.float32)])
 def test_winattn_bwd_workspace_route_matches_atomic_route(C, H, W, dtype):
     """rssf_winattn_bwd with prod_ws (products + reduce launch, domega overwritten) and without (atomics into a zeroed
-    domega) are the same sums in a different order: every other output is bit-identical, domega agrees to fp32 rounding."""
+    domega) are the same sums in a different order (fp32 mode; in bf16 mode the scratch products are bf16): every other output is
+    bit-identical, domega agrees to the rounding of its summands."""
     from representationlearning_amd import ops
     B, N = 2, H * W
     P, ln = _attn_params(C)
@@ -190,6 +191,7 @@ def test_winattn_bwd_workspace_route_matches_atomic_route(C, H, W, dtype):
     (dx0, dy0, dom0, gw0), (dx1, dy1, dom1, gw1) = res
     assert torch.equal(dx0, dx1) and torch.equal(dy0, dy1)
     assert torch.isfinite(dom0).all() and dom0.abs().max() > 0
-    assert rel_err(dom0.cpu(), dom1.cpu()) < 1e-5
+    # the workspace route keeps the products in the activation dtype: bf16 rounding of each of the C summands in bf16 mode
+    assert rel_err(dom0.cpu(), dom1.cpu()) < (1e-5 if dtype == torch.float32 else 5e-3)
     for k in gw0:
         assert rel_err(gw0[k].cpu(), gw1[k].cpu()) < 1e-5, k

@@ -288,3 +288,22 @@ def test_cgfl_loss_full_size_properties():
     gsum = lg.grad.float().sum(1)
     assert float(gsum.abs().max()) < 1e-6
     assert float(lg.grad.float().abs().sum(1)[y == -1].max()) == 0.0
+
+
+def test_lane_reductions_without_lds():
+    """The DPP / v_permlane16_swap / v_permlane32_swap reductions of common.hip.h (softmax row max / sum of the window attention
+    without ds_bpermute) - lane semantics MEASURED, like the transpose read above."""
+    from representationlearning_amd import _lib as L
+    torch.manual_seed(3)
+    v = torch.randn(64, device=DEV)
+    out = torch.empty(6, 64, device=DEV)
+    L.check(L.load().rssf_debug_lane_reduce(L.ptr(v), L.ptr(out), L.stream()), "rssf_debug_lane_reduce")
+    v, out = v.cpu().double(), out.cpu().double()
+    lanes = torch.arange(64)
+    assert torch.allclose(out[0], v + v[lanes ^ 16], atol=1e-6), (out[0], v + v[lanes ^ 16])
+    assert torch.allclose(out[1], v + v[lanes ^ 32], atol=1e-6)
+    rows = v.view(4, 16)
+    assert torch.allclose(out[2], rows.sum(0).repeat(4), atol=1e-6)
+    assert torch.equal(out[3], rows.max(0).values.repeat(4))
+    assert torch.allclose(out[4], v.sum().expand(64), atol=1e-5)
+    assert torch.equal(out[5], v.max().expand(64))

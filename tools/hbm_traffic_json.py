@@ -1,0 +1,18 @@
+"""tools/hbm_traffic.sh table -> profiles JSON that bench.py's roofline.traffic reads, stamped with the hash of the kernel sources
+the counters were taken on (bench.py reports null when the sources have changed since):
+    python tools/hbm_traffic_json.py gpurun_out/<tag>.txt profiles/r02_hbm_traffic.json"""
+import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+src, dst = sys.argv[1], sys.argv[2]
+out = {"_source": "%s (tools/hbm_traffic.sh: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum in a "
+                  "pass of its own; reads = RDREQ x 64 B x 2 per MI355X_MICROARCH.md (HBM, gfx950), writes = 32 B / 64 B requests; "
+                  "B=16, 128x128 tokens, C=32, bf16)" % os.path.basename(src),
+       "source_sha16": bench._source_sha16(*bench.ATTN_SOURCES)}
+for line in open(src):
+    m = re.match(r"(\S*?(winattn_fwd_kernel|winattn_bwd_kernel|domega_reduce_kernel)\S*)\s+(\d+)\s+\S+\s+\S+\s+([\d.]+)\s+([\d.]+)\s*$", line)
+    if m and m.group(2) not in out:
+        out[m.group(2)] = {"read_bytes": int(float(m.group(4)) * 1e6), "write_bytes": int(float(m.group(5)) * 1e6), "launches": int(m.group(3))}
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
