@@ -163,10 +163,27 @@ int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float
  * workspace: fp32 scratch of rssf_conv_wgrad_workspace_elems() elements for the split-K partials (two-stage
  * reduction); NULL selects the slower atomic path. */
 int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Cin, int Cout, int ntaps);
+/* The second (reduction) stage of the split-K gradient can be DEFERRED: with defer_reduce != NULL only the first stage is
+ * launched and *defer_reduce (host memory) receives the description of the pending reduction - the workspace must then stay
+ * untouched until the caller has run it through rssf_conv_wgrad_reduce_batch, which serves any number of pending
+ * reductions (e.g. all ~330 convolutions of a training step) in ONE launch.  jobs / block_map are DEVICE arrays; block_map
+ * holds, for each of the nblocks workgroups, {job index, block index within the job}, a job contributing
+ * rssf_conv_wgrad_reduce_blocks(job) consecutive blocks (0 when nothing is pending: partial == NULL). */
+typedef struct rssf_wgrad_reduce_job {
+  const float* partial;           /* [ksplit][ntaps][cout][cin] fp32 */
+  float* dw[3];                   /* torch-layout fp32 gradients of the source convolutions (+=) */
+  int ks[3];
+  int ntaps, cout, cin, ksplit;
+  int src_of_tap[RSSF_MAX_TAPS];
+  int kpos_of_tap[RSSF_MAX_TAPS];
+  int alias_of_tap[RSSF_MAX_TAPS][4];
+} rssf_wgrad_reduce_job;
 int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes, int nsrc,
                     const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias, float* workspace,
                     int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy,
-                    const int* dx, int dtype, void* stream);
+                    const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream);
+int rssf_conv_wgrad_reduce_blocks(const rssf_wgrad_reduce_job* job);
+int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, const int* block_map, int nblocks, void* stream);
 
 /* ---- BatchNorm2d (+ activation + residual adds), channels-last: nn.BatchNorm2d / nn.SyncBatchNorm call sites of
  *      _hrnet_rssformer.py, hrnet_aux.py:47 and ffn_block.py:222-234 (momentum 0.1, eps 1e-5) -------------------- */
@@ -282,8 +299,8 @@ int rssf_comm_destroy(rssf_comm* comm);
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 /* D[16][16] = A[16][K] * B[16][K]^T through the library's MFMA tile helper (layout self-check). */
 int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, void* stream);
-/* probe of the DPP / v_permlane{16,32}_swap lane reductions: in[64] -> out[6][64] = per lane {xor-16 pair sum, xor-32 pair sum,
- * 4-row sum, 4-row max, wave sum, wave max} */
+/* probe of the DPP / v_permlane{16,32}_swap lane reductions: in[64] -> out[10][64] = per lane {xor-16 pair sum, xor-32 pair sum,
+ * 4-row sum, 4-row max, wave sum, wave max}, then the two results of swap16 and of swap32 on (1000 + lane, 2000 + lane) */
 int rssf_debug_lane_reduce(const float* in, float* out, void* stream);
 /* probe of the LDS transpose read (ds_read_b64_tr_b16): lds[i] = i, lane l reads at element address addr[l] */
 int rssf_debug_trread(const int* addr, short* out, void* stream);

@@ -36,6 +36,11 @@ class PackJob(ctypes.Structure):       # rssf_pack_job
         ("src_of_tap", c_int * MAX_TAPS), ("kpos_of_tap", c_int * MAX_TAPS), ("alias_of_tap", (c_int * 4) * MAX_TAPS)]
 
 
+class WgradReduceJob(ctypes.Structure):       # rssf_wgrad_reduce_job
+    _fields_ = [("partial", c_void_p), ("dw", c_void_p * 3), ("ks", c_int * 3)] + [(n, c_int) for n in ("ntaps", "cout", "cin", "ksplit")] + [
+        ("src_of_tap", c_int * MAX_TAPS), ("kpos_of_tap", c_int * MAX_TAPS), ("alias_of_tap", (c_int * 4) * MAX_TAPS)]
+
+
 # name -> (restype, argtypes); every symbol include/rssf.h declares must appear here (tests check it)
 SIGNATURES = {
     "rssf_version": (ctypes.c_char_p, []),
@@ -61,7 +66,9 @@ SIGNATURES = {
     "rssf_conv_stats_workspace_elems": (c_int64, [c_int] * 4),
     "rssf_conv_gather_add": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_workspace_elems": (c_int64, [c_int] * 6),
-    "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv_wgrad_reduce_blocks": (c_int, [c_void_p]),
+    "rssf_conv_wgrad_reduce_batch": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),
     "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),

@@ -18,6 +18,7 @@
 // scatters to its three source convs); measured: per-element atomics from ~1000 blocks cost 300-470 us per call,
 // ~10x the GEMM itself.  (Without a workspace the kernel falls back to atomics.)
 // Optional bias gradient (sum_p dout) for convolutions without a following BatchNorm.
+#include <cstring>
 #include "conv.hip.h"
 using namespace rssf;
 using namespace rssf::cv;
@@ -266,11 +267,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 // gradient elements (128-byte rows of the partial planes); its 8 thread groups walk interleaved k planes with four
 // loads in flight each, fold through LDS, and one thread per element does the (non-atomic) read-modify-write.
 constexpr int RI = 32, RG = 8;
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
+// second stage of the split-K weight gradient: dw += sum over the ksplit planes of `partial`, for one job (= one convolution).
+// `blk` = block index within the job (RI columns of the [ntaps*Cout*Cin] plane each).
+__device__ __forceinline__ void wgrad_reduce_body(const rssf_wgrad_reduce_job& a, int blk) {
   __shared__ float red[RG][RI];
-  const int64_t per = (int64_t)a.ntaps_total * a.Cout * a.Cin;
+  const int64_t per = (int64_t)a.ntaps * a.cout * a.cin;
   const int ii = threadIdx.x % RI, kg = threadIdx.x / RI;
-  const int64_t i = (int64_t)blockIdx.x * RI + ii;
+  const int64_t i = (int64_t)blk * RI + ii;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < per) {
     const float* p = a.partial + i;
@@ -293,14 +296,42 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < RG; ++g) s += red[g][ii];
-    const int ci = (int)(i % a.Cin), co = (int)((i / a.Cin) % a.Cout), tap = (int)(i / ((int64_t)a.Cin * a.Cout));
+    const int ci = (int)(i % a.cin), co = (int)((i / a.cin) % a.cout), tap = (int)(i / ((int64_t)a.cin * a.cout));
     const int sc = a.src_of_tap[tap], kk = a.ks[sc] * a.ks[sc];
-    a.dw[sc][((int64_t)co * a.Cin + ci) * kk + a.kpos_of_tap[tap]] += s;
+    a.dw[sc][((int64_t)co * a.cin + ci) * kk + a.kpos_of_tap[tap]] += s;
     for (int e = 0; e < 4; e += 2) {
-      const int s2 = a.alias[tap][e];
-      if (s2 >= 0) a.dw[s2][((int64_t)co * a.Cin + ci) * (a.ks[s2] * a.ks[s2]) + a.alias[tap][e + 1]] += s;
+      const int s2 = a.alias_of_tap[tap][e];
+      if (s2 >= 0) a.dw[s2][((int64_t)co * a.cin + ci) * (a.ks[s2] * a.ks[s2]) + a.alias_of_tap[tap][e + 1]] += s;
     }
   }
+}
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(rssf_wgrad_reduce_job a) { wgrad_reduce_body(a, blockIdx.x); }
+// every deferred reduction of a training step in ONE launch: block b serves job block_map[2b], block block_map[2b+1] of it
+// (331 launches of ~5.6 us - each a latency-bound walk over ~9 MB of partials - become one bandwidth-bound pass)
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const rssf_wgrad_reduce_job* __restrict__ jobs, const int* __restrict__ block_map) {
+  wgrad_reduce_body(jobs[block_map[2 * blockIdx.x]], block_map[2 * blockIdx.x + 1]);
+}
+
+rssf_wgrad_reduce_job make_job(const WgradArgs& a) {
+  rssf_wgrad_reduce_job j;
+  memset(&j, 0, sizeof(j));            // padding bytes too: callers compare job descriptions bytewise
+  j.partial = a.partial;
+  for (int i = 0; i < 3; ++i) { j.dw[i] = a.dw[i]; j.ks[i] = a.ks[i]; }
+  j.ntaps = a.ntaps_total; j.cout = a.Cout; j.cin = a.Cin; j.ksplit = a.ksplit;
+  for (int t = 0; t < MAX_TAPS; ++t) {
+    const bool live = t < a.ntaps_total;
+    j.src_of_tap[t] = live ? a.src_of_tap[t] : 0; j.kpos_of_tap[t] = live ? a.kpos_of_tap[t] : 0;
+    for (int e = 0; e < 4; ++e) j.alias_of_tap[t][e] = live ? a.alias[t][e] : -1;
+  }
+  return j;
+}
+// run the second stage now, or hand its description to the caller (who batches it: rssf_conv_wgrad_reduce_batch)
+int finish_reduce(const WgradArgs& a, rssf_wgrad_reduce_job* defer, hipStream_t st) {
+  const rssf_wgrad_reduce_job j = make_job(a);
+  if (defer) { *defer = j; return RSSF_OK; }
+  const int64_t per = (int64_t)j.ntaps * j.cout * j.cin;
+  wgrad_reduce_kernel<<<(unsigned)((per + RI - 1) / RI), 256, 0, st>>>(j);
+  return check_launch("conv_wgrad_reduce");
 }
 
 // ---- halo-tiled weight gradient of the 3x3 / stride-1 / "same" bf16 convolutions (HRNet BasicBlock / Bottleneck) -------
@@ -500,7 +531,7 @@ int launch_group(WgradArgs& a, int tap0, int ntap, hipStream_t st) {
 }
 
 template <typename T>
-int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
+int launch_all(WgradArgs& a, int ntaps, rssf_wgrad_reduce_job* defer, hipStream_t st) {
   // tap groups: consecutive taps of one source conv (1 for a 1x1, 9 for a 3x3)
   int t = 0;
   const int tile = tile_of(a.Cout, a.Cin);
@@ -517,11 +548,8 @@ int launch_all(WgradArgs& a, int ntaps, hipStream_t st) {
     if (rc) return rc;
     t += n;
   }
-  if (a.partial) {
-    const int64_t per = (int64_t)ntaps * a.Cout * a.Cin;
-    wgrad_reduce_kernel<<<(unsigned)((per + RI - 1) / RI), 256, 0, st>>>(a);
-    return check_launch("conv_wgrad_reduce");
-  }
+  if (a.partial) return finish_reduce(a, defer, st);
+  if (defer) defer->partial = nullptr;      // atomics path: nothing left to do
   return RSSF_OK;
 }
 
@@ -536,7 +564,7 @@ extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Ci
 extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
                                int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
                                float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
-                               const int* dy, const int* dx, int dtype, void* stream) {
+                               const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream) {
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
@@ -571,12 +599,21 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
     for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
     conv3x3_wgrad_halo_kernel<<<(unsigned)h.xcd_per * 8, HWG_THREADS, 0, st>>>(h);
     if (int rc = check_launch("conv3x3_wgrad_halo")) return rc;
-    const int64_t per = (int64_t)ntaps * Cout * Cin;
-    wgrad_reduce_kernel<<<(unsigned)((per + RI - 1) / RI), 256, 0, st>>>(a);
-    return check_launch("conv_wgrad_reduce");
+    return finish_reduce(a, defer_reduce, st);
   }
-  if (dtype == RSSF_F32) return launch_all<float>(a, ntaps, st);
-  if (dtype == RSSF_BF16) return launch_all<bf16_t>(a, ntaps, st);
+  if (dtype == RSSF_F32) return launch_all<float>(a, ntaps, defer_reduce, st);
+  if (dtype == RSSF_BF16) return launch_all<bf16_t>(a, ntaps, defer_reduce, st);
   set_error("conv_wgrad: unsupported dtype %d", dtype);
   return RSSF_ERR_UNSUPPORTED;
+}
+
+extern "C" int rssf_conv_wgrad_reduce_blocks(const rssf_wgrad_reduce_job* job) {
+  if (!job || !job->partial) return 0;
+  return (int)(((int64_t)job->ntaps * job->cout * job->cin + RI - 1) / RI);
+}
+
+extern "C" int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, const int* block_map, int nblocks, void* stream) {
+  RSSF_REQUIRE(jobs && block_map && nblocks > 0, "conv_wgrad_reduce_batch: bad arguments");
+  wgrad_reduce_batch_kernel<<<(unsigned)nblocks, 256, 0, (hipStream_t)stream>>>(jobs, block_map);
+  return check_launch("conv_wgrad_reduce_batch");
 }

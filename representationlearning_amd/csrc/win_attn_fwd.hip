@@ -38,7 +38,10 @@ template <typename T, typename DM> struct FwdLayout {
   static constexpr int W_ELEMS = 3 * DM::CV * LDW + DM::CP * LDO;
   static constexpr int F_ELEMS = 3 * DM::CV + 3 * DM::CP;   // biases + LN affine (fp32)
   static constexpr size_t SHARED_OFF = (sizeof(T) * W_ELEMS + sizeof(float) * F_ELEMS + 15) / 16 * 16;
-  static constexpr size_t WAVE_BYTES = sizeof(T) * 2 * REGION;
+  // bf16: a third tile per wave keeps the RAW x tokens for the residual (they are in registers when the tile is staged; re-reading
+  // them from global cost 9 MB of fabric traffic per launch on top of the L2 hits)
+  static constexpr int NREG = sizeof(T) == 2 ? 3 : 2;
+  static constexpr size_t WAVE_BYTES = sizeof(T) * NREG * REGION;
   // waves per workgroup: as many (<= 4) as fit the 160 KiB LDS of one CU
   static constexpr int WAVES = (SHARED_OFF + 4 * WAVE_BYTES <= 160 * 1024) ? 4 : (SHARED_OFF + 2 * WAVE_BYTES <= 160 * 1024) ? 2 : 1;
   static constexpr size_t BYTES = SHARED_OFF + WAVE_BYTES * WAVES;
@@ -159,7 +162,7 @@ __device__ __forceinline__ void tiles_issue(TileRegs<T, DM>& R, const rssf_winat
 // LayerNorm (given stats) * gate weight omega[(n*C+c) mod N] -> LDS as T, zero rows for padded / dead slots
 template <typename T, typename DM, bool CONTIG>
 __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rssf_winattn_fwd_params& p, int64_t img, const Geom& g,
-                                             const float* sLn, const float* om0, T* xs, T* ys, int ldx, int lane) {
+                                             const float* sLn, const float* om0, T* xs, T* ys, T* xr, int ldx, int lane) {
   using TR = TileRegs<T, DM>;
   constexpr int V = TR::V;
 #if !RSSF_FWD_PREFETCH_STATS
@@ -223,6 +226,7 @@ __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rss
     ox.set_all(fx); oy.set_all(fy);
     ox.store(xs + t * ldx + c0);
     oy.store(ys + t * ldx + c0);
+    R.vx[it].store(xr + t * ldx + c0);            // raw tokens for the residual of step 4 (dead slots: never read back)
   }
 }
 
@@ -252,8 +256,9 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
   float* sLn = sB + 3 * CV + CP;                     // gamma[CP] beta[CP]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l15 = lane & 15, grp = lane >> 4;
-  T* xs = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)wave * 2 * LY::REGION;   // [LP][LDX] gated LN(x)
+  T* xs = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)wave * LY::NREG * LY::REGION;   // [LP][LDX] gated LN(x)
   T* ys = xs + LY::REGION;                                                                    // [LP][LDX] gated LN(y)
+  T* xr = ys + LY::REGION;                                                                    // [LP][LDX] raw x (bf16 pipeline only)
 
   const T* X = reinterpret_cast<const T*>(p.x);
   const T* Y = reinterpret_cast<const T*>(p.y);
@@ -307,7 +312,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
     // ---- 1. both 49xC tiles: LayerNorm (given stats) * gate weight -> LDS as T, zero padded ------------------------------
     wave_sync();
     if constexpr (PIPE) {
-      tiles_finish<T, DM, CONTIG>(R, p, img, g, sLn, om0, xs, ys, LDX, lane);
+      tiles_finish<T, DM, CONTIG>(R, p, img, g, sLn, om0, xs, ys, xr, LDX, lane);
       const int nx = wi + stride < g.nWin ? wi + stride : g.nWin - 1;     // clamped, never branched around: a conditional load
       tiles_issue<T, DM>(R, p, g, X, Y, nx, lane, nc, rcp_nc);                         // makes every later s_waitcnt drain to zero
     } else {
@@ -425,10 +430,18 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
     }
 
     // ---- 4. out-projection (transposed) + bias + residual; each lane stores 4 consecutive channels of one token ----------
-    // residual values: re-read from the lines this wave fetched a moment ago (L2 / infinity-cache hits), issued before the
-    // out-projection MFMAs that cover their latency - not carried in registers across steps 2-3
+    // residual values: from the raw-x tile in LDS (bf16 pipeline) or re-read from global just before the out-projection MFMAs
+    // that cover their latency - not carried in registers across steps 2-3
     typename Quad<T>::raw xres[NT][CT];
-    if constexpr (C % 4 == 0) {
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c0 = ct * 16 + grp * 4;
+          xres[qt][ct] = Quad<T>::load_raw(xr + (qt * 16 + l15) * LDX + (c0 < C ? c0 : 0));       // LDS
+        }
+    } else if constexpr (C % 4 == 0) {
 #pragma unroll
       for (int qt = 0; qt < NT; ++qt)
 #pragma unroll

@@ -78,6 +78,7 @@ class Runtime:
         self.side_streams = {}
         self.zero_pool = ZeroPool()
         self.pack_plan = None
+        self.wgrad_plan = None
         # fixed-order reductions for the BatchNorm statistics (bit-identical runs): RSSF_DETERMINISTIC=1 or set by the caller
         self.deterministic = os.environ.get("RSSF_DETERMINISTIC", "0") == "1"
 
@@ -313,11 +314,82 @@ class PackPlan:
         return self.views.get(key) if (self.built and self.fresh) else None
 
 
-def step_begin(device, plan=None, rt=None):
+class WgradPlan:
+    """Deferred second stage of the split-K weight gradients: the ~330 `wgrad_reduce` launches of a step (5.6 us each, a
+    latency-bound walk over ~9 MB of partials) become ONE `rssf_conv_wgrad_reduce_batch` launch at the end of backward.
+    Step 1 records the sequence of weight-gradient calls and their workspace sizes; then one arena holds every layer's partials
+    at a fixed address (the captured hipGraph needs that anyway), and from step 2 on `_conv_wgrad` launches the first stage
+    only.  The device-side job table is built from the first deferred step and checked against every later one."""
+
+    def __init__(self):
+        self.sizes, self.keys = [], []          # recorded call sequence
+        self.recording, self.built = False, False
+        self.cursor = 0
+        self.jobs_host, self.jobs_dev, self.bmap_dev, self.nblocks = [], None, None, 0
+        self.pending = False
+
+    def begin(self):
+        self.cursor = 0
+        self.pending = False
+
+    def record(self, key, elems):
+        self.keys.append(key)
+        self.sizes.append(int(elems))
+
+    def build(self, device):
+        offs, tot = [], 0
+        for n in self.sizes:
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64
+        self.arena = torch.empty(max(tot, 1), device=device, dtype=torch.float32)
+        self.offs = offs
+        self.built = True
+
+    def slot(self, key):
+        """Workspace slice + job struct for the next weight-gradient call of the step, or None if the call sequence changed."""
+        i = self.cursor
+        if not self.built or i >= len(self.keys) or self.keys[i] != key:
+            self.built = False                       # a different step shape: fall back to immediate reductions for good
+            return None
+        self.cursor += 1
+        ws = self.arena[self.offs[i]:self.offs[i] + self.sizes[i]]
+        if len(self.jobs_host) <= i:
+            self.jobs_host.append(L.WgradReduceJob())
+            return ws, self.jobs_host[i], None
+        return ws, L.WgradReduceJob(), self.jobs_host[i]
+
+    def flush(self):
+        """Run every pending reduction (one launch)."""
+        if not self.pending:
+            return
+        lib = L.load()
+        if self.jobs_dev is None:
+            if self.cursor != len(self.keys):
+                raise RuntimeError("WgradPlan: %d of %d recorded weight-gradient calls ran in this step" % (self.cursor, len(self.keys)))
+            arr = (L.WgradReduceJob * len(self.jobs_host))(*self.jobs_host)
+            bmap = []
+            for j in range(len(self.jobs_host)):
+                bmap += [(j, b) for b in range(lib.rssf_conv_wgrad_reduce_blocks(ctypes.byref(arr[j])))]
+            dev = self.arena.device
+            self.jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.bmap_dev = torch.tensor(bmap, dtype=torch.int32).reshape(-1, 2).to(dev).contiguous()
+            self.nblocks = len(bmap)
+        if self.nblocks:
+            L.check(lib.rssf_conv_wgrad_reduce_batch(L.ptr(self.jobs_dev), L.ptr(self.bmap_dev), self.nblocks, L.stream()),
+                    "rssf_conv_wgrad_reduce_batch")
+        self.pending = False
+
+
+def step_begin(device, plan=None, rt=None, wgrad_plan=None):
     """Trainer hook: start of a training step (zero pool reset + batched weight packing)."""
     rt = rt or current()
     rt.zero_pool.begin(device)
     rt.pack_plan = plan
+    rt.wgrad_plan = wgrad_plan
+    if wgrad_plan is not None:
+        wgrad_plan.begin()
+        if not wgrad_plan.built and not wgrad_plan.keys:
+            wgrad_plan.recording = True
     if plan is not None:
         if plan.built:
             plan.refresh()
@@ -336,6 +408,14 @@ def step_end(rt=None):
             plan.build()
         plan.fresh = False
     rt.pack_plan = None
+    wp = rt.wgrad_plan
+    if wp is not None:
+        wp.flush()
+        if wp.recording:
+            wp.recording = False
+            if wp.keys:
+                wp.build(rt.zero_pool.buf.device if rt.zero_pool.buf is not None else torch.device("cuda"))
+    rt.wgrad_plan = None
 
 
 def _zeros(n, device, rt=None):
@@ -412,8 +492,9 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None):
     return dx
 
 
-def _conv_wgrad(spec, dout, xh, dws, db):
-    """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional)."""
+def _conv_wgrad(spec, dout, xh, dws, db, rt=None):
+    """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional).  Under a WgradPlan the split-K
+    reduction is deferred to the plan's one batched launch (the gradients are complete after WgradPlan.flush())."""
     xh, dout = _pad_channels(xh), _pad_channels(dout)
     B, H, W, C = xh.shape
     _, OH, OW, CO = dout.shape
@@ -424,10 +505,27 @@ def _conv_wgrad(spec, dout, xh, dws, db):
         tdb = torch.zeros(CO, device=xh.device, dtype=torch.float32) if db is not None else None
     d = tgt + [None, None]
     lib = L.load()
-    ws = torch.empty(lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, CO, spec.ntaps), device=xh.device, dtype=torch.float32)
+    nws = lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, CO, spec.ntaps)
+    plan = (rt or current()).wgrad_plan
+    ws = job = ref = None
+    if plan is not None and not padded and tdb is None:
+        key = (id(spec), B, H, W, C, OH, OW, CO, xh.dtype, tuple(t.data_ptr() for t in dws))
+        if plan.recording:
+            plan.record(key, nws)
+        else:
+            got = plan.slot(key)
+            if got is not None:
+                ws, job, ref = got
+    if ws is None:
+        ws = torch.empty(nws, device=xh.device, dtype=torch.float32)
     L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws),
                                      spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb), L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps,
-                                     spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()), "rssf_conv_wgrad")
+                                     spec.c_dy, spec.c_dx, None if job is None else ctypes.byref(job), L.dtype_code(xh), L.stream()),
+            "rssf_conv_wgrad")
+    if job is not None:
+        if ref is not None and bytes(job) != bytes(ref):
+            raise RuntimeError("WgradPlan: a deferred weight-gradient reduction changed between steps")
+        plan.pending = True
     if padded:
         for g, t in zip(dws, tgt):
             g += t[:spec.cout, :spec.cin]
@@ -521,7 +619,7 @@ class _ConvBNAct(torch.autograd.Function):
             dx = None
         wt = [grad_target(w, rt) for w in p_weights]
         db = _zeros(C, raw.device, rt) if nbias else None
-        _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db)
+        _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt)
         gws = [grad_result(w, t[0], t[1], rt) for w, t in zip(p_weights, wt)]
         gbs = []
         for b in p_biases:      # every summed conv's bias sees the same gradient
@@ -557,7 +655,7 @@ class _ConvBias(torch.autograd.Function):
         p_w, p_b = ctx.params
         tw, wd = grad_target(p_w, rt)
         tb, bd = grad_target(p_b, rt) if has_bias else (None, False)
-        _conv_wgrad(spec, dyh, xh, [tw], tb)
+        _conv_wgrad(spec, dyh, xh, [tw], tb, rt)
         return dx, None, grad_result(p_w, tw, wd, rt), (grad_result(p_b, tb, bd, rt) if has_bias else None)
 
 

@@ -203,6 +203,9 @@ class Trainer:
         # and the SyncBN exchanges of a DP step must reach the communicator in one fixed order, so both keep a single stream
         self.rt.branch_streams = self.use_graph and not dp and os.environ.get("RSSF_BRANCH_STREAMS", "1") != "0"
         self.pack_plan = nnf.PackPlan() if os.environ.get("RSSF_PACK_PLAN", "1") != "0" else None
+        # one batched split-K reduction per step instead of ~330 (nnf.WgradPlan).  With gradient buckets in flight during
+        # backward a bucket's gradients must be final when its parameters report ready, so the reductions stay immediate there.
+        self.wgrad_plan = nnf.WgradPlan() if (self.buckets is None and os.environ.get("RSSF_WGRAD_PLAN", "1") != "0") else None
         self.graph = None
         self._static = None
         self._side = None
@@ -229,7 +232,7 @@ class Trainer:
             self.buckets.begin()
         with nnf.use(self.rt):
             # one zero-fill and one weight re-pack for the whole step (nnf.ZeroPool / nnf.PackPlan)
-            nnf.step_begin(self.flat.flat.device, self.pack_plan)
+            nnf.step_begin(self.flat.flat.device, self.pack_plan, wgrad_plan=self.wgrad_plan)
             try:
                 with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
                     out = self.model(img, target)

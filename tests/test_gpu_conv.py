@@ -296,7 +296,7 @@ def test_lane_reductions_without_lds():
     from representationlearning_amd import _lib as L
     torch.manual_seed(3)
     v = torch.randn(64, device=DEV)
-    out = torch.empty(6, 64, device=DEV)
+    out = torch.empty(10, 64, device=DEV)
     L.check(L.load().rssf_debug_lane_reduce(L.ptr(v), L.ptr(out), L.stream()), "rssf_debug_lane_reduce")
     v, out = v.cpu().double(), out.cpu().double()
     lanes = torch.arange(64)
@@ -307,3 +307,10 @@ def test_lane_reductions_without_lds():
     assert torch.equal(out[3], rows.max(0).values.repeat(4))
     assert torch.allclose(out[4], v.sum().expand(64), atol=1e-5)
     assert torch.equal(out[5], v.max().expand(64))
+    # raw semantics of the two swaps on a = 1000 + lane, b = 2000 + lane (what common.hip.h documents)
+    a, b = 1000 + lanes, 2000 + lanes
+    ar, br = a.view(4, 16), b.view(4, 16)
+    assert out[6].long().tolist() == torch.cat([ar[0], br[0], ar[2], br[2]]).tolist()
+    assert out[7].long().tolist() == torch.cat([ar[1], br[1], ar[3], br[3]]).tolist()
+    assert out[8].long().tolist() == torch.cat([a[:32], b[:32]]).tolist()
+    assert out[9].long().tolist() == torch.cat([a[32:], b[32:]]).tolist()

@@ -11,8 +11,9 @@ out = {"_source": "%s (tools/hbm_traffic.sh: rocprofv3 --kernel-trace --pmc TCC_
                   "B=16, 128x128 tokens, C=32, bf16)" % os.path.basename(src),
        "source_sha16": bench._source_sha16(*bench.ATTN_SOURCES)}
 for line in open(src):
-    m = re.match(r"(\S*?(winattn_fwd_kernel|winattn_bwd_kernel|domega_reduce_kernel)\S*)\s+(\d+)\s+\S+\s+\S+\s+([\d.]+)\s+([\d.]+)\s*$", line)
-    if m and m.group(2) not in out:
-        out[m.group(2)] = {"read_bytes": int(float(m.group(4)) * 1e6), "write_bytes": int(float(m.group(5)) * 1e6), "launches": int(m.group(3))}
+    for name in ("winattn_fwd_kernel", "winattn_bwd_kernel", "domega_reduce_kernel"):
+        if name in line and name not in out:
+            f = line.split()
+            out[name] = {"read_bytes": int(float(f[-2]) * 1e6), "write_bytes": int(float(f[-1]) * 1e6), "launches": int(f[-5])}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
