@@ -166,7 +166,7 @@ def measure_window_attention(B, S, iters=30):
 def measure_mlp_conv(B, S, iters=20):
     """Average duration of the MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12} convolution (ONE implicit-GEMM launch, 17 distinct taps,
     128 -> 128 channels on the (S/4)^2 map): the largest single GEMM of the step, MFMA-bound."""
-    from representationlearning_amd import nnf
+    from representationlearning_amd import _lib as L, nnf
     H = W = S // 4
     C = 128
     dev = "cuda"
@@ -175,17 +175,17 @@ def measure_mlp_conv(B, S, iters=20):
     convs = [c.to(dev) for c in convs]
     spec = nnf.spec_of(convs)
     x = torch.nn.functional.gelu(torch.randn(B, H, W, C, device=dev)).bfloat16()      # the distribution fc1 + GELU feeds it
-    ws = [c.weight for c in convs]
-    for _ in range(3):
-        nnf._conv_forward(spec, x, ws, None, None)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        nnf._conv_forward(spec, x, ws, None, None)          # includes the (4 us) weight packing launch
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    # as in the training step: the weights are packed once per step for ALL convolutions (nnf.PackPlan, one launch), the
+    # convolution itself is the rssf_conv_gather_add launch timed here
+    wpk = nnf._pack(spec, [c.weight for c in convs], False, x.dtype, x.device)
+    out = torch.empty(B, H, W, C, device=dev, dtype=x.dtype)
+    lib = L.load()
+
+    def launch():
+        L.check(lib.rssf_conv_gather_add(L.ptr(x), L.ptr(wpk), L.ptr(out), None, None, None, None, B, H, W, C, H, W, C, 1, 1, spec.ntaps,
+                                         spec.c_dy, spec.c_dx, L.dtype_code(x), L.stream()), "rssf_conv_gather_add")
+
+    ms = _time_us(launch, iters) / 1e3
     flops = 2.0 * B * H * W * C * C * 19             # the reference's three convolutions: 1 + 9 + 9 kernel positions
     tf = flops / (ms * 1e-3) / 1e12
     return dict(bound="mfma", kernel="conv_gather_kernel<bf16,256,128> (MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12}, 128->128 ch)",

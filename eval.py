@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """eval.py — surface of the reference's RSSFormer-TIP2023/eval.py (:17-24, :32-81): `evaluate(ckpt_path, config_path,
 use_tta)`: load a checkpoint (DDP `module.` prefix stripped, :37-38), softmax -> argmax -> ignore(-1) mask -> confusion
-matrix -> mIoU, optionally with the six-scale test-time augmentation (module/tta.py).  The LoveDA loader is not part of this round
-(SURVEY.md §8f rank 3): without a dataset the synthetic validation tiles are used."""
+matrix -> mIoU, optionally with the six-scale test-time augmentation (module/tta.py).  Tiles: the LoveDA validation folders named by the config
+(data/loveda.py reader, normalised on the GPU) when they exist, else the synthetic validation tiles."""
 import argparse
 import os
 import sys
@@ -31,7 +31,13 @@ def evaluate(ckpt_path, config_path="baseline.hrnetw32", use_tta=False, batches=
         model.load_state_dict(remove_module_prefix(torch.load(ckpt_path, map_location="cpu")))
     model = model.cuda().eval()
     if batches is None:
-        batches = [synthetic_batch(4, 512, classes=cfg.model.params.classes, seed=7)]
+        test = cfg.data.test.params
+        dirs = [test.image_dir] if isinstance(test.image_dir, str) else list(test.image_dir)
+        if all(os.path.isdir(d) for d in dirs):         # the LoveDA validation folders of configs/base/loveda.py:47-56
+            from representationlearning_amd.data.loveda import DeviceLoader, LoveDA
+            batches = ((img, gt["cls"]) for img, gt in DeviceLoader(LoveDA(dirs, test.mask_dir), batch_size=test.batch_size))
+        else:
+            batches = [synthetic_batch(4, 512, classes=cfg.model.params.classes, seed=7)]
     # eval.py:57-64 of the reference: six bilinear scales when --tta
     scales = (0.5, 0.75, 1.0, 1.25, 1.5, 1.75) if use_tta else None
     # eval.py:48-50: palette PNGs next to the checkpoint (vis-<ckpt name>); without a checkpoint only when vis_dir is given

@@ -215,19 +215,22 @@ int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift,
                       const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
                       double n, int training, float param_grad_scale, int dtype, void* stream);
 
-/* ---- Device input pipeline: RandomCrop -> OneOf(HorizontalFlip, VerticalFlip, RandomRotate90) -> Normalize
- *      -> ToTensor and the LoveDA `mask - 1` shift (configs/base/loveda.py:18-36, data/loveda.py:82-91) as one gather over a
- *      device-resident uint8 dataset img [nsrc][SH][SW][3], mask [nsrc][SH][SW] (optional).  params [B][4] (device, int32) =
- *      {source image, crop y0, crop x0, op}; out_img [B][OH][OW][3] channels-last of `dtype`; out_mask [B][OH][OW] int64.
- *      Normalize as albumentations does it: (float32(v) - mean*max_pixel_value) * reciprocal(std*max_pixel_value).
- *      The rot90 ops need a square crop.  ShiftScaleRotate is not implemented. ------------------------------------------------ */
+/* ---- Device input pipeline: RandomCrop -> OneOf(HorizontalFlip, VerticalFlip, RandomRotate90) ->
+ *      ShiftScaleRotate -> Normalize -> ToTensor and the LoveDA `mask - 1` shift (configs/base/loveda.py:18-36,
+ *      data/loveda.py:82-91) as one gather over a device-resident uint8 dataset img [nsrc][SH][SW][3], mask [nsrc][SH][SW]
+ *      (optional).  params [B][4] (device, int32) = {source image, crop y0, crop x0, op}; affine (optional) [B][6] (device, double):
+ *      the INVERSE 2x3 matrix of the image's ShiftScaleRotate warp (cv2.invertAffineTransform of getRotationMatrix2D + shift), a NaN
+ *      in its first element = "this image is not warped"; the warp follows cv2.warpAffine on 8-bit data (fixed-point coordinates,
+ *      1/32-step bilinear taps, nearest for the mask, BORDER_REFLECT_101).  out_img [B][OH][OW][3] channels-last of `dtype`;
+ *      out_mask [B][OH][OW] int64.  Normalize as albumentations does it: (float32(v) - mean*max_pixel_value) *
+ *      reciprocal(std*max_pixel_value).  The rot90 ops need a square crop. ---------------------------------------------------- */
 #define RSSF_AUG_NONE 0
 #define RSSF_AUG_HFLIP 1
 #define RSSF_AUG_VFLIP 2
 #define RSSF_AUG_ROT90 3        /* + k, k = 0..3 quarter turns counter-clockwise (np.rot90) */
-int rssf_input_pipeline(const uint8_t* img, const uint8_t* mask, const int* params, void* out_img, int64_t* out_mask, int B,
-                        int nsrc, int SH, int SW, int OH, int OW, const float* mean3, const float* std3, float max_pixel_value,
-                        int dtype, void* stream);
+int rssf_input_pipeline(const uint8_t* img, const uint8_t* mask, const int* params, const double* affine, void* out_img,
+                        int64_t* out_mask, int B, int nsrc, int SH, int SW, int OH, int OW, const float* mean3, const float* std3,
+                        float max_pixel_value, int dtype, void* stream);
 
 /* ---- Up-sampling, channels-last ------------------------------------------------------------------------------
  * bilinear with align_corners=True: F.interpolate x3 in SimpleFusion8 (hrnet_aux.py:61-65), UpsamplingBilinear2d(x4)
@@ -241,6 +244,12 @@ int rssf_upsample_bilinear(const void* in, void* out, int B, int IH, int IW, int
  * copies.  IH == OH, IW == OW is the identity (the un-resized branch 0). */
 int rssf_upsample_bilinear_slice(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int ld_wide, int backward,
                                  int dtype, void* stream);
+/* Evaluation head in one pass: bilinear (align_corners=True) resize of the class logits [B,IH,IW,K] (K <= 32) to [B,OH,OW], softmax
+ * over K and/or argmax - nn.UpsamplingBilinear2d + `logit.softmax(dim=1)` of HRNetFusion.forward (hrnet_aux.py:80, 103-104) and
+ * `pred.argmax(dim=1)` of eval.py:66 / predict.py:42.  probs [B,OH,OW,K] fp32 channels-last (optional), pred [B,OH,OW] int32
+ * (optional; the first maximum wins, as torch.argmax); at least one of them. */
+int rssf_head_upsample_softmax(const void* logits, float* probs, int32_t* pred, int B, int IH, int IW, int OH, int OW, int K,
+                               int dtype, void* stream);
 /* nearest up-sampling by an integer factor fused with the running branch sum of the HRNet fuse layers
  * (_hrnet_rssformer.py:380, 424-427).  backward = 0: out [B,IH*s,IW*s,C] = (acc ? acc : 0) + up(in);
  * backward = 1: `in` is the output gradient, `out` [B,IH,IW,C] = its s x s block sums (acc ignored). */

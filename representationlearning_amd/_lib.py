@@ -75,9 +75,10 @@ SIGNATURES = {
     "rssf_bn_bwd_reduce_workspace_elems": (c_int64, [c_int64, c_int]),
     "rssf_bn_bwd_reduce": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "rssf_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_float, c_int, c_void_p]),
-    "rssf_input_pipeline": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_int, c_void_p]),
+    "rssf_input_pipeline": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "rssf_upsample_bilinear": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "rssf_upsample_bilinear_slice": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "rssf_head_upsample_softmax": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rssf_upsample_nearest_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rssf_cgfl_loss_fwd": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "rssf_cgfl_loss_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),

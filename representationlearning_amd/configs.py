@@ -34,4 +34,15 @@ def config_by_name(name):
         train=dict(forward_times=1, num_iters=30000, eval_per_epoch=True, summary_grads=False, summary_weights=False,
                    distributed=True, apex_sync_bn=True, sync_bn=True, eval_after_train=True, log_interval_step=50,
                    save_ckpt_interval_epoch=1000, eval_interval_epoch=20),
+        # data sections of configs/base/loveda.py:6-66 (paths and loader parameters; the transforms run on the GPU: data/loveda.py)
+        data=dict(
+            train=dict(type="LoveDALoader", params=dict(
+                image_dir=["./LoveDA/Train/Urban/images_png/", "./LoveDA/Train/Rural/images_png/"],
+                mask_dir=["./LoveDA/Train/Urban/masks_png/", "./LoveDA/Train/Rural/masks_png/"],
+                crop=512, p_oneof=0.75, shift_scale_rotate=dict(shift_limit=0.0625, scale_limit=0.2, rotate_limit=45, p=0.2),
+                CV=dict(k=10, i=-1), training=True, batch_size=8, num_workers=2)),
+            test=dict(type="LoveDALoader", params=dict(
+                image_dir=["./LoveDA/Val/Urban/images_png/", "./LoveDA/Val/Rural/images_png/"],
+                mask_dir=["./LoveDA/Val/Urban/masks_png/", "./LoveDA/Val/Rural/masks_png/"],
+                CV=dict(k=10, i=-1), training=False, batch_size=4, num_workers=0))),
         test=dict())

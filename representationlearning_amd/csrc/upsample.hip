@@ -212,6 +212,64 @@ int nearest_launch(const void* acc, const void* in, void* out, int B, int IH, in
 }
 }  // namespace
 
+namespace {
+// Evaluation head (hrnet_aux.py:80, 103-104; eval.py:66-71 / predict.py:41-43 of the reference): nn.UpsamplingBilinear2d(x s)
+// of the [B,IH,IW,K] class logits -> softmax over K -> (optional) argmax, one thread per output pixel, the K interpolated
+// logits never leave registers.  Replaces a bilinear pass + an ATen softmax pass (+ an argmax pass) over the full-resolution
+// [B,OH,OW,K] tensor by ONE write of the probabilities (fp32, channels-last) and/or the int32 class map.
+constexpr int HEAD_MAXK = 32;
+template <typename T>
+__global__ void __launch_bounds__(256) head_softmax_kernel(const T* __restrict__ in, float* __restrict__ probs, int32_t* __restrict__ pred,
+                                                           int B, int IH, int IW, int OH, int OW, int K, float sy, float sx) {
+  const int64_t total = (int64_t)B * OH * OW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const float fy = src_coord(oy, sy), fx = src_coord(ox, sx);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < IH ? y0 + 1 : IH - 1, x1 = x0 + 1 < IW ? x0 + 1 : IW - 1;
+    const float wy = fy - y0, wx = fx - x0;
+    const float w00 = (1.f - wy) * (1.f - wx), w01 = (1.f - wy) * wx, w10 = wy * (1.f - wx), w11 = wy * wx;
+    const T* base = in + (int64_t)b * IH * IW * K;
+    const T* p00 = base + ((int64_t)y0 * IW + x0) * K;
+    const T* p01 = base + ((int64_t)y0 * IW + x1) * K;
+    const T* p10 = base + ((int64_t)y1 * IW + x0) * K;
+    const T* p11 = base + ((int64_t)y1 * IW + x1) * K;
+    float v[HEAD_MAXK], mx = -INFINITY;
+    int arg = 0;
+    for (int k = 0; k < K; ++k) {
+      v[k] = w00 * ldf(p00 + k) + w01 * ldf(p01 + k) + w10 * ldf(p10 + k) + w11 * ldf(p11 + k);     // same order as bilinear_fwd_kernel
+      if (v[k] > mx) { mx = v[k]; arg = k; }                                                          // first maximum wins (torch.argmax)
+    }
+    if (pred) pred[i] = arg;
+    if (probs) {
+      float se = 0.f;
+      for (int k = 0; k < K; ++k) { v[k] = expf(v[k] - mx); se += v[k]; }
+      const float inv = 1.f / se;
+      float* dst = probs + i * K;
+      for (int k = 0; k < K; ++k) dst[k] = v[k] * inv;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int rssf_head_upsample_softmax(const void* logits, float* probs, int32_t* pred, int B, int IH, int IW, int OH, int OW, int K,
+                                          int dtype, void* stream) {
+  RSSF_REQUIRE(logits && (probs || pred) && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && K > 0 && K <= HEAD_MAXK,
+               "head_upsample_softmax: bad arguments (K <= %d)", HEAD_MAXK);
+  const float sy = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f, sx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+  const int64_t total = (int64_t)B * OH * OW;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) head_softmax_kernel<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)logits, probs, pred, B, IH, IW, OH, OW, K, sy, sx);
+  else if (dtype == RSSF_BF16) head_softmax_kernel<bf16_t><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)logits, probs, pred, B, IH, IW, OH, OW, K, sy, sx);
+  else { set_error("head_upsample_softmax: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  return check_launch("head_upsample_softmax");
+}
+
 extern "C" int rssf_upsample_bilinear_slice(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int ld_wide,
                                             int backward, int dtype, void* stream) {
   RSSF_REQUIRE(in && out && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && ld_wide >= C, "upsample_bilinear: bad arguments");

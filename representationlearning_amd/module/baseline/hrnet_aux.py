@@ -42,11 +42,30 @@ class HRNetFusion(ConfigModule):
         aux = self.headaux(self.avg_pool(f0).flatten(1).float())
         lg = nnf.conv_bias(fused, self.head[0])
         sc = self.head[1].scale_factor
-        logit = nnf.upsample_bilinear(lg, (int(lg.shape[2] * sc), int(lg.shape[3] * sc)))
+        size = (int(lg.shape[2] * sc), int(lg.shape[3] * sc))
+        if not self.training and not torch.is_grad_enabled():
+            # inference: x4 bilinear + softmax in one pass over the full-resolution map (the logits never reach HBM)
+            self._last_logits = None
+            return nnf.head_upsample_softmax(lg, size)[0]
+        logit = nnf.upsample_bilinear(lg, size)
         self._last_logits = logit          # debug tap used by the parity tests
         if self.training:
             return self.loss(logit, y["cls"].long(), aux)
         return logit.float().softmax(dim=1)
+
+    @torch.no_grad()
+    def predict(self, x):
+        """argmax class map [B,H,W] int32 of an image batch (predict.py:41-42 of the reference: `model(img).argmax(dim=1)`) without
+        materialising the probabilities: x4 bilinear + argmax fused in the head kernel."""
+        was = self.training
+        self.eval()
+        feats = self.backbone(x)
+        fused, _ = self.neck(feats)
+        lg = nnf.conv_bias(fused, self.head[0])
+        sc = self.head[1].scale_factor
+        pred = nnf.head_upsample_softmax(lg, (int(lg.shape[2] * sc), int(lg.shape[3] * sc)), want_probs=False, want_pred=True)[1]
+        self.train(was)
+        return pred
 
     def set_default_config(self):
         self.config.update(dict(

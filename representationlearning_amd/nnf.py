@@ -757,6 +757,20 @@ def upsample_bilinear(x, size):
     return _Bilinear.apply(x, int(size[0]), int(size[1]))
 
 
+def head_upsample_softmax(logits, size, want_probs=True, want_pred=False):
+    """Inference head: F.interpolate(logits, size, 'bilinear', align_corners=True).softmax(1) [and .argmax(1)] as ONE launch
+    (no autograd: evaluation only).  Returns (probs logical [B,K,OH,OW] fp32 channels-last or None, pred [B,OH,OW] int32 or None)."""
+    L.require_gpu(logits)
+    lh = _nhwc(logits.detach())
+    B, IH, IW, K = lh.shape
+    OH, OW = int(size[0]), int(size[1])
+    probs = torch.empty(B, OH, OW, K, device=lh.device, dtype=torch.float32) if want_probs else None
+    pred = torch.empty(B, OH, OW, device=lh.device, dtype=torch.int32) if want_pred else None
+    L.check(L.load().rssf_head_upsample_softmax(L.ptr(lh), L.ptr(probs), L.ptr(pred), B, IH, IW, OH, OW, K, L.dtype_code(lh), L.stream()),
+            "rssf_head_upsample_softmax")
+    return (None if probs is None else _nchw(probs)), pred
+
+
 def upsample_nearest_add(acc, x, scale):
     """(acc or 0) + nn.Upsample(scale_factor=scale, mode='nearest')(x)."""
     return _NearestAdd.apply(acc, x, int(scale))

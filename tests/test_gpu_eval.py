@@ -105,3 +105,63 @@ def test_evaluate_writes_palette_pngs(tmp_path):
     assert np.array_equal(gt, lab[1].cpu().numpy().astype(np.uint8) & 15)      # 4-bit palette file: ignore (-1 -> 255) reads as 15
     pred = np.asarray(Image.open(tmp_path / "0000_00.png"))
     assert pred.shape == (64, 64) and pred.max() < 6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,K,IH,IW,s", [(2, 6, 16, 16, 4), (1, 7, 9, 13, 4), (1, 19, 5, 7, 3)])
+def test_head_upsample_softmax_kernel(B, K, IH, IW, s, dtype):
+    """x s bilinear (align_corners=True) + softmax + argmax in one launch == F.interpolate + softmax + argmax."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(K)
+    lg = torch.randn(B, K, IH, IW).to(dtype)
+    ref_l = F.interpolate(lg.float(), size=(IH * s, IW * s), mode="bilinear", align_corners=True)
+    ref_p = ref_l.softmax(1)
+    probs, pred = nnf.head_upsample_softmax(lg.to(DEV).contiguous(memory_format=torch.channels_last), (IH * s, IW * s), want_pred=True)
+    assert probs.shape == ref_p.shape and probs.dtype == torch.float32
+    assert rel_err(probs.cpu(), ref_p) < 2e-6
+    assert float((probs.sum(1) - 1).abs().max()) < 1e-5
+    # argmax: identical wherever the reference's top-2 margin is above fp32 rounding of the interpolation
+    top2 = ref_l.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(pred.cpu().long()[clear], ref_l.argmax(1)[clear])
+
+
+def test_predict_writes_class_maps(tmp_path):
+    """predict.py surface (reference predict.py:29-48): one uint8 class-id PNG per tile; the fused head's class map equals the
+    argmax of the eval-mode probabilities."""
+    import predict
+    from PIL import Image
+    files = predict.predict_test(None, "baseline.hrnetw18", str(tmp_path), image_dir=str(tmp_path / "no_such_dir"), synthetic_tiles=2)
+    assert len(files) == 2
+    arr = np.asarray(Image.open(files[0]))
+    assert arr.dtype == np.uint8 and arr.shape == (512, 512) and arr.max() < 7
+    m = build("tiny", classes=7).eval()
+    x = seeded_input((1, 3, 64, 64), 5).to(DEV)
+    with torch.no_grad():
+        pr = m(x)
+    assert torch.equal(m.predict(x).long().cpu(), pr.argmax(1).cpu())
+
+
+def test_loveda_folder_reader_and_device_loader(tmp_path):
+    """data/loveda.py: the reference's folder layout (images_png/*.png + masks_png/<same name>), `mask - 1`, Normalize with
+    max_pixel_value=1 on the GPU; batches keep the file names (predict.py / eval.py name their outputs after them)."""
+    from PIL import Image
+    from representationlearning_amd.data.loveda import DeviceLoader, LoveDA, LOVEDA_MEAN, LOVEDA_STD
+    rng = np.random.default_rng(0)
+    (tmp_path / "images_png").mkdir(); (tmp_path / "masks_png").mkdir()
+    imgs, masks = {}, {}
+    for name in ("10.png", "7.png", "3.png"):
+        imgs[name] = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+        masks[name] = rng.integers(0, 8, (32, 32), dtype=np.uint8)
+        Image.fromarray(imgs[name]).save(tmp_path / "images_png" / name)
+        Image.fromarray(masks[name]).save(tmp_path / "masks_png" / name)
+    ds = LoveDA([str(tmp_path / "images_png")], [str(tmp_path / "masks_png")])
+    assert len(ds) == 3
+    seen = []
+    for img, gt in DeviceLoader(ds, batch_size=2):
+        for i, name in enumerate(gt["fname"]):
+            want = (imgs[name].astype(np.float32) - np.array(LOVEDA_MEAN, np.float32)) * (1.0 / np.array(LOVEDA_STD, np.float32))
+            assert np.allclose(img[i].permute(1, 2, 0).cpu().numpy(), want, atol=1e-5)
+            assert np.array_equal(gt["cls"][i].cpu().numpy(), masks[name].astype(np.int64) - 1)
+            seen.append(name)
+    assert sorted(seen) == sorted(imgs)

@@ -61,3 +61,47 @@ def test_bad_parameters_are_rejected():
             aug.apply(np.array(bad, dtype=np.int32))
     with pytest.raises(ValueError):
         DeviceAugment(torch.from_numpy(img).to(DEV), crop=32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shift_scale_rotate_matches_oracle_bit_exact(dtype):
+    """ShiftScaleRotate after crop + flip (configs/base/loveda.py:31): the fixed-point cv2.warpAffine restatement of the kernel and
+    of the numpy oracle agree bit for bit on image and mask, for rotations, scales and shifts incl. the reflected border."""
+    from representationlearning_amd.data import DeviceAugment, LOVEDA_MEAN, LOVEDA_STD
+    from representationlearning_amd.data.loveda import ssr_inverse_matrix
+    img, msk = _tiles(2, 48, 56, 5)
+    S = 32
+    aug = DeviceAugment(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV), crop=S, dtype=dtype, seed=0)
+    params = np.array([[0, 0, 0, 0], [1, 8, 20, 1], [0, 3, 5, 2], [1, 8, 0, 4], [0, 0, 20, 5], [1, 7, 19, 6], [0, 4, 4, 0]], dtype=np.int32)
+    warps = [(30.0, 1.1, 0.05, -0.03), (-44.9, 0.8, -0.0625, 0.0625), (0.0, 1.0, 0.0, 0.0), (12.5, 1.2, 0.0, 0.01), (90.0, 1.0, 0.0, 0.0),
+             (-7.0, 0.93, 0.02, 0.02), None]
+    aff = np.full((7, 6), np.nan)
+    for b, w in enumerate(warps):
+        if w is not None:
+            aff[b] = ssr_inverse_matrix(S, S, *w)
+    x, y = aug.apply(params, aff)
+    ri, rl = O.pipeline(img, msk, params, S, LOVEDA_MEAN, LOVEDA_STD, affine=aff)
+    assert np.array_equal(y.cpu().numpy(), rl)
+    ref = torch.from_numpy(ri).permute(0, 3, 1, 2)
+    if dtype == torch.bfloat16:
+        ref = ref.bfloat16()
+    assert torch.equal(x.cpu(), ref)
+    # the identity warp (angle 0, scale 1, no shift) is the un-warped crop; a NaN row is "no warp"
+    plain, yp = aug.apply(params)
+    assert torch.equal(x[2], plain[2]) and torch.equal(y[2], yp[2]) and torch.equal(x[6], plain[6])
+    assert not torch.equal(x[0], plain[0])
+
+
+def test_shift_scale_rotate_draws():
+    from representationlearning_amd.data import DeviceAugment
+    img, msk = _tiles(1, 64, 64, 6)
+    aug = DeviceAugment(torch.from_numpy(img).to(DEV), torch.from_numpy(msk).to(DEV), crop=32, seed=1,
+                        shift_scale_rotate=dict(shift_limit=0.0625, scale_limit=0.2, rotate_limit=45, p=0.2))
+    a = aug.draw_affine(2000)
+    frac = np.isfinite(a[:, 0]).mean()
+    assert 0.16 < frac < 0.24                                  # p = 0.2
+    m = a[np.isfinite(a[:, 0])]
+    scale_inv = np.sqrt(m[:, 0] ** 2 + m[:, 1] ** 2)           # inverse matrix: 1 / scale
+    assert scale_inv.min() > 1 / 1.2 - 1e-9 and scale_inv.max() < 1 / 0.8 + 1e-9
+    xb, yb = aug(8)
+    assert xb.shape == (8, 3, 32, 32) and int(yb.min()) >= -1

@@ -118,3 +118,26 @@ def test_palette_png_writer(tmp_path):
     assert im.mode == "P" and im.size == (4, 2)
     assert np.array_equal(np.asarray(im), np.array([[0, 1, 2, 3], [4, 5, 6, 15]], dtype=np.uint8))
     assert im.getpalette()[:21] == LOVEDA_PALETTE and im.convert("RGB").getpixel((1, 0)) == (255, 0, 0)
+
+
+def test_input_oracle_warp_affine_properties():
+    """oracle/input_cpu.py::warp_affine_u8 (the cv2.warpAffine restatement, parity unpinned): identity, integer shifts with
+    BORDER_REFLECT_101, nearest for masks, and the 180-degree rotation about the crop centre."""
+    import numpy as np
+    from oracle import input_cpu as O
+    from representationlearning_amd.data.loveda import ssr_inverse_matrix
+    rng = np.random.RandomState(0)
+    im = rng.randint(0, 256, (16, 20, 3)).astype(np.uint8)
+    mk = rng.randint(0, 8, (16, 20)).astype(np.uint8)
+    ident = ssr_inverse_matrix(20, 16, 0, 1, 0, 0)
+    assert np.array_equal(O.warp_affine_u8(im, ident), im) and np.array_equal(O.warp_affine_u8(mk, ident, nearest=True), mk)
+    right3 = ssr_inverse_matrix(20, 16, 0, 1, 3 / 20, 0)
+    w = O.warp_affine_u8(im, right3)
+    assert np.array_equal(w[:, 3:], im[:, :-3])
+    assert np.array_equal(w[:, 0], im[:, 3]) and np.array_equal(w[:, 1], im[:, 2]) and np.array_equal(w[:, 2], im[:, 1])   # ..3 2 1 | 0 1 2..
+    down2 = ssr_inverse_matrix(20, 16, 0, 1, 0, 2 / 16)
+    assert np.array_equal(O.warp_affine_u8(mk, down2, nearest=True)[2:], mk[:-2])
+    # rotation by 180 degrees about (w/2, h/2): dst(x, y) = src(w - x, h - y) -> one pixel of reflected border on the top / left
+    half = ssr_inverse_matrix(20, 16, 180, 1, 0, 0)
+    r = O.warp_affine_u8(mk, half, nearest=True)
+    assert np.array_equal(r[1:, 1:], mk[::-1, ::-1][:-1, :-1])
