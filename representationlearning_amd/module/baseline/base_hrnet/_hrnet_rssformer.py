@@ -156,9 +156,102 @@ class HighResolutionModule(nn.Module):
     def get_num_inchannels(self):
         return self.num_inchannels
 
+    def _lockstep_ok(self):
+        """Data parallel with SyncBN on every BatchNorm: walk the branches block by block so that the BatchNorm statistics of all
+        branches (and of all fuse paths of one depth) travel in ONE collective (nnf.conv_bn_act_group)."""
+        rt = nnf.current()
+        if not (rt.exchanging() and rt.sync_all_bn and self.training and self.num_branches > 1):
+            return False
+        nblk = len(self.branches[0])
+        return all(len(b) == nblk and all(isinstance(m, BasicBlock) and m.downsample is None for m in b) for b in self.branches)
+
+    def _branches_lockstep(self, xs):
+        xs = list(xs)
+        nb = self.num_branches
+        for k in range(len(self.branches[0])):
+            blks = [self.branches[i][k] for i in range(nb)]
+            links = [nnf.residual_link(xs[i], xs[i]) for i in range(nb)]
+            mid = nnf.conv_bn_act_group([dict(x=xs[i], conv=blks[i].conv1, bn=blks[i].bn1, act=nnf.ACT_RELU, grad_sink=links[i])
+                                         for i in range(nb)])
+            xs = nnf.conv_bn_act_group([dict(x=mid[i], conv=blks[i].conv2, bn=blks[i].bn2, act=nnf.ACT_RELU, res_pre=xs[i],
+                                             grad_deposit=links[i]) for i in range(nb)])
+        return xs
+
+    def _fuse_lockstep(self, x):
+        """The fuse layers (:361-405, 424-435 of the reference) depth by depth: depth 0 holds every 1x1 (j > i) convolution and the
+        first stride-2 convolution of every down-sampling chain (j < i), depth d the d-th convolution of the chains that are that
+        long.  The chain from branch 0 ends in `relu(bn(conv(.)) + low_i)`; its last convolution waits for the depth at which
+        `low_i` is complete (depth max(i - 1, 1)).  Sums are formed in the reference's order (j ascending)."""
+        nb, nout = self.num_branches, len(self.fuse_layers)
+        up, cur, done = {}, {}, {}                # (i,j) -> 1x1 output / running chain value / finished chain value
+        last_depth = {i: max(i - 1, 1) for i in range(1, nout)}
+        lows, outs = {}, [None] * nout
+
+        def low_of(i):
+            low = None
+            for j in range(1, nb):
+                if j == i:
+                    low = x[j] if low is None else low + x[j]
+                elif j > i:
+                    low = nnf.upsample_nearest_add(low, up[(i, j)], int(self.fuse_layers[i][j][2].scale_factor))
+                else:
+                    low = done[(i, j)] if low is None else low + done[(i, j)]
+            return low
+
+        depth = 0
+        while True:
+            items, tags = [], []
+            for i in range(nout):
+                for j in range(nb):
+                    if j > i and depth == 0:
+                        fl = self.fuse_layers[i][j]
+                        items.append(dict(x=x[j], conv=fl[0], bn=fl[1], act=nnf.ACT_NONE))
+                        tags.append(("up", i, j))
+                    elif j < i:
+                        chain = self.fuse_layers[i][j]
+                        length = len(chain)
+                        final0 = j == 0                           # ends in + low_i, ReLU
+                        d = depth
+                        if final0 and depth == last_depth[i] and (length - 1) <= depth:
+                            d = length - 1                        # the (possibly delayed) last convolution of the branch-0 chain
+                        elif final0 and depth >= length - 1:
+                            continue
+                        elif not final0 and depth >= length:
+                            continue
+                        stage = chain[d]
+                        src = x[j] if d == 0 else cur[(i, j)]
+                        if final0 and d == length - 1:
+                            if depth != last_depth[i]:
+                                continue
+                            if i not in lows:
+                                lows[i] = low_of(i)
+                            items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU, res_pre=lows[i]))
+                            tags.append(("out", i, j))
+                        else:
+                            relu = len(stage) > 2
+                            items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU if relu else nnf.ACT_NONE))
+                            tags.append(("last" if d == length - 1 else "mid", i, j))
+            if not items:
+                break
+            res = nnf.conv_bn_act_group(items)
+            for (kind, i, j), t in zip(tags, res):
+                if kind == "up":
+                    up[(i, j)] = t
+                elif kind == "mid":
+                    cur[(i, j)] = t
+                elif kind == "last":
+                    done[(i, j)] = t
+                else:
+                    outs[i] = t
+            depth += 1
+        outs[0] = self.relu(self.transformer(low_of(0), x[0]))
+        return outs
+
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
+        if self._lockstep_ok():
+            return self._fuse_lockstep(self._branches_lockstep(x[:self.num_branches]))
         x = nnf.parallel_map(list(self.branches), x[:self.num_branches])       # Sequentials of BasicBlocks, one stream each
         fused = []
         for i in range(len(self.fuse_layers)):

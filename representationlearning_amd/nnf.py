@@ -630,6 +630,150 @@ class _ConvBNAct(torch.autograd.Function):
                 grad_result(p_beta, dbeta, db_direct, rt), None, None, None, None, None, None, None, None, None, None, *gws, *gbs)
 
 
+class _ConvBNActGroup(torch.autograd.Function):
+    """N INDEPENDENT Conv2d -> BatchNorm2d -> act (+ residual before the activation) layers as one autograd node with ONE SyncBN
+    exchange per direction: the convolutions of all items are launched, their statistics buffers - carved out of one contiguous
+    allocation - are summed over the ranks by a single collective, then every item is normalised; backward mirrors it (all
+    reductions, one exchange, all applies / data gradients / weight gradients).  Used in data-parallel runs for the parallel
+    branches and fuse paths of a HighResolutionModule: the ~660 per-layer exchanges of a step, all of them on the critical path,
+    become ~250 (representationlearning_amd/module/.../_hrnet_rssformer.py::HighResolutionModule._forward_lockstep).
+    Per item (7 tensor slots): x, res_pre, gamma, beta, running_mean, running_var, weight.  Single bias-free convolutions only
+    (every HRNet convolution); meta = (spec, act, training, momentum, eps, sync, sink link, deposit link)."""
+
+    SLOTS = 7
+
+    @staticmethod
+    def forward(ctx, metas, *flat):
+        rt = current()
+        lib = L.load()
+        n_items = len(metas)
+        it = [flat[i * 7:(i + 1) * 7] for i in range(n_items)]
+        L.require_gpu(*[t[0] for t in it])
+        dev = it[0][0].device
+        training = [m[2] for m in metas]
+        sizes = [BN_SLOTS * 2 * m[0].cout if tr else 0 for m, tr in zip(metas, training)]
+        stats_all = _zeros(sum(sizes), dev, rt) if sum(sizes) else None
+        xs, raws, stats, o = [], [], [], 0
+        for (x, rp, gamma, beta, rm, rv, w), m, sz in zip(it, metas, sizes):
+            xh = _nhwc(x)
+            st = stats_all[o:o + sz] if sz else None
+            o += sz
+            xs.append(xh)
+            stats.append(st)
+            raws.append(_conv_forward(m[0], xh, [w], None, st, rt))
+        exchanged = stats_all is not None and rt.exchanging() and all(m[5] for m in metas)
+        if exchanged:
+            rt.comm.syncbn_exchange_(stats_all)
+        outs, saved, ns = [], [], []
+        for (x, rp, gamma, beta, rm, rv, w), m, xh, raw, st in zip(it, metas, xs, raws, stats):
+            spec, act, tr, mom, eps = m[:5]
+            C = spec.cout
+            rows = raw.numel() // C
+            n = float(rows) * (rt.world if (exchanged and tr) else 1)
+            mi = torch.empty(2, C, device=dev, dtype=torch.float32)
+            ss = torch.empty(2, C, device=dev, dtype=torch.float32)
+            rph = None if rp is None else _nhwc(rp)
+            if rph is not None and (rph.dtype != raw.dtype or rph.shape != raw.shape):
+                raise RuntimeError("conv_bn_act_group: residual dtype/shape mismatch")
+            y = torch.empty_like(raw)
+            L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(mi), L.ptr(ss),
+                                               L.ptr(rph), None, L.ptr(y), rows, C, act, n, mom, eps, int(tr), L.dtype_code(raw), L.stream()),
+                    "rssf_bn_finalize_apply")
+            outs.append(_nchw(y))
+            saved += [xh, raw, ss, mi, rph, w]
+            ns.append(n)
+        ctx.save_for_backward(*saved)
+        ctx.metas, ctx.ns, ctx.exchanged, ctx.rt = metas, ns, exchanged, rt
+        ctx.params = [(t[2], t[3], t[6]) for t in it]
+        ctx.x_req = [t[0].requires_grad for t in it]
+        ctx.has_pre = [t[1] is not None for t in it]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        rt, metas, lib = ctx.rt, ctx.metas, L.load()
+        sv = ctx.saved_tensors
+        n_items = len(metas)
+        dev = sv[1].device
+        sizes = [BN_BWD_SLOTS * 2 * m[0].cout for m in metas]
+        sums_all = _zeros(sum(sizes), dev, rt)
+        dyhs, sums, o = [], [], 0
+        for i, (m, sz) in enumerate(zip(metas, sizes)):
+            xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
+            dyh = _nhwc(dys[i])
+            if dyh.dtype != raw.dtype:
+                dyh = dyh.to(raw.dtype)
+            C = m[0].cout
+            rows = raw.numel() // C
+            sm = sums_all[o:o + sz]
+            o += sz
+            dws = None
+            if rt.deterministic:
+                dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=dev, dtype=torch.float32)
+            L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rph), L.ptr(sm), rows, C, m[1], L.ptr(dws), L.dtype_code(raw),
+                                           L.stream()), "rssf_bn_bwd_reduce")
+            dyhs.append(dyh)
+            sums.append(sm)
+        pscale = 1.0
+        if ctx.exchanged:
+            rt.comm.syncbn_exchange_(sums_all)
+            pscale = 1.0 / rt.world
+        grads = []
+        for i, m in enumerate(metas):
+            spec, act, tr = m[0], m[1], m[2]
+            sink, deposit = m[6], m[7]
+            xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
+            p_gamma, p_beta, p_w = ctx.params[i]
+            C = spec.cout
+            rows = raw.numel() // C
+            draw = torch.empty_like(raw)
+            dres = torch.empty_like(raw) if ctx.has_pre[i] else None
+            dgamma, dg_direct = grad_target(p_gamma, rt)
+            dbeta, db_direct = grad_target(p_beta, rt)
+            L.check(lib.rssf_bn_bwd_apply(L.ptr(dyhs[i]), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums[i]), L.ptr(rph), L.ptr(draw), L.ptr(dres),
+                                          L.ptr(dgamma), L.ptr(dbeta), rows, C, act, ctx.ns[i], int(tr), pscale if tr else 1.0,
+                                          L.dtype_code(raw), L.stream()), "rssf_bn_bwd_apply")
+            if deposit is not None and dres is not None:
+                deposit.value, dres = dres, None
+            addend = None
+            if sink is not None:
+                addend, sink.value = sink.value, None
+            if ctx.x_req[i]:
+                dx = _nchw(_conv_dgrad(spec, draw, [w], xh.shape, addend, rt))
+            else:
+                if addend is not None:
+                    raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
+                dx = None
+            tw, wd = grad_target(p_w, rt)
+            _conv_wgrad(spec, draw, xh, [tw], None, rt)
+            grads += [dx, None if dres is None else _nchw(dres), grad_result(p_gamma, dgamma, dg_direct, rt),
+                      grad_result(p_beta, dbeta, db_direct, rt), None, None, grad_result(p_w, tw, wd, rt)]
+        return (None, *grads)
+
+
+def conv_bn_act_group(items):
+    """items: dicts with x, conv, bn, act and optionally res_pre, grad_sink, grad_deposit (see conv_bn_act).  Returns the list of
+    outputs.  One SyncBN exchange for the whole group (see _ConvBNActGroup); falls back to individual nodes for a single item."""
+    if len(items) == 1:
+        d = items[0]
+        return [conv_bn_act(d["x"], d["conv"], d["bn"], d.get("act", ACT_NONE), res_pre=d.get("res_pre"), grad_sink=d.get("grad_sink"),
+                            grad_deposit=d.get("grad_deposit"))]
+    rt = current()
+    metas, flat = [], []
+    for d in items:
+        conv, bn = d["conv"], d["bn"]
+        if conv.bias is not None:
+            raise NotImplementedError("conv_bn_act_group: bias-free convolutions only")
+        training = bn.training or not bn.track_running_stats
+        if training and bn.track_running_stats:
+            bn._rssf_steps = getattr(bn, "_rssf_steps", 0) + 1
+        sync = isinstance(bn, nn.SyncBatchNorm) or rt.sync_all_bn
+        metas.append((spec_of([conv]), d.get("act", ACT_NONE), training, 0.1 if bn.momentum is None else bn.momentum, bn.eps, sync,
+                      d.get("grad_sink"), d.get("grad_deposit")))
+        flat += [d["x"], d.get("res_pre"), bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight]
+    return list(_ConvBNActGroup.apply(metas, *flat))
+
+
 class _ConvBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, spec, weight, bias):

@@ -46,6 +46,7 @@ class Communicator:
         L.check(lib.rssf_comm_init(ctypes.byref(self._h), self.rank, self.world, ctypes.create_string_buffer(box[0], 128), path),
                 "rssf_comm_init")
         self._lib = lib
+        self.n_syncbn = 0           # exchanges issued so far (reported by bench.py / checked by the DP tests)
 
     @staticmethod
     def _chk(t):
@@ -55,6 +56,7 @@ class Communicator:
     def syncbn_exchange_(self, stats):
         """In-place sum over ranks of a BatchNorm statistics buffer, on torch's current stream."""
         self._chk(stats)
+        self.n_syncbn += 1
         L.check(self._lib.rssf_syncbn_exchange(L.ptr(stats), stats.numel(), self._h, L.stream()), "rssf_syncbn_exchange")
         return stats
 
@@ -79,8 +81,10 @@ class TorchComm:
     def __init__(self, group=None):
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n_syncbn = 0
 
     def syncbn_exchange_(self, stats):
+        self.n_syncbn += 1
         dist.all_reduce(stats, group=self.group)
         return stats
 

@@ -55,10 +55,11 @@ def _worker(rank, port, out_dir, sync_bn):
     xs = x[rank * B_LOCAL:(rank + 1) * B_LOCAL].cuda()
     ys = y[rank * B_LOCAL:(rank + 1) * B_LOCAL].cuda()
     loss = float(tr.step(xs, dict(cls=ys)))                 # lr = 0: parameters stay, gradients and BN statistics are the result
+    n_exchanges = tr.comm.n_syncbn
     assert all(tr.buckets.launched)
     grad = (tr.flat.grad / WORLD).cpu()                     # the 1/world factor lives in the SGD kernel
     flush_bn_counters(tr)
-    out = dict(loss=loss, grad_sum=float(grad.double().sum()), grad_abs=float(grad.double().abs().sum()),
+    out = dict(loss=loss, n_exchanges=n_exchanges, grad_sum=float(grad.double().sum()), grad_abs=float(grad.double().abs().sum()),
                param_sum=float(tr.flat.flat.double().sum()))
     if rank == 0:
         names = [k for k, p in model.named_parameters() if p.requires_grad]
@@ -130,6 +131,9 @@ def test_two_ranks_match_pooled_bn_mean_of_shard_gradients():
               "backbone.hrnet.stage4.2.branches.3.3.bn2.running_var"):
         assert rel_err(bufs[k], P[k]) < 1e-3, (k, rel_err(bufs[k], P[k]))
     assert int(bufs["backbone.hrnet.bn1.num_batches_tracked"]) == 1       # flushed after the first (lr = 0) step
+    # SyncBN exchanges of one step: 330 BatchNorm layers x {forward, backward} = 660 one by one; the lock-step walk of the HRNet
+    # branches / fuse paths (nnf.conv_bn_act_group) sends the statistics of independent layers together
+    assert res[0]["n_exchanges"] == res[1]["n_exchanges"] and res[0]["n_exchanges"] <= 280, res[0]["n_exchanges"]
 
 
 def test_two_ranks_without_sync_bn_keep_local_statistics_except_mlp():
