@@ -256,6 +256,13 @@ int rssf_head_upsample_softmax(const void* logits, float* probs, int32_t* pred, 
 int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B, int IH, int IW, int scale, int C, int backward,
                               int dtype, void* stream);
 
+/* ---- image-level auxiliary head: `self.headaux(self.avg_pool(f0).flatten(1))` (module/baseline/hrnet_aux.py:86-87, 99-100):
+ *      global average pool of the channels-last branch-0 feature [B, HW, C] (C <= 64) -> Linear(C, K) (K <= 16), forward only (the
+ *      loss reads it under no_grad).  workspace: rssf_aux_head_workspace_elems() floats; out [B][K] fp32. ---- */
+int64_t rssf_aux_head_workspace_elems(int B, int C);
+int rssf_aux_head_fwd(const void* feat, const float* weight, const float* bias, float* workspace, float* out, int B, int HW, int C,
+                      int K, int dtype, void* stream);
+
 /* ---- CGFL loss: SegmentationLossaux.forward (module/CGFL.py:201-227) -> MCTransAuxLoss (losses/auxloss.py:257-305)
  *      -> softmax_focalloss (module/CGFL.py:72-101), on channels-last logits [B, HW, K] and int64 labels [B, HW] ---- */
 /* acc: fp32 scratch [B][6] (zeroed inside); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);
@@ -276,6 +283,10 @@ int rssf_argmax_confusion(const void* scores, const int64_t* labels, int32_t* pr
 
 /* ---- optimizer over flat fp32 buffers: the external `ever` trainer's clip_grad_norm_(35) + SGD(momentum .9,
  *      wd 1e-4) of configs/base/loveda.py:68-77 as two launches over all parameters ----------------------- */
+/* p[0..n) = 0 as a KERNEL launch.  Inside a captured hipGraph a memset NODE (hipMemsetAsync, which is also what some framework
+ * zero-fills lower to) stopped taking effect after a device synchronisation between replays on ROCm 7.0 / MI355X; every buffer the
+ * training step clears per replay (flat gradient, statistics pool) goes through this instead. */
+int rssf_zero_f32(float* p, int64_t n, void* stream);
 /* out[0] = sum g^2; `out` holds 1 + RSSF_SQNORM_BLOCKS floats (out[1..] = per-block partials, added in a fixed order:
  * bit-identical on every data-parallel replica, no float atomics). */
 #define RSSF_SQNORM_BLOCKS 2048

@@ -80,9 +80,12 @@ SIGNATURES = {
     "rssf_upsample_bilinear_slice": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "rssf_head_upsample_softmax": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rssf_upsample_nearest_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "rssf_aux_head_workspace_elems": (c_int64, [c_int, c_int]),
+    "rssf_aux_head_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rssf_cgfl_loss_fwd": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "rssf_cgfl_loss_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rssf_argmax_confusion": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "rssf_zero_f32": (c_int, [c_void_p, c_int64, c_void_p]),
     "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p, c_float, c_float,
                               c_float, c_int, c_void_p]),

@@ -194,6 +194,14 @@ __device__ __forceinline__ s16x4 pack_bf16x4(f32x4 v) {
 
 }  // namespace rssf
 
+// ---- zero-fill as a KERNEL -------------------------------------------------------------------------------------------------
+// hipMemsetAsync nodes inside a captured training step stopped taking effect after a device synchronisation between two replays
+// (MI355X, ROCm 7.0: the loss accumulators then carried the previous replay's sums - loss 1.75 -> 0.99 / NaN; found with
+// tools/graph_vs_eager.py).  Scratch the library must clear is cleared by a kernel node instead.
+namespace rssf {
+int zero_floats(float* p, int64_t n, hipStream_t st);
+}
+
 // ---- host-side error plumbing ------------------------------------------------------------------------
 namespace rssf {
 void set_error(const char* fmt, ...);

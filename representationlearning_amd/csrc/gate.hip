@@ -345,10 +345,7 @@ extern "C" int rssf_gate_weights_bwd(const float* domega, const float* pooled, c
   // the caller passes dpooled sized [B][6][N]; planes 4..5 hold dpre.
   float* dpre = dpooled + (int64_t)B * 4 * N;
   float* slots = dpooled + (int64_t)B * 6 * N;
-  if (hipMemsetAsync(slots, 0, sizeof(float) * RSSF_GATE_SLOTS * GATE_SLOT_ELEMS, st) != hipSuccess) {
-    set_error("gate_weights_bwd: memset failed");
-    return RSSF_ERR_LAUNCH;
-  }
+  if (int rcz = zero_floats(slots, (int64_t)RSSF_GATE_SLOTS * GATE_SLOT_ELEMS, st)) return rcz;     // a kernel, not a memset node (common.hip.h)
   gate_weights_bwd1_kernel<<<grid, 256, 0, st>>>(domega, gsig, omega, wl, dpre, slots, B, N);
   int rc = check_launch("gate_weights_bwd1");
   if (rc) return rc;

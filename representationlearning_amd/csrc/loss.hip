@@ -98,12 +98,71 @@ __global__ void __launch_bounds__(256) loss_bwd_kernel(const T* __restrict__ log
 }
 }  // namespace
 
+namespace {
+// Image-level auxiliary head: AdaptiveAvgPool2d(1) of branch 0 -> Linear(C, KA)  (hrnet_aux.py:86-87, 99-100).  Its output only
+// modulates the loss under no_grad (CGFL.py:75-97), so there is no backward.  Two small launches with a fixed summation order
+// instead of ATen's mean-reduce + a hipBLASLt GEMM: the library GEMM was the one foreign kernel left inside the captured training
+// step, and it did not survive a replay after a device synchronisation (its output turned to garbage / NaN: the argument buffer it
+// reads at run time is filled at enqueue time, outside the graph).
+constexpr int AUX_CHUNKS = 32, AUX_MAXC = 64, AUX_MAXK = 16;
+template <typename T>
+__global__ void __launch_bounds__(256) aux_pool_kernel(const T* __restrict__ f, float* __restrict__ partial, int HW, int C) {
+  __shared__ float red[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int groups = 256 / C, c = threadIdx.x % C, g = threadIdx.x / C;          // `groups` pixel lanes x C channels
+  const int per = (HW + AUX_CHUNKS - 1) / AUX_CHUNKS;
+  const int p0 = chunk * per, p1 = p0 + per < HW ? p0 + per : HW;
+  float acc = 0.f;
+  if (g < groups)
+    for (int p = p0 + g; p < p1; p += groups) acc += ldf(f + ((int64_t)b * HW + p) * C + c);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int k = 0; k < groups; ++k) t += red[k * C + threadIdx.x];
+    partial[((int64_t)b * AUX_CHUNKS + chunk) * C + threadIdx.x] = t;
+  }
+}
+__global__ void aux_linear_kernel(const float* __restrict__ partial, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float* __restrict__ out, int HW, int C, int K) {
+  __shared__ float mean[AUX_MAXC];
+  const int b = blockIdx.x;
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int k = 0; k < AUX_CHUNKS; ++k) t += partial[((int64_t)b * AUX_CHUNKS + k) * C + threadIdx.x];
+    mean[threadIdx.x] = t / (float)HW;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    float t = bias ? bias[threadIdx.x] : 0.f;
+    for (int c = 0; c < C; ++c) t += w[threadIdx.x * C + c] * mean[c];
+    out[b * K + threadIdx.x] = t;
+  }
+}
+}  // namespace
+
+extern "C" int64_t rssf_aux_head_workspace_elems(int B, int C) { return (int64_t)B * AUX_CHUNKS * C; }
+
+extern "C" int rssf_aux_head_fwd(const void* feat, const float* weight, const float* bias, float* workspace, float* out, int B, int HW,
+                                 int C, int K, int dtype, void* stream) {
+  RSSF_REQUIRE(feat && weight && workspace && out && B > 0 && HW > 0 && C > 0 && C <= AUX_MAXC && K > 0 && K <= AUX_MAXK,
+               "aux_head_fwd: bad arguments (C <= %d, K <= %d)", AUX_MAXC, AUX_MAXK);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(AUX_CHUNKS, (unsigned)B);
+  if (dtype == RSSF_F32) aux_pool_kernel<float><<<grid, 256, 0, st>>>((const float*)feat, workspace, HW, C);
+  else if (dtype == RSSF_BF16) aux_pool_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)feat, workspace, HW, C);
+  else { set_error("aux_head_fwd: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  int rc = check_launch("aux_head_pool");
+  if (rc) return rc;
+  aux_linear_kernel<<<(unsigned)B, 64, 0, st>>>(workspace, weight, bias, out, HW, C, K);
+  return check_launch("aux_head_linear");
+}
+
 extern "C" int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* aux, float* acc, float* out, int B, int HW, int K,
                                   int KA, int ignore_index, int deterministic, int dtype, void* stream) {
   RSSF_REQUIRE(logits && labels && aux && acc && out && B > 0 && HW > 0 && K > 0 && K <= MAXK && KA >= 2, "cgfl_loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * 6 * B, st);
-  if (e != hipSuccess) { set_error("cgfl_loss_fwd: memset failed: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
+  if (int rcz = zero_floats(acc, (int64_t)6 * B, st)) return rcz;      // a kernel, not a memset node (common.hip.h)
   int bx = (HW + 255) / 256;
   if (bx > 128) bx = 128;
   if (deterministic) bx = 1;           // one block per sample: wave shuffles + an ordered 4-way sum, a single add into the zeroed acc

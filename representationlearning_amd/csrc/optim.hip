@@ -80,6 +80,26 @@ __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const f
 }
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(256) zero_kernel(float* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
+}  // namespace
+namespace rssf {
+int zero_floats(float* p, int64_t n, hipStream_t st) {
+  if (n <= 0) return RSSF_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  zero_kernel<<<(unsigned)blocks, 256, 0, st>>>(p, n);
+  return check_launch("zero_floats");
+}
+}  // namespace rssf
+
+extern "C" int rssf_zero_f32(float* p, int64_t n, void* stream) {
+  RSSF_REQUIRE(p || n == 0, "zero_f32: null buffer");
+  return zero_floats(p, n, (hipStream_t)stream);
+}
+
 extern "C" int rssf_grad_sqnorm(const float* g, int64_t n, float* out, void* stream) {
   RSSF_REQUIRE(g && out && n > 0, "grad_sqnorm: bad arguments");
   hipStream_t st = (hipStream_t)stream;

@@ -6,6 +6,8 @@ channels-last memory (NHWC physically) end to end — the layout the HIP kernels
 Every Conv2d -> BatchNorm2d (-> ReLU / + residual) group runs as one fused autograd node on the hand-written
 implicit-GEMM / BN kernels (representationlearning_amd.nnf), nearest upsampling is fused with the branch sum;
 the remaining branch adds / ReLU are ATen elementwise kernels.  nn.Conv2d / nn.BatchNorm2d modules only hold the parameters."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -160,7 +162,7 @@ class HighResolutionModule(nn.Module):
         """Data parallel with SyncBN on every BatchNorm: walk the branches block by block so that the BatchNorm statistics of all
         branches (and of all fuse paths of one depth) travel in ONE collective (nnf.conv_bn_act_group)."""
         rt = nnf.current()
-        if not (rt.exchanging() and rt.sync_all_bn and self.training and self.num_branches > 1):
+        if not (rt.exchanging() and rt.sync_all_bn and self.training and self.num_branches > 1) or os.environ.get("RSSF_LOCKSTEP", "1") == "0":
             return False
         nblk = len(self.branches[0])
         return all(len(b) == nblk and all(isinstance(m, BasicBlock) and m.downsample is None for m in b) for b in self.branches)

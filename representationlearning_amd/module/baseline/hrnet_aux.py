@@ -39,7 +39,10 @@ class HRNetFusion(ConfigModule):
     def forward(self, x, y=None):
         feats = self.backbone(x)
         fused, f0 = self.neck(feats)
-        aux = self.headaux(self.avg_pool(f0).flatten(1).float())
+        # image-level scores for the loss's modulating term: used under no_grad only (CGFL.py:75-97) -> forward-only HIP kernels,
+        # no ATen reduce / library GEMM inside the captured step
+        aux = nnf.aux_head(f0, self.headaux[0]) if self.training else None
+        self._dbg = (fused, f0, aux) if getattr(self, '_keep_dbg', False) else None
         lg = nnf.conv_bias(fused, self.head[0])
         sc = self.head[1].scale_factor
         size = (int(lg.shape[2] * sc), int(lg.shape[3] * sc))

@@ -39,7 +39,8 @@ class ZeroPool:
         if self.last_need and (self.buf is None or self.buf.numel() < self.last_need or self.buf.device != device):
             self.buf = torch.zeros(self.last_need, device=device, dtype=torch.float32)
         elif self.buf is not None and self.off:
-            self.buf[:self.off].zero_()                   # only what the previous step handed out
+            from . import ops
+            ops.zero_(self.buf[:self.off])                # only what the previous step handed out (a kernel, never a memset node)
         self.off, self.need, self.active = 0, 0, True
 
     def end(self):
@@ -947,6 +948,25 @@ class _CGFLLoss(torch.autograd.Function):
         L.check(L.load().rssf_cgfl_loss_bwd(L.ptr(lh), L.ptr(labels), L.ptr(out), L.ptr(d), L.ptr(dl), B, H * W, K, ctx.ignore_index,
                                             L.dtype_code(lh), L.stream()), "rssf_cgfl_loss_bwd")
         return _nchw(dl), None, None, None      # the aux head receives no gradient (the bracket is detached, CGFL.py:75-97)
+
+
+def aux_head(f0, linear):
+    """`linear(AdaptiveAvgPool2d(1)(f0).flatten(1))` for the image-level auxiliary scores (hrnet_aux.py:86-87, 99-100), forward only -
+    the loss uses them under no_grad.  f0: logical NCHW channels-last; returns fp32 [B, K]."""
+    L.require_gpu(f0)
+    fh = _nhwc(f0.detach())
+    B, H, W, C = fh.shape
+    K = linear.out_features
+    lib = L.load()
+    ws = torch.empty(lib.rssf_aux_head_workspace_elems(B, C), device=fh.device, dtype=torch.float32)
+    out = torch.empty(B, K, device=fh.device, dtype=torch.float32)
+    w = linear.weight.detach()
+    bias = None if linear.bias is None else linear.bias.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    L.check(lib.rssf_aux_head_fwd(L.ptr(fh), L.ptr(w), L.ptr(bias), L.ptr(ws), L.ptr(out), B, H * W, C, K, L.dtype_code(fh), L.stream()),
+            "rssf_aux_head_fwd")
+    return out
 
 
 def cgfl_loss(logits, labels, aux, ignore_index=-1):

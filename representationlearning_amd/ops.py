@@ -170,6 +170,16 @@ def argmax_confusion(scores, labels=None, cm=None, ignore_index=-1, want_pred=Tr
     return pred
 
 
+def zero_(t):
+    """t.zero_() for a contiguous fp32 device tensor as a librssf kernel launch (never a memset node: see rssf_zero_f32)."""
+    if t.numel() == 0:
+        return t
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        return t.zero_()
+    L.check(L.load().rssf_zero_f32(L.ptr(t), t.numel(), L.stream()), "rssf_zero_f32")
+    return t
+
+
 SQNORM_ELEMS = 1 + 2048          # 1 + RSSF_SQNORM_BLOCKS
 
 

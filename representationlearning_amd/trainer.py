@@ -38,7 +38,7 @@ class FlatParams:
         self.numel = n
 
     def zero_grad(self):
-        self.grad.zero_()
+        ops.zero_(self.grad)
         for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-seat the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
@@ -84,6 +84,7 @@ class GradBuckets:
         self.launched = [False] * len(self.members)
         self.index_of = {id(p): i for i, p in enumerate(flat.params)}
         self.side = torch.cuda.Stream() if comm.direct else None
+        self.compute_stream = None
         # The post-accumulate-grad hook fires once per parameter and backward pass, after the LAST node that uses the parameter
         # has run - also when that node returned None because its kernels accumulated straight into p.grad (nnf's direct
         # gradient accumulation): AccumulateGrad is scheduled for undefined gradients too (tests/test_dp_gloo.py pins this).
@@ -106,15 +107,24 @@ class GradBuckets:
         self.launched[b] = True
         s, e = self.bounds[b]
         g = self.flat.grad[s:e]
+        # The kernels that produced this bucket's gradients are already enqueued on the step's COMPUTE stream (recorded by
+        # begin()).  Not torch.cuda.current_stream(): this runs inside a post-accumulate-grad hook, and autograd executes an
+        # AccumulateGrad node on the stream its parameter was first used on (the warm-up stream, the default stream, ...) - ordering
+        # the collective after THAT stream leaves it unordered against the backward kernels: a captured step then carries a race
+        # that shows up as NaN losses as soon as the replay starts on an idle GPU (tools/dp_nan_probe.py).
+        cs = self.compute_stream if (self.compute_stream is not None or not g.is_cuda) else torch.cuda.current_stream()
         if self.comm.direct:
-            # the kernels that produced this bucket's gradients are already enqueued on the current (compute) stream
-            self.side.wait_stream(torch.cuda.current_stream())
+            self.side.wait_stream(cs)
             with torch.cuda.stream(self.side):
                 self.comm.allreduce_bucket_(g)
+        elif g.is_cuda:
+            with torch.cuda.stream(cs):                 # the process group orders its work after the stream current at the call
+                self.handles.append(self.comm.allreduce_bucket_async(g))
         else:
             self.handles.append(self.comm.allreduce_bucket_async(g))
 
     def begin(self):
+        self.compute_stream = torch.cuda.current_stream() if self.flat.grad.is_cuda else None
         self.pending = [len(m) for m in self.members]
         self.launched = [False] * len(self.members)
         self.handles = []
@@ -126,7 +136,7 @@ class GradBuckets:
         for h in self.handles:
             h.wait()
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            (self.compute_stream or torch.cuda.current_stream()).wait_stream(self.side)
 
 
 def flush_bn_counters(trainer):

@@ -158,3 +158,31 @@ def test_sgd_skips_parameters_without_gradient():
     assert not torch.equal(m.backbone.hrnet.conv1.weight.detach(), c0)
     covered = sum(e - s for s, e in t.sgd_ranges)
     assert covered == t.flat.numel - (t.flat.offsets[-1] - t.flat.offsets[-3])       # everything but headaux.0.{weight,bias}
+
+
+@pytest.mark.parametrize("branch_streams", ["1", "0"])
+def test_graph_replay_survives_device_sync_and_foreign_work(branch_streams):
+    """A replayed step must not depend on anything outside the graph: a device synchronisation and unrelated allocations / kernels
+    between replays leave the loss sequence where eager launches put it.  (Round 1's step kept a hipBLASLt GEMM - the aux head's
+    Linear - inside the capture; after a torch.cuda.synchronize() its replays returned garbage: the loss jumped from 1.75 to 0.99,
+    with the label check of this round to NaN.  Single-stream captures - the data-parallel configuration - hit it every time.)"""
+    from representationlearning_amd.trainer import Trainer
+    from representationlearning_amd.configs import synthetic_batch
+    img, lab = synthetic_batch(2, 128, seed=5)
+    os.environ["RSSF_BRANCH_STREAMS"] = branch_streams
+    try:
+        te = Trainer(_mk(6), bf16=True, base_lr=0.002, use_graph=False, deterministic=True)
+        le = [float(te.step(img, dict(cls=lab))) for _ in range(9)]
+        tg = Trainer(_mk(6), bf16=True, base_lr=0.002, use_graph=True, deterministic=True)
+        lg = []
+        for i in range(9):
+            if i >= 4:
+                torch.cuda.synchronize()
+                junk = [torch.randn(1 << 20, device="cuda").square().sum() for _ in range(4)]       # foreign allocations + kernels
+                del junk
+            lg.append(float(tg.step(img, dict(cls=lab))))
+    finally:
+        os.environ.pop("RSSF_BRANCH_STREAMS")
+    assert tg.graph is not None and tg._replayed >= 5
+    assert all(l == l for l in lg), lg
+    assert max(abs(a - b) / abs(b) for a, b in zip(lg, le)) < 2e-3, (lg, le)
