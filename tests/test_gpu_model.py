@@ -251,3 +251,46 @@ def test_large_config4_full_size_bf16():
     """BASELINE config 4: RSSFormer-Large, 4 x 3 x 1024 x 1024 per GPU, bf16 (the HBM-bound window-attention stress:
     256 x 256 tokens x 48 channels on branch 0, 37 x 37 windows after padding to 259).  Same gate as config 2."""
     _bf16_gate(*_full_size_modes("large", 4, 1024))
+
+
+def test_base_trained_model_bf16_vs_fp32_end_to_end():
+    """END-TO-END bf16 acceptance on a model whose logits mean something: Base 16 x 512^2 trained for 300 hipGraph-replayed bf16
+    steps on the bench's fixed batch (it memorises it: loss 1.79 -> 0.03, mIoU 0.93), then the SAME weights forwarded in fp32-I/O
+    mode and in bf16.  The rounding noise the network accumulates over its 300 layers (tools/mode_diff.py: 55 % of the logits'
+    norm at random initialisation) is 10 % here, and what SURVEY §8d's gate asks can be read off directly - measured on MI355X:
+    argmax agreement 96.9 % over all pixels, 98.5 % where the fp32 top-2 margin exceeds 0.1 standard deviations (the disagreements sit
+    on the 16 x 16 label-block boundaries, where the trained network itself is undecided), mIoU 0.930 (fp32) vs 0.923 (bf16).  The
+    99 % / 0.5 pt of §8d hold module by module (test_base_full_size_bf16_acceptance), not across 300 accumulated layers; the bars
+    below are the measured end-to-end values with margin, so that a regression of any bf16 kernel shows."""
+    from representationlearning_amd import nnf
+    from representationlearning_amd.configs import rssformer_config, synthetic_batch
+    from representationlearning_amd.core import registry
+    from representationlearning_amd.trainer import Trainer
+    registry.register_all()
+    torch.manual_seed(2333)
+    m = registry.MODEL["RSSFormer"](rssformer_config("base")).to(DEV)
+    tr = Trainer(m, bf16=True)
+    img, lab = synthetic_batch(16, 512, seed=2333)
+    first = float(tr.step(img, dict(cls=lab)))
+    for _ in range(299):
+        last = tr.step(img, dict(cls=lab))
+    last = float(last)
+    assert tr.graph is not None and last < 0.1 < first, (first, last)          # the optimisation optimises (through graph replays)
+    rt = nnf.Runtime()
+    rt.deterministic = True
+    res = {}
+    m.train()
+    for mode in ("fp32", "bf16"):
+        with torch.no_grad(), nnf.use(rt), torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode == "bf16"):
+            loss = m(img, dict(cls=lab))["fc_loss"]
+        res[mode] = (float(loss), m._last_logits.float())
+    (l32, g32), (l16, g16) = res["fp32"], res["bf16"]
+    assert abs(l16 - l32) < 0.15 * abs(l32), (l16, l32)                          # measured 6 % (of a loss of 0.03)
+    assert float((g16 - g32).norm() / g32.norm()) < 0.2                           # measured 0.10
+    top2 = g32.topk(2, dim=1).values
+    margin, sd = top2[:, 0] - top2[:, 1], float(g32.std())
+    agree = g32.argmax(1) == g16.argmax(1)
+    assert float(agree.float().mean()) > 0.95                                      # measured 0.969
+    assert float(agree[margin > 0.1 * sd].float().mean()) > 0.975                  # measured 0.985
+    m32, m16 = _miou(g32.argmax(1).cpu(), lab.cpu()), _miou(g16.argmax(1).cpu(), lab.cpu())
+    assert m32 > 0.85 and abs(m32 - m16) < 0.02, (m32, m16)                        # measured 0.930 / 0.923
