@@ -263,6 +263,10 @@ int64_t rssf_aux_head_workspace_elems(int B, int C);
 int rssf_aux_head_fwd(const void* feat, const float* weight, const float* bias, float* workspace, float* out, int B, int HW, int C,
                       int K, int dtype, void* stream);
 
+/* ---- nn.MaxPool2d(3, stride 2, padding 1), channels-last, forward only: the stem pooling of the ResNet-50 CAM inference path
+ *      (WaveCAM-TMM2023/net/resnet50.py:68,88 - BASELINE config 5's conv-only relative).  out [B, (IH-1)/2+1, (IW-1)/2+1, C]. ---- */
+int rssf_maxpool3x3s2(const void* in, void* out, int B, int IH, int IW, int C, int dtype, void* stream);
+
 /* ---- CGFL loss: SegmentationLossaux.forward (module/CGFL.py:201-227) -> MCTransAuxLoss (losses/auxloss.py:257-305)
  *      -> softmax_focalloss (module/CGFL.py:72-101), on channels-last logits [B, HW, K] and int64 labels [B, HW] ---- */
 /* acc: fp32 scratch [B][6] (zeroed inside); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);

@@ -246,6 +246,44 @@ def case_eval():
          cm=npy(cm), cm_tta=npy(cm_tta))
 
 
+def case_cam():
+    """BASELINE config 5's conv-only relative: WaveCAM ResNet-50 CAM inference (net/resnet50_cam.py:112-126) on a synthetic
+    VOC-sized 321 x 321 image and its horizontal flip.  The constructor downloads ImageNet weights (resnet50.py:106-111): no
+    network here, so model_zoo.load_url is replaced by an empty dict (load_state_dict(strict=False) then keeps the init) and the
+    seeded weights are loaded on top."""
+    import importlib
+    wc = "/root/reference/WaveCAM-TMM2023"
+    sys.path.insert(0, wc)
+    for k in [k for k in sys.modules if k == "net" or k.startswith("net.") or k == "misc" or k.startswith("misc.")]:
+        del sys.modules[k]
+    r50 = importlib.import_module("net.resnet50")
+    r50.model_zoo.load_url = lambda url: {}
+    cam_mod = importlib.import_module("net.resnet50_cam")
+    from oracle import cam_cpu
+    torch.manual_seed(0)
+    m = cam_mod.CAM(stride=16, n_classes=20)
+    m.eval()               # (the reference's Net.train() override returns None: no chaining)
+    sd = m.state_dict()
+    # the reference registers every backbone module three times (resnet50.*, stage*.*, backbone.*): seed the canonical copy and
+    # let the aliases follow (they are the same tensors)
+    canon = {k: v for k, v in sd.items() if k.startswith("resnet50.") or k == "classifier.weight"}
+    seeded = seeded_state(canon, 4321)
+    with torch.no_grad():
+        for k, v in seeded.items():
+            sd[k].copy_(v)
+    x1 = seeded_input((1, 3, 321, 321), 21)
+    x = torch.cat([x1, x1.flip(-1)], 0)
+    with torch.no_grad():
+        out = m(x)
+        sep = m(x, separate=True)
+    P = {k: v.clone() for k, v in seeded.items()}
+    chk = cam_cpu.cam_forward(x, P)
+    assert torch.allclose(chk, out, rtol=1e-4, atol=1e-5), float((chk - out).abs().max())
+    save("cam_r50_321", cams=npy(out), sep_sample=npy(sep[:, :, ::4, ::4]), sum_sep=npy(sep.double().sum()), keys=np.array(sorted(canon.keys())),
+         all_keys=np.array(list(sd.keys())))
+    sys.path.remove(wc)
+
+
 def case_state_keys():
     for variant in ("tiny", "base", "large"):
         m = build_model(variant)
@@ -257,7 +295,7 @@ def case_state_keys():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["mhca", "attention", "block", "mlp", "loss", "neck_head", "keys", "models", "eval"]
+    which = sys.argv[1:] or ["mhca", "attention", "block", "mlp", "loss", "neck_head", "keys", "models", "eval", "cam"]
     if "eval" in which: case_eval()
     if "mhca" in which: case_mhca()
     if "attention" in which: case_attention()
@@ -266,6 +304,7 @@ if __name__ == "__main__":
     if "loss" in which: case_loss()
     if "neck_head" in which: case_neck_head()
     if "keys" in which: case_state_keys()
+    if "cam" in which: case_cam()
     if "models" in which:
         case_model("tiny", 2, 256, "tiny_2x256")      # BASELINE config 1
         case_model("base", 2, 64, "base_2x64")

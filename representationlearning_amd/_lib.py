@@ -82,6 +82,7 @@ SIGNATURES = {
     "rssf_upsample_nearest_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rssf_aux_head_workspace_elems": (c_int64, [c_int, c_int]),
     "rssf_aux_head_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "rssf_maxpool3x3s2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_cgfl_loss_fwd": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "rssf_cgfl_loss_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rssf_argmax_confusion": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

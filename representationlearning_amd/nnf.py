@@ -182,7 +182,7 @@ def _ia(vals):
 class ConvSpec:
     """Tap list of a convolution (or of a sum of convolutions sharing input/output, stride 1)."""
 
-    def __init__(self, convs):
+    def __init__(self, convs, tap_range=None):
         c0 = convs[0]
         self.cin, self.cout = c0.in_channels, c0.out_channels
         self.stride = c0.stride[0]
@@ -209,14 +209,26 @@ class ConvSpec:
                     self.dy.append(off[0])
                     self.dx.append(off[1])
                     self.alias.append([-1, -1, -1, -1])
+        # more than RSSF_MAX_TAPS positions (the 7 x 7 stem of the ResNet-50 CAM path: 49): the convolution runs as a chain of
+        # <= 19-tap launches, each adding its taps' contribution to the previous partial sum (rssf_conv_gather_add's addend)
+        self.parts = None
+        if tap_range is None and len(self.src) > 19:
+            if len(convs) != 1:
+                raise NotImplementedError("librssf conv: tap splitting needs a single convolution")
+            n = len(self.src)
+            self.parts = [ConvSpec(convs, (a, min(a + 19, n))) for a in range(0, n, 19)]
+        if tap_range is not None:
+            a_, b_ = tap_range
+            self.src, self.kpos, self.dy, self.dx, self.alias = (self.src[a_:b_], self.kpos[a_:b_], self.dy[a_:b_], self.dx[a_:b_],
+                                                                 self.alias[a_:b_])
         self.ntaps = len(self.src)
         self.c_alias = _ia([v for a4 in self.alias for v in a4])
         # ctypes views of the tap tables, built once (they are passed to every launch of this convolution)
         self.c_ksizes, self.c_src, self.c_kpos = _ia(self.ksizes), _ia(self.src), _ia(self.kpos)
         self.c_dy, self.c_dx = _ia(self.dy), _ia(self.dx)
         self.c_ndy, self.c_ndx = _ia([-v for v in self.dy]), _ia([-v for v in self.dx])
-        if self.ntaps > 19 or len(convs) > 3:
-            raise NotImplementedError("librssf conv: at most 19 taps / 3 fused convolutions")
+        if (self.ntaps > 19 and self.parts is None) or len(convs) > 3:
+            raise NotImplementedError("librssf conv: at most 19 taps per launch / 3 fused convolutions")
         c = c0
         self._out_hw = lambda h, w: ((h + 2 * c.padding[0] - c.dilation[0] * (c.kernel_size[0] - 1) - 1) // self.stride + 1,
                                      (w + 2 * c.padding[0] - c.dilation[0] * (c.kernel_size[0] - 1) - 1) // self.stride + 1)
@@ -450,7 +462,14 @@ def _pad_channels(t):
     return t if c % v == 0 else torch.nn.functional.pad(t, (0, v - c % v))
 
 
-def _conv_forward(spec, xh, weights, bias, stats, rt=None):
+def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None):
+    if spec.parts is not None:                      # > 19 taps: partial sums chained through the epilogue's addend (inference)
+        if stats is not None:
+            raise NotImplementedError("librssf conv: fused statistics are not available for tap-split convolutions")
+        out = None
+        for k, part in enumerate(spec.parts):
+            out = _conv_forward(part, xh, weights, bias if k == 0 else None, None, rt, addend=out)
+        return out
     xh = _pad_channels(xh)
     B, H, W, C = xh.shape
     OH, OW = spec.out_hw(H, W)
@@ -460,7 +479,7 @@ def _conv_forward(spec, xh, weights, bias, stats, rt=None):
     ws = None
     if stats is not None and (rt or current()).deterministic:       # fixed-order statistics: per-tile partials + ordered fold
         ws = torch.empty(lib.rssf_conv_stats_workspace_elems(B, OH, OW, spec.cout), device=xh.device, dtype=torch.float32)
-    L.check(lib.rssf_conv_gather_add(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), None, L.ptr(ws), B, H, W, C, OH, OW,
+    L.check(lib.rssf_conv_gather_add(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), L.ptr(addend), L.ptr(ws), B, H, W, C, OH, OW,
                                      spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
             "rssf_conv_gather")
     return out
@@ -577,6 +596,8 @@ class _ConvBNAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         spec, act, training, n, exchanged, nbias, nw, has_pre, has_post, x_req = ctx.meta
+        if spec.parts is not None:
+            raise NotImplementedError("librssf conv: convolutions of more than 19 taps are forward-only (the CAM path's frozen stem)")
         rt = ctx.rt
         xh, raw, ss, mi, rp = ctx.saved_tensors[:5]
         weights = ctx.saved_tensors[5:]
@@ -914,6 +935,16 @@ def head_upsample_softmax(logits, size, want_probs=True, want_pred=False):
     L.check(L.load().rssf_head_upsample_softmax(L.ptr(lh), L.ptr(probs), L.ptr(pred), B, IH, IW, OH, OW, K, L.dtype_code(lh), L.stream()),
             "rssf_head_upsample_softmax")
     return (None if probs is None else _nchw(probs)), pred
+
+
+def max_pool_3x3_s2(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1), forward only (inference stem of the ResNet-50 CAM path)."""
+    L.require_gpu(x)
+    xh = _nhwc(x.detach())
+    B, IH, IW, C = xh.shape
+    out = torch.empty(B, (IH - 1) // 2 + 1, (IW - 1) // 2 + 1, C, device=xh.device, dtype=xh.dtype)
+    L.check(L.load().rssf_maxpool3x3s2(L.ptr(xh), L.ptr(out), B, IH, IW, C, L.dtype_code(xh), L.stream()), "rssf_maxpool3x3s2")
+    return _nchw(out)
 
 
 def upsample_nearest_add(acc, x, scale):

@@ -245,3 +245,21 @@ def test_dp_emulation_oracle_consistency():
     # pooled statistics: running buffers equal those of the full-batch forward
     k = "backbone.hrnet.bn1.running_var"
     assert torch.allclose(P3[k], P2[k], rtol=1e-6, atol=1e-7)
+
+
+def test_cam_resnet50_oracle_vs_reference_golden():
+    """oracle/cam_cpu.py (WaveCAM ResNet-50 CAM inference, BASELINE config 5's conv-only relative) against the output of the
+    reference's own net.resnet50_cam.CAM on a 321 x 321 image and its flip."""
+    from oracle import cam_cpu
+    g = golden("cam_r50_321")
+    t = cam_cpu.cam_template()
+    assert sorted(t.keys()) == g["keys"].tolist()
+    P = seeded_state(t, 4321)
+    x1 = seeded_input((1, 3, 321, 321), 21)
+    x = torch.cat([x1, x1.flip(-1)], 0)
+    with torch.no_grad():
+        out = cam_cpu.cam_forward(x, P)
+        sep = cam_cpu.cam_forward(x, P, separate=True)
+    assert out.shape == (20, 21, 21)
+    assert rel_err(out, g["cams"]) < TOL and rel_err(sep[:, :, ::4, ::4], g["sep_sample"]) < TOL
+    assert abs(float(sep.double().sum()) - float(g["sum_sep"])) < 1e-4 * abs(float(g["sum_sep"]))
