@@ -208,3 +208,23 @@ def test_fuse_lockstep_schedule_equals_reference_order(monkeypatch):
                     low = t if low is None else low + t
             ref = torch.relu(low) if i == 0 else chain(m.fuse_layers[i][0], xs[0], res_pre=low, act_last=True)
             assert torch.equal(ref, outs[i]), (nb, i)
+
+
+def test_padblock_and_local_permute_methods_match_oracle_partition():
+    """The reference's PadBlock.pad_if_needed / depad_if_needed and LocalPermuteModule.permute / rev_permute
+    (multihead_isa_attention.py:373-426) on the mirror classes: same tensors as the oracle's window_partition / window_merge."""
+    from oracle import rssformer_cpu as O
+    from representationlearning_amd.module.baseline.base_hrnet.modules.multihead_isa_attention import LocalPermuteModule, PadBlock
+    pad, perm = PadBlock(7), LocalPermuteModule(7)
+    for (B, H, W, C) in ((2, 10, 10, 5), (1, 14, 21, 3), (1, 9, 11, 4), (3, 7, 7, 2)):
+        t = torch.randn(B, H, W, C)
+        p = pad.pad_if_needed(t, t.shape)
+        Hp, Wp = pad.padded_size(H, W)
+        assert p.shape == (B, Hp, Wp, C)
+        w = perm.permute(p, (B, Hp, Wp, C))
+        ref, geom = O.window_partition(t)
+        assert torch.equal(w, ref)
+        back = pad.depad_if_needed(perm.rev_permute(w, (B, Hp, Wp, C)), t.shape)
+        assert torch.equal(back, t) and torch.equal(O.window_merge(ref, geom), t)
+        n_, slot = perm.window_of(B - 1, Hp - 1, Wp - 1, Hp, Wp)
+        assert n_ == w.shape[1] - 1 and slot == 48
