@@ -61,6 +61,7 @@ template <> struct Vec<float> {
   __device__ __forceinline__ float get(int i) const { return raw[i]; }
   __device__ __forceinline__ void set(int i, float v) { raw[i] = v; }
   __device__ __forceinline__ void set_all(const float (&v)[4]) { raw = f32x4{v[0], v[1], v[2], v[3]}; }
+  __device__ __forceinline__ void clear() { raw = f32x4{0.f, 0.f, 0.f, 0.f}; }
 };
 template <> struct Vec<bf16_t> {
   static constexpr int N = 8;
@@ -78,6 +79,7 @@ template <> struct Vec<bf16_t> {
   __device__ __forceinline__ void set_all(const float (&v)[8]) {     // 4 x v_cvt_pk_bf16_f32
     raw = u32x4{f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7])};
   }
+  __device__ __forceinline__ void clear() { raw = u32x4{0u, 0u, 0u, 0u}; }
 };
 
 // ---- wave reductions ------------------------------------------------------------------------------

@@ -48,9 +48,9 @@ template <typename T, typename DM> struct FwdLayout {
 };
 
 // projection tile: D(16x16) = A[16 rows][K] * B[16 rows][K]^T with the widest MFMA the dtype / K allow
+// `acc` = the bias tile (C-layout), so that no separate bias add follows the MFMA
 template <typename T>
-__device__ __forceinline__ f32x4 proj_tile(const T* A, int lda, const T* B, int ldb, int K) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ f32x4 proj_tile(const T* A, int lda, const T* B, int ldb, int K, f32x4 acc) {
   const int lane = threadIdx.x & 63;
   if constexpr (sizeof(T) == 2) {
     if (K % 32 == 0) {                       // v_mfma_f32_16x16x32_bf16: half the instructions of the K=16 form
@@ -63,6 +63,24 @@ __device__ __forceinline__ f32x4 proj_tile(const T* A, int lda, const T* B, int 
     }
   }
   return mma_tile<T>(A, lda, B, ldb, K, acc);
+}
+
+// Address = wave-uniform base + 32-bit BYTE offset per lane: the form the backend turns into `global_load ... v_off, s[base:base+1]`
+// (scalar base, zero-extended VGPR offset).  An element index scaled by the pointer type does not qualify - the shift may carry out
+// of 32 bits as far as the compiler knows - and costs a 64-bit VALU add per access.
+template <typename U> __device__ __forceinline__ const U* at_bytes(const void* base, unsigned byte_off) {
+  return reinterpret_cast<const U*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename U> __device__ __forceinline__ U* at_bytes(void* base, unsigned byte_off) {
+  return reinterpret_cast<U*>(reinterpret_cast<char*>(base) + byte_off);
+}
+
+// {a.x - b.x, a.y - b.x} as ONE packed instruction (the compiler emits two v_sub_f32 for scores that come out of an MFMA)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sub_lo(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
 }
 
 // 8-byte (bf16) / 16-byte (f32) access to 4 consecutive channels of one token
@@ -109,6 +127,11 @@ template <typename T, typename DM> struct TileRegs {
   int tok[ITERS];                    // LN statistics are fetched when the tile is finished (L2-resident: written by the pass before)
 #endif
   int pp[ITERS];                     // gate-weight index of the chunk's first element, -1: dead slot / padding chunk
+  // gate weights of the chunk (x tile / y tile).  L2-resident (128 KB per image) but still a vector-memory round trip: they are
+  // requested at the END of the previous window (gates_issue), so that between "finish this window's tiles" and "request the next
+  // window's tokens" no load is outstanding whose arrival somebody waits for - vmcnt counts in order, and a wait for a gate weight
+  // issued after the next window's token loads is a wait for those HBM loads too (46 % of the wave cycles were parked that way).
+  float4 wa[ITERS][V / 4], wb[ITERS][V / 4];
 };
 
 // n mod d for 0 <= n < 2^24 with a precomputed float reciprocal: one multiply, a truncation and one correction step (the
@@ -145,17 +168,33 @@ __device__ __forceinline__ void tiles_issue(TileRegs<T, DM>& R, const rssf_winat
     const bool ok = t < WIN * WIN && (unsigned)u < (unsigned)g.H && (unsigned)v < (unsigned)g.W && c0 < DM::C && e < LP * TR::CPR;
     const int nn = ok ? u * g.W + v : 0;
     const unsigned f = (unsigned)(nn * DM::C + (ok ? c0 : 0));                // N*C < 2^31 (checked by the entry points); unsigned:
-    R.vx[it].load(Xi + f);                                                    // scalar base + 32-bit lane offset, no 64-bit VALU
-    R.vy[it].load(Yi + f);
+    R.vx[it].load(at_bytes<T>(Xi, f * (unsigned)sizeof(T)));                  // scalar base + 32-bit lane offset, no 64-bit VALU
+    R.vy[it].load(at_bytes<T>(Yi, f * (unsigned)sizeof(T)));
 #if RSSF_FWD_PREFETCH_STATS
-    R.sx[it] = *reinterpret_cast<const float2*>(Sx + (unsigned)(nn * 2));
-    R.sy[it] = *reinterpret_cast<const float2*>(Sy + (unsigned)(nn * 2));
+    R.sx[it] = *at_bytes<float2>(Sx, (unsigned)nn * 8u);
+    R.sy[it] = *at_bytes<float2>(Sy, (unsigned)nn * 8u);
 #else
     R.tok[it] = nn;
 #endif
     // gate-weight index (n*C + c) mod N: with N = nc*C it is (n mod nc)*C + c
     const int pp = nc ? fast_mod(nn, nc, rcp_nc) * DM::C + c0 : (int)(f % (unsigned)g.N);
     R.pp[it] = ok ? pp : -1;
+  }
+}
+
+// gate weights of the window whose tokens `R` holds (CONTIG geometry: the V weights of a chunk are contiguous)
+template <typename T, typename DM>
+__device__ __forceinline__ void gates_issue(TileRegs<T, DM>& R, const float* om0, int N) {
+  using TR = TileRegs<T, DM>;
+  const float* om1 = om0 + N;
+#pragma unroll
+  for (int it = 0; it < TR::ITERS; ++it) {
+    const unsigned q = R.pp[it] < 0 ? 0u : (unsigned)R.pp[it];
+#pragma unroll
+    for (int i = 0; i < TR::V / 4; ++i) {
+      R.wa[it][i] = *at_bytes<float4>(om0, q * 4u + 16u * i);
+      R.wb[it][i] = *at_bytes<float4>(om1, q * 4u + 16u * i);
+    }
   }
 }
 
@@ -173,20 +212,7 @@ __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rss
     syv[it] = *reinterpret_cast<const float2*>(p.stats_y + img * 2 + (unsigned)(R.tok[it] * 2));
   }
 #endif
-  constexpr bool contiguous = CONTIG;        // N % C == 0: the V gate weights of a chunk are contiguous (no wrap inside a token row)
-  const float* om1 = om0 + g.N;
-  // gate weights: L2-resident (128 KB per image, every token row of a 512-token stripe reads the same 2 x C floats); fetched
-  // one iteration ahead of their use instead of all up front (64 registers for 4 iterations kept the kernel at 2 waves/SIMD)
-  float4 wa[2][V / 4], wb[2][V / 4];
-  auto fetch = [&](int it, int slot) {
-    const unsigned q = R.pp[it] < 0 ? 0u : (unsigned)R.pp[it];
-#pragma unroll
-    for (int i = 0; i < V / 4; ++i) {
-      wa[slot][i] = *reinterpret_cast<const float4*>(om0 + (q + 4 * i));
-      wb[slot][i] = *reinterpret_cast<const float4*>(om1 + (q + 4 * i));
-    }
-  };
-  if constexpr (contiguous) fetch(0, 0);
+  static_assert(CONTIG, "tiles_finish: the pipelined path is the N % C == 0 one");
 #pragma unroll
   for (int it = 0; it < TR::ITERS; ++it) {
     const int e = lane + it * 64;
@@ -194,21 +220,11 @@ __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rss
     const int t = e / TR::CPR, c0 = (e % TR::CPR) * V;
     const bool ok = R.pp[it] >= 0;
     float w0[V], w1[V];
-    if constexpr (contiguous) {
-      if (it + 1 < TR::ITERS) fetch(it + 1, (it + 1) & 1);
 #pragma unroll
-      for (int i = 0; i < V / 4; ++i) {
-        const float4 a4 = wa[it & 1][i], b4 = wb[it & 1][i];
-        w0[4 * i] = a4.x; w0[4 * i + 1] = a4.y; w0[4 * i + 2] = a4.z; w0[4 * i + 3] = a4.w;
-        w1[4 * i] = b4.x; w1[4 * i + 1] = b4.y; w1[4 * i + 2] = b4.z; w1[4 * i + 3] = b4.w;
-      }
-    } else {
-      int q = ok ? R.pp[it] : 0;
-#pragma unroll
-      for (int i = 0; i < V; ++i) {
-        w0[i] = om0[q]; w1[i] = om0[g.N + q];
-        if (++q == g.N) q = 0;
-      }
+    for (int i = 0; i < V / 4; ++i) {
+      const float4 a4 = R.wa[it][i], b4 = R.wb[it][i];
+      w0[4 * i] = a4.x; w0[4 * i + 1] = a4.y; w0[4 * i + 2] = a4.z; w0[4 * i + 3] = a4.w;
+      w1[4 * i] = b4.x; w1[4 * i + 1] = b4.y; w1[4 * i + 2] = b4.z; w1[4 * i + 3] = b4.w;
     }
     float fx[V], fy[V];
 #pragma unroll
@@ -219,11 +235,12 @@ __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rss
 #else
       const float2 sx = sxv[it], sy = syv[it];
 #endif
-      fx[i] = ok ? ((R.vx[it].get(i) - sx.x) * sx.y * ga + be) * w0[i] : 0.f;
-      fy[i] = ok ? ((R.vy[it].get(i) - sy.x) * sy.y * ga + be) * w1[i] : 0.f;
+      fx[i] = ((R.vx[it].get(i) - sx.x) * sx.y * ga + be) * w0[i];
+      fy[i] = ((R.vy[it].get(i) - sy.x) * sy.y * ga + be) * w1[i];
     }
     Vec<T> ox, oy;
     ox.set_all(fx); oy.set_all(fy);
+    if (!ok) { ox.clear(); oy.clear(); }          // dead / padded slots: zero rows (selected on the PACKED words, not per element)
     ox.store(xs + t * ldx + c0);
     oy.store(ys + t * ldx + c0);
     R.vx[it].store(xr + t * ldx + c0);            // raw tokens for the residual of step 4 (dead slots: never read back)
@@ -254,7 +271,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
   T* sWo = sWv + CV * LDW;                           // [CP][LDO]  rows = output channel, k = virtual channel
   float* sB = reinterpret_cast<float*>(sWo + CP * LDO);   // bq[CV] bk[CV] bv[CV] bo[CP]
   float* sLn = sB + 3 * CV + CP;                     // gamma[CP] beta[CP]
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform: window arithmetic on the SALU, scalar-base global loads
   const int l15 = lane & 15, grp = lane >> 4;
   T* xs = reinterpret_cast<T*>(smem_raw + LY::SHARED_OFF) + (size_t)wave * LY::NREG * LY::REGION;   // [LP][LDX] gated LN(x)
   T* ys = xs + LY::REGION;                                                                    // [LP][LDX] gated LN(y)
@@ -266,16 +283,24 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
   const int wpi = g.QH * g.QW;
   const int stride = gridDim.x * LY::WAVES;
   int wi = blockIdx.x * LY::WAVES + wave;
+  // softmax in base 2 with the scale folded into the q projection: Wq and bq are staged multiplied by log2(e)/sqrt(d), so q needs no
+  // epilogue arithmetic at all (v_exp_f32 is a base-2 exponential).  M = q^T k is linear in q: alpha reads mean(M) + max(M) back
+  // through 1/log2(e).
+  const float scale2 = rsqrtf((float)D) * 1.4426950408889634f;
   TileRegs<T, DM> R;
   const int nc = CONTIG ? g.N / C : 0;
   const float rcp_nc = nc ? 1.0f / (float)nc : 0.f;
-  if constexpr (PIPE) tiles_issue<T, DM>(R, p, g, X, Y, wi < g.nWin ? wi : g.nWin - 1, lane, nc, rcp_nc);   // under the weight staging below
+  if constexpr (PIPE) {                                                                                      // under the weight staging below
+    const int w0 = wi < g.nWin ? wi : g.nWin - 1;
+    tiles_issue<T, DM>(R, p, g, X, Y, w0, lane, nc, rcp_nc);
+    gates_issue<T, DM>(R, p.omega + (int64_t)(w0 / wpi) * 2 * g.N, g.N);
+  }
 
   for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
     const int m = i / LDW, k = i % LDW;
     const int rc = real_ch<DM>(m);
     const bool ok = rc >= 0 && k < C;
-    stf(sWq + i, ok ? p.wq[rc * C + k] : 0.f);
+    stf(sWq + i, ok ? p.wq[rc * C + k] * scale2 : 0.f);
     stf(sWk + i, ok ? p.wk[rc * C + k] : 0.f);
     stf(sWv + i, ok ? p.wv[rc * C + k] : 0.f);
   }
@@ -286,7 +311,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
   }
   for (int i = threadIdx.x; i < CV; i += blockDim.x) {
     const int rc = real_ch<DM>(i);
-    sB[i] = rc >= 0 ? p.bq[rc] : 0.f;
+    sB[i] = rc >= 0 ? p.bq[rc] * scale2 : 0.f;
     sB[CV + i] = rc >= 0 ? p.bk[rc] : 0.f;
     sB[2 * CV + i] = rc >= 0 ? p.bv[rc] : 0.f;
   }
@@ -297,10 +322,17 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
   }
   __syncthreads();
 
-  // softmax in base 2: log2(e) rides on the q scale of the S operand (v_exp_f32 is a base-2 exponential; one multiply per
-  // score less).  The q that enters M = q^T k keeps the plain 1/sqrt(d) scale.
-  const float scale = rsqrtf((float)D);
-  const float scale2 = scale * 1.4426950408889634f;
+  // bias tiles, loop-invariant: the MFMAs of the projections start from them.  Transposed tiles (rows = channels): four different
+  // row biases per lane; straight tiles (column = channel): one bias per lane in all four rows.
+  f32x4 bqT[MT], bqN[MT], bkN[MT], bvN[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int mrow = mt * 16 + grp * 4, mcol = mt * 16 + l15;
+    bqT[mt] = f32x4{sB[mrow], sB[mrow + 1], sB[mrow + 2], sB[mrow + 3]};
+    bqN[mt] = f32x4{sB[mcol], sB[mcol], sB[mcol], sB[mcol]};
+    bkN[mt] = f32x4{sB[CV + mcol], sB[CV + mcol], sB[CV + mcol], sB[CV + mcol]};
+    bvN[mt] = f32x4{sB[2 * CV + mcol], sB[2 * CV + mcol], sB[2 * CV + mcol], sB[2 * CV + mcol]};
+  }
 
   for (; wi < g.nWin; wi += stride) {
     const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;
@@ -313,8 +345,10 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
     wave_sync();
     if constexpr (PIPE) {
       tiles_finish<T, DM, CONTIG>(R, p, img, g, sLn, om0, xs, ys, xr, LDX, lane);
+      __builtin_amdgcn_sched_barrier(0);          // no token load of the next window above the last use of this window's registers
       const int nx = wi + stride < g.nWin ? wi + stride : g.nWin - 1;     // clamped, never branched around: a conditional load
       tiles_issue<T, DM>(R, p, g, X, Y, nx, lane, nc, rcp_nc);                         // makes every later s_waitcnt drain to zero
+      __builtin_amdgcn_sched_barrier(0);
     } else {
       load_gated_tiles<T, DM>(p, g, sLn, X, Y, om0, img, qh, qw, xs, ys, LDX, lane);
     }
@@ -328,6 +362,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
     //         transposed  q^T,k^T [channel][token] (k-slot = channel)  -> operands of S^T = k q^T
     //         straight    q,k,v   [token][channel] (k-slot = token)    -> operands of M = q^T k and of O^T = v^T P^T
     using PK = Packed<T>;
+    const typename PK::type ones = PK::pack(f32x4{1.f, 1.f, 1.f, 1.f});
     typename PK::type o[MT][NT];
 #pragma unroll
     for (int h = 0; h < DM::HEADS; ++h) {
@@ -343,20 +378,16 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
 #pragma unroll
         for (int mi = 0; mi < TPH; ++mi) {
           const int mt = h * TPH + mi;
-          const int mrow = mt * 16 + grp * 4, mcol = mt * 16 + l15;
-          f32x4 aq = proj_tile<T>(sWq + mt * 16 * LDW, LDW, xs + tt * 16 * LDX, LDX, CP);
-          f32x4 ak = proj_tile<T>(sWk + mt * 16 * LDW, LDW, ys + tt * 16 * LDX, LDX, CP);
-          f32x4 nq = proj_tile<T>(xs + tt * 16 * LDX, LDX, sWq + mt * 16 * LDW, LDW, CP);
-          f32x4 nk = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWk + mt * 16 * LDW, LDW, CP);
-          f32x4 nv = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWv + mt * 16 * LDW, LDW, CP);
+          const f32x4 aq = proj_tile<T>(sWq + mt * 16 * LDW, LDW, xs + tt * 16 * LDX, LDX, CP, bqT[mt]);
+          // k^T enters only S = q.k: its bias adds q.bk to every key of a query - a shift the softmax does not see - and is left out
+          const f32x4 ak = proj_tile<T>(sWk + mt * 16 * LDW, LDW, ys + tt * 16 * LDX, LDX, CP, f32x4{0.f, 0.f, 0.f, 0.f});
+          f32x4 nq = proj_tile<T>(xs + tt * 16 * LDX, LDX, sWq + mt * 16 * LDW, LDW, CP, bqN[mt]);
+          const f32x4 nk = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWk + mt * 16 * LDW, LDW, CP, bkN[mt]);
+          const f32x4 nv = proj_tile<T>(ys + tt * 16 * LDX, LDX, sWv + mt * 16 * LDW, LDW, CP, bvN[mt]);
+          if (tt * 16 + 15 >= LW) {                                  // compile-time: only the last token tile has dead slots
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            aq[r] = (aq[r] + sB[mrow + r]) * scale2;
-            ak[r] += sB[CV + mrow + r];
-            const bool live = tt * 16 + grp * 4 + r < LW;           // tokens >= 49 must not enter M (DAL.py:1003)
-            nq[r] = live ? (nq[r] + sB[mcol]) * scale : 0.f;
-            nk[r] += sB[CV + mcol];
-            nv[r] += sB[2 * CV + mcol];
+            for (int r = 0; r < 4; ++r)
+              if (tt * 16 + grp * 4 + r >= LW) nq[r] = 0.f;           // tokens >= 49 must not enter M (DAL.py:1003)
           }
           qT[mi][tt] = PK::pack(aq); kT[mi][tt] = PK::pack(ak); qN[mi] = PK::pack(nq); kN[mi] = PK::pack(nk);
           vN[tt][mi] = PK::pack(nv);
@@ -381,7 +412,8 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
           }
       msum = wave_reduce_dpp<OpSum>(msum);
       mmax = wave_reduce_dpp<OpMax>(mmax);
-      const float alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-(msum * (1.0f / (float)(D * D)) + mmax)));   // sigmoid, v_rcp_f32 (1 ulp)
+      // M was formed from q * log2(e): undo it on the two statistics.  sigmoid through v_rcp_f32 (1 ulp)
+      const float alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-(msum * (1.0f / (float)(D * D)) + mmax) * 0.6931471805599453f));
 
       // per query tile: S^T = k q^T, softmax over keys, O^T = v^T P^T
 #pragma unroll
@@ -395,35 +427,45 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
           s[kt] = acc;
         }
         // softmax over the 49 live keys (no mask, no bias: DAL.py:959,996); LW is a constant: only key tile 3 has dead rows
-        float mx = -INFINITY;
+        // Of key tile 3 (keys 48..63) only key 48 is live - element r = 0 of lane group 0: the other three rows of that tile are
+        // constants (-inf / 0) and cost no arithmetic.
+        static_assert(LW == 3 * 16 + 1 && NT == 4, "softmax: 49 live keys in four 16-key tiles");
+        s[3][0] = grp == 0 ? s[3][0] : -INFINITY;
+        float mx = s[3][0];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (kt * 16 + grp * 4 + r >= LW) s[kt][r] = -INFINITY;
-            mx = fmaxf(mx, s[kt][r]);
-          }
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = rows_reduce<OpMax>(mx);
-        float sum = 0.f;
+        const f32x2 mx2 = {mx, mx};
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx); sum += s[kt][r]; }
-        sum = rows_reduce<OpSum>(sum);
-        const float inv = alpha * __builtin_amdgcn_rcpf(sum);      // fold alpha into the normalisation: o = alpha * (P v)
+        for (int kt = 0; kt < 3; ++kt) {
+          const f32x2 lo = pk_sub_lo(f32x2{s[kt][0], s[kt][1]}, mx2), hi = pk_sub_lo(f32x2{s[kt][2], s[kt][3]}, mx2);
+          s[kt][0] = __builtin_amdgcn_exp2f(lo[0]); s[kt][1] = __builtin_amdgcn_exp2f(lo[1]);
+          s[kt][2] = __builtin_amdgcn_exp2f(hi[0]); s[kt][3] = __builtin_amdgcn_exp2f(hi[1]);
+        }
+        s[3][0] = __builtin_amdgcn_exp2f(s[3][0] - mx);
+        s[3][1] = 0.f; s[3][2] = 0.f; s[3][3] = 0.f;
         typename PK::type pk[NT];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+        for (int kt = 0; kt < NT; ++kt) pk[kt] = PK::pack(s[kt]);
+        // Row sums on the matrix pipe (the VALU is the busy one): ones[16][key] * P^T[key][query] puts sum_key P[query][key] into
+        // all four accumulator rows of the lane that owns `query` - no adds, no cross-lane reduction, and the sum is over exactly
+        // the (bf16-rounded) probabilities that multiply v below.
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
-          pk[kt] = PK::pack(s[kt]);
-        }
+        for (int kt = 0; kt < NT; ++kt) sacc = PK::mma(ones, pk[kt], sacc);
+        // P stays UN-normalised (values in (0, 1]): 1/sum - and alpha, o = alpha * (P v) - scale the 4 values of the O tile of this
+        // lane's query instead of the 16 probabilities
+        const float inv = alpha * __builtin_amdgcn_rcpf(sacc[0]);
         // O^T[dcol][query] = sum_key v[key][dcol] P^T[key][query]   (A = straight v tile: row index = dcol lane, k-slot = key)
 #pragma unroll
         for (int mi = 0; mi < TPH; ++mi) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kt = 0; kt < NT; ++kt) acc = PK::mma(vN[kt][mi], pk[kt], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] *= inv;
           o[h * TPH + mi][qt] = PK::pack(acc);
         }
       }
@@ -434,6 +476,12 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
     // that cover their latency - not carried in registers across steps 2-3
     typename Quad<T>::raw xres[NT][CT];
     if constexpr (PIPE) {
+      // the next window's gate weights, one out-projection ahead of their use (64 registers that are free from here to the next
+      // tiles_finish); the stores below queue up behind them and are never waited for
+      const int nx = wi + stride < g.nWin ? wi + stride : g.nWin - 1;
+      __builtin_amdgcn_sched_barrier(0);
+      gates_issue<T, DM>(R, p.omega + (int64_t)(nx / wpi) * 2 * g.N, g.N);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int qt = 0; qt < NT; ++qt)
 #pragma unroll
@@ -465,7 +513,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
           Quad<T>::unpack(xres[qt][ct], xr);
 #pragma unroll
           for (int r = 0; r < 4; ++r) xr[r] += acc[r] + sB[3 * CV + (c0 < C ? c0 : 0) + r];
-          if (n >= 0 && c0 < C) Quad<T>::store(OUTimg + off, xr);
+          if (n >= 0 && c0 < C) Quad<T>::store(at_bytes<T>(OUTimg, off * (unsigned)sizeof(T)), xr);
         } else {
           if (n < 0) continue;
 #pragma unroll
