@@ -16,6 +16,9 @@
 using namespace rssf;
 using namespace rssf::wa;
 
+#ifndef RSSF_BWD_DBG
+#define RSSF_BWD_DBG 0      // timing experiments only: 1 = no S1 loads, 2 = no S9 (results are garbage)
+#endif
 #ifndef RSSF_BWD_COMPACT_BF16
 #define RSSF_BWD_COMPACT_BF16 0
 #endif
@@ -48,7 +51,7 @@ template <typename T, typename DM, bool ACC_LDS> struct BwdLayout {
   static_assert(DM::HEADS == 2, "the backward kernel maps one head to each wave of a pair");
   static constexpr int PAIR_ELEMS = 3 * REGX + 3 * REGV + 2 * SCRATCH;
   static constexpr size_t WAVE_BYTES = sizeof(T) * PAIR_ELEMS;            // per pair
-  static constexpr size_t LIM = 160 * 1024;
+  static constexpr size_t LIM = 160 * 1024 - 64;     // 64 B: the statically allocated pair-barrier counters
   static constexpr int PAIRS = (SHARED_OFF + 4 * WAVE_BYTES <= LIM) ? 4 : (SHARED_OFF + 3 * WAVE_BYTES <= LIM) ? 3
                              : (SHARED_OFF + 2 * WAVE_BYTES <= LIM) ? 2 : 1;
   static constexpr int WAVES = 2 * PAIRS;
@@ -116,6 +119,19 @@ __device__ __forceinline__ void store_tok_major(T* buf, int ld, int mt, int tt, 
   store4(buf + tok * ld + mt * 16 + grp * 4, tok < L ? v : z);
 }
 
+// Barrier of the TWO waves that serve one window (a monotonic LDS counter: both add 1 per barrier, both wait for 2 x phase).  The
+// phases of a window used to be separated by workgroup barriers, which marched all pairs of a CU in lockstep: every wave of the CU
+// sat in the same global-memory phase at the same time, and nothing overlapped its latency (49 % of the wave cycles were parked).
+// Pairs now drift apart and cover each other.  Both waves of a pair are resident in the same workgroup, so the spin cannot
+// deadlock; LDS is coherent within the CU once the writer's lgkmcnt has drained.
+__device__ __forceinline__ void pair_barrier(unsigned* ctr, unsigned& phase, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  phase += 2;
+  if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <typename T, typename DM, bool ACC_LDS>
 __global__ void __launch_bounds__((BwdLayout<T, DM, ACC_LDS>::WAVES * 64))
 winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
@@ -124,6 +140,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   constexpr int C = DM::C, CP = DM::CP, CV = DM::CV, MT = DM::MT, CT = DM::CT, TPH = DM::TPH, D = DM::D, DP = DM::DP;
   const rssf_winattn_fwd_params& p = bp.f;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ unsigned pbar[4];                   // pair barriers (LY::PAIRS <= 4)
   T* sWq = reinterpret_cast<T*>(smem_raw);       // [CV][LDW]
   T* sWk = sWq + CV * LDW;
   T* sWv = sWk + CV * LDW;
@@ -159,6 +176,8 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
     sLn[CP + i] = i < C ? p.ln_beta[i] : 0.f;
   }
   if (ACC_LDS) for (int i = threadIdx.x; i < LY::A_ELEMS; i += blockDim.x) aW[i] = 0.f;
+  if (threadIdx.x < 4) pbar[threadIdx.x] = 0u;
+  unsigned bar_phase = 0u;
   __syncthreads();
 
   // accumulate one weight-gradient element: which = 0 q, 1 k, 2 v (index [m][c]); 3 = o (index [m][c] meaning dWo[c][m])
@@ -216,12 +235,14 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
 
     f32x4 dxt[CT][NT], dyt[CT][NT];     // d(x~)^T, d(y~)^T accumulators (this head's share): rows = real channel, col = token
     // ---- S1: gated LN'ed inputs and dout tile, token-major; the two waves of the pair stage half of the chunks each ----
-    __syncthreads();                    // the previous window's exchange buffers (which alias these tiles) have been read
+    pair_barrier(pbar + pair, bar_phase, lane);                    // the previous window's exchange buffers (which alias these tiles) have been read
+#if RSSF_BWD_DBG != 1
     if (active) {
       load_gated_tiles<T, DM, 2>(p, g, sLn, X, Y, om0, img, qh, qw, XS, YS, LDX, lane, hw);
       load_plain_tile<T, DM>(g, DOUT, img, qh, qw, GS, LDX, lane, hw);
     }
-    __syncthreads();
+#endif
+    pair_barrier(pbar + pair, bar_phase, lane);
     if (active) {
     // ---- S2: projections of THIS wave's head; q,k,v staged token-major (K = tokens contractions use RowFrag) -----------
 #pragma unroll
@@ -298,8 +319,27 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
       // orientation they chain straight into dWo (here) and dv (S5) from registers - no LDS copies of O / dU.
       f32x4 dq[TPH][NT], dk[TPH][NT], dv[TPH][NT];
       typename Packed<T>::type dUq[NT][TPH];               // alpha * dO, rows = query, col = head channel
+      // FOLD: dk / dv accumulate inside the query-tile loop below from TRANSPOSED P / dS tiles.  Only for one channel tile per head
+      // (C = 32 / 18).  The C = 48 instantiations (two tiles per head, 512 VGPRs + 100-200 spilled registers) keep the validated
+      // second pass: built with the folded form, the fp32 C = 48 kernel returned v_proj gradients 60x too large at -O3 / -O2 and
+      // correct ones at -O1 (same source; tools/attn_c48_dbg.py) - a code-generation problem at that register pressure, not
+      // worth chasing for the parity-mode kernel.
+      constexpr bool FOLD = TPH == 1;
+      if constexpr (FOLD)
+#pragma unroll
+      for (int mi = 0; mi < TPH; ++mi)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) { dk[mi][kt] = {0.f, 0.f, 0.f, 0.f}; dv[mi][kt] = dk[mi][kt]; }
+      // identity tile as an MFMA B operand (chain slot order): X^T = mma(A = X read as a chained C-layout tile, B = I).  dk and dv
+      // contract over the QUERY axis, i.e. need P and dS with rows = queries: one MFMA per 16x16 tile turns the (keys x queries)
+      // tiles of this loop around - the second orientation used to be RECOMPUTED (scores, 256 exponentials and ~1 500 VALU
+      // instructions per window and wave, plus the per-query statistics through LDS).
+      f32x4 idv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) idv[r] = (grp * 4 + r == l15) ? 1.f : 0.f;
+      const typename Packed<T>::type ident = Packed<T>::pack(idv);
 
-      float smx[NT], sinv[NT], srs[NT];
+      float smx[NT], sinv[NT], srs[NT];     // !FOLD only
       float dalpha = 0.f;
 #pragma unroll
       for (int qt = 0; qt < NT; ++qt) {
@@ -330,7 +370,6 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
-        smx[qt] = mx; sinv[qt] = inv;
         // U[q][m] = sum_key P[q][key] v[key][m] ; dalpha += <dO, U> ; O = alpha U -> dWo ; dU = alpha dO (both orientations)
 #pragma unroll
         for (int mi = 0; mi < TPH; ++mi) {
@@ -366,7 +405,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           for (int r = 0; r < 4; ++r) rs += s[kt][r] * acc[r];
         }
         rs = rows_reduce<OpSum>(rs);
-        srs[qt] = rs;
+        if constexpr (!FOLD) { smx[qt] = mx; sinv[qt] = inv; srs[qt] = rs; }
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
@@ -379,8 +418,24 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
           for (int kt = 0; kt < NT; ++kt) acc = mma_row_chain<T>(KS, LDV, hoff + mi * 16, kt * 16, dp[kt], acc);
           dq[mi][qt] = acc;
         }
+        // rows = queries: dk^T[m][key] += sum_q q^T[m][q] dS[q][key] ; dv^T[m][key] += sum_q dU[q][m] P[q][key]
+        // (the transposed tiles hold exactly the bf16 values that fed dq / U above: re-packing them is exact)
+        if constexpr (FOLD)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 pt = Packed<T>::mma(Packed<T>::pack(s[kt]), ident, z);
+          const f32x4 dst = Packed<T>::mma(Packed<T>::pack(dp[kt]), ident, z);
+          const typename Packed<T>::type ptp = Packed<T>::pack(pt);
+#pragma unroll
+          for (int mi = 0; mi < TPH; ++mi) {
+            dk[mi][kt] = mma_row_chain<T>(QS, LDV, hoff + mi * 16, qt * 16, dst, dk[mi][kt]);
+            dv[mi][kt] = Packed<T>::mma(dUq[qt][mi], ptp, dv[mi][kt]);
+          }
+        }
       }
       dalpha = wave_reduce_dpp<OpSum>(dalpha);            // each tile element lives in exactly one lane: plain sum
+      if constexpr (!FOLD) {
       // per-query softmax statistics for orientation 2 (there a lane needs the values of queries 4g..4g+3, which live in lanes
       // 4g..4g+3 of this orientation): parked in the dM scratch (free until S6) and read back as one 16-byte LDS read per tile,
       // instead of 192 variable-lane shuffles per window (ds_bpermute + a v_readlane waterfall: 536 instructions)
@@ -429,6 +484,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
       }
 
       wave_sync();      // the per-query statistics (float view of the dM scratch) have been read: S6 overwrites the scratch
+      }
       __builtin_amdgcn_sched_barrier(0);
       // ---- S6: alpha path: dM = du * (1/d^2 + onehot(argmax)) -> dq += k dM^T, dk += q dM ---------------------------
       const float du = dalpha * alpha * (1.f - alpha);
@@ -524,9 +580,37 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
     }
     }   // active: S2 .. S8
 
+    // ---- S9's global operands: raw x / y, LN statistics, gate weights of the two token tiles this wave finishes (L2 hits: S1 read
+    //      them).  Requesting them ahead of the two exchange barriers was measured and dropped: the ~60 registers they hold across
+    //      the exchange spill (58 at C = 32 bf16) and the kernel went from 173 to 218 us ---------------------------------------
+    const bool vec9 = (C % 4 == 0) && (g.N % 4 == 0);
+    float2 s9sx[2], s9sy[2];
+    typename Quad4<T>::raw s9x[2][CT], s9y[2][CT];
+    f32x4 s9w0[2][CT], s9w1[2][CT];
+    int s9n[2], s9pp[2][CT];
+    auto s9_load = [&](int tl) {
+      {
+        const int n = slot_token(g, qh, qw, (2 * hw + tl) * 16 + l15);
+        const int nn = n >= 0 ? n : 0;
+        s9n[tl] = n;
+        s9sx[tl] = *reinterpret_cast<const float2*>(p.stats_x + (img + nn) * 2);
+        s9sy[tl] = *reinterpret_cast<const float2*>(p.stats_y + (img + nn) * 2);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int c0 = ct * 16 + grp * 4;
+          const int64_t f = (int64_t)nn * C + (c0 < C ? c0 : 0);
+          s9pp[tl][ct] = (int)((unsigned)f % (unsigned)g.N);
+          s9x[tl][ct] = Quad4<T>::load(X + img * C + f);
+          s9y[tl][ct] = Quad4<T>::load(Y + img * C + f);
+          s9w0[tl][ct] = *reinterpret_cast<const f32x4*>(om0 + s9pp[tl][ct]);
+          s9w1[tl][ct] = *reinterpret_cast<const f32x4*>(om0 + g.N + s9pp[tl][ct]);
+        }
+      }
+    };
+
     // ---- head sum of d(x~), d(y~): wave hw keeps token tiles 2hw, 2hw+1 and receives the partner's share of them through
     //      LDS (the six tiles are dead now): partner 0's inbox = {XS, YS}, partner 1's = {GS, QS} -------------------------
-    __syncthreads();
+    pair_barrier(pbar + pair, bar_phase, lane);
     f32x4* inbox0 = reinterpret_cast<f32x4*>(XS);
     f32x4* inbox1 = reinterpret_cast<f32x4*>(GS);
     auto send = [&](auto TT0, f32x4* box) {               // TT0: first token tile of the RECEIVER
@@ -543,7 +627,7 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
       if (hw == 0) send(std::integral_constant<int, 2>{}, inbox1);
       else send(std::integral_constant<int, 0>{}, inbox0);
     }
-    __syncthreads();
+    pair_barrier(pbar + pair, bar_phase, lane);
     if (active) {
     auto finish = [&](auto TT0, const f32x4* box) {
       constexpr int t0 = decltype(TT0)::value;
@@ -561,27 +645,16 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
     // 4: the 4 gate weights are contiguous and never wrap): all global loads of a token tile are issued branch-free
     // (dead / padded slots read token 0) before anything is consumed; 8-byte stores; only the stores / atomics are
     // predicated.
-    if ((C % 4 == 0) && (g.N % 4 == 0)) {
+    if (vec9) {
 #pragma unroll
       for (int tt = t0; tt < t0 + 2; ++tt) {
-        const int n = slot_token(g, qh, qw, tt * 16 + l15);
-        const int nn = n >= 0 ? n : 0;
-        const float2 sx = *reinterpret_cast<const float2*>(p.stats_x + (img + nn) * 2);
-        const float2 sy = *reinterpret_cast<const float2*>(p.stats_y + (img + nn) * 2);
-        typename Quad4<T>::raw rx[CT], ry[CT];
-        f32x4 w0[CT], w1[CT];
-        int pp[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const int c0 = ct * 16 + grp * 4;
-          const int cc = c0 < C ? c0 : 0;
-          const int64_t f = (int64_t)nn * C + cc;
-          pp[ct] = (int)((unsigned)f % (unsigned)g.N);
-          rx[ct] = Quad4<T>::load(X + img * C + f);
-          ry[ct] = Quad4<T>::load(Y + img * C + f);
-          w0[ct] = *reinterpret_cast<const f32x4*>(om0 + pp[ct]);
-          w1[ct] = *reinterpret_cast<const f32x4*>(om0 + g.N + pp[ct]);
-        }
+        const int tl = tt - t0;
+        s9_load(tl);
+        const int n = s9n[tl];
+        const float2 sx = s9sx[tl], sy = s9sy[tl];
+        const auto& rx = s9x[tl]; const auto& ry = s9y[tl];
+        const auto& w0 = s9w0[tl]; const auto& w1 = s9w1[tl];
+        const auto& pp = s9pp[tl];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int c0 = ct * 16 + grp * 4;
@@ -644,8 +717,10 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
     }
     };   // finish
     static_assert(NT == 4, "two token tiles per wave of a pair");
+#if RSSF_BWD_DBG != 2
     if (hw == 0) finish(std::integral_constant<int, 0>{}, inbox0);
     else finish(std::integral_constant<int, 2>{}, inbox1);
+#endif
     }   // active: exchange + S9
   }
 
