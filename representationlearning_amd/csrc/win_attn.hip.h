@@ -47,6 +47,10 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// 4 consecutive elements to an 8-byte (bf16) / 16-byte (f32) aligned address
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) { *reinterpret_cast<s16x4*>(p) = pack_bf16x4(v); }
+__device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+
 // real channel of virtual channel m (= h*dp + dc), or -1 for a padding row
 template <typename DM>
 __device__ __forceinline__ int real_ch(int m) {

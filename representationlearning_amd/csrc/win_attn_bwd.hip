@@ -110,8 +110,6 @@ template <> struct Quad4<float> {
   static __device__ __forceinline__ raw load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
   static __device__ __forceinline__ f32x4 unpack(const raw& u) { return u; }
 };
-__device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) { *reinterpret_cast<s16x4*>(p) = pack_bf16x4(v); }
-__device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <typename T>
 __device__ __forceinline__ void store_tok_major(T* buf, int ld, int mt, int tt, const f32x4& v, int l15, int grp, int L) {
   const int tok = tt * 16 + l15;
@@ -156,24 +154,44 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   T* QS = GS + LY::REGX;        T* KS = QS + LY::REGV;     T* VS = KS + LY::REGV;      // later dq, dk, dv (head by head)
   T* dMs = VS + LY::REGV + hw * LY::SCRATCH;
 
-  for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
-    const int m = i / LDW, k = i % LDW;
-    const int rc = real_ch<DM>(m);
-    const bool ok = rc >= 0 && k < C;
-    stf(sWq + i, ok ? p.wq[rc * C + k] : 0.f);
-    stf(sWk + i, ok ? p.wk[rc * C + k] : 0.f);
-    stf(sWv + i, ok ? p.wv[rc * C + k] : 0.f);
-    stf(sWoT + i, ok ? p.wo[k * C + rc] : 0.f);
+  if constexpr (CV == C && C % 4 == 0) {
+    // head width = its padded width (C = 32): the staged images are the row-major matrices themselves - one 16-byte load per
+    // thread and matrix instead of ~1 500 dynamic instructions of element-wise index arithmetic per wave and launch.  The pad
+    // columns k >= C of a row are never read (every contraction stops at CP = C).
+    for (int i = threadIdx.x; i < C * C / 4; i += blockDim.x) {
+      const int m = (i * 4) / C, k = (i * 4) % C;
+      store4(sWq + m * LDW + k, reinterpret_cast<const f32x4*>(p.wq)[i]);
+      store4(sWk + m * LDW + k, reinterpret_cast<const f32x4*>(p.wk)[i]);
+      store4(sWv + m * LDW + k, reinterpret_cast<const f32x4*>(p.wv)[i]);
+      const f32x4 o4 = reinterpret_cast<const f32x4*>(p.wo)[i];      // Wo[c = m][m' = k..k+3] -> WoT[m'][c]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) stf(sWoT + (k + j) * LDW + m, o4[j]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < CV * LDW; i += blockDim.x) {
+      const int m = i / LDW, k = i % LDW;
+      const int rc = real_ch<DM>(m);
+      const bool ok = rc >= 0 && k < C;
+      stf(sWq + i, ok ? p.wq[rc * C + k] : 0.f);
+      stf(sWk + i, ok ? p.wk[rc * C + k] : 0.f);
+      stf(sWv + i, ok ? p.wv[rc * C + k] : 0.f);
+      stf(sWoT + i, ok ? p.wo[k * C + rc] : 0.f);
+    }
   }
-  for (int i = threadIdx.x; i < CV; i += blockDim.x) {
-    const int rc = real_ch<DM>(i);
-    sB[i] = rc >= 0 ? p.bq[rc] : 0.f;
-    sB[CV + i] = rc >= 0 ? p.bk[rc] : 0.f;
-    sB[2 * CV + i] = rc >= 0 ? p.bv[rc] : 0.f;
-  }
-  for (int i = threadIdx.x; i < CP; i += blockDim.x) {
-    sLn[i] = i < C ? p.ln_gamma[i] : 0.f;
-    sLn[CP + i] = i < C ? p.ln_beta[i] : 0.f;
+  // biases and LayerNorm affine: the five loads of a thread in flight together (clamped indices, selected afterwards)
+  for (int i = threadIdx.x; i < (CV > CP ? CV : CP); i += blockDim.x) {
+    const int rc = i < CV ? real_ch<DM>(i) : -1;
+    const int rq = rc >= 0 ? rc : 0, ci = i < C ? i : 0;
+    const float vq = p.bq[rq], vk = p.bk[rq], vv = p.bv[rq], vg = p.ln_gamma[ci], vb = p.ln_beta[ci];
+    if (i < CV) {
+      sB[i] = rc >= 0 ? vq : 0.f;
+      sB[CV + i] = rc >= 0 ? vk : 0.f;
+      sB[2 * CV + i] = rc >= 0 ? vv : 0.f;
+    }
+    if (i < CP) {
+      sLn[i] = i < C ? vg : 0.f;
+      sLn[CP + i] = i < C ? vb : 0.f;
+    }
   }
   if (ACC_LDS) for (int i = threadIdx.x; i < LY::A_ELEMS; i += blockDim.x) aW[i] = 0.f;
   if (threadIdx.x < 4) pbar[threadIdx.x] = 0u;
