@@ -143,6 +143,7 @@ typedef struct rssf_pack_job {
 /* rows_p / cols_p of the packed slabs for a (rows, cols) weight matrix (rows = cout, or cin when transposed) */
 int rssf_conv_packed_rows(int rows);
 int rssf_conv_packed_cols(int cols, int dtype);
+/* (a job's packed image must stay below 2^31 elements: the kernel indexes it with 32-bit arithmetic) */
 int rssf_conv_pack_batch(const rssf_pack_job* jobs, const int* block_map, int nblocks, int dtype, void* stream);
 /* the gather convolution itself.  bias [Cout] optional; stats [RSSF_BN_SLOTS][2][Cout] optional: per-channel sum and sum of squares of
  * the OUTPUT (incl. bias) atomically accumulated for the BatchNorm that follows (fused statistics). */

@@ -383,23 +383,27 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a, T* out) {
 template <typename T>
 __global__ void __launch_bounds__(256) pack_batch_kernel(const rssf_pack_job* __restrict__ jobs, const int* __restrict__ block_map) {
   const rssf_pack_job& j = jobs[block_map[2 * blockIdx.x]];
-  const int64_t total = (int64_t)j.ntaps * j.rows_p * j.cols_p;
-  const int64_t base = (int64_t)block_map[2 * blockIdx.x + 1] * RSSF_PACK_CHUNK;
+  // 32-bit index arithmetic (a packed image stays far below 2^31 elements - rssf_conv_pack_batch's caller sizes it - and the
+  // 64-bit divisions by run-time values were most of this kernel's 255 us per training step)
+  const unsigned total = (unsigned)j.ntaps * (unsigned)j.rows_p * (unsigned)j.cols_p;
+  const unsigned base = (unsigned)block_map[2 * blockIdx.x + 1] * (unsigned)RSSF_PACK_CHUNK;
+  const unsigned cols_p = (unsigned)j.cols_p, rows_p = (unsigned)j.rows_p;
   T* out = reinterpret_cast<T*>(j.out);
 #pragma unroll
   for (int u = 0; u < RSSF_PACK_CHUNK / 256; ++u) {
-    const int64_t i = base + u * 256 + threadIdx.x;
+    const unsigned i = base + u * 256 + threadIdx.x;
     if (i >= total) break;
-    const int col = (int)(i % j.cols_p), row = (int)((i / j.cols_p) % j.rows_p), t = (int)(i / ((int64_t)j.cols_p * j.rows_p));
-    const int co = j.transpose ? col : row, ci = j.transpose ? row : col;
+    const unsigned rt = i / cols_p, col = i - rt * cols_p, t = rt / rows_p, row = rt - t * rows_p;
+    const unsigned co = j.transpose ? col : row, ci = j.transpose ? row : col;
     float v = 0.f;
-    if (co < j.cout && ci < j.cin) {
+    if (co < (unsigned)j.cout && ci < (unsigned)j.cin) {
       const int s = j.src_of_tap[t], kk = j.ks[s] * j.ks[s];
-      v = j.w[s][((int64_t)co * j.cin + ci) * kk + j.kpos_of_tap[t]];
+      const unsigned e0 = co * (unsigned)j.cin + ci;
+      v = j.w[s][e0 * (unsigned)kk + (unsigned)j.kpos_of_tap[t]];
 #pragma unroll
       for (int e = 0; e < 4; e += 2) {
         const int s2 = j.alias_of_tap[t][e];
-        if (s2 >= 0) v += j.w[s2][((int64_t)co * j.cin + ci) * (j.ks[s2] * j.ks[s2]) + j.alias_of_tap[t][e + 1]];
+        if (s2 >= 0) v += j.w[s2][e0 * (unsigned)(j.ks[s2] * j.ks[s2]) + (unsigned)j.alias_of_tap[t][e + 1]];
       }
     }
     stf(out + i, v);

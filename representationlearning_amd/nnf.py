@@ -640,14 +640,19 @@ class _ConvBNAct(torch.autograd.Function):
                 raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
             dx = None
         wt = [grad_target(w, rt) for w in p_weights]
-        db = _zeros(C, raw.device, rt) if nbias else None
-        _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt)
-        gws = [grad_result(w, t[0], t[1], rt) for w, t in zip(p_weights, wt)]
         gbs = []
-        for b in p_biases:      # every summed conv's bias sees the same gradient
-            tb, direct = grad_target(b, rt)
-            tb += db
-            gbs.append(grad_result(b, tb, direct, rt))
+        if nbias == 1:          # the weight-gradient kernel accumulates straight into the bias gradient: no staging buffer, no add
+            tb, direct = grad_target(p_biases[0], rt)
+            _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt)
+            gbs.append(grad_result(p_biases[0], tb, direct, rt))
+        else:
+            db = _zeros(C, raw.device, rt) if nbias else None
+            _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt)
+            for b in p_biases:      # every summed conv's bias sees the same gradient
+                tb, direct = grad_target(b, rt)
+                tb += db
+                gbs.append(grad_result(b, tb, direct, rt))
+        gws = [grad_result(w, t[0], t[1], rt) for w, t in zip(p_weights, wt)]
         return (dx, None if dres is None else _nchw(dres), dy if has_post else None, grad_result(p_gamma, dgamma, dg_direct, rt),
                 grad_result(p_beta, dbeta, db_direct, rt), None, None, None, None, None, None, None, None, None, None, *gws, *gbs)
 
