@@ -11,6 +11,7 @@
 // O and dU never touch LDS: they are formed in both register orientations by swapping MFMA operands.
 // Softmax / dS tiles stay in registers and are computed in both orientations instead of being transposed through LDS.
 // Weight gradients are accumulated in LDS per workgroup and flushed once.
+#include <mutex>
 #include <type_traits>
 #include "win_attn.hip.h"
 using namespace rssf;
@@ -800,14 +801,24 @@ template <typename T, typename DM, bool ACC_LDS>
 int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) {
   using LY = BwdLayout<T, DM, ACC_LDS>;
   int blocks = (g.nWin + LY::PAIRS - 1) / LY::PAIRS;
-  if (blocks > 256) blocks = 256;           // one resident workgroup per CU (157 KB LDS): persistent, one gradient flush each
   auto kern = winattn_bwd_kernel<T, DM, ACC_LDS>;
-  static bool attr_set = false;     // idempotent per instantiation; kept out of replayed hipGraph captures
-  if (LY::BYTES > 64 * 1024 && !attr_set) {
-    attr_set = true;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES);
-    if (e != hipSuccess) { set_error("winattn_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
-  }
+  // once per (instantiation, device), outside any replayed hipGraph capture: the dynamic-LDS limit and the CU count
+  constexpr int MAX_DEVICES = 32;
+  static std::once_flag once[MAX_DEVICES];
+  static int cus[MAX_DEVICES];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= MAX_DEVICES) dev = 0;
+  hipError_t e = hipSuccess;
+  std::call_once(once[dev], [&] {
+    if (LY::BYTES > 64 * 1024) e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LY::BYTES);
+    int v = 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    (void)hipGetLastError();
+    cus[dev] = v;
+  });
+  if (e != hipSuccess) { set_error("winattn_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
+  if (blocks > cus[dev]) blocks = cus[dev];   // one resident workgroup per CU (157 KB LDS): persistent, one gradient flush each
   kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, g);
   int rc = check_launch("winattn_bwd");
   if (rc || !p->prod_ws) return rc;

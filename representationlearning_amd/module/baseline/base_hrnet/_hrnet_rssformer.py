@@ -185,6 +185,7 @@ class HighResolutionModule(nn.Module):
         long.  The chain from branch 0 ends in `relu(bn(conv(.)) + low_i)`; its last convolution waits for the depth at which
         `low_i` is complete (depth max(i - 1, 1)).  Sums are formed in the reference's order (j ascending)."""
         nb, nout = self.num_branches, len(self.fuse_layers)
+        x, accs = self._fanout(x)
         up, cur, done = {}, {}, {}                # (i,j) -> 1x1 output / running chain value / finished chain value
         last_depth = {i: max(i - 1, 1) for i in range(1, nout)}
         lows, outs = {}, [None] * nout
@@ -207,7 +208,7 @@ class HighResolutionModule(nn.Module):
                 for j in range(nb):
                     if j > i and depth == 0:
                         fl = self.fuse_layers[i][j]
-                        items.append(dict(x=x[j], conv=fl[0], bn=fl[1], act=nnf.ACT_NONE))
+                        items.append(dict(x=x[j], conv=fl[0], bn=fl[1], act=nnf.ACT_NONE, grad_accum=accs[j]))
                         tags.append(("up", i, j))
                     elif j < i:
                         chain = self.fuse_layers[i][j]
@@ -222,16 +223,17 @@ class HighResolutionModule(nn.Module):
                             continue
                         stage = chain[d]
                         src = x[j] if d == 0 else cur[(i, j)]
+                        acc = accs[j] if d == 0 else None
                         if final0 and d == length - 1:
                             if depth != last_depth[i]:
                                 continue
                             if i not in lows:
                                 lows[i] = low_of(i)
-                            items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU, res_pre=lows[i]))
+                            items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU, res_pre=lows[i], grad_accum=acc))
                             tags.append(("out", i, j))
                         else:
                             relu = len(stage) > 2
-                            items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU if relu else nnf.ACT_NONE))
+                            items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU if relu else nnf.ACT_NONE, grad_accum=acc))
                             tags.append(("last" if d == length - 1 else "mid", i, j))
             if not items:
                 break
@@ -255,6 +257,7 @@ class HighResolutionModule(nn.Module):
         if self._lockstep_ok():
             return self._fuse_lockstep(self._branches_lockstep(x[:self.num_branches]))
         x = nnf.parallel_map(list(self.branches), x[:self.num_branches])       # Sequentials of BasicBlocks, one stream each
+        x, accs = self._fanout(x)
         fused = []
         for i in range(len(self.fuse_layers)):
             low = None
@@ -263,17 +266,27 @@ class HighResolutionModule(nn.Module):
                     low = x[j] if low is None else low + x[j]
                 elif j > i:      # 1x1 conv + BN, then nearest upsample fused with the running sum
                     fl = self.fuse_layers[i][j]
-                    t = nnf.conv_bn_act(x[j], fl[0], fl[1])
+                    t = nnf.conv_bn_act(x[j], fl[0], fl[1], grad_accum=accs[j])
                     low = nnf.upsample_nearest_add(low, t, int(fl[2].scale_factor))
                 else:
-                    t = nnf.run_sequential(self.fuse_layers[i][j], x[j])
+                    t = nnf.run_sequential(self.fuse_layers[i][j], x[j], grad_accum=accs[j])
                     low = t if low is None else low + t
             if i == 0:
                 y = self.relu(self.transformer(low, x[0]))        # residual comes from `low`; x[0] only feeds K/V (:430-431)
             else:       # relu(fuse[i][0](x[0]) + low) (:432-435): sum and ReLU ride in the last down-sampling conv's BatchNorm pass
-                y = nnf.run_sequential(self.fuse_layers[i][0], x[0], res_pre=low, act_last=nnf.ACT_RELU)
+                y = nnf.run_sequential(self.fuse_layers[i][0], x[0], res_pre=low, act_last=nnf.ACT_RELU, grad_accum=accs[0])
             fused.append(y)
         return fused
+
+    def _fanout(self, x):
+        """Branch output j feeds one convolution per fuse path (i != j): their data gradients accumulate in one buffer
+        (nnf.GradAccum) instead of being summed by autograd with an elementwise kernel per consumer."""
+        xs, accs = [], []
+        for j in range(self.num_branches):
+            t, acc = nnf.fanout(x[j], sum(1 for i in range(len(self.fuse_layers)) if i != j))
+            xs.append(t)
+            accs.append(acc)
+        return xs, accs
 
 
 class HighResolutionNet(nn.Module):
@@ -360,11 +373,13 @@ class HighResolutionNet(nn.Module):
             trans = getattr(self, "transition{}".format(s - 1))
             nb = getattr(self, "stage{}_cfg".format(s))["num_branches"]
             xs = []
+            # (transition1: layer1's 256-channel output feeds both new branches - its two data gradients share one buffer)
+            last, acc = nnf.fanout(ys[-1], sum(1 for i in range(nb) if trans[i] is not None))
             for i in range(nb):
                 if trans[i] is None:
                     xs.append(ys[i])
                 else:
-                    xs.append(nnf.run_sequential(trans[i], ys[-1]))
+                    xs.append(nnf.run_sequential(trans[i], last, grad_accum=acc))
             ys = getattr(self, "stage{}".format(s))(xs)
         return ys
 

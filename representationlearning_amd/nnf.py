@@ -497,12 +497,59 @@ class GradLink:
         self.value = None
 
 
-def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None):
+class GradAccum:
+    """Gradient of a tensor that feeds SEVERAL convolutions (a branch output of a HighResolutionModule feeds every fuse path;
+    layer1's output feeds both transition convolutions).  Autograd would sum the per-consumer gradients with one elementwise
+    kernel each (87 bf16 adds per step, up to 134 MB apiece).  Here the tensor passes through `fanout(x, acc)` once, every
+    convolution consumer is given `grad_accum=acc` and returns None for its input gradient: the first to run in backward writes its
+    data gradient into `acc.buf`, the others accumulate IN PLACE through the data-gradient epilogue's addend (out == addend; each
+    element is read and written by the same thread).  The fan-out node - which autograd runs after all consumers, in whatever
+    order those came - returns the buffer, plus the ordinary gradients of consumers that are not convolutions.  All consumers
+    must run on ONE stream (the fuse layers / transitions do)."""
+
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class _Fanout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, acc):
+        ctx.acc = acc
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.acc.buf = ctx.acc.buf, None
+        if buf is None:
+            return g, None
+        t = _nchw(buf)
+        return (t if g is None else t.add_(g.to(t.dtype))), None
+
+
+def fanout(x, n_conv_consumers):
+    """(x', GradAccum) for a tensor with >= 2 convolution consumers that take `grad_accum=`; (x, None) when there is nothing to fuse."""
+    if n_conv_consumers < 2 or not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
+        return x, None
+    acc = GradAccum()
+    return _Fanout.apply(x, acc), acc
+
+
+def _accumulate_dgrad(accum, spec, dout, weights, in_shape, rt):
+    if accum.buf is None:
+        accum.buf = _conv_dgrad(spec, dout, weights, in_shape, None, rt)
+    else:
+        _conv_dgrad(spec, dout, weights, in_shape, accum.buf, rt, out=accum.buf)
+
+
+def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None):
     B, H, W, C = in_shape
     dout = _pad_channels(dout)
     _, OH, OW, cout_p = dout.shape
     wpk = _pack(spec, weights, True, dout.dtype, dout.device, rt)
-    dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype)
+    dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype) if out is None else out
     if addend is not None and (addend.shape != dx.shape or addend.dtype != dx.dtype or not addend.is_contiguous()):
         raise RuntimeError("conv dgrad: fused skip gradient has shape/dtype %s %s, expected %s %s"
                            % (tuple(addend.shape), addend.dtype, tuple(dx.shape), dx.dtype))
@@ -590,7 +637,8 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.meta = (spec, act, training, n, exchanged, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
         ctx.rt = rt
         ctx.params = (gamma, beta, weights, biases)
-        ctx.links = links                 # (sink, deposit) GradLinks or (None, None)
+        ctx.links = links[:2]             # (sink, deposit) GradLinks or (None, None)
+        ctx.accum = links[2] if len(links) > 2 else None      # GradAccum of a multi-consumer input
         return _nchw(y)
 
     @staticmethod
@@ -633,7 +681,13 @@ class _ConvBNAct(torch.autograd.Function):
         addend = None
         if sink is not None:
             addend, sink.value = sink.value, None
-        if x_req:
+        accum = ctx.accum
+        if x_req and accum is not None:
+            if addend is not None:
+                raise RuntimeError("GradAccum: a convolution cannot be both the sink of a residual link and an accumulating consumer")
+            _accumulate_dgrad(accum, spec, draw, weights, xh.shape, rt)
+            dx = None
+        elif x_req:
             dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape, addend, rt))
         else:
             if addend is not None:
@@ -665,7 +719,7 @@ class _ConvBNActGroup(torch.autograd.Function):
     branches and fuse paths of a HighResolutionModule: the ~660 per-layer exchanges of a step, all of them on the critical path,
     become ~250 (representationlearning_amd/module/.../_hrnet_rssformer.py::HighResolutionModule._forward_lockstep).
     Per item (7 tensor slots): x, res_pre, gamma, beta, running_mean, running_var, weight.  Single bias-free convolutions only
-    (every HRNet convolution); meta = (spec, act, training, momentum, eps, sync, sink link, deposit link)."""
+    (every HRNet convolution); meta = (spec, act, training, momentum, eps, sync, sink link, deposit link, GradAccum)."""
 
     SLOTS = 7
 
@@ -765,7 +819,13 @@ class _ConvBNActGroup(torch.autograd.Function):
             addend = None
             if sink is not None:
                 addend, sink.value = sink.value, None
-            if ctx.x_req[i]:
+            accum = m[8] if len(m) > 8 else None
+            if ctx.x_req[i] and accum is not None:
+                if addend is not None:
+                    raise RuntimeError("GradAccum: a convolution cannot be both the sink of a residual link and an accumulating consumer")
+                _accumulate_dgrad(accum, spec, draw, [w], xh.shape, rt)
+                dx = None
+            elif ctx.x_req[i]:
                 dx = _nchw(_conv_dgrad(spec, draw, [w], xh.shape, addend, rt))
             else:
                 if addend is not None:
@@ -779,12 +839,12 @@ class _ConvBNActGroup(torch.autograd.Function):
 
 
 def conv_bn_act_group(items):
-    """items: dicts with x, conv, bn, act and optionally res_pre, grad_sink, grad_deposit (see conv_bn_act).  Returns the list of
+    """items: dicts with x, conv, bn, act and optionally res_pre, grad_sink, grad_deposit, grad_accum (see conv_bn_act).  Returns the list of
     outputs.  One SyncBN exchange for the whole group (see _ConvBNActGroup); falls back to individual nodes for a single item."""
     if len(items) == 1:
         d = items[0]
         return [conv_bn_act(d["x"], d["conv"], d["bn"], d.get("act", ACT_NONE), res_pre=d.get("res_pre"), grad_sink=d.get("grad_sink"),
-                            grad_deposit=d.get("grad_deposit"))]
+                            grad_deposit=d.get("grad_deposit"), grad_accum=d.get("grad_accum"))]
     rt = current()
     metas, flat = [], []
     for d in items:
@@ -796,7 +856,7 @@ def conv_bn_act_group(items):
             bn._rssf_steps = getattr(bn, "_rssf_steps", 0) + 1
         sync = isinstance(bn, nn.SyncBatchNorm) or rt.sync_all_bn
         metas.append((spec_of([conv]), d.get("act", ACT_NONE), training, 0.1 if bn.momentum is None else bn.momentum, bn.eps, sync,
-                      d.get("grad_sink"), d.get("grad_deposit")))
+                      d.get("grad_sink"), d.get("grad_deposit"), d.get("grad_accum")))
         flat += [d["x"], d.get("res_pre"), bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight]
     return list(_ConvBNActGroup.apply(metas, *flat))
 
@@ -1012,9 +1072,9 @@ def cgfl_loss(logits, labels, aux, ignore_index=-1):
     return _CGFLLoss.apply(logits, labels, aux.detach(), int(ignore_index))
 
 
-def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_sink=None, grad_deposit=None):
+def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_sink=None, grad_deposit=None, grad_accum=None):
     """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm.
-    grad_sink / grad_deposit: GradLink of a residual block (see GradLink)."""
+    grad_sink / grad_deposit: GradLink of a residual block (see GradLink); grad_accum: GradAccum of a multi-consumer input."""
     convs = convs if isinstance(convs, (list, tuple)) else [convs]
     spec = spec_of(convs)
     training = bn.training or not bn.track_running_stats
@@ -1027,7 +1087,7 @@ def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_si
         raise NotImplementedError("conv_bn_act: either all or none of the summed convs carry a bias")
     mom = 0.1 if bn.momentum is None else bn.momentum
     return _ConvBNAct.apply(x, res_pre, res_post, bn.weight, bn.bias, bn.running_mean, bn.running_var, spec, act, training, mom, bn.eps,
-                            sync, len(biases), (grad_sink, grad_deposit), *weights, *biases)
+                            sync, len(biases), (grad_sink, grad_deposit, grad_accum), *weights, *biases)
 
 
 def residual_link(x, res):
@@ -1051,11 +1111,12 @@ def flush_bn_counters(model, extra=0):
             m._rssf_steps = 0
 
 
-def run_sequential(seq, x, res_pre=None, act_last=None):
+def run_sequential(seq, x, res_pre=None, act_last=None, grad_accum=None):
     """Execute an nn.Sequential of the reference's shape (Conv2d, BatchNorm2d[, ReLU][, Upsample] or nested
     Sequentials thereof) through the fused ops.  res_pre / act_last: the sequence must END in a Conv2d + BatchNorm2d pair
     (possibly inside a nested Sequential), which then computes act_last(bn(conv(.)) + res_pre) in its own epilogue - the
-    `fuse(x0) + low` -> ReLU of a HighResolutionModule output without separate add / clamp launches."""
+    `fuse(x0) + low` -> ReLU of a HighResolutionModule output without separate add / clamp launches.
+    grad_accum: GradAccum of the sequence's INPUT (handed to its first convolution)."""
     mods = list(seq)
     tail = res_pre is not None or act_last is not None
     i = 0
@@ -1063,17 +1124,19 @@ def run_sequential(seq, x, res_pre=None, act_last=None):
         m = mods[i]
         if isinstance(m, nn.Sequential):
             last = tail and i + 1 == len(mods)
-            x = run_sequential(m, x, res_pre if last else None, act_last if last else None)
+            x = run_sequential(m, x, res_pre if last else None, act_last if last else None, grad_accum=grad_accum)
+            grad_accum = None
             tail = tail and not last
             i += 1
         elif isinstance(m, nn.Conv2d):
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.modules.batchnorm._BatchNorm):
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
                 if tail and not relu and i + 2 == len(mods):
-                    x = conv_bn_act(x, m, mods[i + 1], ACT_NONE if act_last is None else act_last, res_pre=res_pre)
+                    x = conv_bn_act(x, m, mods[i + 1], ACT_NONE if act_last is None else act_last, res_pre=res_pre, grad_accum=grad_accum)
                     tail = False
                 else:
-                    x = conv_bn_act(x, m, mods[i + 1], ACT_RELU if relu else ACT_NONE)
+                    x = conv_bn_act(x, m, mods[i + 1], ACT_RELU if relu else ACT_NONE, grad_accum=grad_accum)
+                grad_accum = None
                 i += 3 if relu else 2
             else:
                 x = conv_bias(x, m)
@@ -1089,4 +1152,6 @@ def run_sequential(seq, x, res_pre=None, act_last=None):
             raise NotImplementedError("run_sequential: no HIP kernel for %s on the RSSFormer path" % type(m).__name__)
     if tail:
         raise NotImplementedError("run_sequential: res_pre / act_last need a sequence that ends in Conv2d + BatchNorm2d")
+    if grad_accum is not None:
+        raise NotImplementedError("run_sequential: grad_accum needs a sequence that starts with Conv2d + BatchNorm2d")
     return x

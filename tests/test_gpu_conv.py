@@ -158,6 +158,37 @@ def test_conv_bias_head():
     assert rel_err(conv.bias.grad.cpu(), conv_r.bias.grad) < 2e-4
 
 
+@pytest.mark.parametrize("order", [(0, 1, 2), (2, 0, 1)])
+def test_grad_accum_matches_autograd_sum(order):
+    """nnf.fanout / GradAccum: a tensor feeding three convolutions (3x3 stride 1, 3x3 stride 2, 1x1) and one non-convolution consumer
+    gets the same gradient as through autograd's own accumulation, whatever order the consumers were built in; the convolutions'
+    parameter gradients are untouched by the in-place accumulation (reference: the fuse layer fan-out, _hrnet_rssformer.py:361-435)."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(3)
+    convs = [_mk_conv(32, 32, 3, 1, 1, seed=1).to(DEV), _mk_conv(32, 64, 3, 2, 1, seed=2).to(DEV), _mk_conv(32, 16, 1, seed=3).to(DEV)]
+    bns = [_mk_bn(32, 1).to(DEV).train(), _mk_bn(64, 2).to(DEV).train(), _mk_bn(16, 3).to(DEV).train()]
+    x0 = torch.randn(2, 32, 24, 20, device=DEV).contiguous(memory_format=torch.channels_last)
+    gs = [torch.randn(2, 32, 24, 20, device=DEV), torch.randn(2, 64, 12, 10, device=DEV), torch.randn(2, 16, 24, 20, device=DEV)]
+    res = {}
+    for fused in (False, True):
+        for c in convs:
+            c.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        src = x * 1.0                                        # a non-leaf, as in the model
+        xa, acc = nnf.fanout(src, 3) if fused else (src, None)
+        assert (acc is not None) == fused
+        loss = (xa * xa).sum() * 0.01                          # the non-convolution consumer
+        for k in order:
+            y = nnf.conv_bn_act(xa, convs[k], bns[k], nnf.ACT_RELU, grad_accum=acc)
+            loss = loss + (y * gs[k]).sum()
+        loss.backward()
+        assert acc is None or acc.buf is None                  # handed over and released
+        res[fused] = (x.grad.clone(), [c.weight.grad.clone() for c in convs])
+    assert rel_err(res[True][0].cpu(), res[False][0].cpu()) < 1e-5
+    for a_, b_ in zip(res[True][1], res[False][1]):
+        assert rel_err(a_.cpu(), b_.cpu()) < 1e-6
+
+
 def test_conv_base_shape_linearity_bf16():
     """BASELINE config-2 size (B=16, 128->128 @128x128, 19 taps): linearity + finite (size-independent property)."""
     from representationlearning_amd import nnf
