@@ -85,8 +85,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 
   const int64_t M = (int64_t)a.B * a.OH * a.OW;
   const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);   // channel tiles of a pixel tile, then neighbouring pixel tiles, on one XCD
   if (q >= a.total) return;
-  const int64_t m0 = (q / a.ntiles_n) * BM;
-  const int n0 = (int)(q % a.ntiles_n) * BNT;
+  // (the logical block index fits 32 bits - it is bounded by the grid size; 64-bit scalar divisions are a ~60-instruction serial
+  // chain each, in front of the first global load of the block)
+  const unsigned q32 = (unsigned)q, qt = q32 / (unsigned)a.ntiles_n;
+  const int64_t m0 = (int64_t)qt * BM;
+  const int n0 = (int)(q32 - qt * (unsigned)a.ntiles_n) * BNT;
   const T* IN = reinterpret_cast<const T*>(a.in);
   const T* W = reinterpret_cast<const T*>(a.wpk);
 
@@ -301,8 +304,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 
         if (m0 + row < M) { s1 += v; s2 += v * v; }
       }
     if (a.stats) {
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      s1 = rows_reduce<OpSum>(s1);                         // over the four 16-lane groups: lane swaps, no LDS round trip
+      s2 = rows_reduce<OpSum>(s2);
       if (grp == 0) { sstat[wave_m * 2 * BNT + lcol] = s1; sstat[(wave_m * 2 + 1) * BNT + lcol] = s2; }     // one writer per entry
     }
   }
@@ -581,7 +584,7 @@ extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, 
   a.CoutP = (Cout + bnt - 1) / bnt * bnt;
   a.CinP = (Cin + bk - 1) / bk * bk;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RSSF_BF16 && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx)) {
+  if (dtype == RSSF_BF16 && (int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx)) {
     HaloArgs h;
     h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats; h.stats_ws = a.stats_ws;
     h.addend = (const bf16_t*)addend;

@@ -36,13 +36,19 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   bf16_t* Bs = lds + A_ELEMS;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
-  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);
-  if (q >= a.total) return;
-  int t = (int)(q / a.ntiles_n);
-  const int tile_id = t;
-  const int tx = t % a.tiles_x; t /= a.tiles_x;
-  const int ty = t % a.tiles_y; const int b = t / a.tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = (int)(q % a.ntiles_n) * BN;
+  const int64_t q64 = xcd_logical(blockIdx.x, a.xcd_per);
+  if (q64 >= a.total) return;
+  // 32-bit unsigned tile arithmetic (launch_halo keeps the block count below 2^31): the 64-bit scalar divisions were a serial
+  // ~150-instruction chain in front of the first global load of every block
+  const unsigned q = (unsigned)q64, ntn = (unsigned)a.ntiles_n, ntx = (unsigned)a.tiles_x, nty = (unsigned)a.tiles_y;
+  unsigned t = q / ntn;
+  const int tile_id = (int)t;
+  const int n0 = (int)(q - t * ntn) * BN;
+  const unsigned t1 = t / ntx;
+  const int tx = (int)(t - t1 * ntx);
+  const int b = (int)(t1 / nty);
+  const int ty = (int)(t1 - (unsigned)b * nty);
+  const int y0 = ty * TH, x0 = tx * TW;
 
   // fixed per-thread staging slots.  All loads are hardware-bounds-checked buffer loads with 32-bit byte offsets: an
   // out-of-image halo pixel or an out-of-range channel chunk gets the out-of-range sentinel and the load returns zeros (no
@@ -161,8 +167,8 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
           }
         }
       }
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      s1 = rows_reduce<OpSum>(s1);                         // over the four 16-lane groups: lane swaps, no LDS round trip
+      s2 = rows_reduce<OpSum>(s2);
       if (grp == 0) { sstat[wave * 2 * BN + lcol] = s1; sstat[(wave * 2 + 1) * BN + lcol] = s2; }
     }
   }
@@ -181,26 +187,40 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
     }
   }
   constexpr int OCPR = BN / 8;
-  const bool ovec = (a.Cout % 8) == 0;
-  for (int c = tid; c < BMP * OCPR; c += 256) {
-    const int pix = c / OCPR, cc = (c % OCPR) * 8;
-    const int gy = y0 + pix / TW, gx = x0 + pix % TW, col = n0 + cc;
-    if (gy >= a.H || gx >= a.W || col >= a.Cout) continue;
-    bf16_t* dst = a.out + (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + col;
-    const bf16_t* add = a.addend ? a.addend + (dst - a.out) : nullptr;
-    if (ovec) {
+  if ((a.Cout % 8) == 0) {
+    // 16-byte rows through bounds-checked buffer accesses with 32-bit byte offsets (the dispatcher keeps the output below 2^31
+    // bytes): a pixel outside the image or a channel chunk past Cout gets the out-of-range offset - the store is dropped, the
+    // addend load returns zeros - so there is no branch and no 64-bit address arithmetic in the loop
+    const int out_bytes = (int)((int64_t)a.B * a.H * a.W * a.Cout * 2);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.addend ? a.addend : a.out), 0, out_bytes, 0x00020000);
+    static_assert((BMP * OCPR) % 256 == 0, "whole passes of the 256 threads over the output chunks");
+#pragma unroll
+    for (int it = 0; it < BMP * OCPR / 256; ++it) {
+      const int c = tid + it * 256;
+      const int pix = c / OCPR, cc = (c % OCPR) * 8;
+      const int gy = y0 + pix / TW, gx = x0 + pix % TW, col = n0 + cc;
+      const bool ok = gy < a.H && gx < a.W && col < a.Cout;
+      const unsigned off = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.Cout + col) * 2) : OOB;
       Vec<bf16_t> v;
       v.load(Cs + pix * LDC + cc);
-      if (add) {
+      if (a.addend) {
         Vec<bf16_t> w;
-        w.load(add);
+        w.raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, off, 0, 0));
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = v.get(e) + w.get(e);
         v.set_all(o);
       }
-      v.store(dst);
-    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v.raw), rout, off, 0, 0);
+    }
+  } else {
+    for (int c = tid; c < BMP * OCPR; c += 256) {
+      const int pix = c / OCPR, cc = (c % OCPR) * 8;
+      const int gy = y0 + pix / TW, gx = x0 + pix % TW, col = n0 + cc;
+      if (gy >= a.H || gx >= a.W || col >= a.Cout) continue;
+      bf16_t* dst = a.out + (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + col;
+      const bf16_t* add = a.addend ? a.addend + (dst - a.out) : nullptr;
       for (int e = 0; e < 8 && col + e < a.Cout; ++e) stf(dst + e, ldf(Cs + pix * LDC + cc + e) + (add ? ldf(add + e) : 0.f));
     }
   }
@@ -235,6 +255,7 @@ int launch_halo(HaloArgs a, hipStream_t st) {
   a.tiles_y = (a.H + th - 1) / th;
   a.ntiles_n = (a.Cout + bn - 1) / bn;
   a.total = (int64_t)a.B * a.tiles_y * a.tiles_x * a.ntiles_n;
+  if (a.total >= ((int64_t)1 << 31)) { set_error("conv3x3_halo: %lld tiles exceed the 32-bit tile arithmetic", (long long)a.total); return RSSF_ERR_UNSUPPORTED; }
   a.xcd_per = xcd_per(a.total);
   dim3 grid((unsigned)a.xcd_per * 8);
   const bool mirror = tap_order(a.dy, a.dx) < 0;

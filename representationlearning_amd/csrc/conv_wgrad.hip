@@ -88,8 +88,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   // shifted, the input rows), successive ranges of an XCD are adjacent in memory
   const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);
   if (q >= (int64_t)a.inner * a.ksplit) return;
-  const int range = (int)(q / a.inner);
-  int bid = (int)(q % a.inner);
+  const unsigned q32 = (unsigned)q;                         // bounded by the grid size: 32-bit divisions
+  const int range = (int)(q32 / (unsigned)a.inner);
+  int bid = (int)(q32 - (unsigned)range * (unsigned)a.inner);
   const int cit = bid % a.ctiles_n; bid /= a.ctiles_n;
   const int cot = bid % a.ctiles_m; bid /= a.ctiles_m;
   const int tbase = a.tap0 + (TG == 1 ? bid : 0);        // TG == 1: the taps of the group are spread over blockIdx.x
@@ -371,7 +372,8 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
   bf16_t* DS = lds_raw + HHP * HLD;
   const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);       // the (co, ci) tiles of one pixel range share an XCD's L2
   if (q >= a.total) return;
-  const int pair = (int)(q % a.npairs), range = (int)(q / a.npairs);
+  const unsigned q32 = (unsigned)q;                         // bounded by the grid size: 32-bit divisions
+  const int range = (int)(q32 / (unsigned)a.npairs), pair = (int)(q32 - (unsigned)range * (unsigned)a.npairs);
   const int co0 = (pair / a.ptiles_n) * HCT, ci0 = (pair % a.ptiles_n) * HCT;
   const int t_begin = range * a.tiles_per_block;
   const int t_end = t_begin + a.tiles_per_block < a.ntiles ? t_begin + a.tiles_per_block : a.ntiles;
