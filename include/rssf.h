@@ -160,6 +160,18 @@ int64_t rssf_conv_stats_workspace_elems(int B, int OH, int OW, int Cout);
 int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend,
                          float* stats_ws, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
                          const int* dy, const int* dx, int dtype, void* stream);
+/* DATA-GRADIENT launch that also produces the BatchNorm-backward statistics of the layer whose output gradient it computes
+ * (torch autograd: native_batch_norm_backward's reduction over dy, reference chain _hrnet_rssformer.py:216-246 conv -> bn -> relu ->
+ * conv): `out` = d(loss)/d(act(bn(raw) + res_pre)) of the PREVIOUS layer, so
+ *     bn_sums[slot][2][Cout] += { sum dz, sum dz * raw },   dz = out * act'(raw * scale + shift + res_pre)
+ * exactly what rssf_bn_bwd_reduce(out, bn_raw, ...) would add - computed on the bf16 values being stored, in the epilogue that
+ * already holds them, instead of a separate pass that reads `out` and `bn_raw` again.  bn_sums is [RSSF_BN_BWD_SLOTS][2][Cout],
+ * zeroed by the caller; bn_res_pre optional; bn_act as in rssf_bn_*.  Shapes without a statistics epilogue run the plain
+ * convolution followed by rssf_bn_bwd_reduce: the result is the same either way.  Only valid when `out` (+ addend) is the
+ * COMPLETE gradient of that activation (a single consumer). */
+int rssf_conv_gather_bnbwd(const void* in, const void* wpk, void* out, const void* addend, const void* bn_raw, const void* bn_res_pre,
+                           const float* bn_scale_shift, int bn_act, float* bn_sums, int B, int IH, int IW, int Cin, int OH, int OW,
+                           int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype, void* stream);
 /* weight gradient, accumulated (+=) into the torch-layout fp32 gradients of the source convs; dbias optional (+=).
  * workspace: fp32 scratch of rssf_conv_wgrad_workspace_elems() elements for the split-K partials (two-stage
  * reduction); NULL selects the slower atomic path. */

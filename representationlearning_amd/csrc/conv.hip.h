@@ -51,6 +51,13 @@ struct HaloArgs {
   float* stats;          // [RSSF_BN_SLOTS][2][Cout] or null
   float* stats_ws;       // deterministic mode: per-tile partials [tiles][2][Cout] or null (see ConvArgs in conv_fwd.hip)
   const bf16_t* addend;  // [B, H, W, Cout] added to the output (fused gradient accumulation) or null
+  // BatchNorm-backward statistics of the layer whose OUTPUT gradient this (data-gradient) launch produces, or bn_sums == null:
+  // sums[block % RSSF_BN_BWD_SLOTS][2][Cout] += { sum dz, sum dz * raw },  dz = out * act'(raw * scale + shift + res_pre)
+  const bf16_t* bn_raw;  // [B, H, W, Cout] pre-normalisation output of that layer's convolution
+  const bf16_t* bn_res;  // [B, H, W, Cout] residual added before the activation, or null
+  const float* bn_ss;    // [2][Cout] scale, shift
+  float* bn_sums;
+  int bn_act;
   int B, H, W, Cin, Cout, CinP, CoutP;
   int tiles_y, tiles_x, ntiles_n, xcd_per;
   int64_t total;

@@ -565,9 +565,13 @@ extern "C" int64_t rssf_conv_stats_workspace_elems(int B, int OH, int OW, int Co
   return (gemm_tiles > halo_tiles ? gemm_tiles : halo_tiles) * 2 * Cout;
 }
 
-extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend,
-                                    float* stats_ws, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
-                                    const int* dy, const int* dx, int dtype, void* stream) {
+namespace {
+struct BnBwdStats {            // see HaloArgs::bn_* (conv.hip.h)
+  const void* raw; const void* res; const float* ss; float* sums; int act;
+};
+int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, float* stats_ws,
+                     const BnBwdStats* bn, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
+                     const int* dy, const int* dx, int dtype, void* stream) {
   RSSF_REQUIRE(in && wpk && out && dy && dx && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 &&
                    ntaps >= 1 && ntaps <= MAX_TAPS && mul >= 1 && div >= 1,
                "conv_gather: bad arguments");
@@ -588,12 +592,38 @@ extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, 
     HaloArgs h;
     h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats; h.stats_ws = a.stats_ws;
     h.addend = (const bf16_t*)addend;
+    const bool fused = bn && (Cout % 8) == 0;               // the 16-byte-row epilogue carries the statistics
+    h.bn_raw = fused ? (const bf16_t*)bn->raw : nullptr; h.bn_res = fused ? (const bf16_t*)bn->res : nullptr;
+    h.bn_ss = fused ? bn->ss : nullptr; h.bn_sums = fused ? bn->sums : nullptr; h.bn_act = fused ? bn->act : 0;
     h.B = B; h.H = IH; h.W = IW; h.Cin = Cin; h.Cout = Cout; h.CinP = a.CinP; h.CoutP = a.CoutP;
     for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
-    return launch_halo(h, st);
+    const int rc = launch_halo(h, st);
+    if (rc || !bn || fused) return rc;
+    return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
   }
-  if (dtype == RSSF_F32) return launch_conv<float>(a, st);
-  if (dtype == RSSF_BF16) return launch_conv<bf16_t>(a, st);
-  set_error("conv_gather: unsupported dtype %d", dtype);
-  return RSSF_ERR_UNSUPPORTED;
+  int rc;
+  if (dtype == RSSF_F32) rc = launch_conv<float>(a, st);
+  else if (dtype == RSSF_BF16) rc = launch_conv<bf16_t>(a, st);
+  else { set_error("conv_gather: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  if (rc || !bn) return rc;
+  // no kernel with a statistics epilogue for this shape: the separate pass
+  return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
+}
+}  // namespace
+
+extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend,
+                                    float* stats_ws, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
+                                    const int* dy, const int* dx, int dtype, void* stream) {
+  return conv_gather_impl(in, wpk, out, bias, stats, addend, stats_ws, nullptr, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype,
+                          stream);
+}
+
+extern "C" int rssf_conv_gather_bnbwd(const void* in, const void* wpk, void* out, const void* addend, const void* bn_raw,
+                                      const void* bn_res_pre, const float* bn_scale_shift, int bn_act, float* bn_sums, int B, int IH,
+                                      int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx,
+                                      int dtype, void* stream) {
+  RSSF_REQUIRE(bn_raw && bn_scale_shift && bn_sums && bn_act >= 0 && bn_act <= 2, "conv_gather_bnbwd: bad BatchNorm arguments");
+  const BnBwdStats bn = {bn_raw, bn_res_pre, bn_scale_shift, bn_sums, bn_act};
+  return conv_gather_impl(in, wpk, out, nullptr, nullptr, addend, nullptr, &bn, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype,
+                          stream);
 }

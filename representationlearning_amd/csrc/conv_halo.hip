@@ -10,6 +10,7 @@
 //
 // Epilogue identical to the gather kernel: + bias, fused BatchNorm statistics (slotted atomics), LDS transpose
 // for 16-byte coalesced stores.
+#include <type_traits>
 #include "conv.hip.h"
 using namespace rssf;
 using namespace rssf::cv;
@@ -194,7 +195,20 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
     const int out_bytes = (int)((int64_t)a.B * a.H * a.W * a.Cout * 2);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.addend ? a.addend : a.out), 0, out_bytes, 0x00020000);
-    static_assert((BMP * OCPR) % 256 == 0, "whole passes of the 256 threads over the output chunks");
+    static_assert((BMP * OCPR) % 256 == 0 && 256 % OCPR == 0, "whole passes of the 256 threads over the output chunks, fixed channel chunk");
+    // fused BatchNorm-backward statistics (data-gradient launches): this thread's 8 channels are the same in every pass
+    const bool bnb = a.bn_sums != nullptr;
+    const int ccl = (tid % OCPR) * 8;                         // channel chunk of this thread inside the block's BN columns
+    const __amdgpu_buffer_rsrc_t rraw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(bnb ? a.bn_raw : a.out), 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(bnb && a.bn_res ? a.bn_res : a.out), 0, out_bytes, 0x00020000);
+    float bsc[8], bsh[8], t1[8], t2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool cok = bnb && n0 + ccl + e < a.Cout;
+      bsc[e] = cok ? a.bn_ss[n0 + ccl + e] : 0.f;
+      bsh[e] = cok ? a.bn_ss[a.Cout + n0 + ccl + e] : 0.f;
+      t1[e] = 0.f; t2[e] = 0.f;
+    }
 #pragma unroll
     for (int it = 0; it < BMP * OCPR / 256; ++it) {
       const int c = tid + it * 256;
@@ -202,7 +216,11 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
       const int gy = y0 + pix / TW, gx = x0 + pix % TW, col = n0 + cc;
       const bool ok = gy < a.H && gx < a.W && col < a.Cout;
       const unsigned off = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.Cout + col) * 2) : OOB;
-      Vec<bf16_t> v;
+      Vec<bf16_t> v, xr, xp;
+      if (bnb) {
+        xr.raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rraw, off, 0, 0));
+        if (a.bn_res) xp.raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, 0));
+      }
       v.load(Cs + pix * LDC + cc);
       if (a.addend) {
         Vec<bf16_t> w;
@@ -213,6 +231,46 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
         v.set_all(o);
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v.raw), rout, off, 0, 0);
+      if (bnb) {                                               // on the bf16 values just stored: what a separate pass would read
+        if (!ok) v.clear();                                    // (an out-of-range chunk loaded zeros for raw: dz * raw is 0 anyway)
+        auto accumulate = [&](auto ACT) {                      // block-uniform activation: one specialised loop runs
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = xr.get(e);
+            float z = fmaf(x, bsc[e], bsh[e]);
+            if (a.bn_res) z += xp.get(e);
+            const float g = v.get(e);
+            const float dz = decltype(ACT)::value == 1 ? (z > 0.f ? g : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
+            t1[e] += dz; t2[e] = fmaf(dz, x, t2[e]);
+          }
+        };
+        if (a.bn_act == 1) accumulate(std::integral_constant<int, 1>{});
+        else if (a.bn_act == 2) accumulate(std::integral_constant<int, 2>{});
+        else accumulate(std::integral_constant<int, 0>{});
+      }
+    }
+    if (bnb) {
+      // lanes with the same channel chunk: every OCPR-th lane of a 16-lane row (rotations by 4 / 8 inside the row), then the four
+      // rows; one LDS row of partials per wave, summed in a fixed order, one global atomic per channel and sum per block
+      __syncthreads();                                         // sstat may still be read by the forward statistics above
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (OCPR == 4) { t1[e] += dpp_mov<0x124>(t1[e]); t2[e] += dpp_mov<0x124>(t2[e]); }      // row_ror:4
+        t1[e] += dpp_mov<0x128>(t1[e]); t2[e] += dpp_mov<0x128>(t2[e]);                          // row_ror:8
+        t1[e] = rows_reduce<OpSum>(t1[e]); t2[e] = rows_reduce<OpSum>(t2[e]);
+      }
+      if (lane < OCPR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sstat[wave * 2 * BN + ccl + e] = t1[e]; sstat[(wave * 2 + 1) * BN + ccl + e] = t2[e]; }
+      }
+      __syncthreads();
+      float* slot = a.bn_sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * a.Cout;
+      for (int i = tid; i < BN; i += 256) {
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { u1 += sstat[w * 2 * BN + i]; u2 += sstat[(w * 2 + 1) * BN + i]; }
+        if (n0 + i < a.Cout) { atomicAdd(slot + n0 + i, u1); atomicAdd(slot + a.Cout + n0 + i, u2); }
+      }
     }
   } else {
     for (int c = tid; c < BMP * OCPR; c += 256) {

@@ -57,11 +57,19 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, producer=None, want_link=False):
+        """producer: nnf.BnBwdLink of the layer whose output x is, when this block is that output's only consumer (run_blocks);
+        want_link: also return the link of bn2 for the next block."""
         res = x if self.downsample is None else nnf.run_sequential(self.downsample, x)
         link = nnf.residual_link(x, res)          # the skip gradient rides on conv1's data-gradient launch
-        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, grad_sink=link)
-        return nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU, res_pre=res, grad_deposit=link)
+        # BatchNorm-backward statistics come out of the consumer's data-gradient launch: bn1's out of conv2's; the producer's out
+        # of conv1's, whose launch (with the skip gradient as addend) forms the COMPLETE gradient of x when `link` is active
+        l1 = nnf.bwd_stats_link()
+        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, grad_sink=link, stats_out=l1,
+                              stats_in=producer if link is not None else None)
+        l2 = nnf.bwd_stats_link() if want_link else None
+        y = nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU, res_pre=res, grad_deposit=link, stats_out=l2, stats_in=l1)
+        return (y, l2) if want_link else y
 
 
 class Bottleneck(nn.Module):
@@ -79,15 +87,42 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, producer=None, want_link=False):
         res = x if self.downsample is None else nnf.run_sequential(self.downsample, x)
         link = nnf.residual_link(x, res)
-        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, grad_sink=link)
-        out = nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU)
-        return nnf.conv_bn_act(out, self.conv3, self.bn3, nnf.ACT_RELU, res_pre=res, grad_deposit=link)
+        l1, l2 = nnf.bwd_stats_link(), nnf.bwd_stats_link()
+        out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, grad_sink=link, stats_out=l1,
+                              stats_in=producer if link is not None else None)
+        out = nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU, stats_out=l2, stats_in=l1)
+        l3 = nnf.bwd_stats_link() if want_link else None
+        y = nnf.conv_bn_act(out, self.conv3, self.bn3, nnf.ACT_RELU, res_pre=res, grad_deposit=link, stats_out=l3, stats_in=l2)
+        return (y, l3) if want_link else y
 
 
 blocks_dict = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
+
+
+def run_blocks(seq, x):
+    """nn.Sequential of residual blocks, block by block: the output of a block is consumed by the next block only, so the
+    BatchNorm-backward statistics of its last BatchNorm ride on the next block's first data-gradient launch (nnf.BnBwdLink)."""
+    mods = list(seq)
+    link = None
+    for k, m in enumerate(mods):
+        if isinstance(m, (BasicBlock, Bottleneck)):
+            if k + 1 < len(mods):
+                x, link = m(x, producer=link, want_link=True)
+            else:
+                x, link = m(x, producer=link), None
+        else:
+            x, link = m(x), None
+    return x
+
+
+class BlockChain(nn.Sequential):
+    """nn.Sequential of residual blocks (same parameters / state_dict keys) whose forward is run_blocks."""
+
+    def forward(self, x):
+        return run_blocks(self, x)
 
 
 def _down_chain(cin, cout, steps):
@@ -131,7 +166,7 @@ class HighResolutionModule(nn.Module):
         layers = [block(self.num_inchannels[i], num_channels[i], stride, downsample)]
         self.num_inchannels[i] = width
         layers += [block(width, num_channels[i]) for _ in range(1, num_blocks[i])]
-        return nn.Sequential(*layers)
+        return BlockChain(*layers)
 
     def _make_branches(self, num_branches, block, num_blocks, num_channels):
         return nn.ModuleList([self._make_one_branch(i, block, num_blocks, num_channels) for i in range(num_branches)])
@@ -256,7 +291,7 @@ class HighResolutionModule(nn.Module):
             return [self.branches[0](x[0])]
         if self._lockstep_ok():
             return self._fuse_lockstep(self._branches_lockstep(x[:self.num_branches]))
-        x = nnf.parallel_map(list(self.branches), x[:self.num_branches])       # Sequentials of BasicBlocks, one stream each
+        x = nnf.parallel_map(list(self.branches), x[:self.num_branches])       # BlockChains of BasicBlocks, one stream each
         x, accs = self._fanout(x)
         fused = []
         for i in range(len(self.fuse_layers)):
@@ -340,7 +375,7 @@ class HighResolutionNet(nn.Module):
                                        BatchNorm2d(planes * block.expansion, momentum=BN_MOMENTUM))
         layers = [block(inplanes, planes, stride, downsample)]
         layers += [block(planes * block.expansion, planes) for _ in range(1, blocks)]
-        return nn.Sequential(*layers)
+        return BlockChain(*layers)
 
     def _frozen_stages(self):
         if self.frozen_stages >= 0:

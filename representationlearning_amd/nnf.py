@@ -497,6 +497,28 @@ class GradLink:
         self.value = None
 
 
+class BnBwdLink:
+    """BatchNorm-backward statistics of layer L produced by the data-gradient launch of its ONLY consumer, layer L + 1
+    (`rssf_conv_gather_bnbwd`): conv_bn_act(.., stats_out=link) fills in what the statistics need (raw, scale/shift, the residual
+    added before the activation, the activation) and, in backward, takes `link.sums` instead of launching rssf_bn_bwd_reduce;
+    conv_bn_act(y, .., stats_in=link) - y being that layer's output, consumed by nothing else but a residual skip whose gradient
+    rides on the same launch (GradLink) - produces them.  The caller vouches for the single consumer."""
+
+    __slots__ = ("raw", "ss", "rp", "act", "C", "sums")
+
+    def __init__(self):
+        self.raw = self.ss = self.rp = self.sums = None
+        self.act, self.C = ACT_NONE, 0
+
+
+_FUSED_BN_STATS = os.environ.get("RSSF_FUSED_BN_STATS", "1") != "0"      # A/B switch (tools, DESIGN.md section 4)
+
+
+def bwd_stats_link():
+    """A BnBwdLink when gradients are being recorded (and the run is not in deterministic-statistics mode), else None."""
+    return BnBwdLink() if (_FUSED_BN_STATS and torch.is_grad_enabled() and not current().deterministic) else None
+
+
 class GradAccum:
     """Gradient of a tensor that feeds SEVERAL convolutions (a branch output of a HighResolutionModule feeds every fuse path;
     layer1's output feeds both transition convolutions).  Autograd would sum the per-consumer gradients with one elementwise
@@ -544,7 +566,9 @@ def _accumulate_dgrad(accum, spec, dout, weights, in_shape, rt):
         _conv_dgrad(spec, dout, weights, in_shape, accum.buf, rt, out=accum.buf)
 
 
-def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None):
+def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, bn=None):
+    """bn: (BnBwdLink, zeroed sums buffer) - the launch also accumulates the BatchNorm-backward statistics of the layer that
+    produced the convolution's input (see BnBwdLink)."""
     B, H, W, C = in_shape
     dout = _pad_channels(dout)
     _, OH, OW, cout_p = dout.shape
@@ -553,6 +577,15 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None):
     if addend is not None and (addend.shape != dx.shape or addend.dtype != dx.dtype or not addend.is_contiguous()):
         raise RuntimeError("conv dgrad: fused skip gradient has shape/dtype %s %s, expected %s %s"
                            % (tuple(addend.shape), addend.dtype, tuple(dx.shape), dx.dtype))
+    if bn is not None:
+        link, sums = bn
+        if link.raw.shape != dx.shape or link.raw.dtype != dx.dtype or link.C != C:
+            raise RuntimeError("BnBwdLink: the producer's output %s %s is not this convolution's input %s %s"
+                               % (tuple(link.raw.shape), link.raw.dtype, tuple(dx.shape), dx.dtype))
+        L.check(L.load().rssf_conv_gather_bnbwd(L.ptr(dout), L.ptr(wpk), L.ptr(dx), L.ptr(addend), L.ptr(link.raw), L.ptr(link.rp), L.ptr(link.ss),
+                                                link.act, L.ptr(sums), B, OH, OW, cout_p, H, W, C, 1, spec.stride, spec.ntaps, spec.c_ndy,
+                                                spec.c_ndx, L.dtype_code(dout), L.stream()), "rssf_conv_gather_bnbwd")
+        return dx
     L.check(L.load().rssf_conv_gather_add(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, L.ptr(addend), None, B, OH, OW, cout_p, H, W, C, 1, spec.stride,
                                       spec.ntaps, spec.c_ndy, spec.c_ndx, L.dtype_code(dout),
                                       L.stream()), "rssf_conv_gather(dgrad)")
@@ -639,6 +672,10 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.params = (gamma, beta, weights, biases)
         ctx.links = links[:2]             # (sink, deposit) GradLinks or (None, None)
         ctx.accum = links[2] if len(links) > 2 else None      # GradAccum of a multi-consumer input
+        ctx.stats_out, ctx.stats_in = (links[3], links[4]) if len(links) > 4 else (None, None)      # BnBwdLinks
+        if ctx.stats_out is not None:
+            so = ctx.stats_out
+            so.raw, so.ss, so.rp, so.act, so.C, so.sums = raw, ss, rp, act, C, None
         return _nchw(y)
 
     @staticmethod
@@ -655,12 +692,17 @@ class _ConvBNAct(torch.autograd.Function):
         C = spec.cout
         rows = raw.numel() // C
         lib = L.load()
-        sums = _zeros(BN_BWD_SLOTS * 2 * C, raw.device, rt)
-        dws = None
-        if rt.deterministic:
-            dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=raw.device, dtype=torch.float32)
-        L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.ptr(dws), L.dtype_code(raw),
-                                       L.stream()), "rssf_bn_bwd_reduce")
+        so = ctx.stats_out
+        sums = None
+        if so is not None:               # the consumer's data-gradient launch already summed {dz, dz*raw} (BnBwdLink)
+            sums, so.raw, so.ss, so.rp, so.sums = so.sums, None, None, None, None
+        if sums is None:
+            sums = _zeros(BN_BWD_SLOTS * 2 * C, raw.device, rt)
+            dws = None
+            if rt.deterministic:
+                dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=raw.device, dtype=torch.float32)
+            L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, C, act, L.ptr(dws), L.dtype_code(raw),
+                                           L.stream()), "rssf_bn_bwd_reduce")
         pscale = 1.0
         if exchanged:
             # the input gradient needs the GLOBAL {sum dz, sum dz*raw}; gamma/beta take the data-parallel MEAN of the local
@@ -688,7 +730,11 @@ class _ConvBNAct(torch.autograd.Function):
             _accumulate_dgrad(accum, spec, draw, weights, xh.shape, rt)
             dx = None
         elif x_req:
-            dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape, addend, rt))
+            si, bn = ctx.stats_in, None
+            if si is not None and si.raw is not None and not rt.deterministic:
+                si.sums = _zeros(BN_BWD_SLOTS * 2 * si.C, raw.device, rt)
+                bn = (si, si.sums)
+            dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape, addend, rt, bn=bn))
         else:
             if addend is not None:
                 raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
@@ -1072,9 +1118,11 @@ def cgfl_loss(logits, labels, aux, ignore_index=-1):
     return _CGFLLoss.apply(logits, labels, aux.detach(), int(ignore_index))
 
 
-def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_sink=None, grad_deposit=None, grad_accum=None):
+def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_sink=None, grad_deposit=None, grad_accum=None,
+                stats_out=None, stats_in=None):
     """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm.
-    grad_sink / grad_deposit: GradLink of a residual block (see GradLink); grad_accum: GradAccum of a multi-consumer input."""
+    grad_sink / grad_deposit: GradLink of a residual block (see GradLink); grad_accum: GradAccum of a multi-consumer input;
+    stats_out / stats_in: BnBwdLink of this layer / of the layer that produced x (see BnBwdLink)."""
     convs = convs if isinstance(convs, (list, tuple)) else [convs]
     spec = spec_of(convs)
     training = bn.training or not bn.track_running_stats
@@ -1087,7 +1135,7 @@ def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_si
         raise NotImplementedError("conv_bn_act: either all or none of the summed convs carry a bias")
     mom = 0.1 if bn.momentum is None else bn.momentum
     return _ConvBNAct.apply(x, res_pre, res_post, bn.weight, bn.bias, bn.running_mean, bn.running_var, spec, act, training, mom, bn.eps,
-                            sync, len(biases), (grad_sink, grad_deposit, grad_accum), *weights, *biases)
+                            sync, len(biases), (grad_sink, grad_deposit, grad_accum, stats_out, stats_in), *weights, *biases)
 
 
 def residual_link(x, res):
