@@ -11,6 +11,7 @@
 // chunk's global loads issued before the MFMAs of the current one (register double buffering).  Epilogue:
 // + bias, per-channel sum / sum-of-squares partials for the following BatchNorm (fused statistics: the
 // activation is not re-read for the mean/var pass), tile transposed through LDS for 16-byte coalesced stores.
+#include <type_traits>
 #include "conv.hip.h"
 using namespace rssf;
 using namespace rssf::cv;
@@ -26,6 +27,8 @@ struct ConvArgs {
   float* stats;          // [RSSF_BN_SLOTS][2][Cout] sum, sumsq (atomically accumulated, slot = block % slots) or null
   float* stats_ws;       // deterministic mode: per-pixel-tile partials [tiles_m][2][Cout] (plain stores; folded in tile order by
                          // stats_fold_kernel into slot 0 of `stats`) or null
+  // BatchNorm-backward statistics of the layer whose output gradient this data-gradient launch produces (bf16; see HaloArgs)
+  const void* bn_raw; const void* bn_res; const float* bn_ss; float* bn_sums; int bn_act;
   int B, IH, IW, Cin, OH, OW, Cout, CinP, CoutP;
   int ntiles_n, xcd_per;
   int64_t total;
@@ -326,6 +329,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 
   T* OUT = reinterpret_cast<T*>(a.out);
   constexpr int OCPR = BNT / V;                          // 16-byte chunks per output row of the tile
   const bool ovec = (a.Cout % V) == 0;
+  // fused BatchNorm-backward statistics (bf16 data-gradient launches, Cout % 8 == 0 - the dispatcher checks): a thread's channel
+  // chunk is the same in every pass (256 % OCPR == 0), so its 2 x 8 partial sums stay in registers
+  constexpr bool BNB = sizeof(T) == 2 && (256 % OCPR) == 0 && OCPR <= 16;
+  const bool bnb = BNB && a.bn_sums != nullptr;
+  const int ccl = (tid % OCPR) * V;
+  float bsc[V], bsh[V], t1[V], t2[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const bool cok = bnb && n0 + ccl + e < a.Cout;
+    bsc[e] = cok ? a.bn_ss[n0 + ccl + e] : 0.f;
+    bsh[e] = cok ? a.bn_ss[a.Cout + n0 + ccl + e] : 0.f;
+    t1[e] = 0.f; t2[e] = 0.f;
+  }
   for (int c = tid; c < BM * OCPR; c += 256) {
     const int row = c / OCPR, cc = (c % OCPR) * V;
     const int64_t m = m0 + row;
@@ -334,7 +350,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 
     T* dst = OUT + m * a.Cout + col;
     const T* add = a.addend ? reinterpret_cast<const T*>(a.addend) + m * a.Cout + col : nullptr;
     if (ovec) {
-      Vec<T> v;
+      Vec<T> v, xr, xp;
+      if (bnb) {
+        xr.load(reinterpret_cast<const T*>(a.bn_raw) + m * a.Cout + col);
+        if (a.bn_res) xp.load(reinterpret_cast<const T*>(a.bn_res) + m * a.Cout + col);
+      }
       v.load(Cs + row * LDC + cc);
       if (add) {
         Vec<T> w;
@@ -345,8 +365,51 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 
         v.set_all(o);
       }
       v.store(dst);
+      if (bnb) {                                           // on the values just stored: what a separate pass would read
+        auto accumulate = [&](auto ACT) {                  // block-uniform activation: one specialised loop runs
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            const float x = xr.get(e);
+            float z = fmaf(x, bsc[e], bsh[e]);
+            if (a.bn_res) z += xp.get(e);
+            const float g = v.get(e);
+            const float dz = decltype(ACT)::value == 1 ? (z > 0.f ? g : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
+            t1[e] += dz; t2[e] = fmaf(dz, x, t2[e]);
+          }
+        };
+        if (a.bn_act == 1) accumulate(std::integral_constant<int, 1>{});
+        else if (a.bn_act == 2) accumulate(std::integral_constant<int, 2>{});
+        else accumulate(std::integral_constant<int, 0>{});
+      }
     } else {
       for (int e = 0; e < V && col + e < a.Cout; ++e) stf(dst + e, ldf(Cs + row * LDC + cc + e) + (add ? ldf(add + e) : 0.f));
+    }
+  }
+  if constexpr (BNB) {
+    if (bnb) {
+      // lanes with the same channel chunk: every OCPR-th lane of a 16-lane row (rotations inside the row), then the four rows; one
+      // row of partials per wave in the (now idle) output tile, summed in a fixed order, one global atomic per channel and sum
+      __syncthreads();
+      float* sbn = reinterpret_cast<float*>(lds);            // [4 waves][2][BNT]
+      static_assert(sizeof(float) * 4 * 2 * BNT <= sizeof(T) * BM * LDC, "partials fit the output tile");
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        if (OCPR <= 4) { t1[e] += dpp_mov<0x124>(t1[e]); t2[e] += dpp_mov<0x124>(t2[e]); }      // row_ror:4
+        if (OCPR <= 8) { t1[e] += dpp_mov<0x128>(t1[e]); t2[e] += dpp_mov<0x128>(t2[e]); }      // row_ror:8
+        t1[e] = rows_reduce<OpSum>(t1[e]); t2[e] = rows_reduce<OpSum>(t2[e]);
+      }
+      if (lane < OCPR) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { sbn[wave * 2 * BNT + ccl + e] = t1[e]; sbn[(wave * 2 + 1) * BNT + ccl + e] = t2[e]; }
+      }
+      __syncthreads();
+      float* slot = a.bn_sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * a.Cout;
+      for (int i = tid; i < BNT; i += 256) {
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { u1 += sbn[w * 2 * BNT + i]; u2 += sbn[(w * 2 + 1) * BNT + i]; }
+        if (n0 + i < a.Cout) { atomicAdd(slot + n0 + i, u1); atomicAdd(slot + a.Cout + n0 + i, u2); }
+      }
     }
   }
 }
@@ -601,11 +664,14 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
     if (rc || !bn || fused) return rc;
     return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
   }
+  const bool gfused = bn && dtype == RSSF_BF16 && (Cout % 8) == 0;          // the gather kernels' 16-byte-row epilogue carries them too
+  a.bn_raw = gfused ? bn->raw : nullptr; a.bn_res = gfused ? bn->res : nullptr; a.bn_ss = gfused ? bn->ss : nullptr;
+  a.bn_sums = gfused ? bn->sums : nullptr; a.bn_act = gfused ? bn->act : 0;
   int rc;
   if (dtype == RSSF_F32) rc = launch_conv<float>(a, st);
   else if (dtype == RSSF_BF16) rc = launch_conv<bf16_t>(a, st);
   else { set_error("conv_gather: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
-  if (rc || !bn) return rc;
+  if (rc || !bn || gfused) return rc;
   // no kernel with a statistics epilogue for this shape: the separate pass
   return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
 }

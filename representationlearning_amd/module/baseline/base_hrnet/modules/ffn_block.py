@@ -32,9 +32,11 @@ class MlpDWBN(nn.Module):
         for a in (self.act1, self.act2, self.act3):
             if not isinstance(a, nn.GELU):
                 raise NotImplementedError("MlpDWBN (HIP): GELU activations only (the RSSFormer configuration)")
-        t = nnf.conv_bn_act(t, self.fc1, self.norm1, nnf.ACT_GELU)
-        t = nnf.conv_bn_act(t, [self.dw, self.dw6, self.dw12], self.norm2, nnf.ACT_GELU)
-        return nnf.conv_bn_act(t, self.fc2, self.norm3, nnf.ACT_GELU, res_post=residual)
+        # each hidden activation has ONE consumer: its BatchNorm-backward statistics ride on that consumer's data-gradient launch
+        l1, l2 = nnf.bwd_stats_link(), nnf.bwd_stats_link()
+        t = nnf.conv_bn_act(t, self.fc1, self.norm1, nnf.ACT_GELU, stats_out=l1)
+        t = nnf.conv_bn_act(t, [self.dw, self.dw6, self.dw12], self.norm2, nnf.ACT_GELU, stats_out=l2, stats_in=l1)
+        return nnf.conv_bn_act(t, self.fc2, self.norm3, nnf.ACT_GELU, res_post=residual, stats_in=l2)
 
     def forward(self, x, H, W, residual=None):
         if x.dim() != 3:
