@@ -400,8 +400,9 @@ class HighResolutionNet(nn.Module):
         if torch.is_autocast_enabled():          # activation dtype policy: bf16 activations, fp32 parameters/statistics
             x = x.to(torch.get_autocast_dtype("cuda"))
         x = x.contiguous(memory_format=torch.channels_last)
-        x = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU)
-        x = nnf.conv_bn_act(x, self.conv2, self.bn2, nnf.ACT_RELU)
+        l1 = nnf.bwd_stats_link()                 # bn1's backward statistics ride on conv2's data-gradient launch
+        x = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, stats_out=l1)
+        x = nnf.conv_bn_act(x, self.conv2, self.bn2, nnf.ACT_RELU, stats_in=l1)
         x = self.layer1(x)
         ys = [x]
         for s in (2, 3, 4):

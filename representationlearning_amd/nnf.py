@@ -1159,7 +1159,7 @@ def flush_bn_counters(model, extra=0):
             m._rssf_steps = 0
 
 
-def run_sequential(seq, x, res_pre=None, act_last=None, grad_accum=None):
+def run_sequential(seq, x, res_pre=None, act_last=None, grad_accum=None, _chain=None):
     """Execute an nn.Sequential of the reference's shape (Conv2d, BatchNorm2d[, ReLU][, Upsample] or nested
     Sequentials thereof) through the fused ops.  res_pre / act_last: the sequence must END in a Conv2d + BatchNorm2d pair
     (possibly inside a nested Sequential), which then computes act_last(bn(conv(.)) + res_pre) in its own epilogue - the
@@ -1168,33 +1168,40 @@ def run_sequential(seq, x, res_pre=None, act_last=None, grad_accum=None):
     mods = list(seq)
     tail = res_pre is not None or act_last is not None
     i = 0
-    while i < len(mods):
+    chain = _chain if _chain is not None else [None]       # [BnBwdLink of the layer that produced x]: inside a sequence every
+    while i < len(mods):                                     # activation has ONE consumer, the next convolution
         m = mods[i]
         if isinstance(m, nn.Sequential):
             last = tail and i + 1 == len(mods)
-            x = run_sequential(m, x, res_pre if last else None, act_last if last else None, grad_accum=grad_accum)
+            x = run_sequential(m, x, res_pre if last else None, act_last if last else None, grad_accum=grad_accum, _chain=chain)
             grad_accum = None
             tail = tail and not last
             i += 1
         elif isinstance(m, nn.Conv2d):
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.modules.batchnorm._BatchNorm):
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                link = bwd_stats_link()
                 if tail and not relu and i + 2 == len(mods):
-                    x = conv_bn_act(x, m, mods[i + 1], ACT_NONE if act_last is None else act_last, res_pre=res_pre, grad_accum=grad_accum)
+                    x = conv_bn_act(x, m, mods[i + 1], ACT_NONE if act_last is None else act_last, res_pre=res_pre, grad_accum=grad_accum,
+                                    stats_out=link, stats_in=chain[0])
                     tail = False
                 else:
-                    x = conv_bn_act(x, m, mods[i + 1], ACT_RELU if relu else ACT_NONE, grad_accum=grad_accum)
+                    x = conv_bn_act(x, m, mods[i + 1], ACT_RELU if relu else ACT_NONE, grad_accum=grad_accum, stats_out=link, stats_in=chain[0])
+                chain[0] = link
                 grad_accum = None
                 i += 3 if relu else 2
             else:
                 x = conv_bias(x, m)
+                chain[0] = None
                 i += 1
         elif isinstance(m, nn.Upsample) and m.mode == "nearest":
             x = upsample_nearest_add(None, x, int(m.scale_factor))
+            chain[0] = None
             i += 1
         elif isinstance(m, (nn.Upsample, nn.UpsamplingBilinear2d)) and m.mode == "bilinear" and m.align_corners:
             s = m.scale_factor
             x = upsample_bilinear(x, (int(x.shape[2] * s), int(x.shape[3] * s)))
+            chain[0] = None
             i += 1
         else:
             raise NotImplementedError("run_sequential: no HIP kernel for %s on the RSSFormer path" % type(m).__name__)
