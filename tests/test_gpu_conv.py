@@ -189,6 +189,56 @@ def test_grad_accum_matches_autograd_sum(order):
         assert rel_err(a_.cpu(), b_.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("k,stride,cin,cout,H,W,act,res,dtype", [
+    (3, 1, 32, 32, 24, 20, 1, False, torch.bfloat16),      # halo kernel
+    (3, 1, 64, 64, 17, 33, 1, True, torch.bfloat16),       # halo kernel, ragged edges, residual before the activation
+    (3, 1, 128, 128, 16, 16, 2, False, torch.bfloat16),    # halo kernel, GELU
+    (1, 1, 128, 32, 20, 24, 2, False, torch.bfloat16),     # 1x1 (MlpDWBN fc2's data gradient: 128-wide statistics)
+    (1, 1, 32, 128, 20, 24, 0, True, torch.bfloat16),      # 1x1, no activation, residual
+    (3, 2, 64, 64, 24, 24, 1, False, torch.bfloat16),      # stride 2 (the stem's conv2): strided data gradient
+    (3, 1, 18, 18, 12, 12, 1, False, torch.bfloat16),      # channels not a multiple of 8: convolution + separate pass inside
+    (3, 1, 32, 32, 12, 16, 1, True, torch.float32),        # fp32 mode: convolution + separate pass inside
+])
+def test_conv_gather_bnbwd_equals_separate_reduce(k, stride, cin, cout, H, W, act, res, dtype):
+    """rssf_conv_gather_bnbwd (data gradient + the BatchNorm-backward statistics of the previous layer in one launch) against
+    rssf_conv_gather_add followed by rssf_bn_bwd_reduce: identical gradient, statistics equal up to summation order.
+    `cin` = channels of the convolution INPUT (= of the gradient produced = of the BatchNorm whose statistics are formed)."""
+    from representationlearning_amd import _lib as L, nnf
+    lib = L.load()
+    torch.manual_seed(5)
+    B = 3
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    OH, OW = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    dout = torch.randn(B, OH, OW, cout, device=DEV).to(dtype)
+    raw = torch.randn(B, H, W, cin, device=DEV).to(dtype)
+    rp = torch.randn(B, H, W, cin, device=DEV).to(dtype) if res else None
+    ss = torch.cat([torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.3]).contiguous()
+    dp = nnf._pad_channels(dout)
+    wpk = nnf._pack(spec, [conv.weight], True, dout.dtype, dout.device)
+    dx1, dx2 = torch.empty_like(raw), torch.empty_like(raw)
+    s1 = torch.zeros(nnf.BN_BWD_SLOTS * 2 * cin, device=DEV)
+    s2 = torch.zeros_like(s1)
+    common = (B, OH, OW, dp.shape[3], H, W, cin, 1, spec.stride, spec.ntaps, spec.c_ndy, spec.c_ndx, L.dtype_code(dout), L.stream())
+    L.check(lib.rssf_conv_gather_add(L.ptr(dp), L.ptr(wpk), L.ptr(dx1), None, None, None, None, *common), "dgrad")
+    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dx1), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(s1), B * H * W, cin, act, None, L.dtype_code(raw), L.stream()),
+            "reduce")
+    L.check(lib.rssf_conv_gather_bnbwd(L.ptr(dp), L.ptr(wpk), L.ptr(dx2), None, L.ptr(raw), L.ptr(rp), L.ptr(ss), act, L.ptr(s2), *common), "fused")
+    assert torch.equal(dx1, dx2)
+    a_, b_ = s1.view(-1, 2, cin).sum(0), s2.view(-1, 2, cin).sum(0)
+    assert rel_err(b_.cpu(), a_.cpu()) < 2e-6
+    # with the skip gradient as addend (the BasicBlock case): the statistics see the SUM
+    add = torch.randn_like(raw)
+    s3, s4 = torch.zeros_like(s1), torch.zeros_like(s1)
+    dx3, dx4 = torch.empty_like(raw), torch.empty_like(raw)
+    L.check(lib.rssf_conv_gather_add(L.ptr(dp), L.ptr(wpk), L.ptr(dx3), None, None, L.ptr(add), None, *common), "dgrad+add")
+    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dx3), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(s3), B * H * W, cin, act, None, L.dtype_code(raw), L.stream()),
+            "reduce")
+    L.check(lib.rssf_conv_gather_bnbwd(L.ptr(dp), L.ptr(wpk), L.ptr(dx4), L.ptr(add), L.ptr(raw), L.ptr(rp), L.ptr(ss), act, L.ptr(s4), *common), "fused+add")
+    assert torch.equal(dx3, dx4)
+    assert rel_err(s4.view(-1, 2, cin).sum(0).cpu(), s3.view(-1, 2, cin).sum(0).cpu()) < 2e-6
+
+
 def test_conv_base_shape_linearity_bf16():
     """BASELINE config-2 size (B=16, 128->128 @128x128, 19 taps): linearity + finite (size-independent property)."""
     from representationlearning_amd import nnf
