@@ -205,13 +205,18 @@ class HighResolutionModule(nn.Module):
     def _branches_lockstep(self, xs):
         xs = list(xs)
         nb = self.num_branches
-        for k in range(len(self.branches[0])):
+        nblk = len(self.branches[0])
+        prev = None                               # GroupBwdLink of the previous block's bn2 group (see run_blocks / nnf.BnBwdLink)
+        for k in range(nblk):
             blks = [self.branches[i][k] for i in range(nb)]
             links = [nnf.residual_link(xs[i], xs[i]) for i in range(nb)]
+            g1 = nnf.group_stats_link(nb)
             mid = nnf.conv_bn_act_group([dict(x=xs[i], conv=blks[i].conv1, bn=blks[i].bn1, act=nnf.ACT_RELU, grad_sink=links[i])
-                                         for i in range(nb)])
+                                         for i in range(nb)], stats_out=g1, stats_in=prev if all(l is not None for l in links) else None)
+            g2 = nnf.group_stats_link(nb) if k + 1 < nblk else None
             xs = nnf.conv_bn_act_group([dict(x=mid[i], conv=blks[i].conv2, bn=blks[i].bn2, act=nnf.ACT_RELU, res_pre=xs[i],
-                                             grad_deposit=links[i]) for i in range(nb)])
+                                             grad_deposit=links[i]) for i in range(nb)], stats_out=g2, stats_in=g1)
+            prev = g2
         return xs
 
     def _fuse_lockstep(self, x):

@@ -511,6 +511,29 @@ class BnBwdLink:
         self.act, self.C = ACT_NONE, 0
 
 
+class GroupBwdLink:
+    """The BnBwdLinks of the items of one _ConvBNActGroup plus ONE contiguous sums buffer for them, so that the producer group still
+    needs a single SyncBN exchange.  Item i of the consumer group must consume the output of item i of the producer group."""
+
+    __slots__ = ("items", "sums_all", "offs", "filled")
+
+    def __init__(self, n):
+        self.items = [BnBwdLink() for _ in range(n)]
+        self.sums_all, self.offs, self.filled = None, None, 0
+
+    def slot(self, i, device, rt):
+        if self.sums_all is None:
+            sizes = [BN_BWD_SLOTS * 2 * it.C for it in self.items]
+            self.offs = [sum(sizes[:k]) for k in range(len(sizes) + 1)]
+            self.sums_all = _zeros(self.offs[-1], device, rt)
+        self.filled += 1
+        return self.sums_all[self.offs[i]:self.offs[i + 1]]
+
+
+def group_stats_link(n):
+    return GroupBwdLink(n) if (_FUSED_BN_STATS and torch.is_grad_enabled() and not current().deterministic) else None
+
+
 _FUSED_BN_STATS = os.environ.get("RSSF_FUSED_BN_STATS", "1") != "0"      # A/B switch (tools, DESIGN.md section 4)
 
 
@@ -770,7 +793,7 @@ class _ConvBNActGroup(torch.autograd.Function):
     SLOTS = 7
 
     @staticmethod
-    def forward(ctx, metas, *flat):
+    def forward(ctx, metas, glinks, *flat):
         rt = current()
         lib = L.load()
         n_items = len(metas)
@@ -811,6 +834,11 @@ class _ConvBNActGroup(torch.autograd.Function):
             ns.append(n)
         ctx.save_for_backward(*saved)
         ctx.metas, ctx.ns, ctx.exchanged, ctx.rt = metas, ns, exchanged, rt
+        ctx.gout, ctx.gin = glinks
+        if ctx.gout is not None:
+            for i, (lk, m) in enumerate(zip(ctx.gout.items, metas)):
+                xh_, raw_, ss_, mi_, rph_, w_ = saved[i * 6:(i + 1) * 6]
+                lk.raw, lk.ss, lk.rp, lk.act, lk.C, lk.sums = raw_, ss_, rph_, m[1], m[0].cout, None
         ctx.params = [(t[2], t[3], t[6]) for t in it]
         ctx.x_req = [t[0].requires_grad for t in it]
         ctx.has_pre = [t[1] is not None for t in it]
@@ -823,7 +851,13 @@ class _ConvBNActGroup(torch.autograd.Function):
         n_items = len(metas)
         dev = sv[1].device
         sizes = [BN_BWD_SLOTS * 2 * m[0].cout for m in metas]
-        sums_all = _zeros(sum(sizes), dev, rt)
+        gout = ctx.gout
+        fused = gout is not None and gout.sums_all is not None and gout.filled == n_items     # the consumer group's data gradients summed them
+        sums_all = gout.sums_all if fused else _zeros(sum(sizes), dev, rt)
+        if gout is not None:
+            gout.sums_all, gout.filled = None, 0
+            for lk in gout.items:
+                lk.raw = lk.ss = lk.rp = None
         dyhs, sums, o = [], [], 0
         for i, (m, sz) in enumerate(zip(metas, sizes)):
             xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
@@ -834,11 +868,12 @@ class _ConvBNActGroup(torch.autograd.Function):
             rows = raw.numel() // C
             sm = sums_all[o:o + sz]
             o += sz
-            dws = None
-            if rt.deterministic:
-                dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=dev, dtype=torch.float32)
-            L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rph), L.ptr(sm), rows, C, m[1], L.ptr(dws), L.dtype_code(raw),
-                                           L.stream()), "rssf_bn_bwd_reduce")
+            if not fused:
+                dws = None
+                if rt.deterministic:
+                    dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=dev, dtype=torch.float32)
+                L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rph), L.ptr(sm), rows, C, m[1], L.ptr(dws),
+                                               L.dtype_code(raw), L.stream()), "rssf_bn_bwd_reduce")
             dyhs.append(dyh)
             sums.append(sm)
         pscale = 1.0
@@ -872,7 +907,10 @@ class _ConvBNActGroup(torch.autograd.Function):
                 _accumulate_dgrad(accum, spec, draw, [w], xh.shape, rt)
                 dx = None
             elif ctx.x_req[i]:
-                dx = _nchw(_conv_dgrad(spec, draw, [w], xh.shape, addend, rt))
+                gin, bn = ctx.gin, None
+                if gin is not None and gin.items[i].raw is not None and not rt.deterministic:
+                    bn = (gin.items[i], gin.slot(i, dev, rt))
+                dx = _nchw(_conv_dgrad(spec, draw, [w], xh.shape, addend, rt, bn=bn))
             else:
                 if addend is not None:
                     raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
@@ -881,16 +919,18 @@ class _ConvBNActGroup(torch.autograd.Function):
             _conv_wgrad(spec, draw, xh, [tw], None, rt)
             grads += [dx, None if dres is None else _nchw(dres), grad_result(p_gamma, dgamma, dg_direct, rt),
                       grad_result(p_beta, dbeta, db_direct, rt), None, None, grad_result(p_w, tw, wd, rt)]
-        return (None, *grads)
+        return (None, None, *grads)
 
 
-def conv_bn_act_group(items):
+def conv_bn_act_group(items, stats_out=None, stats_in=None):
     """items: dicts with x, conv, bn, act and optionally res_pre, grad_sink, grad_deposit, grad_accum (see conv_bn_act).  Returns the list of
-    outputs.  One SyncBN exchange for the whole group (see _ConvBNActGroup); falls back to individual nodes for a single item."""
+    outputs.  One SyncBN exchange for the whole group (see _ConvBNActGroup); falls back to individual nodes for a single item.
+    stats_out / stats_in: GroupBwdLink of this group / of the group whose item i produced this group's x_i (see BnBwdLink)."""
     if len(items) == 1:
         d = items[0]
         return [conv_bn_act(d["x"], d["conv"], d["bn"], d.get("act", ACT_NONE), res_pre=d.get("res_pre"), grad_sink=d.get("grad_sink"),
-                            grad_deposit=d.get("grad_deposit"), grad_accum=d.get("grad_accum"))]
+                            grad_deposit=d.get("grad_deposit"), grad_accum=d.get("grad_accum"),
+                            stats_out=None if stats_out is None else stats_out.items[0], stats_in=None if stats_in is None else stats_in.items[0])]
     rt = current()
     metas, flat = [], []
     for d in items:
@@ -904,7 +944,7 @@ def conv_bn_act_group(items):
         metas.append((spec_of([conv]), d.get("act", ACT_NONE), training, 0.1 if bn.momentum is None else bn.momentum, bn.eps, sync,
                       d.get("grad_sink"), d.get("grad_deposit"), d.get("grad_accum")))
         flat += [d["x"], d.get("res_pre"), bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight]
-    return list(_ConvBNActGroup.apply(metas, *flat))
+    return list(_ConvBNActGroup.apply(metas, (stats_out, stats_in), *flat))
 
 
 class _ConvBias(torch.autograd.Function):
