@@ -195,6 +195,21 @@ int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, fl
                     const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias, float* workspace,
                     int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy,
                     const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream);
+/* WEIGHT-GRADIENT launch that also performs the BatchNorm-backward apply of its own layer (torch autograd:
+ * native_batch_norm_backward's input gradient + the activation mask, then convolution_backward's weight gradient): the
+ * output-gradient operand of the weight gradient is draw = rssf_bn_bwd_apply(bn_dy, bn_raw, ...), so the halo-tiled 3x3 kernel
+ * forms it while staging that operand (reads bn_dy and bn_raw instead of draw) and also writes it to `draw` for the data-gradient
+ * launch that follows (+ dz to `dres`, + dgamma / dbeta): the separate apply pass (read dy, raw; write draw) disappears.  Same
+ * operation order as rssf_bn_bwd_apply: bit-identical `draw`, `dres`, parameter gradients and weight gradient.  Shapes without
+ * such a kernel run rssf_bn_bwd_apply followed by rssf_conv_wgrad(draw, ...).  The BatchNorm arguments are rssf_bn_bwd_apply's,
+ * the rest rssf_conv_wgrad's (its `dout` is `draw`). */
+int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, const float* bn_scale_shift, const float* bn_mean_invstd,
+                            const float* bn_sums, const void* bn_res_pre, void* draw, void* dres, float* dgamma, float* dbeta,
+                            int bn_act, double bn_n, int bn_training, float param_grad_scale, const void* in, float* dw0, float* dw1,
+                            float* dw2, const int* ksizes, int nsrc, const int* src_of_tap, const int* kpos_of_tap,
+                            const int* alias_of_tap, float* dbias, float* workspace, int B, int IH, int IW, int Cin, int OH, int OW,
+                            int Cout, int stride, int ntaps, const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce,
+                            int dtype, void* stream);
 int rssf_conv_wgrad_reduce_blocks(const rssf_wgrad_reduce_job* job);
 int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, const int* block_map, int nblocks, void* stream);
 

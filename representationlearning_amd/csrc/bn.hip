@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float x = vr.get(e);
-        float z = x * sc[e] + sh[e];
+        float z = fmaf(x, sc[e], sh[e]);
         if (res_pre) z += vp.get(e);
         const float dz = vd.get(e) * act_bwd(z, act);
         a1[e] += dz; a2[e] += dz * x;
@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
   for (int e = 0; e < VEC; ++e) {
     const int c = c0 + e;
     const float s1 = tot[col * VEC + e], s2 = tot[cols * VEC + col * VEC + e];
-    const float dot = (s2 - mean[e] * s1) * istd[e];        // sum dz*xhat
+    float dot;
+    bn_bwd_constants(sc[e], mean[e], istd[e], s1, s2, n, dot, cb[e], cc[e]);
     k1[e] = s1 / n;
     k2[e] = dot / n;
     // one writer per channel.  pscale = 1/world under SyncBN: `sums` are then the GLOBAL totals, while DDP averages the LOCAL
@@ -349,8 +350,6 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     if (dgamma && blockIdx.x == 0 && rlocal == 0) { dgamma[c] += dot * pscale; dbeta[c] += s1 * pscale; }
     // draw = sc*(dz - k1 - (x - mean)*istd*k2) = sc*dz + cb*x + cc : two FMAs per element instead of six operations (the pass
     // runs 8 waves per SIMD at 22 % VALU-active each: instruction issue, not the fabric, was its limit)
-    cb[e] = -sc[e] * istd[e] * k2[e];
-    cc[e] = -sc[e] * k1[e] - cb[e] * mean[e];
   }
   if constexpr (VEC > 1) {
     while (have) {
@@ -365,7 +364,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float x = vr.get(e);
-        const float z = x * sc[e] + sh[e] + (res_pre ? vp.get(e) : 0.f);
+        float z = fmaf(x, sc[e], sh[e]);                       // explicit: the fused forms (conv_wgrad.hip, conv_halo.hip) round alike
+        if (res_pre) z += vp.get(e);
         const float dz = vd.get(e) * act_bwd(z, act);
         o2[e] = dz;
         o1[e] = training ? fmaf(sc[e], dz, fmaf(cb[e], x, cc[e])) : sc[e] * dz;
@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     for (; r < rows; r += stride) {
       const int64_t off = r * C + c0;
       const float x = ldf(raw + off);
-      const float z = x * sc[0] + sh[0] + (res_pre ? ldf(res_pre + off) : 0.f);
+      float z = fmaf(x, sc[0], sh[0]);
+      if (res_pre) z += ldf(res_pre + off);
       const float dz = ldf(dy + off) * act_bwd(z, act);
       stf(draw + off, training ? sc[0] * (dz - k1[0] - (x - mean[0]) * istd[0] * k2[0]) : sc[0] * dz);
       if (dres) stf(dres + off, dz);

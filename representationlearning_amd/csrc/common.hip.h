@@ -130,6 +130,17 @@ template <typename OP> __device__ __forceinline__ float wave_reduce_dpp(float v)
   return rows_reduce<OP>(v);
 }
 
+// Per-channel constants of the BatchNorm-backward apply, draw = sc*dz + cb*x + cc (= sc*(dz - k1 - xhat*k2)), from the channel's
+// sums s1 = sum dz, s2 = sum dz*raw.  ONE definition with explicit fused multiply-adds: bn_bwd_apply_kernel (bn.hip) and the
+// weight-gradient kernel that applies on the fly (conv_wgrad.hip) must round alike for bit-identical results.
+__device__ __forceinline__ void bn_bwd_constants(float sc, float mean, float istd, float s1, float s2, float n, float& dot, float& cb,
+                                                 float& cc) {
+  dot = fmaf(-mean, s1, s2) * istd;                        // sum dz * xhat
+  const float k1 = s1 / n, k2 = dot / n;
+  cb = -(sc * istd) * k2;
+  cc = fmaf(-cb, mean, -(sc * k1));
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) given e = exp(-u*u): one v_rcp + 6 FMA.
 // The library erff costs ~35 VALU instructions with two range branches and made the GELU BatchNorm passes (128 channels
 // at 1/4 resolution, 33 M elements) VALU-bound at 2.4 TB/s; the exponential is shared with the Gaussian of the gradient.

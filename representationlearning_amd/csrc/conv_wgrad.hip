@@ -19,6 +19,7 @@
 // ~10x the GEMM itself.  (Without a workspace the kernel falls back to atomics.)
 // Optional bias gradient (sum_p dout) for convolutions without a following BatchNorm.
 #include <cstring>
+#include <type_traits>
 #include "conv.hip.h"
 using namespace rssf;
 using namespace rssf::cv;
@@ -355,6 +356,17 @@ struct WgradHaloArgs {
   int B, H, W, Cin, Cout, tiles_y, tiles_x, ntiles, tiles_per_block, npairs, ptiles_n, xcd_per;
   int64_t total;
   int dy[9], dx[9];
+  // Fused BatchNorm-backward APPLY (bn_dy != null; `dout` is then not read): the output-gradient tile of the convolution is
+  // COMPUTED while it is staged, draw = scale * (dz - k1 - xhat * k2), dz = bn_dy * act'(bn_raw * scale + shift + bn_res) - the
+  // arithmetic of bn_bwd_apply_kernel (bn.hip), same operation order - and the blocks of input-channel tile 0 also write it to
+  // `draw_out` (the data-gradient launch reads it) and dz to `dres_out` (optional); the blocks of pixel range 0 add the
+  // parameter gradients.  One tensor pass (read dy, raw; write draw) and a launch less per layer.
+  const bf16_t* bn_dy; const bf16_t* bn_raw; const bf16_t* bn_res;
+  const float* bn_ss; const float* bn_mi; const float* bn_sums;       // [2][Cout] x 2, [RSSF_BN_BWD_SLOTS][2][Cout]
+  bf16_t* draw_out; bf16_t* dres_out;
+  float* dgamma; float* dbeta;
+  float bn_n, bn_pscale;
+  int bn_act, bn_training;
 };
 constexpr int HTH = 8, HTW = 16, HHP = (HTH + 2) * (HTW + 2), HNPX = HTH * HTW, HCT = 32, HLD = HCT + 16;
 
@@ -385,8 +397,39 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
 
-  Vec<bf16_t> rx[X_LOADS], rd[D_LOADS];
+  // ---- fused BatchNorm-backward apply: per-channel constants of this block's 32 output channels through LDS -----------------
+  const bool fuse = a.bn_dy != nullptr;
+  __shared__ float sbn[4][HCT];                               // scale, shift, cb, cc (bn_bwd_apply_kernel's names)
+  static_assert(D_LOADS == 1, "a thread stages ONE 8-channel chunk of the dout tile: its constants are fixed");
+  float bsc[8], bsh[8], bcb[8], bcc[8];
+  if (fuse) {
+    if (tid < HCT) {
+      const int c = co0 + tid;
+      float sc = 0.f, sh = 0.f, cb = 0.f, cc = 0.f;
+      if (c < a.Cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RSSF_BN_BWD_SLOTS; ++k) { s1 += a.bn_sums[(size_t)k * 2 * a.Cout + c]; s2 += a.bn_sums[(size_t)k * 2 * a.Cout + a.Cout + c]; }
+        const float mean = a.bn_mi[c], istd = a.bn_mi[a.Cout + c];
+        sc = a.bn_ss[c]; sh = a.bn_ss[a.Cout + c];
+        float dot;
+        bn_bwd_constants(sc, mean, istd, s1, s2, a.bn_n, dot, cb, cc);
+        if (a.dgamma && range == 0 && ci0 == 0) { a.dgamma[c] += dot * a.bn_pscale; a.dbeta[c] += s1 * a.bn_pscale; }      // one writer per channel
+      }
+      sbn[0][tid] = sc; sbn[1][tid] = sh; sbn[2][tid] = cb; sbn[3][tid] = cc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int lc = (tid & 3) * 8 + e;
+      bsc[e] = sbn[0][lc]; bsh[e] = sbn[1][lc]; bcb[e] = sbn[2][lc]; bcc[e] = sbn[3][lc];
+    }
+  }
+  const bool writer = fuse && ci0 == 0;                       // the (co, ci = 0) blocks own the global copy of draw / dres
+
+  Vec<bf16_t> rx[X_LOADS], rd[D_LOADS], rr[D_LOADS], rq[D_LOADS];
   bool xok[X_LOADS], dok[D_LOADS];
+  int64_t doff[D_LOADS];
   auto load_tile = [&](int t) {
     const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
     const int y0 = ty * HTH, x0 = tx * HTW;
@@ -402,8 +445,30 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
       const int idx = tid + i * NT_, p = idx >> 2, ch = co0 + (idx & 3) * 8;
       const int gy = y0 + p / HTW, gx = x0 + p % HTW;
       dok[i] = gy < a.H && gx < a.W && ch < a.Cout;
-      rd[i].load(a.dout + (dok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + ch : 0));
+      doff[i] = dok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + ch : 0;
+      if (fuse) {
+        rd[i].load(a.bn_dy + doff[i]);
+        rr[i].load(a.bn_raw + doff[i]);
+        if (a.bn_res) rq[i].load(a.bn_res + doff[i]);
+      } else {
+        rd[i].load(a.dout + doff[i]);
+      }
     }
+  };
+  // draw / dz of one staged chunk (see WgradHaloArgs): block-uniform activation, one specialised loop runs
+  auto apply_chunk = [&](auto ACT, int i, Vec<bf16_t>& vdraw, Vec<bf16_t>& vdz) {
+    float o1[8], o2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = rr[i].get(e);
+      float z = fmaf(x, bsc[e], bsh[e]);
+      if (a.bn_res) z += rq[i].get(e);
+      const float g = rd[i].get(e);
+      const float dz = decltype(ACT)::value == 1 ? g * (z > 0.f ? 1.f : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
+      o2[e] = dz;
+      o1[e] = a.bn_training ? fmaf(bsc[e], dz, fmaf(bcb[e], x, bcc[e])) : bsc[e] * dz;
+    }
+    vdraw.set_all(o1); vdz.set_all(o2);
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -417,6 +482,16 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
     for (int i = 0; i < D_LOADS; ++i) {
       const int idx = tid + i * NT_;
       Vec<bf16_t> v = rd[i];
+      if (fuse) {
+        Vec<bf16_t> vz;
+        if (a.bn_act == 1) apply_chunk(std::integral_constant<int, 1>{}, i, v, vz);
+        else if (a.bn_act == 2) apply_chunk(std::integral_constant<int, 2>{}, i, v, vz);
+        else apply_chunk(std::integral_constant<int, 0>{}, i, v, vz);
+        if (writer && dok[i]) {
+          v.store(a.draw_out + doff[i]);
+          if (a.dres_out) vz.store(a.dres_out + doff[i]);
+        }
+      }
       if (!dok[i]) v.raw = {0, 0, 0, 0};
       v.store(DS + (idx >> 2) * HLD + (idx & 3) * 8);
     }
@@ -568,10 +643,15 @@ extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Ci
   return (int64_t)ks * ntaps * Cout * Cin;
 }
 
-extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
-                               int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
-                               float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
-                               const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream) {
+namespace {
+struct BnApply {               // arguments of rssf_bn_bwd_apply (see WgradHaloArgs::bn_*)
+  const void* dy; const void* raw; const float* ss; const float* mi; const float* sums; const void* res; void* draw; void* dres;
+  float* dgamma; float* dbeta; double n; int act, training; float pscale;
+};
+int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
+                    int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
+                    float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
+                    const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, const BnApply* bn, int dtype, void* stream) {
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
@@ -604,14 +684,52 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
     h.total = (int64_t)a.ksplit * h.npairs;
     h.xcd_per = xcd_per(h.total);
     for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
+    h.bn_dy = nullptr;
+    if (bn) {                  // the BatchNorm-backward apply rides in this kernel's staging of the output-gradient tile
+      h.bn_dy = (const bf16_t*)bn->dy; h.bn_raw = (const bf16_t*)bn->raw; h.bn_res = (const bf16_t*)bn->res;
+      h.bn_ss = bn->ss; h.bn_mi = bn->mi; h.bn_sums = bn->sums;
+      h.draw_out = (bf16_t*)bn->draw; h.dres_out = (bf16_t*)bn->dres; h.dgamma = bn->dgamma; h.dbeta = bn->dbeta;
+      h.bn_n = (float)bn->n; h.bn_pscale = bn->pscale; h.bn_act = bn->act; h.bn_training = bn->training;
+    }
     conv3x3_wgrad_halo_kernel<<<(unsigned)h.xcd_per * 8, HWG_THREADS, 0, st>>>(h);
     if (int rc = check_launch("conv3x3_wgrad_halo")) return rc;
     return finish_reduce(a, defer_reduce, st);
+  }
+  if (bn) {                    // no kernel with a fused apply for this shape: the separate pass, then the plain weight gradient
+    const int rc = rssf_bn_bwd_apply(bn->dy, bn->raw, bn->ss, bn->mi, bn->sums, bn->res, bn->draw, bn->dres, bn->dgamma, bn->dbeta,
+                                     (int64_t)B * OH * OW, Cout, bn->act, bn->n, bn->training, bn->pscale, dtype, stream);
+    if (rc) return rc;
   }
   if (dtype == RSSF_F32) return launch_all<float>(a, ntaps, defer_reduce, st);
   if (dtype == RSSF_BF16) return launch_all<bf16_t>(a, ntaps, defer_reduce, st);
   set_error("conv_wgrad: unsupported dtype %d", dtype);
   return RSSF_ERR_UNSUPPORTED;
+}
+}  // namespace
+
+extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
+                               int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
+                               float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
+                               const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream) {
+  return conv_wgrad_impl(dout, in, dw0, dw1, dw2, ksizes, nsrc, src_of_tap, kpos_of_tap, alias_of_tap, dbias, workspace, B, IH, IW, Cin, OH,
+                         OW, Cout, stride, ntaps, dy, dx, defer_reduce, nullptr, dtype, stream);
+}
+
+extern "C" int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, const float* bn_scale_shift, const float* bn_mean_invstd,
+                                       const float* bn_sums, const void* bn_res_pre, void* draw, void* dres, float* dgamma, float* dbeta,
+                                       int bn_act, double bn_n, int bn_training, float param_grad_scale, const void* in, float* dw0,
+                                       float* dw1, float* dw2, const int* ksizes, int nsrc, const int* src_of_tap, const int* kpos_of_tap,
+                                       const int* alias_of_tap, float* dbias, float* workspace, int B, int IH, int IW, int Cin, int OH,
+                                       int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx,
+                                       rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream) {
+  RSSF_REQUIRE(bn_dy && bn_raw && bn_scale_shift && bn_mean_invstd && bn_sums && draw && bn_act >= 0 && bn_act <= 2,
+               "conv_wgrad_bnapply: bad BatchNorm arguments");
+  RSSF_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "conv_wgrad_bnapply: dgamma and dbeta go together");
+  const BnApply bn = {bn_dy, bn_raw, bn_scale_shift, bn_mean_invstd, bn_sums, bn_res_pre, draw, dres, dgamma, dbeta, bn_n, bn_act,
+                      bn_training, param_grad_scale};
+  // `draw` doubles as the weight gradient's output-gradient operand: it is complete when this call returns to the stream
+  return conv_wgrad_impl(draw, in, dw0, dw1, dw2, ksizes, nsrc, src_of_tap, kpos_of_tap, alias_of_tap, dbias, workspace, B, IH, IW, Cin, OH,
+                         OW, Cout, stride, ntaps, dy, dx, defer_reduce, &bn, dtype, stream);
 }
 
 extern "C" int rssf_conv_wgrad_reduce_blocks(const rssf_wgrad_reduce_job* job) {

@@ -534,6 +534,7 @@ def group_stats_link(n):
     return GroupBwdLink(n) if (_FUSED_BN_STATS and torch.is_grad_enabled() and not current().deterministic) else None
 
 
+_FUSED_BN_APPLY = os.environ.get("RSSF_FUSED_BN_APPLY", "1") != "0"      # A/B switch: BatchNorm-backward apply inside the weight-gradient launch
 _FUSED_BN_STATS = os.environ.get("RSSF_FUSED_BN_STATS", "1") != "0"      # A/B switch (tools)
 
 
@@ -615,9 +616,11 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, b
     return dx
 
 
-def _conv_wgrad(spec, dout, xh, dws, db, rt=None):
+def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None):
     """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional).  Under a WgradPlan the split-K
-    reduction is deferred to the plan's one batched launch (the gradients are complete after WgradPlan.flush())."""
+    reduction is deferred to the plan's one batched launch (the gradients are complete after WgradPlan.flush()).
+    bn: (dy, raw, ss, mi, sums, res_pre, dres, dgamma, dbeta, act, n, training, pscale) - `dout` is then an OUTPUT: the launch
+    performs the layer's BatchNorm-backward apply on the way (rssf_conv_wgrad_bnapply) and leaves draw in `dout` (dz in dres)."""
     xh, dout = _pad_channels(xh), _pad_channels(dout)
     B, H, W, C = xh.shape
     _, OH, OW, CO = dout.shape
@@ -641,10 +644,17 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None):
                 ws, job, ref = got
     if ws is None:
         ws = torch.empty(nws, device=xh.device, dtype=torch.float32)
-    L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws),
-                                     spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb), L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps,
-                                     spec.c_dy, spec.c_dx, None if job is None else ctypes.byref(job), L.dtype_code(xh), L.stream()),
-            "rssf_conv_wgrad")
+    tail = (L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws), spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb),
+            L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps, spec.c_dy, spec.c_dx, None if job is None else ctypes.byref(job),
+            L.dtype_code(xh), L.stream())
+    if bn is not None:
+        if padded:
+            raise RuntimeError("conv_wgrad: the fused BatchNorm-backward apply needs channel counts the kernels take unpadded")
+        bdy, braw, bss, bmi, bsums, brp, bdres, bdg, bdb, bact, bn_n, btr, bps = bn
+        L.check(lib.rssf_conv_wgrad_bnapply(L.ptr(bdy), L.ptr(braw), L.ptr(bss), L.ptr(bmi), L.ptr(bsums), L.ptr(brp), L.ptr(dout), L.ptr(bdres),
+                                            L.ptr(bdg), L.ptr(bdb), bact, bn_n, int(btr), bps, *tail), "rssf_conv_wgrad_bnapply")
+    else:
+        L.check(lib.rssf_conv_wgrad(L.ptr(dout), *tail), "rssf_conv_wgrad")
     if job is not None:
         if ref is not None and bytes(job) != bytes(ref):
             raise RuntimeError("WgradPlan: a deferred weight-gradient reduction changed between steps")
@@ -737,9 +747,33 @@ class _ConvBNAct(torch.autograd.Function):
         p_gamma, p_beta, p_weights, p_biases = ctx.params
         dgamma, dg_direct = grad_target(p_gamma, rt)
         dbeta, db_direct = grad_target(p_beta, rt)
-        L.check(lib.rssf_bn_bwd_apply(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres),
-                                      L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), pscale, L.dtype_code(raw), L.stream()),
-                "rssf_bn_bwd_apply")
+        wt = [grad_target(w, rt) for w in p_weights]
+
+        def weight_grads(bn):
+            gbs = []
+            if nbias == 1:          # the weight-gradient kernel accumulates straight into the bias gradient: no staging buffer, no add
+                tb, direct = grad_target(p_biases[0], rt)
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn)
+                gbs.append(grad_result(p_biases[0], tb, direct, rt))
+            else:
+                db = _zeros(C, raw.device, rt) if nbias else None
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt, bn=bn)
+                for b in p_biases:      # every summed conv's bias sees the same gradient
+                    tb, direct = grad_target(b, rt)
+                    tb += db
+                    gbs.append(grad_result(b, tb, direct, rt))
+            return gbs
+
+        # the BatchNorm-backward apply rides in the weight-gradient launch where a kernel for that exists (rssf_conv_wgrad_bnapply:
+        # the entry point falls back to the two launches itself); channel counts the kernels would see padded keep the two calls
+        vch = 8 if raw.dtype == torch.bfloat16 else 4
+        fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0
+        if fuse_apply:
+            gbs = weight_grads((dyh, raw, ss, mi, sums, rp, dres, dgamma, dbeta, act, n, training, pscale))
+        else:
+            L.check(lib.rssf_bn_bwd_apply(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres),
+                                          L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), pscale, L.dtype_code(raw), L.stream()),
+                    "rssf_bn_bwd_apply")
         sink, deposit = ctx.links
         if deposit is not None and dres is not None:
             deposit.value, dres = dres, None              # the first conv of the block folds it into its data gradient
@@ -762,19 +796,8 @@ class _ConvBNAct(torch.autograd.Function):
             if addend is not None:
                 raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
             dx = None
-        wt = [grad_target(w, rt) for w in p_weights]
-        gbs = []
-        if nbias == 1:          # the weight-gradient kernel accumulates straight into the bias gradient: no staging buffer, no add
-            tb, direct = grad_target(p_biases[0], rt)
-            _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt)
-            gbs.append(grad_result(p_biases[0], tb, direct, rt))
-        else:
-            db = _zeros(C, raw.device, rt) if nbias else None
-            _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt)
-            for b in p_biases:      # every summed conv's bias sees the same gradient
-                tb, direct = grad_target(b, rt)
-                tb += db
-                gbs.append(grad_result(b, tb, direct, rt))
+        if not fuse_apply:
+            gbs = weight_grads(None)
         gws = [grad_result(w, t[0], t[1], rt) for w, t in zip(p_weights, wt)]
         return (dx, None if dres is None else _nchw(dres), dy if has_post else None, grad_result(p_gamma, dgamma, dg_direct, rt),
                 grad_result(p_beta, dbeta, db_direct, rt), None, None, None, None, None, None, None, None, None, None, *gws, *gbs)

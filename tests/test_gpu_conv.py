@@ -239,6 +239,54 @@ def test_conv_gather_bnbwd_equals_separate_reduce(k, stride, cin, cout, H, W, ac
     assert rel_err(s4.view(-1, 2, cin).sum(0).cpu(), s3.view(-1, 2, cin).sum(0).cpu()) < 2e-6
 
 
+@pytest.mark.parametrize("k,cin,cout,H,W,act,res,training,dtype", [
+    (3, 32, 32, 24, 20, 1, False, 1, torch.bfloat16),      # halo weight-gradient kernel
+    (3, 64, 64, 17, 33, 1, True, 1, torch.bfloat16),       # 2 x 2 channel tiles, ragged edges, residual (dres written)
+    (3, 32, 128, 16, 16, 2, False, 1, torch.bfloat16),     # GELU, more output than input tiles
+    (3, 32, 32, 16, 16, 1, True, 0, torch.bfloat16),       # eval-mode BatchNorm (draw = scale * dz)
+    (1, 32, 64, 20, 24, 1, False, 1, torch.bfloat16),      # 1x1: apply + plain weight gradient inside the entry point
+    (3, 32, 32, 12, 16, 1, True, 1, torch.float32),        # fp32: likewise
+])
+def test_conv_wgrad_bnapply_equals_apply_then_wgrad(k, cin, cout, H, W, act, res, training, dtype):
+    """rssf_conv_wgrad_bnapply (BatchNorm-backward apply inside the weight-gradient launch) against rssf_bn_bwd_apply followed by
+    rssf_conv_wgrad: draw, dres, dgamma / dbeta and the weight gradient are bit-identical (same operation order)."""
+    from representationlearning_amd import _lib as L, nnf
+    lib = L.load()
+    torch.manual_seed(7)
+    B = 3
+    conv = nn.Conv2d(cin, cout, k, 1, k // 2, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    x = torch.randn(B, H, W, cin, device=DEV).to(dtype)
+    dy = torch.randn(B, H, W, cout, device=DEV).to(dtype)
+    raw = torch.randn(B, H, W, cout, device=DEV).to(dtype)
+    rp = torch.randn(B, H, W, cout, device=DEV).to(dtype) if res else None
+    ss = torch.cat([torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.3]).contiguous()
+    mi = torch.cat([torch.randn(cout, device=DEV) * 0.2, torch.rand(cout, device=DEV) + 0.5]).contiguous()
+    sums = torch.randn(nnf.BN_BWD_SLOTS * 2 * cout, device=DEV)
+    n = float(B * H * W)
+    nws = lib.rssf_conv_wgrad_workspace_elems(B, H, W, cin, cout, spec.ntaps)
+    out = {}
+    for fused in (False, True):
+        draw = torch.empty_like(raw)
+        dres = torch.empty_like(raw) if res else None
+        dg, db = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+        dw = torch.zeros_like(conv.weight, dtype=torch.float32)
+        ws = torch.empty(nws, device=DEV)
+        tail = (L.ptr(x), L.ptr(dw), None, None, spec.c_ksizes, 1, spec.c_src, spec.c_kpos, spec.c_alias, None, L.ptr(ws), B, H, W, cin, H, W, cout, 1,
+                spec.ntaps, spec.c_dy, spec.c_dx, None, L.dtype_code(x), L.stream())
+        if fused:
+            L.check(lib.rssf_conv_wgrad_bnapply(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres), L.ptr(dg),
+                                                L.ptr(db), act, n, training, 0.5, *tail), "fused")
+        else:
+            L.check(lib.rssf_bn_bwd_apply(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres), L.ptr(dg),
+                                          L.ptr(db), B * H * W, cout, act, n, training, 0.5, L.dtype_code(raw), L.stream()), "apply")
+            L.check(lib.rssf_conv_wgrad(L.ptr(draw), *tail), "wgrad")
+        out[fused] = (draw, dres, dg, db, dw)
+    for a_, b_, name in zip(out[True], out[False], ("draw", "dres", "dgamma", "dbeta", "dw")):
+        if a_ is not None:
+            assert torch.equal(a_, b_), name
+
+
 def test_conv_base_shape_linearity_bf16():
     """BASELINE config-2 size (B=16, 128->128 @128x128, 19 taps): linearity + finite (size-independent property)."""
     from representationlearning_amd import nnf
