@@ -915,9 +915,16 @@ class _ConvBNActGroup(torch.autograd.Function):
             dres = torch.empty_like(raw) if ctx.has_pre[i] else None
             dgamma, dg_direct = grad_target(p_gamma, rt)
             dbeta, db_direct = grad_target(p_beta, rt)
-            L.check(lib.rssf_bn_bwd_apply(L.ptr(dyhs[i]), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums[i]), L.ptr(rph), L.ptr(draw), L.ptr(dres),
-                                          L.ptr(dgamma), L.ptr(dbeta), rows, C, act, ctx.ns[i], int(tr), pscale if tr else 1.0,
-                                          L.dtype_code(raw), L.stream()), "rssf_bn_bwd_apply")
+            tw, wd = grad_target(p_w, rt)
+            vch = 8 if raw.dtype == torch.bfloat16 else 4
+            fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0      # see _ConvBNAct.backward
+            if fuse_apply:
+                _conv_wgrad(spec, draw, xh, [tw], None, rt,
+                            bn=(dyhs[i], raw, ss, mi, sums[i], rph, dres, dgamma, dbeta, act, ctx.ns[i], tr, pscale if tr else 1.0))
+            else:
+                L.check(lib.rssf_bn_bwd_apply(L.ptr(dyhs[i]), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums[i]), L.ptr(rph), L.ptr(draw),
+                                              L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), rows, C, act, ctx.ns[i], int(tr), pscale if tr else 1.0,
+                                              L.dtype_code(raw), L.stream()), "rssf_bn_bwd_apply")
             if deposit is not None and dres is not None:
                 deposit.value, dres = dres, None
             addend = None
@@ -938,8 +945,8 @@ class _ConvBNActGroup(torch.autograd.Function):
                 if addend is not None:
                     raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
                 dx = None
-            tw, wd = grad_target(p_w, rt)
-            _conv_wgrad(spec, draw, xh, [tw], None, rt)
+            if not fuse_apply:
+                _conv_wgrad(spec, draw, xh, [tw], None, rt)
             grads += [dx, None if dres is None else _nchw(dres), grad_result(p_gamma, dgamma, dg_direct, rt),
                       grad_result(p_beta, dbeta, db_direct, rt), None, None, grad_result(p_w, tw, wd, rt)]
         return (None, None, *grads)
