@@ -374,6 +374,9 @@ constexpr int HTH = 8, HTW = 16, HHP = (HTH + 2) * (HTW + 2), HNPX = HTH * HTW, 
 // footprint - the block is latency-bound, one resident block per CU); group 1's accumulators are folded into group 0's
 // through LDS once, after the last tile.
 constexpr int HWG_THREADS = 512;
+// FUSE / RES are template parameters: a run-time branch around the staging loads would make the compiler drain vmcnt at the join,
+// i.e. wait for a tile's loads where they are issued instead of one tile later (measured: 16 -> 27 us per launch)
+template <bool FUSE, bool RES>
 __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
   constexpr int NT_ = HWG_THREADS;
   constexpr int X_LOADS = (HHP * 4 + NT_ - 1) / NT_, D_LOADS = HNPX * 4 / NT_;
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
   for (int t = 0; t < 9; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
 
   // ---- fused BatchNorm-backward apply: per-channel constants of this block's 32 output channels through LDS -----------------
-  const bool fuse = a.bn_dy != nullptr;
+  constexpr bool fuse = FUSE;
   __shared__ float sbn[4][HCT];                               // scale, shift, cb, cc (bn_bwd_apply_kernel's names)
   static_assert(D_LOADS == 1, "a thread stages ONE 8-channel chunk of the dout tile: its constants are fixed");
   float bsc[8], bsh[8], bcb[8], bcc[8];
@@ -427,9 +430,14 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
   }
   const bool writer = fuse && ci0 == 0;                       // the (co, ci = 0) blocks own the global copy of draw / dres
 
-  Vec<bf16_t> rx[X_LOADS], rd[D_LOADS], rr[D_LOADS], rq[D_LOADS];
+  Vec<bf16_t> rx[X_LOADS], rd[D_LOADS], rr[D_LOADS], rq[D_LOADS], vdk[D_LOADS], vzk[D_LOADS];
   bool xok[X_LOADS], dok[D_LOADS];
   int64_t doff[D_LOADS];
+  unsigned soff[D_LOADS];
+  constexpr unsigned SOOB = 0x80000000u;                    // >= num_records (the entry point keeps the tensors below 2^31 bytes)
+  const int dbytes = (int)((int64_t)a.B * a.H * a.W * a.Cout * 2);
+  const __amdgpu_buffer_rsrc_t rdraw = __builtin_amdgcn_make_buffer_rsrc(fuse ? a.draw_out : const_cast<bf16_t*>(a.dout), 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdres = __builtin_amdgcn_make_buffer_rsrc(fuse && a.dres_out ? a.dres_out : (fuse ? a.draw_out : const_cast<bf16_t*>(a.dout)), 0, dbytes, 0x00020000);
   auto load_tile = [&](int t) {
     const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, b = t / (a.tiles_x * a.tiles_y);
     const int y0 = ty * HTH, x0 = tx * HTW;
@@ -446,10 +454,10 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
       const int gy = y0 + p / HTW, gx = x0 + p % HTW;
       dok[i] = gy < a.H && gx < a.W && ch < a.Cout;
       doff[i] = dok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + ch : 0;
-      if (fuse) {
+      if constexpr (fuse) {
         rd[i].load(a.bn_dy + doff[i]);
         rr[i].load(a.bn_raw + doff[i]);
-        if (a.bn_res) rq[i].load(a.bn_res + doff[i]);
+        if constexpr (RES) rq[i].load(a.bn_res + doff[i]);
       } else {
         rd[i].load(a.dout + doff[i]);
       }
@@ -462,7 +470,7 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
     for (int e = 0; e < 8; ++e) {
       const float x = rr[i].get(e);
       float z = fmaf(x, bsc[e], bsh[e]);
-      if (a.bn_res) z += rq[i].get(e);
+      if constexpr (RES) z += rq[i].get(e);
       const float g = rd[i].get(e);
       const float dz = decltype(ACT)::value == 1 ? g * (z > 0.f ? 1.f : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
       o2[e] = dz;
@@ -482,18 +490,26 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
     for (int i = 0; i < D_LOADS; ++i) {
       const int idx = tid + i * NT_;
       Vec<bf16_t> v = rd[i];
-      if (fuse) {
-        Vec<bf16_t> vz;
-        if (a.bn_act == 1) apply_chunk(std::integral_constant<int, 1>{}, i, v, vz);
-        else if (a.bn_act == 2) apply_chunk(std::integral_constant<int, 2>{}, i, v, vz);
-        else apply_chunk(std::integral_constant<int, 0>{}, i, v, vz);
-        if (writer && dok[i]) {
-          v.store(a.draw_out + doff[i]);
-          if (a.dres_out) vz.store(a.dres_out + doff[i]);
-        }
+      if constexpr (fuse) {
+        if (a.bn_act == 1) apply_chunk(std::integral_constant<int, 1>{}, i, v, vzk[i]);
+        else if (a.bn_act == 2) apply_chunk(std::integral_constant<int, 2>{}, i, v, vzk[i]);
+        else apply_chunk(std::integral_constant<int, 0>{}, i, v, vzk[i]);
+        vdk[i] = v;
+        soff[i] = (writer && dok[i]) ? (unsigned)(doff[i] * 2) : SOOB;
       }
       if (!dok[i]) v.raw = {0, 0, 0, 0};
       v.store(DS + (idx >> 2) * HLD + (idx & 3) * 8);
+    }
+  };
+  // draw / dz of the tile just staged go to global memory AFTER the next tile's loads have been issued: vmcnt counts in order, so
+  // stores issued before those loads would have to complete before the loads can be waited for.  Unconditional bounds-checked
+  // buffer stores (non-writer blocks, pixels outside the image and a null dres get the out-of-range offset: dropped).
+  auto flush_stores = [&]() {
+#pragma unroll
+    for (int i = 0; i < D_LOADS; ++i) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, vdk[i].raw), rdraw, soff[i], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, vzk[i].raw), rdres,
+                                             a.dres_out ? soff[i] : SOOB, 0, 0);
     }
   };
   // this lane's transpose-read base rows: dout tile row (pixel) / halo row of tap (0,0) for the 32-pixel k-step 0
@@ -514,6 +530,7 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
     store_tile();
     __syncthreads();
     if (t + 1 < t_end) load_tile(t + 1);
+    if constexpr (fuse) flush_stores();
 #pragma unroll
     for (int kk = 0; kk < HNPX / 64; ++kk) {                  // 32 pixels = image rows 2ks, 2ks+1 of the tile
       const int ks = 2 * wg + kk;
@@ -691,7 +708,10 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
       h.draw_out = (bf16_t*)bn->draw; h.dres_out = (bf16_t*)bn->dres; h.dgamma = bn->dgamma; h.dbeta = bn->dbeta;
       h.bn_n = (float)bn->n; h.bn_pscale = bn->pscale; h.bn_act = bn->act; h.bn_training = bn->training;
     }
-    conv3x3_wgrad_halo_kernel<<<(unsigned)h.xcd_per * 8, HWG_THREADS, 0, st>>>(h);
+    const dim3 hgrid((unsigned)h.xcd_per * 8);
+    if (!bn) conv3x3_wgrad_halo_kernel<false, false><<<hgrid, HWG_THREADS, 0, st>>>(h);
+    else if (bn->res) conv3x3_wgrad_halo_kernel<true, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
+    else conv3x3_wgrad_halo_kernel<true, false><<<hgrid, HWG_THREADS, 0, st>>>(h);
     if (int rc = check_launch("conv3x3_wgrad_halo")) return rc;
     return finish_reduce(a, defer_reduce, st);
   }
