@@ -172,6 +172,21 @@ int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float
 int rssf_conv_gather_bnbwd(const void* in, const void* wpk, void* out, const void* addend, const void* bn_raw, const void* bn_res_pre,
                            const float* bn_scale_shift, int bn_act, float* bn_sums, int B, int IH, int IW, int Cin, int OH, int OW,
                            int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype, void* stream);
+/* FORWARD convolution whose input is still the RAW output of the producing convolution: the operand convolved is
+ * act(bn(in_raw)) of the producer's BatchNorm, formed while the 3x3 halo tile is staged and zero outside the image like the
+ * padding of the activation - the producer's finalize+apply pass (rssf_bn_finalize_apply) never runs and its activation is
+ * never stored (conv -> bn -> relu -> conv, _hrnet_rssformer.py:216-246, when the activation has no other consumer).  The
+ * launch FINALIZES that BatchNorm too: the pre_* arguments are rssf_bn_finalize's (statistics from the producer's epilogue,
+ * all-reduced under SyncBN; running statistics updated in place; mean / invstd and scale / shift written for the backward pass
+ * and for rssf_conv_wgrad_bnapply(in_scale_shift)).  Results are those of rssf_bn_finalize_apply + rssf_conv_gather.  Only shapes
+ * for which rssf_conv_gather_preact_supported() returns 1 (bf16, 3x3 / stride 1 / "same", channels multiples of 8, Cin <= 256). */
+int rssf_conv_gather_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
+                                      const int* dy, const int* dx, int dtype);
+int rssf_conv_gather_preact(const void* in_raw, const float* pre_stats, const float* pre_gamma, const float* pre_beta,
+                            float* pre_running_mean, float* pre_running_var, float* pre_mean_invstd, float* pre_scale_shift, double pre_n,
+                            float pre_momentum, float pre_eps, int pre_training, int pre_act, const void* wpk, void* out,
+                            const float* bias, float* stats, float* stats_ws, int B, int IH, int IW, int Cin, int OH, int OW, int Cout,
+                            int mul, int div, int ntaps, const int* dy, const int* dx, int dtype, void* stream);
 /* weight gradient, accumulated (+=) into the torch-layout fp32 gradients of the source convs; dbias optional (+=).
  * workspace: fp32 scratch of rssf_conv_wgrad_workspace_elems() elements for the split-K partials (two-stage
  * reduction); NULL selects the slower atomic path. */
@@ -202,10 +217,16 @@ int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, fl
  * launch that follows (+ dz to `dres`, + dgamma / dbeta): the separate apply pass (read dy, raw; write draw) disappears.  Same
  * operation order as rssf_bn_bwd_apply: bit-identical `draw`, `dres`, parameter gradients and weight gradient.  Shapes without
  * such a kernel run rssf_bn_bwd_apply followed by rssf_conv_wgrad(draw, ...).  The BatchNorm arguments are rssf_bn_bwd_apply's,
- * the rest rssf_conv_wgrad's (its `dout` is `draw`). */
+ * the rest rssf_conv_wgrad's (its `dout` is `draw`).
+ * in_scale_shift (optional, [2][Cin]) / in_act: `in` is then the RAW output of the producing convolution and the operand
+ * contracted is act(in * scale + shift) - the layer was run forward by rssf_conv_gather_preact; only where
+ * rssf_conv_wgrad_preact_supported() says so. */
+int rssf_conv_wgrad_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, int nsrc,
+                                     const int* dy, const int* dx, int has_bias, int dtype);
 int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, const float* bn_scale_shift, const float* bn_mean_invstd,
                             const float* bn_sums, const void* bn_res_pre, void* draw, void* dres, float* dgamma, float* dbeta,
-                            int bn_act, double bn_n, int bn_training, float param_grad_scale, const void* in, float* dw0, float* dw1,
+                            int bn_act, double bn_n, int bn_training, float param_grad_scale, const void* in,
+                            const float* in_scale_shift, int in_act, float* dw0, float* dw1,
                             float* dw2, const int* ksizes, int nsrc, const int* src_of_tap, const int* kpos_of_tap,
                             const int* alias_of_tap, float* dbias, float* workspace, int B, int IH, int IW, int Cin, int OH, int OW,
                             int Cout, int stride, int ntaps, const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce,

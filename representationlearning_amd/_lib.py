@@ -68,7 +68,10 @@ SIGNATURES = {
     "rssf_conv_gather_bnbwd": (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_workspace_elems": (c_int64, [c_int] * 6),
     "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "rssf_conv_wgrad_bnapply": (c_int, [c_void_p] * 10 + [c_int, ctypes.c_double, c_int, c_float] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv_wgrad_bnapply": (c_int, [c_void_p] * 10 + [c_int, ctypes.c_double, c_int, c_float] + [c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv_wgrad_preact_supported": (c_int, [c_int] * 10 + [c_void_p, c_void_p, c_int, c_int]),
+    "rssf_conv_gather_preact_supported": (c_int, [c_int] * 10 + [c_void_p, c_void_p, c_int]),
+    "rssf_conv_gather_preact": (c_int, [c_void_p] * 8 + [ctypes.c_double, c_float, c_float, c_int, c_int] + [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_reduce_blocks": (c_int, [c_void_p]),
     "rssf_conv_wgrad_reduce_batch": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),

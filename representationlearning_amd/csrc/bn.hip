@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ raw
       float ov[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float z = v.get(e) * sc[e] + sh[e];
+        float z = fmaf(v.get(e), sc[e], sh[e]);               // explicit: conv_halo.hip's pre-activation staging rounds alike
         if (res_pre) z += rp.get(e);
         float t = act_fwd(z, act);
         if (res_post) t += rq.get(e);
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) bn_finapply_kernel(const T* __restrict__ 
       float ov[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float z = v.get(e) * sc[e] + sh[e];
+        float z = fmaf(v.get(e), sc[e], sh[e]);               // explicit: conv_halo.hip's pre-activation staging rounds alike
         if (res_pre) z += rp.get(e);
         float t = act_fwd(z, act);
         if (res_post) t += rq.get(e);

@@ -58,6 +58,19 @@ struct HaloArgs {
   const float* bn_ss;    // [2][Cout] scale, shift
   float* bn_sums;
   int bn_act;
+  // PRE-activation input (forward launches, pre_ss != null): `in` is the RAW output of the producing convolution and the
+  // operand actually convolved is act(in * scale + shift), formed while the halo tile is staged (zero outside the image, as
+  // padding of the activation would be) - the producer's BatchNorm apply pass never runs and its activation is never stored
+  // The producer's BatchNorm is FINALIZED here as well (no launch of its own): every block folds the statistics slots of the Cin
+  // channels into scale / shift (LDS), block 0 publishes mean / invstd / scale / shift and updates the running statistics -
+  // the arithmetic of bn_finalize_kernel (bn.hip).
+  const float* pre_stats;   // [RSSF_BN_SLOTS][2][Cin] (training) or null (eval: running statistics)
+  const float* pre_gamma; const float* pre_beta;
+  float* pre_rmean; float* pre_rvar;      // running statistics (updated in training mode; the source in eval mode)
+  float* pre_mi; float* pre_ss;           // OUT [2][Cin] each: mean / invstd, scale / shift; pre_ss != null selects the PRE kernel
+  float pre_n, pre_momentum, pre_eps;
+  int pre_training;
+  int pre_act;
   int B, H, W, Cin, Cout, CinP, CoutP;
   int tiles_y, tiles_x, ntiles_n, xcd_per;
   int64_t total;

@@ -636,8 +636,15 @@ namespace {
 struct BnBwdStats {            // see HaloArgs::bn_* (conv.hip.h)
   const void* raw; const void* res; const float* ss; float* sums; int act;
 };
+bool halo_path(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype) {
+  return dtype == RSSF_BF16 && (int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx);
+}
+struct PreAct {              // see HaloArgs::pre_* (conv.hip.h)
+  const float* stats; const float* gamma; const float* beta; float* rmean; float* rvar; float* mi; float* ss;
+  float n, momentum, eps; int training, act;
+};
 int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, float* stats_ws,
-                     const BnBwdStats* bn, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
+                     const BnBwdStats* bn, const PreAct* pre, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
                      const int* dy, const int* dx, int dtype, void* stream) {
   RSSF_REQUIRE(in && wpk && out && dy && dx && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 &&
                    ntaps >= 1 && ntaps <= MAX_TAPS && mul >= 1 && div >= 1,
@@ -655,8 +662,14 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
   a.CoutP = (Cout + bnt - 1) / bnt * bnt;
   a.CinP = (Cin + bk - 1) / bk * bk;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RSSF_BF16 && (int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx)) {
+  if (halo_path(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype)) {
     HaloArgs h;
+    h.pre_ss = nullptr; h.pre_act = 0;
+    if (pre) {
+      h.pre_stats = pre->stats; h.pre_gamma = pre->gamma; h.pre_beta = pre->beta; h.pre_rmean = pre->rmean; h.pre_rvar = pre->rvar;
+      h.pre_mi = pre->mi; h.pre_ss = pre->ss; h.pre_n = pre->n; h.pre_momentum = pre->momentum; h.pre_eps = pre->eps;
+      h.pre_training = pre->training; h.pre_act = pre->act;
+    }
     h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats; h.stats_ws = a.stats_ws;
     h.addend = (const bf16_t*)addend;
     const bool fused = bn && (Cout % 8) == 0;               // the 16-byte-row epilogue carries the statistics
@@ -668,6 +681,7 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
     if (rc || !bn || fused) return rc;
     return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
   }
+  if (pre) { set_error("conv_gather_preact: no kernel with a pre-activation input for this shape (ask rssf_conv_gather_preact_supported)"); return RSSF_ERR_UNSUPPORTED; }
   const bool gfused = bn && dtype == RSSF_BF16 && (Cout % 8) == 0;          // the gather kernels' 16-byte-row epilogue carries them too
   a.bn_raw = gfused ? bn->raw : nullptr; a.bn_res = gfused ? bn->res : nullptr; a.bn_ss = gfused ? bn->ss : nullptr;
   a.bn_sums = gfused ? bn->sums : nullptr; a.bn_act = gfused ? bn->act : 0;
@@ -684,7 +698,7 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
 extern "C" int rssf_conv_gather_add(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend,
                                     float* stats_ws, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
                                     const int* dy, const int* dx, int dtype, void* stream) {
-  return conv_gather_impl(in, wpk, out, bias, stats, addend, stats_ws, nullptr, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype,
+  return conv_gather_impl(in, wpk, out, bias, stats, addend, stats_ws, nullptr, nullptr, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype,
                           stream);
 }
 
@@ -694,6 +708,26 @@ extern "C" int rssf_conv_gather_bnbwd(const void* in, const void* wpk, void* out
                                       int dtype, void* stream) {
   RSSF_REQUIRE(bn_raw && bn_scale_shift && bn_sums && bn_act >= 0 && bn_act <= 2, "conv_gather_bnbwd: bad BatchNorm arguments");
   const BnBwdStats bn = {bn_raw, bn_res_pre, bn_scale_shift, bn_sums, bn_act};
-  return conv_gather_impl(in, wpk, out, nullptr, nullptr, addend, nullptr, &bn, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype,
+  return conv_gather_impl(in, wpk, out, nullptr, nullptr, addend, nullptr, &bn, nullptr, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype,
                           stream);
+}
+
+extern "C" int rssf_conv_gather_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
+                                                 const int* dy, const int* dx, int dtype) {
+  return dy && dx && Cin <= 256 && halo_path(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype) ? 1 : 0;
+}
+
+extern "C" int rssf_conv_gather_preact(const void* in_raw, const float* pre_stats, const float* pre_gamma, const float* pre_beta,
+                                       float* pre_running_mean, float* pre_running_var, float* pre_mean_invstd, float* pre_scale_shift,
+                                       double pre_n, float pre_momentum, float pre_eps, int pre_training, int pre_act, const void* wpk,
+                                       void* out, const float* bias, float* stats, float* stats_ws, int B, int IH, int IW, int Cin, int OH,
+                                       int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype, void* stream) {
+  RSSF_REQUIRE(pre_gamma && pre_beta && pre_mean_invstd && pre_scale_shift && pre_act >= 0 && pre_act <= 2,
+               "conv_gather_preact: bad pre-activation arguments");
+  RSSF_REQUIRE(pre_training ? (pre_stats != nullptr && pre_n >= 1) : (pre_running_mean && pre_running_var),
+               "conv_gather_preact: missing statistics of the producer's BatchNorm");
+  const PreAct pre = {pre_stats, pre_gamma, pre_beta, pre_running_mean, pre_running_var, pre_mean_invstd, pre_scale_shift, (float)pre_n,
+                      pre_momentum, pre_eps, pre_training, pre_act};
+  return conv_gather_impl(in_raw, wpk, out, bias, stats, nullptr, stats_ws, nullptr, &pre, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx,
+                          dtype, stream);
 }

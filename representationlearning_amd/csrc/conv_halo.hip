@@ -25,7 +25,7 @@ constexpr int TW = 16, KC = 32, LDK = KC + 8;             // 80-byte LDS rows: c
 // MIRROR: the nine taps in data-gradient order (offset of tap t = -(t/3 - 1, t%3 - 1)) instead of forward order; the offsets
 // are compile-time, so a tap only changes the IMMEDIATE offset of the A-operand LDS reads (with run-time dy/dx every tap cost
 // two scalar loads and ~6 VALU of address arithmetic per fragment in an issue-bound kernel).
-template <int TH, int BN, bool MIRROR>
+template <int TH, int BN, bool MIRROR, bool PRE = false>
 __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   constexpr int MI = TH / 4, NI = BN / 16, HP = (TH + 2) * (TW + 2), BMP = TH * TW;
   constexpr int A_ELEMS = HP * LDK, B_ELEMS = 9 * BN * LDK, LDC = BN + 8;
@@ -79,6 +79,37 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
     for (int i = 0; i < B_LOADS; ++i) boff[i] = ((9 * BN * 4) % 256 == 0 || tid + i * 256 < 9 * BN * 4) ? b0 + i * bstep : OOB;
   }
   Vec<bf16_t> ra[A_LOADS], rb[B_LOADS];
+  // PRE: finalize the producer's BatchNorm (see HaloArgs::pre_*): scale / shift of all Cin channels into LDS, under the first
+  // chunk's loads below; the constants of a thread's 8 channels of a chunk (its channel group inside a chunk is fixed: tid & 3)
+  // are read back when the chunk is staged
+  constexpr int PRE_MAXC = 256;
+  __shared__ float spre[PRE ? 2 * PRE_MAXC : 1];
+  auto finalize_producer = [&]() {
+    for (int c = tid; c < a.Cin; c += 256) {
+      float mean, var;
+      if (a.pre_training) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RSSF_BN_SLOTS; ++k) { s1 += a.pre_stats[(size_t)k * 2 * a.Cin + c]; s2 += a.pre_stats[(size_t)k * 2 * a.Cin + a.Cin + c]; }
+        mean = s1 / a.pre_n;
+        var = fmaxf(s2 / a.pre_n - mean * mean, 0.f);
+      } else {
+        mean = a.pre_rmean[c];
+        var = a.pre_rvar[c];
+      }
+      const float invstd = rsqrtf(var + a.pre_eps);
+      const float sc = a.pre_gamma[c] * invstd, sh = a.pre_beta[c] - mean * sc;
+      spre[c] = sc; spre[PRE_MAXC + c] = sh;
+      if (q == 0) {                                                          // one block publishes for the backward pass
+        a.pre_mi[c] = mean; a.pre_mi[a.Cin + c] = invstd;
+        a.pre_ss[c] = sc; a.pre_ss[a.Cin + c] = sh;
+        if (a.pre_training && a.pre_rmean) {
+          a.pre_rmean[c] = (1.f - a.pre_momentum) * a.pre_rmean[c] + a.pre_momentum * mean;
+          a.pre_rvar[c] = (1.f - a.pre_momentum) * a.pre_rvar[c] + a.pre_momentum * var * (a.pre_n > 1.f ? a.pre_n / (a.pre_n - 1.f) : 1.f);
+        }
+      }
+    }
+  };
   auto load_chunk = [&](int kc) {
     const int crem = a.Cin - kc * KC;                                        // channels left in this chunk (scalar)
     const int soff = kc * KC * 2, swoff = (n0 * a.CinP + kc * KC) * 2;
@@ -89,10 +120,31 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
     for (int i = 0; i < B_LOADS; ++i)
       rb[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, boff[i], swoff, 0));
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int idx = tid + i * 256;
+      if constexpr (PRE) {
+        // act(raw * scale + shift) of the producer, zero for halo pixels outside the image / channels past Cin (the padding of the
+        // ACTIVATION is zero, not act(shift)); block-uniform activation: one specialised loop runs
+        const bool valid = aoff[i] != OOB && asub[i] < a.Cin - kc * KC;
+        const int c0 = valid ? kc * KC + asub[i] : 0;
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(spre + c0), sc1 = *reinterpret_cast<const f32x4*>(spre + c0 + 4);
+        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(spre + PRE_MAXC + c0), sh1 = *reinterpret_cast<const f32x4*>(spre + PRE_MAXC + c0 + 4);
+        auto apply = [&](auto ACT) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float z = fmaf(ra[i].get(e), e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+            o[e] = decltype(ACT)::value == 1 ? fmaxf(z, 0.f) : decltype(ACT)::value == 2 ? gelu_erf(z) : z;
+          }
+          ra[i].set_all(o);
+        };
+        if (a.pre_act == 1) apply(std::integral_constant<int, 1>{});
+        else if (a.pre_act == 2) apply(std::integral_constant<int, 2>{});
+        else apply(std::integral_constant<int, 0>{});
+        if (!valid) ra[i].clear();
+      }
       if ((HP * 4) % 256 == 0 || idx < HP * 4) ra[i].store(As + (idx >> 2) * LDK + (idx & 3) * 8);
     }
 #pragma unroll
@@ -110,8 +162,9 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
 
   const int nchunks = a.CinP / KC;
   load_chunk(0);
+  if constexpr (PRE) { finalize_producer(); __syncthreads(); }
   for (int kc = 0; kc < nchunks; ++kc) {
-    store_chunk();
+    store_chunk(kc);
     __syncthreads();
     if (kc + 1 < nchunks) load_chunk(kc + 1);
 #pragma unroll
@@ -317,9 +370,11 @@ int launch_halo(HaloArgs a, hipStream_t st) {
   a.xcd_per = xcd_per(a.total);
   dim3 grid((unsigned)a.xcd_per * 8);
   const bool mirror = tap_order(a.dy, a.dx) < 0;
+  if (a.pre_ss && (mirror || a.Cin > 256)) { set_error("conv3x3_halo: a pre-activation input is a forward-launch feature (<= 256 channels)"); return RSSF_ERR_UNSUPPORTED; }
 #define RSSF_HALO(THv, BNv)                                                      \
   do {                                                                           \
     if (mirror) conv3x3_halo_kernel<THv, BNv, true><<<grid, 256, 0, st>>>(a);    \
+    else if (a.pre_ss) conv3x3_halo_kernel<THv, BNv, false, true><<<grid, 256, 0, st>>>(a);  \
     else conv3x3_halo_kernel<THv, BNv, false><<<grid, 256, 0, st>>>(a);          \
   } while (0)
   if (th == 8 && bn == 64) RSSF_HALO(8, 64);

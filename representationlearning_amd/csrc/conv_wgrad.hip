@@ -367,6 +367,10 @@ struct WgradHaloArgs {
   float* dgamma; float* dbeta;
   float bn_n, bn_pscale;
   int bn_act, bn_training;
+  // PRE-activation input operand (x_ss != null): `in` is the RAW output of the producing convolution, the operand contracted is
+  // act(in * scale + shift) formed while the halo tile is staged (see HaloArgs::pre_ss, conv.hip.h)
+  const float* x_ss;     // [2][Cin]
+  int x_act;
 };
 constexpr int HTH = 8, HTW = 16, HHP = (HTH + 2) * (HTW + 2), HNPX = HTH * HTW, HCT = 32, HLD = HCT + 16;
 
@@ -376,7 +380,7 @@ constexpr int HTH = 8, HTW = 16, HHP = (HTH + 2) * (HTW + 2), HNPX = HTH * HTW, 
 constexpr int HWG_THREADS = 512;
 // FUSE / RES are template parameters: a run-time branch around the staging loads would make the compiler drain vmcnt at the join,
 // i.e. wait for a tile's loads where they are issued instead of one tile later (measured: 16 -> 27 us per launch)
-template <bool FUSE, bool RES>
+template <bool FUSE, bool RES, bool XPRE = false>
 __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
   constexpr int NT_ = HWG_THREADS;
   constexpr int X_LOADS = (HHP * 4 + NT_ - 1) / NT_, D_LOADS = HNPX * 4 / NT_;
@@ -429,6 +433,17 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
     }
   }
   const bool writer = fuse && ci0 == 0;                       // the (co, ci = 0) blocks own the global copy of draw / dres
+  // XPRE: scale / shift of this thread's 8 input channels (its channel group inside the 32-channel tile is fixed: tid & 3)
+  float xsc[8], xsh[8];
+  if constexpr (XPRE) {
+    const int c0 = ci0 + (tid & 3) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool cok = c0 + e < a.Cin;
+      xsc[e] = cok ? a.x_ss[c0 + e] : 0.f;
+      xsh[e] = cok ? a.x_ss[a.Cin + c0 + e] : 0.f;
+    }
+  }
 
   Vec<bf16_t> rx[X_LOADS], rd[D_LOADS], rr[D_LOADS], rq[D_LOADS], vdk[D_LOADS], vzk[D_LOADS];
   bool xok[X_LOADS], dok[D_LOADS];
@@ -483,6 +498,20 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
     for (int i = 0; i < X_LOADS; ++i) {
       const int idx = tid + i * NT_;
       Vec<bf16_t> v = rx[i];
+      if constexpr (XPRE) {
+        auto apply = [&](auto ACT) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float z = fmaf(v.get(e), xsc[e], xsh[e]);
+            o[e] = decltype(ACT)::value == 1 ? fmaxf(z, 0.f) : decltype(ACT)::value == 2 ? gelu_erf(z) : z;
+          }
+          v.set_all(o);
+        };
+        if (a.x_act == 1) apply(std::integral_constant<int, 1>{});
+        else if (a.x_act == 2) apply(std::integral_constant<int, 2>{});
+        else apply(std::integral_constant<int, 0>{});
+      }
       if (!xok[i]) v.raw = {0, 0, 0, 0};
       if (idx < HHP * 4) v.store(XH + (idx >> 2) * HLD + (idx & 3) * 8);
     }
@@ -665,10 +694,12 @@ struct BnApply {               // arguments of rssf_bn_bwd_apply (see WgradHaloA
   const void* dy; const void* raw; const float* ss; const float* mi; const float* sums; const void* res; void* draw; void* dres;
   float* dgamma; float* dbeta; double n; int act, training; float pscale;
 };
+struct XPreAct { const float* ss; int act; };
 int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
                     int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
                     float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
-                    const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, const BnApply* bn, int dtype, void* stream) {
+                    const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, const BnApply* bn, const XPreAct* xpre, int dtype,
+                    void* stream) {
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
@@ -709,12 +740,20 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
       h.bn_n = (float)bn->n; h.bn_pscale = bn->pscale; h.bn_act = bn->act; h.bn_training = bn->training;
     }
     const dim3 hgrid((unsigned)h.xcd_per * 8);
-    if (!bn) conv3x3_wgrad_halo_kernel<false, false><<<hgrid, HWG_THREADS, 0, st>>>(h);
-    else if (bn->res) conv3x3_wgrad_halo_kernel<true, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
-    else conv3x3_wgrad_halo_kernel<true, false><<<hgrid, HWG_THREADS, 0, st>>>(h);
+    h.x_ss = xpre ? xpre->ss : nullptr; h.x_act = xpre ? xpre->act : 0;
+    if (xpre) {
+      if (!bn) conv3x3_wgrad_halo_kernel<false, false, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
+      else if (bn->res) conv3x3_wgrad_halo_kernel<true, true, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
+      else conv3x3_wgrad_halo_kernel<true, false, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
+    } else {
+      if (!bn) conv3x3_wgrad_halo_kernel<false, false><<<hgrid, HWG_THREADS, 0, st>>>(h);
+      else if (bn->res) conv3x3_wgrad_halo_kernel<true, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
+      else conv3x3_wgrad_halo_kernel<true, false><<<hgrid, HWG_THREADS, 0, st>>>(h);
+    }
     if (int rc = check_launch("conv3x3_wgrad_halo")) return rc;
     return finish_reduce(a, defer_reduce, st);
   }
+  if (xpre) { set_error("conv_wgrad: no kernel with a pre-activation input operand for this shape (ask rssf_conv_wgrad_preact_supported)"); return RSSF_ERR_UNSUPPORTED; }
   if (bn) {                    // no kernel with a fused apply for this shape: the separate pass, then the plain weight gradient
     const int rc = rssf_bn_bwd_apply(bn->dy, bn->raw, bn->ss, bn->mi, bn->sums, bn->res, bn->draw, bn->dres, bn->dgamma, bn->dbeta,
                                      (int64_t)B * OH * OW, Cout, bn->act, bn->n, bn->training, bn->pscale, dtype, stream);
@@ -732,12 +771,13 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
                                float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
                                const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream) {
   return conv_wgrad_impl(dout, in, dw0, dw1, dw2, ksizes, nsrc, src_of_tap, kpos_of_tap, alias_of_tap, dbias, workspace, B, IH, IW, Cin, OH,
-                         OW, Cout, stride, ntaps, dy, dx, defer_reduce, nullptr, dtype, stream);
+                         OW, Cout, stride, ntaps, dy, dx, defer_reduce, nullptr, nullptr, dtype, stream);
 }
 
 extern "C" int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, const float* bn_scale_shift, const float* bn_mean_invstd,
                                        const float* bn_sums, const void* bn_res_pre, void* draw, void* dres, float* dgamma, float* dbeta,
-                                       int bn_act, double bn_n, int bn_training, float param_grad_scale, const void* in, float* dw0,
+                                       int bn_act, double bn_n, int bn_training, float param_grad_scale, const void* in,
+                                       const float* in_scale_shift, int in_act, float* dw0,
                                        float* dw1, float* dw2, const int* ksizes, int nsrc, const int* src_of_tap, const int* kpos_of_tap,
                                        const int* alias_of_tap, float* dbias, float* workspace, int B, int IH, int IW, int Cin, int OH,
                                        int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx,
@@ -748,8 +788,9 @@ extern "C" int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, co
   const BnApply bn = {bn_dy, bn_raw, bn_scale_shift, bn_mean_invstd, bn_sums, bn_res_pre, draw, dres, dgamma, dbeta, bn_n, bn_act,
                       bn_training, param_grad_scale};
   // `draw` doubles as the weight gradient's output-gradient operand: it is complete when this call returns to the stream
+  const XPreAct xp = {in_scale_shift, in_act};
   return conv_wgrad_impl(draw, in, dw0, dw1, dw2, ksizes, nsrc, src_of_tap, kpos_of_tap, alias_of_tap, dbias, workspace, B, IH, IW, Cin, OH,
-                         OW, Cout, stride, ntaps, dy, dx, defer_reduce, &bn, dtype, stream);
+                         OW, Cout, stride, ntaps, dy, dx, defer_reduce, &bn, in_scale_shift ? &xp : nullptr, dtype, stream);
 }
 
 extern "C" int rssf_conv_wgrad_reduce_blocks(const rssf_wgrad_reduce_job* job) {
@@ -761,4 +802,9 @@ extern "C" int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, c
   RSSF_REQUIRE(jobs && block_map && nblocks > 0, "conv_wgrad_reduce_batch: bad arguments");
   wgrad_reduce_batch_kernel<<<(unsigned)nblocks, 256, 0, (hipStream_t)stream>>>(jobs, block_map);
   return check_launch("conv_wgrad_reduce_batch");
+}
+
+extern "C" int rssf_conv_wgrad_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, int nsrc,
+                                                const int* dy, const int* dx, int has_bias, int dtype) {
+  return dtype == RSSF_BF16 && !has_bias && dy && dx && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx) ? 1 : 0;
 }

@@ -65,8 +65,11 @@ class BasicBlock(nn.Module):
         # BatchNorm-backward statistics come out of the consumer's data-gradient launch: bn1's out of conv2's; the producer's out
         # of conv1's, whose launch (with the skip gradient as addend) forms the COMPLETE gradient of x when `link` is active
         l1 = nnf.bwd_stats_link()
+        # relu(bn1(conv1(x))) is consumed by conv2 alone: where conv2's kernels can apply bn1 + ReLU while they stage conv1's raw
+        # output, that activation is never written (nnf.can_defer_apply)
+        defer = l1 is not None and nnf.can_defer_apply(x, self.conv1, self.conv2)
         out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, grad_sink=link, stats_out=l1,
-                              stats_in=producer if link is not None else None)
+                              stats_in=producer if link is not None else None, defer_apply=defer)
         l2 = nnf.bwd_stats_link() if want_link else None
         y = nnf.conv_bn_act(out, self.conv2, self.bn2, nnf.ACT_RELU, res_pre=res, grad_deposit=link, stats_out=l2, stats_in=l1)
         return (y, l2) if want_link else y

@@ -462,7 +462,7 @@ def _pad_channels(t):
     return t if c % v == 0 else torch.nn.functional.pad(t, (0, v - c % v))
 
 
-def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None):
+def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None, preact=None):
     if spec.parts is not None:                      # > 19 taps: partial sums chained through the epilogue's addend (inference)
         if stats is not None:
             raise NotImplementedError("librssf conv: fused statistics are not available for tap-split convolutions")
@@ -479,10 +479,45 @@ def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None):
     ws = None
     if stats is not None and (rt or current()).deterministic:       # fixed-order statistics: per-tile partials + ordered fold
         ws = torch.empty(lib.rssf_conv_stats_workspace_elems(B, OH, OW, spec.cout), device=xh.device, dtype=torch.float32)
+    if preact is not None:          # xh is the RAW output of the producing convolution: its BatchNorm + activation are applied on load
+        if addend is not None:
+            raise RuntimeError("conv forward: a pre-activation input cannot be combined with an addend")
+        (pst, pga, pbe, prm, prv, pmi, pss, pn, pmom, peps, ptr), pact = preact
+        L.check(lib.rssf_conv_gather_preact(L.ptr(xh), L.ptr(pst), L.ptr(pga), L.ptr(pbe), L.ptr(prm), L.ptr(prv), L.ptr(pmi), L.ptr(pss), pn, pmom,
+                                            peps, int(ptr), pact, L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), L.ptr(ws), B, H, W, C, OH, OW,
+                                            spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
+                "rssf_conv_gather_preact")
+        return out
     L.check(lib.rssf_conv_gather_add(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), L.ptr(addend), L.ptr(ws), B, H, W, C, OH, OW,
                                      spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
             "rssf_conv_gather")
     return out
+
+
+_DEFER_CACHE = {}
+
+
+def can_defer_apply(x, conv_a, conv_b):
+    """True when `act(bn(conv_a(x)))` - consumed by conv_b and nothing else - need not be materialised: conv_b's forward and
+    weight-gradient kernels can apply the producer's BatchNorm + activation to the raw convolution output while they stage it
+    (rssf_conv_gather_preact / rssf_conv_wgrad_bnapply(in_scale_shift); bf16, 3x3 / stride 1, channels multiples of 8)."""
+    if not (_DEFER_BN_APPLY and _FUSED_BN_APPLY and _FUSED_BN_STATS and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16):
+        return False
+    if current().deterministic or conv_b.bias is not None:
+        return False
+    sa, sb = spec_of([conv_a]), spec_of([conv_b])
+    B, _, H, W = x.shape
+    OH, OW = sa.out_hw(H, W)
+    key = (id(sb), B, OH, OW)
+    if key not in _DEFER_CACHE:
+        lib = L.load()
+        OH2, OW2 = sb.out_hw(OH, OW)
+        code = L.RSSF_BF16
+        ok = sb.parts is None and sb.cin % 8 == 0 and sb.cout % 8 == 0
+        ok = ok and lib.rssf_conv_gather_preact_supported(B, OH, OW, sb.cin, OH2, OW2, sb.cout, sb.stride, 1, sb.ntaps, sb.c_dy, sb.c_dx, code) == 1
+        ok = ok and lib.rssf_conv_wgrad_preact_supported(B, OH, OW, sb.cin, OH2, OW2, sb.cout, sb.stride, sb.ntaps, 1, sb.c_dy, sb.c_dx, 0, code) == 1
+        _DEFER_CACHE[key] = bool(ok)
+    return _DEFER_CACHE[key]
 
 
 class GradLink:
@@ -504,11 +539,13 @@ class BnBwdLink:
     conv_bn_act(y, .., stats_in=link) - y being that layer's output, consumed by nothing else but a residual skip whose gradient
     rides on the same launch (GradLink) - produces them.  The caller vouches for the single consumer."""
 
-    __slots__ = ("raw", "ss", "rp", "act", "C", "sums")
+    __slots__ = ("raw", "ss", "rp", "act", "C", "sums", "deferred", "pre")
 
     def __init__(self):
         self.raw = self.ss = self.rp = self.sums = None
         self.act, self.C = ACT_NONE, 0
+        self.deferred = False      # the producer returned its RAW convolution output: the consumer applies BatchNorm + activation on load
+        self.pre = None            # (stats, gamma, beta, running mean / var, mi, ss, n, momentum, eps, training) of a deferred producer
 
 
 class GroupBwdLink:
@@ -534,6 +571,7 @@ def group_stats_link(n):
     return GroupBwdLink(n) if (_FUSED_BN_STATS and torch.is_grad_enabled() and not current().deterministic) else None
 
 
+_DEFER_BN_APPLY = os.environ.get("RSSF_DEFER_BN_APPLY", "1") != "0"      # A/B switch: forward BatchNorm apply inside the consumer's staging
 _FUSED_BN_APPLY = os.environ.get("RSSF_FUSED_BN_APPLY", "1") != "0"      # A/B switch: BatchNorm-backward apply inside the weight-gradient launch
 _FUSED_BN_STATS = os.environ.get("RSSF_FUSED_BN_STATS", "1") != "0"      # A/B switch (tools)
 
@@ -616,7 +654,7 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, b
     return dx
 
 
-def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None):
+def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None):
     """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional).  Under a WgradPlan the split-K
     reduction is deferred to the plan's one batched launch (the gradients are complete after WgradPlan.flush()).
     bn: (dy, raw, ss, mi, sums, res_pre, dres, dgamma, dbeta, act, n, training, pscale) - `dout` is then an OUTPUT: the launch
@@ -644,17 +682,21 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None):
                 ws, job, ref = got
     if ws is None:
         ws = torch.empty(nws, device=xh.device, dtype=torch.float32)
-    tail = (L.ptr(xh), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws), spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb),
+    tail = (L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws), spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb),
             L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps, spec.c_dy, spec.c_dx, None if job is None else ctypes.byref(job),
             L.dtype_code(xh), L.stream())
     if bn is not None:
         if padded:
             raise RuntimeError("conv_wgrad: the fused BatchNorm-backward apply needs channel counts the kernels take unpadded")
         bdy, braw, bss, bmi, bsums, brp, bdres, bdg, bdb, bact, bn_n, btr, bps = bn
+        xss, xact = xpre if xpre is not None else (None, 0)
         L.check(lib.rssf_conv_wgrad_bnapply(L.ptr(bdy), L.ptr(braw), L.ptr(bss), L.ptr(bmi), L.ptr(bsums), L.ptr(brp), L.ptr(dout), L.ptr(bdres),
-                                            L.ptr(bdg), L.ptr(bdb), bact, bn_n, int(btr), bps, *tail), "rssf_conv_wgrad_bnapply")
+                                            L.ptr(bdg), L.ptr(bdb), bact, bn_n, int(btr), bps, L.ptr(xh), L.ptr(xss), xact, *tail),
+                "rssf_conv_wgrad_bnapply")
     else:
-        L.check(lib.rssf_conv_wgrad(L.ptr(dout), *tail), "rssf_conv_wgrad")
+        if xpre is not None:
+            raise RuntimeError("conv_wgrad: a pre-activation input operand needs the fused apply path")
+        L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), *tail), "rssf_conv_wgrad")
     if job is not None:
         if ref is not None and bytes(job) != bytes(ref):
             raise RuntimeError("WgradPlan: a deferred weight-gradient reduction changed between steps")
@@ -680,7 +722,9 @@ class _ConvBNAct(torch.autograd.Function):
         C = spec.cout
         rt = current()
         stats = _zeros(BN_SLOTS * 2 * C, dev, rt) if training else None
-        raw = _conv_forward(spec, xh, weights, bias, stats, rt)
+        si_ = links[4] if len(links) > 4 else None
+        preact = (si_.pre, si_.act) if (si_ is not None and si_.deferred) else None     # x is the producer's RAW output (BnBwdLink)
+        raw = _conv_forward(spec, xh, weights, bias, stats, rt, preact=preact)
         rows = raw.numel() // C
         n = float(rows)
         exchanged = training and sync and rt.exchanging()
@@ -695,10 +739,16 @@ class _ConvBNAct(torch.autograd.Function):
         for r in (rp, rq):
             if r is not None and (r.dtype != raw.dtype or r.shape != raw.shape):
                 raise RuntimeError("conv_bn_act: residual dtype/shape mismatch %s%s vs %s%s" % (r.dtype, tuple(r.shape), raw.dtype, tuple(raw.shape)))
-        y = torch.empty_like(raw)
-        L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi), L.ptr(ss),
-                                           L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, n, momentum, eps, int(training), L.dtype_code(raw),
-                                           L.stream()), "rssf_bn_finalize_apply")
+        defer = len(links) > 5 and links[5] and links[3] is not None and rp is None and rq is None
+        if defer:
+            # the ONLY consumer finalizes and applies this BatchNorm + activation while it stages `raw` (can_defer_apply): its launch
+            # fills mi / ss (saved below for the backward pass) and updates the running statistics
+            y = raw
+        else:
+            y = torch.empty_like(raw)
+            L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi), L.ptr(ss),
+                                               L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, n, momentum, eps, int(training), L.dtype_code(raw),
+                                               L.stream()), "rssf_bn_finalize_apply")
         ctx.save_for_backward(xh, raw, ss, mi, rp, *weights)
         ctx.meta = (spec, act, training, n, exchanged, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
         ctx.rt = rt
@@ -709,6 +759,9 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.stats_out is not None:
             so = ctx.stats_out
             so.raw, so.ss, so.rp, so.act, so.C, so.sums = raw, ss, rp, act, C, None
+            so.deferred = bool(defer)
+            so.pre = (stats, gamma, beta, rmean, rvar, mi, ss, n, momentum, eps, training) if defer else None
+        ctx.xpre = (si_.ss, si_.act) if preact is not None else None
         return _nchw(y)
 
     @staticmethod
@@ -749,15 +802,17 @@ class _ConvBNAct(torch.autograd.Function):
         dbeta, db_direct = grad_target(p_beta, rt)
         wt = [grad_target(w, rt) for w in p_weights]
 
+        xpre = ctx.xpre             # xh is the producer's RAW output: the weight gradient applies its BatchNorm + activation on load
+
         def weight_grads(bn):
             gbs = []
             if nbias == 1:          # the weight-gradient kernel accumulates straight into the bias gradient: no staging buffer, no add
                 tb, direct = grad_target(p_biases[0], rt)
-                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn)
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn, xpre=xpre)
                 gbs.append(grad_result(p_biases[0], tb, direct, rt))
             else:
                 db = _zeros(C, raw.device, rt) if nbias else None
-                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt, bn=bn)
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt, bn=bn, xpre=xpre)
                 for b in p_biases:      # every summed conv's bias sees the same gradient
                     tb, direct = grad_target(b, rt)
                     tb += db
@@ -768,6 +823,8 @@ class _ConvBNAct(torch.autograd.Function):
         # the entry point falls back to the two launches itself); channel counts the kernels would see padded keep the two calls
         vch = 8 if raw.dtype == torch.bfloat16 else 4
         fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0
+        if xpre is not None and not fuse_apply:
+            raise RuntimeError("conv_bn_act: a pre-activation input needs the fused weight-gradient path (can_defer_apply)")
         if fuse_apply:
             gbs = weight_grads((dyh, raw, ss, mi, sums, rp, dres, dgamma, dbeta, act, n, training, pscale))
         else:
@@ -1189,10 +1246,12 @@ def cgfl_loss(logits, labels, aux, ignore_index=-1):
 
 
 def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_sink=None, grad_deposit=None, grad_accum=None,
-                stats_out=None, stats_in=None):
+                stats_out=None, stats_in=None, defer_apply=False):
     """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm.
     grad_sink / grad_deposit: GradLink of a residual block (see GradLink); grad_accum: GradAccum of a multi-consumer input;
-    stats_out / stats_in: BnBwdLink of this layer / of the layer that produced x (see BnBwdLink)."""
+    stats_out / stats_in: BnBwdLink of this layer / of the layer that produced x (see BnBwdLink); defer_apply (needs stats_out): return
+    the RAW convolution output - the single consumer, given the link as stats_in, applies BatchNorm + activation on load
+    (see can_defer_apply)."""
     convs = convs if isinstance(convs, (list, tuple)) else [convs]
     spec = spec_of(convs)
     training = bn.training or not bn.track_running_stats
@@ -1205,7 +1264,7 @@ def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_si
         raise NotImplementedError("conv_bn_act: either all or none of the summed convs carry a bias")
     mom = 0.1 if bn.momentum is None else bn.momentum
     return _ConvBNAct.apply(x, res_pre, res_post, bn.weight, bn.bias, bn.running_mean, bn.running_var, spec, act, training, mom, bn.eps,
-                            sync, len(biases), (grad_sink, grad_deposit, grad_accum, stats_out, stats_in), *weights, *biases)
+                            sync, len(biases), (grad_sink, grad_deposit, grad_accum, stats_out, stats_in, bool(defer_apply)), *weights, *biases)
 
 
 def residual_link(x, res):

@@ -272,19 +272,82 @@ def test_conv_wgrad_bnapply_equals_apply_then_wgrad(k, cin, cout, H, W, act, res
         dg, db = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
         dw = torch.zeros_like(conv.weight, dtype=torch.float32)
         ws = torch.empty(nws, device=DEV)
-        tail = (L.ptr(x), L.ptr(dw), None, None, spec.c_ksizes, 1, spec.c_src, spec.c_kpos, spec.c_alias, None, L.ptr(ws), B, H, W, cin, H, W, cout, 1,
+        tail = (L.ptr(dw), None, None, spec.c_ksizes, 1, spec.c_src, spec.c_kpos, spec.c_alias, None, L.ptr(ws), B, H, W, cin, H, W, cout, 1,
                 spec.ntaps, spec.c_dy, spec.c_dx, None, L.dtype_code(x), L.stream())
         if fused:
             L.check(lib.rssf_conv_wgrad_bnapply(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres), L.ptr(dg),
-                                                L.ptr(db), act, n, training, 0.5, *tail), "fused")
+                                                L.ptr(db), act, n, training, 0.5, L.ptr(x), None, 0, *tail), "fused")
         else:
             L.check(lib.rssf_bn_bwd_apply(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres), L.ptr(dg),
                                           L.ptr(db), B * H * W, cout, act, n, training, 0.5, L.dtype_code(raw), L.stream()), "apply")
-            L.check(lib.rssf_conv_wgrad(L.ptr(draw), *tail), "wgrad")
+            L.check(lib.rssf_conv_wgrad(L.ptr(draw), L.ptr(x), *tail), "wgrad")
         out[fused] = (draw, dres, dg, db, dw)
     for a_, b_, name in zip(out[True], out[False], ("draw", "dres", "dgamma", "dbeta", "dw")):
         if a_ is not None:
             assert torch.equal(a_, b_), name
+
+
+@pytest.mark.parametrize("cin,cout,H,W,act", [(32, 32, 24, 20, 1), (64, 64, 17, 33, 1), (32, 64, 16, 16, 2), (128, 128, 9, 16, 0)])
+def test_conv_preact_input_equals_apply_then_conv(cin, cout, H, W, act):
+    """rssf_conv_gather_preact / rssf_conv_wgrad_bnapply(in_scale_shift): the producer's BatchNorm + activation applied while the
+    consumer stages the RAW tensor, against rssf_bn_apply followed by the plain launches - bit-identical output, fused forward
+    statistics equal up to atomics order, bit-identical weight gradient; the zero padding is that of the ACTIVATION."""
+    from representationlearning_amd import _lib as L, nnf
+    lib = L.load()
+    torch.manual_seed(11)
+    B = 3
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    code = L.RSSF_BF16
+    assert lib.rssf_conv_gather_preact_supported(B, H, W, cin, H, W, cout, 1, 1, spec.ntaps, spec.c_dy, spec.c_dx, code) == 1
+    assert lib.rssf_conv_wgrad_preact_supported(B, H, W, cin, H, W, cout, 1, spec.ntaps, 1, spec.c_dy, spec.c_dx, 0, code) == 1
+    assert lib.rssf_conv_gather_preact_supported(B, H, W, cin, H, W, cout, 1, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.RSSF_F32) == 0
+    raw_in = torch.randn(B, H, W, cin, device=DEV).bfloat16()
+    # the producer's BatchNorm: statistics slots as its convolution epilogue leaves them, beta != 0 so that act(shift) != 0
+    n = float(B * H * W)
+    x32 = raw_in.float().reshape(-1, cin)
+    stats_in = torch.zeros(nnf.BN_SLOTS, 2, cin, device=DEV)
+    stats_in[3, 0], stats_in[3, 1] = x32.sum(0), (x32 * x32).sum(0)
+    gamma, beta = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.5 + 0.3
+    y = torch.empty_like(raw_in)
+    rm1, rv1, mi1, ss1 = torch.zeros(cin, device=DEV), torch.ones(cin, device=DEV), torch.empty(2 * cin, device=DEV), torch.empty(2 * cin, device=DEV)
+    L.check(lib.rssf_bn_finalize_apply(L.ptr(raw_in), L.ptr(stats_in), L.ptr(gamma), L.ptr(beta), L.ptr(rm1), L.ptr(rv1), L.ptr(mi1), L.ptr(ss1), None, None,
+                                       L.ptr(y), B * H * W, cin, act, n, 0.1, 1e-5, 1, code, L.stream()), "finalize+apply")
+    rm2, rv2, mi2, ss_in = torch.zeros(cin, device=DEV), torch.ones(cin, device=DEV), torch.empty(2 * cin, device=DEV), torch.empty(2 * cin, device=DEV)
+    wpk = nnf._pack(spec, [conv.weight], False, y.dtype, y.device)
+    o1, o2 = torch.empty(B, H, W, cout, device=DEV, dtype=y.dtype), torch.empty(B, H, W, cout, device=DEV, dtype=y.dtype)
+    st1 = torch.zeros(nnf.BN_SLOTS * 2 * cout, device=DEV)
+    st2 = torch.zeros_like(st1)
+    dims = (B, H, W, cin, H, W, cout, 1, 1, spec.ntaps, spec.c_dy, spec.c_dx, code, L.stream())
+    L.check(lib.rssf_conv_gather_add(L.ptr(y), L.ptr(wpk), L.ptr(o1), None, L.ptr(st1), None, None, *dims), "conv")
+    L.check(lib.rssf_conv_gather_preact(L.ptr(raw_in), L.ptr(stats_in), L.ptr(gamma), L.ptr(beta), L.ptr(rm2), L.ptr(rv2), L.ptr(mi2), L.ptr(ss_in), n, 0.1,
+                                        1e-5, 1, act, L.ptr(wpk), L.ptr(o2), None, L.ptr(st2), None, *dims), "preact conv")
+    assert torch.equal(o1, o2)
+    for a_, b_ in ((rm1, rm2), (rv1, rv2), (mi1, mi2), (ss1, ss_in)):            # the producer's BatchNorm was finalized by the launch
+        assert torch.equal(a_, b_)
+    assert rel_err(st2.view(-1, 2, cout).sum(0).cpu(), st1.view(-1, 2, cout).sum(0).cpu()) < 2e-6
+    # weight gradient with the same raw operand (and the fused backward apply of THIS layer)
+    dy = torch.randn(B, H, W, cout, device=DEV).bfloat16()
+    raw = torch.randn(B, H, W, cout, device=DEV).bfloat16()
+    ss = torch.cat([torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.3]).contiguous()
+    mi = torch.cat([torch.randn(cout, device=DEV) * 0.2, torch.rand(cout, device=DEV) + 0.5]).contiguous()
+    sums = torch.randn(nnf.BN_BWD_SLOTS * 2 * cout, device=DEV)
+    nws = lib.rssf_conv_wgrad_workspace_elems(B, H, W, cin, cout, spec.ntaps)
+    res = {}
+    for fused in (False, True):
+        draw = torch.empty_like(raw)
+        dg, db = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+        dw = torch.zeros_like(conv.weight, dtype=torch.float32)
+        ws = torch.empty(nws, device=DEV)
+        tail = (L.ptr(dw), None, None, spec.c_ksizes, 1, spec.c_src, spec.c_kpos, spec.c_alias, None, L.ptr(ws), B, H, W, cin, H, W, cout, 1,
+                spec.ntaps, spec.c_dy, spec.c_dx, None, code, L.stream())
+        head = (L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), None, L.ptr(draw), None, L.ptr(dg), L.ptr(db), 1, float(B * H * W), 1, 1.0)
+        if fused:
+            L.check(lib.rssf_conv_wgrad_bnapply(*head, L.ptr(raw_in), L.ptr(ss_in), act, *tail), "fused")
+        else:
+            L.check(lib.rssf_conv_wgrad_bnapply(*head, L.ptr(y), None, 0, *tail), "plain")
+        res[fused] = (draw, dw)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
 
 
 def test_conv_base_shape_linearity_bf16():
