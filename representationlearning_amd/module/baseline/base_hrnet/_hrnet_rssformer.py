@@ -301,32 +301,36 @@ class HighResolutionModule(nn.Module):
             return self._fuse_lockstep(self._branches_lockstep(x[:self.num_branches]))
         x = nnf.parallel_map(list(self.branches), x[:self.num_branches])       # BlockChains of BasicBlocks, one stream each
         x, accs = self._fanout(x)
-        fused = []
-        for i in range(len(self.fuse_layers)):
+
+        def fuse_output(i):
             low = None
             for j in range(1, self.num_branches):
                 if j == i:
                     low = x[j] if low is None else low + x[j]
                 elif j > i:      # 1x1 conv + BN, then nearest upsample fused with the running sum
                     fl = self.fuse_layers[i][j]
-                    t = nnf.conv_bn_act(x[j], fl[0], fl[1], grad_accum=accs[j])
+                    t = nnf.conv_bn_act(x[j], fl[0], fl[1], grad_accum=accs[j] if i > 0 else None)
                     low = nnf.upsample_nearest_add(low, t, int(fl[2].scale_factor))
                 else:
                     t = nnf.run_sequential(self.fuse_layers[i][j], x[j], grad_accum=accs[j])
                     low = t if low is None else low + t
             if i == 0:
-                y = self.relu(self.transformer(low, x[0]))        # residual comes from `low`; x[0] only feeds K/V (:430-431)
-            else:       # relu(fuse[i][0](x[0]) + low) (:432-435): sum and ReLU ride in the last down-sampling conv's BatchNorm pass
-                y = nnf.run_sequential(self.fuse_layers[i][0], x[0], res_pre=low, act_last=nnf.ACT_RELU, grad_accum=accs[0])
-            fused.append(y)
-        return fused
+                return self.relu(self.transformer(low, x[0]))     # residual comes from `low`; x[0] only feeds K/V (:430-431)
+            # relu(fuse[i][0](x[0]) + low) (:432-435): sum and ReLU ride in the last down-sampling conv's BatchNorm pass
+            return nnf.run_sequential(self.fuse_layers[i][0], x[0], res_pre=low, act_last=nnf.ACT_RELU, grad_accum=accs[0])
+
+        # Output 0 ends in the transformer block (attention + MlpDWBN at full resolution: the longest serial chain of the module); the
+        # other outputs - ten small down-sampling convolutions and their sums - depend on the branch outputs only and run beside it
+        # on a side stream (their accumulating consumers share that stream: _fanout counts them alone).
+        rest, y0 = nnf.fork_side(lambda: [fuse_output(i) for i in range(1, len(self.fuse_layers))], lambda: fuse_output(0), x)
+        return [y0] + list(rest)
 
     def _fanout(self, x):
         """Branch output j feeds one convolution per fuse path (i != j): their data gradients accumulate in one buffer
         (nnf.GradAccum) instead of being summed by autograd with an elementwise kernel per consumer."""
         xs, accs = [], []
         for j in range(self.num_branches):
-            t, acc = nnf.fanout(x[j], sum(1 for i in range(len(self.fuse_layers)) if i != j))
+            t, acc = nnf.fanout(x[j], sum(1 for i in range(1, len(self.fuse_layers)) if i != j))      # (path 0 runs on another stream)
             xs.append(t)
             accs.append(acc)
         return xs, accs

@@ -175,6 +175,32 @@ def parallel_map(fns, args):
     return outs
 
 
+def fork_side(fn_side, fn_main, tensors):
+    """(fn_side(), fn_main()): fn_side on a side stream when branch streams are enabled, concurrently with fn_main on the current
+    stream; joined before returning.  `tensors`: what fn_side reads (they were produced on the current stream)."""
+    rt = current()
+    ts = [t for t in tensors if t is not None]
+    if not (rt.branch_streams and _FORK_FUSE and ts and ts[0].is_cuda):
+        return fn_side(), fn_main()
+    dev = ts[0].device
+    cur = torch.cuda.current_stream(dev)
+    pool = rt.side_streams.setdefault(dev, [])
+    if not pool:
+        pool.append(torch.cuda.Stream(dev))
+    s = pool[0]
+    s.wait_stream(cur)
+    for t in ts:
+        t.record_stream(s)
+    with torch.cuda.stream(s):
+        side = fn_side()
+    main = fn_main()
+    cur.wait_stream(s)
+    for t in (side if isinstance(side, (list, tuple)) else [side]):
+        if t is not None:
+            t.record_stream(cur)
+    return side, main
+
+
 def _ia(vals):
     return (ctypes.c_int * len(vals))(*vals)
 
@@ -571,6 +597,7 @@ def group_stats_link(n):
     return GroupBwdLink(n) if (_FUSED_BN_STATS and torch.is_grad_enabled() and not current().deterministic) else None
 
 
+_FORK_FUSE = os.environ.get("RSSF_FORK_FUSE", "1") != "0"      # A/B switch: fuse outputs 1.. beside the transformer block (fork_side)
 _DEFER_BN_APPLY = os.environ.get("RSSF_DEFER_BN_APPLY", "1") != "0"      # A/B switch: forward BatchNorm apply inside the consumer's staging
 _FUSED_BN_APPLY = os.environ.get("RSSF_FUSED_BN_APPLY", "1") != "0"      # A/B switch: BatchNorm-backward apply inside the weight-gradient launch
 _FUSED_BN_STATS = os.environ.get("RSSF_FUSED_BN_STATS", "1") != "0"      # A/B switch (tools)
@@ -591,10 +618,11 @@ class GradAccum:
     order those came - returns the buffer, plus the ordinary gradients of consumers that are not convolutions.  All consumers
     must run on ONE stream (the fuse layers / transitions do)."""
 
-    __slots__ = ("buf",)
+    __slots__ = ("buf", "stream")
 
     def __init__(self):
         self.buf = None
+        self.stream = None          # stream the consumers accumulate on (the fan-out node may run on another one)
 
 
 class _Fanout(torch.autograd.Function):
@@ -609,19 +637,31 @@ class _Fanout(torch.autograd.Function):
         buf, ctx.acc.buf = ctx.acc.buf, None
         if buf is None:
             return g, None
+        if ctx.acc.stream is not None:      # the consumers ran on a side stream (fork_side): order this node after them
+            cur = torch.cuda.current_stream(buf.device)
+            if ctx.acc.stream != cur:
+                cur.wait_stream(ctx.acc.stream)
+                buf.record_stream(cur)
         t = _nchw(buf)
         return (t if g is None else t.add_(g.to(t.dtype))), None
 
 
 def fanout(x, n_conv_consumers):
-    """(x', GradAccum) for a tensor with >= 2 convolution consumers that take `grad_accum=`; (x, None) when there is nothing to fuse."""
-    if n_conv_consumers < 2 or not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
+    """(x', GradAccum) for a tensor with convolution consumers that take `grad_accum=`; (x, None) when there are none.  Also with a
+    SINGLE such consumer: when that consumer runs on a side stream (fork_side), its gradient must not meet the other consumers'
+    in autograd's own cross-stream accumulation - under hipGraph capture that ended in a crash of the capture (ROCm 7.0) - but in
+    the fan-out node, which orders itself after the side stream explicitly."""
+    if n_conv_consumers < 1 or not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
         return x, None
     acc = GradAccum()
     return _Fanout.apply(x, acc), acc
 
 
 def _accumulate_dgrad(accum, spec, dout, weights, in_shape, rt):
+    st = torch.cuda.current_stream(dout.device)
+    if accum.stream is not None and accum.buf is not None and accum.stream != st:
+        raise RuntimeError("GradAccum: the consumers of one accumulator must run on ONE stream")
+    accum.stream = st
     if accum.buf is None:
         accum.buf = _conv_dgrad(spec, dout, weights, in_shape, None, rt)
     else:
