@@ -8,7 +8,7 @@ import bench
 
 B, H, W = int(os.environ.get("B", 16)), 128, 128
 lib = L.load()
-for cin, cout, stats in ((32, 128, True), (32, 128, False), (128, 32, True), (128, 32, False), (64, 64, True), (128, 128, True), (256, 256, True)):
+for cin, cout, stats in ((32, 128, True), (32, 128, False), (128, 32, True), (128, 32, False), (64, 64, True), (128, 128, True), (256, 256, True), (480, 480, True), (64, 256, True), (256, 64, True)):
     conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
     spec = nnf.spec_of([conv])
     x = torch.randn(B, H, W, cin, device="cuda").bfloat16()
