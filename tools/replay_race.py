@@ -1,0 +1,82 @@
+"""Replays one captured training step many times from an unchanged state (lr = 0, deterministic statistics) and reports what is
+not bit-identical between replays: forward module outputs, every gradient tensor in backward execution order, and the inputs /
+outputs of the gate backward inside the attention node.  A replayed hipGraph runs its branches truly concurrently, so this is
+where an intra-kernel problem that needs contention shows up (found with it: DESIGN.md lesson 23).
+
+  python tools/replay_race.py [replays=60]            (GPU box, from the repository root; RSSF_FORK_FUSE etc. are honoured)
+
+Nothing in the package is modified: the hooks are installed from here (autograd pre-hooks through a wrapped Tensor.backward,
+global module forward hooks, a wrapped ops.gate_weights_bwd)."""
+import os, sys, torch
+sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+os.environ.setdefault("RSSF_BRANCH_STREAMS", "1")
+from representationlearning_amd.trainer import Trainer
+from representationlearning_amd.configs import synthetic_batch
+from representationlearning_amd import ops
+from test_gpu_trainer import _mk
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+grads, fwd, gate = [], [], []            # (name, tensor) lists; tensors of the captured step are static: read them after a replay
+
+_backward = torch.Tensor.backward
+def backward(self, *a, **k):
+    del grads[:]
+    seen, stack = set(), [self.grad_fn]
+    while stack:
+        nd = stack.pop()
+        if nd is None or nd in seen:
+            continue
+        seen.add(nd)
+        nd.register_prehook(lambda gs, name=type(nd).__name__: grads.extend((name, g) for g in gs if g is not None) or None)
+        stack.extend(f for f, _ in nd.next_functions)
+    return _backward(self, *a, **k)
+torch.Tensor.backward = backward
+
+def fwd_hook(mod, args, out):
+    outs = out if isinstance(out, (list, tuple)) else [out]
+    fwd.extend((type(mod).__name__, o) for o in outs if isinstance(o, torch.Tensor) and o.is_cuda)
+torch.nn.modules.module.register_module_forward_hook(fwd_hook)
+
+_gate_bwd = ops.gate_weights_bwd
+def gate_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W):
+    out = _gate_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W)
+    gate.append(("gate.domega", domega.clone()))
+    gate.append(("gate.dpooled", out.clone()))
+    return out
+ops.gate_weights_bwd = gate_bwd
+
+img, lab = synthetic_batch(2, 128, seed=5)
+t = Trainer(_mk(6), bf16=True, base_lr=0.0, use_graph=True, deterministic=True)
+while t.graph is None or t._replayed < 1:
+    if t.graph is None:
+        del fwd[:], gate[:]
+    t.step(img, dict(cls=lab))
+groups = (("forward", fwd), ("gate", gate), ("grad", grads))
+print("captured:", ", ".join("%d %s tensors" % (len(g), n) for n, g in groups), flush=True)
+
+def snapshot():
+    t.step(img, dict(cls=lab))
+    torch.cuda.synchronize()
+    return [[x.clone() for _, x in g] for _, g in groups]
+
+ref = snapshot()
+runs = [snapshot() for _ in range(R)]
+for gi, (gname, g) in enumerate(groups):
+    diffs = [[i for i, (a, b) in enumerate(zip(ref[gi], run[gi])) if not torch.equal(a, b)] for run in runs]
+    cnt = {}
+    for d in diffs:
+        for i in d:
+            cnt[i] = cnt.get(i, 0) + 1
+    # parameter gradients summed with fp32 atomics differ in the last bits on most replays: not what is looked for here
+    noise = {i for i, c in cnt.items() if c > 0.5 * R}
+    bad = [(r, [i for i in d if i not in noise]) for r, d in enumerate(diffs)]
+    bad = [(r, d) for r, d in bad if d]
+    print("%-8s %3d of %d replays differ from the first (%d always-noisy tensors ignored: %s)"
+          % (gname, len(bad), R, len(noise), sorted({g[i][0] for i in noise})), flush=True)
+    for r, d in bad[:6]:
+        i = d[0]
+        a, b = ref[gi][i].float(), runs[r][gi][i].float()
+        nz = (a != b).nonzero()
+        print("   replay %d: %d tensors, first #%d %s %s: %d elements, max |diff| %.3g of max %.3g, first index %s"
+              % (r, len(d), i, g[i][0], tuple(a.shape), len(nz), (a - b).abs().max().item(), a.abs().max().item(), nz[0].tolist()), flush=True)
