@@ -3,7 +3,7 @@ not bit-identical between replays: forward module outputs, every gradient tensor
 outputs of the gate backward inside the attention node.  A replayed hipGraph runs its branches truly concurrently, so this is
 where an intra-kernel problem that needs contention shows up (found with it: DESIGN.md lesson 23).
 
-  python tools/replay_race.py [replays=60]            (GPU box, from the repository root; RSSF_FORK_FUSE etc. are honoured)
+  python tools/replay_race.py [replays=60] [batch=2] [size=128]      (GPU box, from the repository root; RSSF_FORK_FUSE etc. are honoured)
 
 Nothing in the package is modified: the hooks are installed from here (autograd pre-hooks through a wrapped Tensor.backward,
 global module forward hooks, a wrapped ops.gate_weights_bwd)."""
@@ -17,6 +17,8 @@ from representationlearning_amd import ops
 from test_gpu_trainer import _mk
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 grads, fwd, gate = [], [], []            # (name, tensor) lists; tensors of the captured step are static: read them after a replay
 
 _backward = torch.Tensor.backward
@@ -46,7 +48,7 @@ def gate_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W):
     return out
 ops.gate_weights_bwd = gate_bwd
 
-img, lab = synthetic_batch(2, 128, seed=5)
+img, lab = synthetic_batch(BATCH, SIZE, seed=5)
 t = Trainer(_mk(6), bf16=True, base_lr=0.0, use_graph=True, deterministic=True)
 while t.graph is None or t._replayed < 1:
     if t.graph is None:
@@ -55,28 +57,34 @@ while t.graph is None or t._replayed < 1:
 groups = (("forward", fwd), ("gate", gate), ("grad", grads))
 print("captured:", ", ".join("%d %s tensors" % (len(g), n) for n, g in groups), flush=True)
 
-def snapshot():
+def replay():
     t.step(img, dict(cls=lab))
     torch.cuda.synchronize()
-    return [[x.clone() for _, x in g] for _, g in groups]
 
-ref = snapshot()
-runs = [snapshot() for _ in range(R)]
+replay()
+ref = [[x.clone() for _, x in g] for _, g in groups]
+# per group and replay: (index, name, shape, differing elements, max |diff|, max |ref|, first index) of every tensor that differs
+found = [[] for _ in groups]
+for r in range(R):
+    replay()
+    for gi, (gname, g) in enumerate(groups):
+        d = []
+        for i, ((name, x), a) in enumerate(zip(g, ref[gi])):
+            if not torch.equal(x, a):
+                ne = x != a
+                d.append((i, name, tuple(x.shape), int(ne.sum()), (x.float() - a.float()).abs().max().item(), a.float().abs().max().item(), ne.nonzero()[0].tolist()))
+        found[gi].append(d)
 for gi, (gname, g) in enumerate(groups):
-    diffs = [[i for i, (a, b) in enumerate(zip(ref[gi], run[gi])) if not torch.equal(a, b)] for run in runs]
     cnt = {}
-    for d in diffs:
-        for i in d:
-            cnt[i] = cnt.get(i, 0) + 1
+    for d in found[gi]:
+        for e in d:
+            cnt[e[0]] = cnt.get(e[0], 0) + 1
     # parameter gradients summed with fp32 atomics differ in the last bits on most replays: not what is looked for here
     noise = {i for i, c in cnt.items() if c > 0.5 * R}
-    bad = [(r, [i for i in d if i not in noise]) for r, d in enumerate(diffs)]
+    bad = [(r, [e for e in d if e[0] not in noise]) for r, d in enumerate(found[gi])]
     bad = [(r, d) for r, d in bad if d]
     print("%-8s %3d of %d replays differ from the first (%d always-noisy tensors ignored: %s)"
           % (gname, len(bad), R, len(noise), sorted({g[i][0] for i in noise})), flush=True)
     for r, d in bad[:6]:
-        i = d[0]
-        a, b = ref[gi][i].float(), runs[r][gi][i].float()
-        nz = (a != b).nonzero()
-        print("   replay %d: %d tensors, first #%d %s %s: %d elements, max |diff| %.3g of max %.3g, first index %s"
-              % (r, len(d), i, g[i][0], tuple(a.shape), len(nz), (a - b).abs().max().item(), a.abs().max().item(), nz[0].tolist()), flush=True)
+        i, name, shape, n, md, mr, idx = d[0]
+        print("   replay %d: %d tensors, first #%d %s %s: %d elements, max |diff| %.3g of max %.3g, first index %s" % (r, len(d), i, name, shape, n, md, mr, idx), flush=True)
