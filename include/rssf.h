@@ -59,12 +59,15 @@ int rssf_gate_pool_fwd(const void* x, const void* y, const float* stats_x, const
 int rssf_gate_weights_fwd(const float* pooled, const float* k, const float* wl, const float* bl, float* gsig,
                           float* omega, float* logits, int B, int H, int W, void* stream);
 /* backward of gate_weights: domega [B][2][N] -> dpooled; dk, dwl, dbl accumulated (+=).
+ * dk [2][2][7][7]; with `dk_stream1` non-null the gradient of k[1] (98 values) is accumulated THERE and dk takes k[0]'s 98
+ * values only - the two 7x7 kernels are separate parameters of the reference module (multihead_isa_pool_attention.py:30-31),
+ * so a caller can hand in the two .grad buffers and needs no staging copy.
  * `dpooled` must hold B*6*N + RSSF_GATE_SLOTS*202 floats: the first B*4*N are the result ([B][4][N]), the rest is
  * scratch ([B][2][N] pre-sigmoid gradients, then slotted partial sums of the 202 parameter gradients). */
 #define RSSF_GATE_SLOTS 16
 int rssf_gate_weights_bwd(const float* domega, const float* pooled, const float* gsig, const float* omega,
-                          const float* k, const float* wl, float* dpooled, float* dk, float* dwl, float* dbl,
-                          int B, int H, int W, void* stream);
+                          const float* k, const float* wl, float* dpooled, float* dk, float* dk_stream1, float* dwl,
+                          float* dbl, int B, int H, int W, void* stream);
 /* backward of gate_pool + merge: dxhat[b,n,c] (+)= gate-path gradient (mean: /C, max: argmax-routed).
  * dxhat/dyhat hold the attention-path gradient w.r.t. LN1 outputs on entry and the total on exit. */
 int rssf_gate_pool_bwd(const float* dpooled, const int32_t* argmax, void* dxhat, void* dyhat, int B, int N, int C,

@@ -50,7 +50,7 @@ SIGNATURES = {
     "rssf_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_void_p]),
     "rssf_gate_pool_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_gate_weights_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
-    "rssf_gate_weights_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),
+    "rssf_gate_weights_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_void_p]),
     "rssf_gate_pool_bwd": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_winattn_fwd": (c_int, [ctypes.POINTER(WinAttnFwdParams), c_void_p]),
     "rssf_winattn_bwd_workspace_elems": (c_int64, [c_int] * 4),

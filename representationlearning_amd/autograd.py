@@ -31,6 +31,7 @@ class GatedWindowCrossAttention(torch.autograd.Function):
         ctx.save_for_backward(x, y, sx, sy, pooled, argmax, gsig, omega, kk, wl2, ln_g, ln_b, wq, bq, wk, bk, wv, bv, wo, bo)
         ctx.dims = (H, W, heads)
         ctx.params = dict(ln_g=ln_g, ln_b=ln_b, wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)
+        ctx.gate_params = (k1, k2, wl, bl)
         ctx.rt = nnf.current()
         return out
 
@@ -44,19 +45,29 @@ class GatedWindowCrossAttention(torch.autograd.Function):
         tg = {n: nnf.grad_target(P[n], rt) for n in P}            # kernels accumulate straight into .grad when possible
         gw = {n: tg[n][0] for n in w}
         dxhat, dyhat, domega = ops.winattn_bwd(dout, x, y, sx, sy, omega, ln_g, ln_b, w, gw, H, W, heads)
-        zb = nnf._zeros(kk.numel() + 8, x.device, rt)            # one slice of the step's pre-zeroed pool instead of three fills
-        dk, dwl, dbl = zb[:kk.numel()].view_as(kk), zb[kk.numel():kk.numel() + 4].view(2, 2), zb[kk.numel() + 4:kk.numel() + 6]
-        dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, kk, wl2, dk, dwl, dbl, H, W)
+        # the four gate parameters (two 7x7 kernels, the 1x1 mixing weight and bias): straight into their .grad buffers when the
+        # trainer owns them (the fold launch of rssf_gate_weights_bwd accumulates) - no staging slice, copy or AccumulateGrad add
+        gate_direct = rt.direct and all(p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+                                        for p in ctx.gate_params)
+        nk = kk.numel()
+        if gate_direct:
+            gt = [nnf.grad_target(p, rt) for p in ctx.gate_params]
+            dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, kk, wl2, gt[0][0].view(-1), gt[2][0].view(-1), gt[3][0], H, W,
+                                           dk_stream1=gt[1][0].view(-1))
+            ggate = tuple(nnf.grad_result(p, t, d, rt) for p, (t, d) in zip(ctx.gate_params, gt))
+        else:
+            zb = nnf._zeros(nk + 8, x.device, rt)            # one slice of the step's pre-zeroed pool instead of three fills
+            dk, dwl, dbl = zb[:nk].view_as(kk), zb[nk:nk + 4].view(2, 2), zb[nk + 4:nk + 6]
+            dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, kk, wl2, dk, dwl, dbl, H, W)
+            gp = zb[:nk + 6].clone()                           # the pool slice is recycled next step: hand autograd a copy
+            h = nk // 2
+            ggate = (gp[:h].view_as(kk[0:1]), gp[h:nk].view_as(kk[1:2]), gp[nk:nk + 4].view(2, 2, 1, 1), gp[nk + 4:nk + 6])
         ops.gate_pool_bwd_(dpooled, argmax, dxhat, dyhat)
         dg, db = tg["ln_g"][0], tg["ln_b"][0]
         dx = ops.layernorm_bwd(dxhat, x, sx, ln_g, dg, db, dx_add=dout)      # + residual path
         dy = ops.layernorm_bwd(dyhat, y, sy, ln_g, dg, db)
         r = {n: nnf.grad_result(P[n], tg[n][0], tg[n][1], rt) for n in P}
-        nk = kk.numel()
-        gp = zb[:nk + 6].clone()                               # the pool slice is recycled next step: hand autograd a copy
-        h = nk // 2
-        return (dx, dy, r["ln_g"], r["ln_b"], gp[:h].view_as(kk[0:1]), gp[h:nk].view_as(kk[1:2]), gp[nk:nk + 4].view(2, 2, 1, 1),
-                gp[nk + 4:nk + 6],
+        return (dx, dy, r["ln_g"], r["ln_b"], *ggate,
                 r["wq"], r["bq"], r["wk"], r["bk"], r["wv"], r["bv"], r["wo"], r["bo"], None, None, None)
 
 

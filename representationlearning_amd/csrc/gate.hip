@@ -234,13 +234,14 @@ __global__ void __launch_bounds__(256) gate_weights_bwd2_kernel(const float* __r
 }
 
 // folds the slot copies into the parameter gradients: dk [196], dwl [4], dbl [2]
-__global__ void __launch_bounds__(256) gate_weights_fold_kernel(const float* __restrict__ slots, float* __restrict__ dk,
+__global__ void __launch_bounds__(256) gate_weights_fold_kernel(const float* __restrict__ slots, float* __restrict__ dk, float* __restrict__ dk1,
                                                                float* __restrict__ dwl, float* __restrict__ dbl) {
   const int i = threadIdx.x;
   if (i >= GATE_SLOT_ELEMS) return;
   float s = 0.f;
   for (int k = 0; k < RSSF_GATE_SLOTS; ++k) s += slots[k * GATE_SLOT_ELEMS + i];
-  if (i < 196) dk[i] += s;
+  if (i < 98) dk[i] += s;
+  else if (i < 196) dk1[i - 98] += s;          // stream 1's kernel: dk + 98, or a buffer of its own (two separate parameters)
   else if (i < 200) dwl[i - 196] += s;
   else dbl[i - 200] += s;
 }
@@ -332,8 +333,8 @@ extern "C" int rssf_gate_weights_fwd(const float* pooled, const float* k, const 
 }
 
 extern "C" int rssf_gate_weights_bwd(const float* domega, const float* pooled, const float* gsig, const float* omega,
-                                     const float* k, const float* wl, float* dpooled, float* dk, float* dwl, float* dbl,
-                                     int B, int H, int W, void* stream) {
+                                     const float* k, const float* wl, float* dpooled, float* dk, float* dk_stream1, float* dwl,
+                                     float* dbl, int B, int H, int W, void* stream) {
   RSSF_REQUIRE(domega && pooled && gsig && omega && k && wl && dpooled && dk && dwl && dbl && B > 0 && H > 0 && W > 0,
                "gate_weights_bwd: bad arguments");
   const int N = H * W;
@@ -354,7 +355,7 @@ extern "C" int rssf_gate_weights_bwd(const float* domega, const float* pooled, c
   gate_weights_bwd2_kernel<<<dim3((unsigned)(B * tiles)), 256, 0, st>>>(dpre, pooled, k, dpooled, slots, B, H, W);
   rc = check_launch("gate_weights_bwd2");
   if (rc) return rc;
-  gate_weights_fold_kernel<<<1, 256, 0, st>>>(slots, dk, dwl, dbl);
+  gate_weights_fold_kernel<<<1, 256, 0, st>>>(slots, dk, dk_stream1 ? dk_stream1 : dk + 98, dwl, dbl);
   return check_launch("gate_weights_fold");
 }
 

@@ -82,13 +82,14 @@ def gate_weights_fwd(pooled, k, wl, bl, H, W, want_logits=False):
     return gsig, omega, logits
 
 
-def gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W):
-    """Returns dpooled [B,4,N]; accumulates dk [2,2,7,7], dwl [2,2], dbl [2]."""
+def gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W, dk_stream1=None):
+    """Returns dpooled [B,4,N]; accumulates dk [2,2,7,7], dwl [2,2], dbl [2] - or, with dk_stream1 (98 values), dk [2,7,7] takes
+    the first 7x7 kernel's gradient and dk_stream1 the second's (the two .grad buffers of the module's two parameters)."""
     B = pooled.shape[0]
     N = H * W
     buf = torch.empty(B * 6 * N + 16 * 202, device=pooled.device, dtype=torch.float32)   # [B][4][N] dpooled + scratch (rssf.h)
     L.check(L.load().rssf_gate_weights_bwd(L.ptr(domega), L.ptr(pooled), L.ptr(gsig), L.ptr(omega), L.ptr(_f32(k)),
-                                           L.ptr(_f32(wl)), L.ptr(buf), L.ptr(_f32(dk)), L.ptr(_f32(dwl)), L.ptr(_f32(dbl)),
+                                           L.ptr(_f32(wl)), L.ptr(buf), L.ptr(_f32(dk)), L.ptr(None if dk_stream1 is None else _f32(dk_stream1)), L.ptr(_f32(dwl)), L.ptr(_f32(dbl)),
                                            B, H, W, L.stream()), "rssf_gate_weights_bwd")
     return buf[: B * 4 * N].view(B, 4, N)
 

@@ -56,6 +56,36 @@ def test_training_steps_decrease_loss_fp32_and_bf16():
         assert all(l == l for l in losses) and min(losses[-3:]) < losses[0], losses
 
 
+def test_direct_gradients_equal_autograd_gradients():
+    """The trainer's kernels accumulate parameter gradients straight into the flat `.grad` buffer (nnf.grad_target: no
+    AccumulateGrad adds; the attention node hands the two 7x7 gate kernels, the mixing weight and bias to
+    rssf_gate_weights_bwd as four destinations).  Same numbers as the plain autograd route of the same model, where every
+    node returns its gradients and autograd accumulates them.  (Deterministic statistics on both sides: this tiny
+    configuration amplifies the last-bit noise of atomically summed BatchNorm statistics to per cents.)"""
+    from representationlearning_amd.trainer import Trainer
+    from representationlearning_amd.configs import synthetic_batch
+    from representationlearning_amd import nnf
+    from tests.helpers import rel_err
+    img, lab = synthetic_batch(2, 128, seed=5)
+    m = _mk(4)
+    rt = nnf.Runtime()
+    rt.deterministic = True
+    with nnf.use(rt):
+        out = m(img, dict(cls=lab))
+        sum(v for k, v in out.items() if k.endswith("loss")).backward()
+    plain = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+    t = Trainer(_mk(4), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=False, deterministic=True)
+    t.step(img, dict(cls=lab))
+    names = {id(p): n for n, p in t.model.named_parameters()}
+    direct = {names[id(p)]: t.flat.grad[o:o + p.numel()].view_as(p) for p, o in zip(t.flat.params, t.flat.offsets)}
+    keys = sorted(n for n in plain if n in direct)
+    gate = [n for n in keys if "atrous_block" in n or "weight_levels" in n]
+    assert len(keys) > 1000 and len(gate) == 8 * 4, (len(keys), len(gate))
+    cat = lambda d, ks: torch.cat([d[n].flatten() for n in ks]).cpu()
+    assert rel_err(cat(direct, keys), cat(plain, keys)) < 1e-6
+    assert rel_err(cat(direct, gate), cat(plain, gate)) < 1e-5
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_deterministic_mode_is_bit_identical(bf16):
     """RSSF_DETERMINISTIC / Trainer(deterministic=True): fixed-order BatchNorm statistics (conv epilogue partials + ordered
