@@ -29,3 +29,17 @@ def test_gate_kernels_have_no_cross_lane_packed_multiply(tmp_path):
     assert "gate_weights_bwd2_kernel" in text
     bad = [l for l in text.splitlines() if re.search(r"v_pk_mul_f32.*op_sel:\[0,1\].*op_sel_hi:\[1,0\]", l)]
     assert not bad, bad[:3]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="no ROCm LLVM tools")
+def test_built_library_has_no_cross_lane_packed_multiply():
+    """The same instruction form anywhere in the built librssf.so (every embedded gfx950 code object is disassembled:
+    tools/isa_scan.py): a kernel that grows it through a compiler choice is caught here, not by a drifting training run."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import isa_scan
+    if not os.path.exists(isa_scan.LIB):
+        pytest.skip("librssf.so not built")
+    hits, n = isa_scan.scan()
+    assert n >= 15, n            # one code object per translation unit with kernels
+    assert not hits, hits[:3]
