@@ -195,3 +195,50 @@ def test_winattn_bwd_workspace_route_matches_atomic_route(C, H, W, dtype):
     assert rel_err(dom0.cpu(), dom1.cpu()) < (1e-5 if dtype == torch.float32 else 5e-3)
     for k in gw0:
         assert rel_err(gw0[k].cpu(), gw1[k].cpu()) < 1e-5, k
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 19, 23), (3, 7, 7)])
+def test_gate_weights_backward_vs_autograd_reference(B, H, W):
+    """rssf_gate_weights_bwd (omega = softmax_2(Wl [sigmoid(conv7x7(pooled_0; k_0)); sigmoid(conv7x7(pooled_1; k_1))] + bl),
+    multihead_isa_pool_attention.py:30-37) against autograd through the same formula in fp32: dpooled, dk, dwl, dbl.  The two 7x7
+    kernels' gradients go to one [2,2,7,7] buffer or to two separate ones (`dk_stream1`): same numbers; and ten launches in a
+    row with a second stream keeping the CUs busy give the same bits (DESIGN.md lesson 23)."""
+    from representationlearning_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + H)
+    N = H * W
+    pooled = torch.randn(B, 4, N, generator=g).to(DEV)
+    k = (torch.randn(2, 2, 7, 7, generator=g) * 0.2).to(DEV)
+    wl = torch.randn(2, 2, generator=g).to(DEV)
+    bl = torch.randn(2, generator=g).to(DEV)
+    domega = torch.randn(B, 2, N, generator=g).to(DEV)
+    gsig, omega, _ = ops.gate_weights_fwd(pooled, k, wl, bl, H, W)
+    # reference
+    pr, kr, wr, br = (t.clone().requires_grad_(True) for t in (pooled, k, wl, bl))
+    maps = pr.view(B, 2, 2, H, W)
+    gs = torch.stack([torch.sigmoid(torch.nn.functional.conv2d(maps[:, s], kr[s:s + 1], padding=3))[:, 0] for s in range(2)], 1)   # [B,2,H,W]
+    logits = torch.einsum("os,bshw->bohw", wr, gs) + br.view(1, 2, 1, 1)
+    om = torch.softmax(logits, 1).reshape(B, 2, N)
+    assert rel_err(omega.cpu(), om.detach().cpu()) < 1e-5
+    (om * domega).sum().backward()
+    dk, dwl, dbl = torch.zeros_like(k), torch.zeros_like(wl), torch.zeros_like(bl)
+    dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W).clone()
+    torch.cuda.synchronize()
+    assert rel_err(dpooled.cpu(), pr.grad.cpu()) < 1e-4
+    assert rel_err(dk.cpu(), kr.grad.cpu()) < 1e-4
+    assert rel_err(dwl.cpu(), wr.grad.cpu()) < 1e-4 and rel_err(dbl.cpu(), br.grad.cpu()) < 1e-4
+    # two destinations
+    dk0, dk1 = torch.zeros(2, 7, 7, device=DEV), torch.zeros(2, 7, 7, device=DEV)
+    dwl2, dbl2 = torch.zeros_like(wl), torch.zeros_like(bl)
+    dp2 = ops.gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk0, dwl2, dbl2, H, W, dk_stream1=dk1).clone()
+    assert torch.equal(dp2, dpooled)
+    assert rel_err(torch.stack([dk0, dk1]).cpu(), dk.cpu()) < 1e-6 and rel_err(dwl2.cpu(), dwl.cpu()) < 1e-6
+    # repeatability under load
+    side = torch.cuda.Stream()
+    junk = torch.randn(64, 1 << 16, device=DEV)
+    for r in range(10):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                junk.mul_(1.0001)
+        d = ops.gate_weights_bwd(domega, pooled, gsig, omega, k, wl, torch.zeros_like(k), torch.zeros_like(wl), torch.zeros_like(bl), H, W)
+        assert torch.equal(d, dpooled), r
+    torch.cuda.synchronize()
