@@ -41,8 +41,8 @@ def fwd_hook(mod, args, out):
 torch.nn.modules.module.register_module_forward_hook(fwd_hook)
 
 _gate_bwd = ops.gate_weights_bwd
-def gate_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W):
-    out = _gate_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W)
+def gate_bwd(domega, *a, **kw):
+    out = _gate_bwd(domega, *a, **kw)
     gate.append(("gate.domega", domega.clone()))
     gate.append(("gate.dpooled", out.clone()))
     return out
