@@ -334,9 +334,11 @@ def main():
             "final_loss": round(final_loss, 5),
             "whole_step_mfma_frac": round(value * FLOP_PER_IMG / (world * MFMA_BF16_PEAK), 5),
         }
+        # the kernel rooflines are per-GPU figures: rank 0 measures them at every N (the other ranks wait at the barrier below);
+        # the CPU baseline is an N = 1 leg only
+        line["roofline"] = measure_window_attention(args.batch, args.size)
+        line["roofline_mfma"] = measure_mlp_conv(args.batch, args.size)
         if world == 1:
-            line["roofline"] = measure_window_attention(args.batch, args.size)
-            line["roofline_mfma"] = measure_mlp_conv(args.batch, args.size)
             line["roofline_kernels"] = measure_dominant_kernels(args.batch, args.size)
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         print(json.dumps(line), flush=True)
