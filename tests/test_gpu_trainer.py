@@ -190,6 +190,30 @@ def test_sgd_skips_parameters_without_gradient():
     assert covered == t.flat.numel - (t.flat.offsets[-1] - t.flat.offsets[-3])       # everything but headaux.0.{weight,bias}
 
 
+def test_replayed_step_repeats_under_its_own_concurrency():
+    """One captured step (branches and forked fuse outputs as parallel graph branches), replayed 40 times from an unchanged state
+    (lr = 0, deterministic statistics): the loss has the same bits every time and the flat gradient moves by fp32 summation noise
+    only (a few parameter sums use float atomics).  Round 2 found a kernel that dropped one term of a 7x7 convolution in 5-15 %
+    of such replays - and in no eager or single-stream run (DESIGN.md lesson 23; tools/replay_race.py is the diagnostic form of
+    this test)."""
+    from representationlearning_amd.trainer import Trainer
+    from representationlearning_amd.configs import synthetic_batch
+    from tests.helpers import rel_err
+    img, lab = synthetic_batch(2, 128, seed=5)
+    t = Trainer(_mk(6), bf16=True, base_lr=0.0, weight_decay=0.0, use_graph=True, deterministic=True)
+    while t.graph is None or t._replayed < 2:
+        l0 = t.step(img, dict(cls=lab)).clone()
+    torch.cuda.synchronize()
+    g0 = t.flat.grad.clone()
+    worst = 0.0
+    for r in range(40):
+        l = t.step(img, dict(cls=lab))
+        torch.cuda.synchronize()
+        assert torch.equal(l, l0), (r, float(l), float(l0))
+        worst = max(worst, rel_err(t.flat.grad.cpu(), g0.cpu()))
+    assert worst < 1e-5, worst
+
+
 @pytest.mark.parametrize("branch_streams", ["1", "0"])
 def test_graph_replay_survives_device_sync_and_foreign_work(branch_streams):
     """A replayed step must not depend on anything outside the graph: a device synchronisation and unrelated allocations / kernels
