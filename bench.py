@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOP_PER_IMG = 528.07e9        # fwd+bwd matmul/conv FLOPs per 512x512 image, Base
+# fwd+bwd FLOPs per image at the size SURVEY §6 counted them on (they scale with the pixel count), branch-0 width, heads
+VARIANTS = {"tiny": (48.17e9, 256, 18), "base": (FLOP_PER_IMG, 512, 32), "large": (4548.4e9, 1024, 48)}
 MFMA_BF16_PEAK = 2.5e15
 
 
@@ -71,14 +73,14 @@ def _time_us(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-def measure_dominant_kernels(B, S, iters=30):
+def measure_dominant_kernels(B, S, iters=30, C=32):
     """In-run HIP-event timings of the kernels that dominate the step BY TIME (profiles/r02_step_census.txt), at the benchmark
     geometry of branch 0 (C = 32, (S/4)^2 map), each against the roofline that bounds it: the BatchNorm passes and the 3x3 halo
     convolution / its weight gradient (HBM: arithmetic intensity 144 FLOP/B at C = 32), the attention backward (HBM)."""
     from representationlearning_amd import _lib as L, nnf, ops
     lib = L.load()
     H = W = S // 4
-    C, dev = 32, "cuda"
+    dev = "cuda"
     rows = B * H * W
     torch.manual_seed(1)
     raw = torch.randn(B, H, W, C, device=dev).bfloat16()
@@ -106,22 +108,22 @@ def measure_dominant_kernels(B, S, iters=30):
 
     us = _time_us(lambda: L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(mi),
                                                              L.ptr(ss), None, None, L.ptr(y), rows, C, 1, float(rows), 0.1, 1e-5, 1, code, st()), "bn"), iters)
-    entry("bn_finapply_kernel<bf16,8>", us, 2 * tensor_bytes, "BatchNorm finalize+apply+ReLU, C=32: read raw, write y")
+    entry("bn_finapply_kernel<bf16,8>", us, 2 * tensor_bytes, "BatchNorm finalize+apply+ReLU, C=%d: read raw, write y" % C)
     us = _time_us(lambda: (sums.zero_(), L.check(lib.rssf_bn_bwd_reduce(L.ptr(dy), L.ptr(raw), L.ptr(ss), None, L.ptr(sums), rows, C, 1, None, code, st()), "bn")), iters)
-    entry("bn_bwd_reduce_kernel<bf16,8> (+ 2 KB memset)", us, 2 * tensor_bytes, "BatchNorm backward statistics, C=32: read dy, raw")
+    entry("bn_bwd_reduce_kernel<bf16,8> (+ 2 KB memset)", us, 2 * tensor_bytes, "BatchNorm backward statistics, C=%d: read dy, raw" % C)
     us = _time_us(lambda: L.check(lib.rssf_bn_bwd_apply(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), None, L.ptr(draw), None, L.ptr(dg),
                                                         L.ptr(db), rows, C, 1, float(rows), 1, 1.0, code, st()), "bn"), iters)
-    entry("bn_bwd_apply_kernel<bf16,8>", us, 3 * tensor_bytes, "BatchNorm backward apply, C=32: read dy, raw, write draw")
+    entry("bn_bwd_apply_kernel<bf16,8>", us, 3 * tensor_bytes, "BatchNorm backward apply, C=%d: read dy, raw, write draw" % C)
     conv = torch.nn.Conv2d(C, C, 3, padding=1, bias=False).to(dev)
     spec = nnf.spec_of([conv])
     x = torch.relu(torch.randn(B, H, W, C, device=dev)).bfloat16()
     cstats = torch.zeros(nnf.BN_SLOTS * 2 * C, device=dev)
     flops = 2.0 * rows * C * C * 9
     us = _time_us(lambda: nnf._conv_forward(spec, x, [conv.weight], None, cstats), iters)
-    entry("conv3x3_halo_kernel<8,32> (+ 4 us weight pack)", us, 2 * tensor_bytes, "3x3 conv 32->32 with fused BN statistics: read in, write out", flops)
+    entry("conv3x3_halo_kernel<8,%d> (+ 4 us weight pack)" % C, us, 2 * tensor_bytes, "3x3 conv %d->%d with fused BN statistics: read in, write out" % (C, C), flops)
     dw = torch.zeros_like(conv.weight)
     us = _time_us(lambda: nnf._conv_wgrad(spec, dy, x, [dw], None), iters)
-    entry("conv3x3_wgrad_halo_kernel + wgrad_reduce_kernel", us, 2 * tensor_bytes, "3x3 weight gradient 32x32: read dout, in", flops)
+    entry("conv3x3_wgrad_halo_kernel + wgrad_reduce_kernel", us, 2 * tensor_bytes, "3x3 weight gradient %dx%d: read dout, in" % (C, C), flops)
     # attention backward (the kernel furthest below its roofline in round 1)
     N = H * W
     xa = torch.randn(B, N, C, device=dev).bfloat16(); ya = torch.randn(B, N, C, device=dev).bfloat16(); da = torch.randn(B, N, C, device=dev).bfloat16()
@@ -133,15 +135,14 @@ def measure_dominant_kernels(B, S, iters=30):
         w["w" + n] = (torch.randn(C, C, device=dev) / C ** 0.5).contiguous(); w["b" + n] = torch.zeros(C, device=dev)
     gw = {k: torch.zeros_like(v) for k, v in w.items()}
     us = _time_us(lambda: ops.winattn_bwd(da, xa, ya, sx, sy, omega, g1, b1, w, gw, H, W, 2), max(5, iters // 3))
-    entry("winattn_bwd_kernel<bf16,Dims<32,2>> + domega_reduce_kernel", us, 5 * B * N * C * 2, "read x, y, dout; write dxhat, dyhat")
+    entry("winattn_bwd_kernel<bf16,Dims<%d,2>> + domega_reduce_kernel" % C, us, 5 * B * N * C * 2, "read x, y, dout; write dxhat, dyhat")
     return out
 
 
-def measure_window_attention(B, S, iters=30):
+def measure_window_attention(B, S, iters=30, C=32):
     """Average duration of one rssf_winattn_fwd launch at the benchmark geometry (branch 0: C=32, (S/4)^2 tokens)."""
     from representationlearning_amd import ops
     H = W = S // 4
-    C = 32
     dev = "cuda"
     x = torch.randn(B, H * W, C, device=dev).bfloat16()
     y = torch.randn(B, H * W, C, device=dev).bfloat16()
@@ -158,17 +159,16 @@ def measure_window_attention(B, S, iters=30):
     ms = _time_us(lambda: ops.winattn_fwd(x, y, sx, sy, omega, g, b, w, H, W, 2), iters, warm=0) / 1e3
     alg_bytes = 3 * B * H * W * C * 2                # read low, read high, write out (bf16)
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return dict(bound="hbm", kernel="winattn_fwd_kernel<bf16,Dims<32,2>,contiguous>", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=_profiled_traffic("winattn_fwd_kernel") if (B, S) == (16, 512) else None,
+    return dict(bound="hbm", kernel="winattn_fwd_kernel<bf16,Dims<%d,2>,contiguous>" % C, achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=_profiled_traffic("winattn_fwd_kernel") if (B, S, C) == (16, 512, 32) else None,
                 us_per_launch=round(ms * 1e3, 2), algorithmic_bytes=alg_bytes)
 
 
-def measure_mlp_conv(B, S, iters=20):
+def measure_mlp_conv(B, S, iters=20, C=128):
     """Average duration of the MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12} convolution (ONE implicit-GEMM launch, 17 distinct taps,
     128 -> 128 channels on the (S/4)^2 map): the largest single GEMM of the step, MFMA-bound."""
     from representationlearning_amd import _lib as L, nnf
     H = W = S // 4
-    C = 128
     dev = "cuda"
     torch.manual_seed(0)
     convs = [torch.nn.Conv2d(C, C, 1), torch.nn.Conv2d(C, C, 3, padding=6, dilation=6), torch.nn.Conv2d(C, C, 3, padding=12, dilation=12)]
@@ -188,7 +188,7 @@ def measure_mlp_conv(B, S, iters=20):
     ms = _time_us(launch, iters) / 1e3
     flops = 2.0 * B * H * W * C * C * 19             # the reference's three convolutions: 1 + 9 + 9 kernel positions
     tf = flops / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="conv_gather_kernel<bf16,256,128> (MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12}, 128->128 ch)",
+    return dict(bound="mfma", kernel="conv_gather_kernel<bf16,256,128> (MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12}, %d->%d ch)" % (C, C),
                 achieved=round(tf, 1), peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s", frac=round(tf * 1e12 / MFMA_BF16_PEAK, 4),
                 traffic=None, us_per_launch=round(ms * 1e3, 2), algorithmic_flops=flops,
                 executed_flops=2.0 * B * H * W * C * C * spec.ntaps)       # the three centre taps share one pixel: 17 taps run
@@ -317,10 +317,12 @@ def main():
     final_loss = float(loss)
 
     if rank == 0:
+        f0, s0, c0 = VARIANTS[args.variant]
+        flop_img = f0 * (args.size / s0) ** 2
         ms = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
         line = {
-            "metric": "train images/sec RSSFormer-Base 512x512 bf16", "value": round(value, 2), "unit": "images/s",
+            "metric": "train images/sec RSSFormer-%s %dx%d bf16" % (args.variant.capitalize(), args.size, args.size), "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
@@ -332,14 +334,14 @@ def main():
                        "collectives": None if world == 1 else ("direct RCCL on the compute stream" if trainer.comm is not None
                                                                else "torch.distributed (bucketed, hook-driven)")},
             "final_loss": round(final_loss, 5),
-            "whole_step_mfma_frac": round(value * FLOP_PER_IMG / (world * MFMA_BF16_PEAK), 5),
+            "whole_step_mfma_frac": round(value * flop_img / (world * MFMA_BF16_PEAK), 5),
         }
         # the kernel rooflines are per-GPU figures: rank 0 measures them at every N (the other ranks wait at the barrier below);
         # the CPU baseline is an N = 1 leg only
-        line["roofline"] = measure_window_attention(args.batch, args.size)
-        line["roofline_mfma"] = measure_mlp_conv(args.batch, args.size)
+        line["roofline"] = measure_window_attention(args.batch, args.size, C=c0)
+        line["roofline_mfma"] = measure_mlp_conv(args.batch, args.size, C=4 * c0)
         if world == 1:
-            line["roofline_kernels"] = measure_dominant_kernels(args.batch, args.size)
+            line["roofline_kernels"] = measure_dominant_kernels(args.batch, args.size, C=c0)
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

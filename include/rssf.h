@@ -343,6 +343,15 @@ int rssf_argmax_confusion(const void* scores, const int64_t* labels, int32_t* pr
  * zero-fills lower to) stopped taking effect after a device synchronisation between replays on ROCm 7.0 / MI355X; every buffer the
  * training step clears per replay (flat gradient, statistics pool) goes through this instead. */
 int rssf_zero_f32(float* p, int64_t n, void* stream);
+/* Small glue launches (csrc/small.hip).  out = a + b (+ c): the ONE epilogue bias of MlpDWBN's three summed convolutions
+ * (reference modules/ffn_block.py:226-228, 250-257); d0 (d1, d2) += src: their common bias gradient.  fp32, c / d1 / d2 may be null. */
+int rssf_vec_sum3(const float* a, const float* b, const float* c, float* out, int n, void* stream);
+int rssf_vec_add_to3(const float* src, float* d0, float* d1, float* d2, int n, void* stream);
+/* fp32 image [B,C,H,W] given by its element strides (NCHW or channels-last memory) -> channels-last [B,H,W,Cp] of `dtype`, channels
+ * zero-padded to the 16-byte vector (Cp = 8 bf16 / 4 fp32): the network input of HighResolutionNet.forward
+ * (_hrnet_rssformer.py:605-613) in one launch. */
+int rssf_image_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                       int dtype, void* stream);
 /* out[0] = sum g^2; `out` holds 1 + RSSF_SQNORM_BLOCKS floats (out[1..] = per-block partials, added in a fixed order:
  * bit-identical on every data-parallel replica, no float atomics). */
 #define RSSF_SQNORM_BLOCKS 2048

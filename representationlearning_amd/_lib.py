@@ -92,6 +92,9 @@ SIGNATURES = {
     "rssf_cgfl_loss_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rssf_argmax_confusion": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_zero_f32": (c_int, [c_void_p, c_int64, c_void_p]),
+    "rssf_vec_sum3": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "rssf_vec_add_to3": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "rssf_image_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_int64] * 4 + [c_int, c_void_p]),
     "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p, c_float, c_float,
                               c_float, c_int, c_void_p]),

@@ -93,6 +93,36 @@ class LayerNormTokens(torch.autograd.Function):
         return dx, nnf.grad_result(pg, dg, gd, rt), nnf.grad_result(pb, db, bd, rt)
 
 
+class LayerNormTokensRes(torch.autograd.Function):
+    """(LN(x), x): norm2 of GeneralTransformerBlock together with the skip that goes around the MLP (MTFM.py:109: x + mlp(norm2(x))).
+    The gradient of x is `ln_bwd(dz) + dskip`; as two autograd edges the sum was a separate element-wise pass over the token
+    tensor per block, here it is the addend of the LayerNorm-backward launch."""
+
+    @staticmethod
+    def forward(ctx, x, g, b):
+        x = x.contiguous()
+        y, st = ops.layernorm_fwd(x, g, b)
+        ctx.save_for_backward(x, st, g)
+        ctx.params = (g, b)
+        ctx.rt = nnf.current()
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, st, g = ctx.saved_tensors
+        pg, pb = ctx.params
+        rt = ctx.rt
+        if dy is None:
+            return dskip, None, None
+        (dg, gd), (db, bd) = nnf.grad_target(pg, rt), nnf.grad_target(pb, rt)
+        add = None if dskip is None else dskip.contiguous()
+        if add is not None and add.dtype != x.dtype:
+            add = add.to(x.dtype)
+        dx = ops.layernorm_bwd(dy.contiguous(), x, st, g, dg, db, dx_add=add)
+        return dx, nnf.grad_result(pg, dg, gd, rt), nnf.grad_result(pb, db, bd, rt)
+
+
 def _identity_ln(x):
     B, N, C = x.shape
     st = torch.tensor([0.0, 1.0], device=x.device, dtype=torch.float32).repeat(B * N, 1).contiguous()

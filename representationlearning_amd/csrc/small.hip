@@ -1,0 +1,78 @@
+// Small glue launches that replace chains of framework element-wise kernels on the training step's critical path:
+//   * the three biases of MlpDWBN's summed convolutions (ffn_block.py:226-228, 250-257: dw(u) + dw6(u) + dw12(u), all with bias)
+//     add up to ONE epilogue bias, and the bias gradient of the fused launch belongs to all three - was stack + sum (3 launches)
+//     forward and three adds backward per block,
+//   * the network input: fp32 NCHW (or channels-last) image -> channels-last activations of the compute dtype, channels zero-padded
+//     to the 16-byte vector width (3 -> 8 bf16 / 4 fp32) - was dtype cast + layout copy + fill + pad copy, and the pad again in
+//     the backward pass of the stem (HighResolutionNet.forward, _hrnet_rssformer.py:605-613).
+#include "common.hip.h"
+using namespace rssf;
+
+namespace {
+
+__global__ void __launch_bounds__(256) vec_sum3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                       float* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (a[i] + b[i]) + (c ? c[i] : 0.f);
+}
+
+__global__ void __launch_bounds__(256) vec_add_to3_kernel(const float* __restrict__ src, float* __restrict__ d0, float* __restrict__ d1,
+                                                          float* __restrict__ d2, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = src[i];
+  d0[i] += v;
+  if (d1) d1[i] += v;
+  if (d2) d2[i] += v;
+}
+
+// one thread per output pixel: C strided reads (coalesced across the threads of a row for NCHW sources), one 16-byte store
+template <typename T>
+__global__ void __launch_bounds__(256) image_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t npix, int HW, int W,
+                                                            int C, int64_t sb, int64_t sc, int64_t sh, int64_t sw) {
+  constexpr int V = Vec<T>::N;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  const int64_t b = i / HW;
+  const int r = (int)(i - b * HW), y = r / W, x = r - y * W;
+  const float* p = src + b * sb + y * sh + x * sw;
+  float v[V];
+#pragma unroll
+  for (int c = 0; c < V; ++c) v[c] = c < C ? p[c * sc] : 0.f;
+  Vec<T> o;
+  o.set_all(v);
+  o.store(dst + i * V);
+}
+
+}  // namespace
+
+extern "C" int rssf_vec_sum3(const float* a, const float* b, const float* c, float* out, int n, void* stream) {
+  RSSF_REQUIRE(a && b && out && n > 0, "vec_sum3: bad arguments");
+  vec_sum3_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(a, b, c, out, n);
+  return check_launch("vec_sum3");
+}
+
+extern "C" int rssf_vec_add_to3(const float* src, float* d0, float* d1, float* d2, int n, void* stream) {
+  RSSF_REQUIRE(src && d0 && n > 0, "vec_add_to3: bad arguments");
+  vec_add_to3_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(src, d0, d1, d2, n);
+  return check_launch("vec_add_to3");
+}
+
+extern "C" int rssf_image_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                                  int dtype, void* stream) {
+  RSSF_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "image_to_nhwc: bad arguments");
+  const int64_t npix = (int64_t)B * H * W;
+  const unsigned blocks = (unsigned)((npix + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_BF16) {
+    RSSF_REQUIRE(C >= 1 && C <= 8, "image_to_nhwc: 1..8 channels fit the bf16 vector (got %d)", C);
+    image_to_nhwc_kernel<bf16_t><<<blocks, 256, 0, st>>>(src, reinterpret_cast<bf16_t*>(dst), npix, H * W, W, C, sb, sc, sh, sw);
+  } else if (dtype == RSSF_F32) {
+    RSSF_REQUIRE(C >= 1 && C <= 4, "image_to_nhwc: 1..4 channels fit the fp32 vector (got %d)", C);
+    image_to_nhwc_kernel<float><<<blocks, 256, 0, st>>>(src, reinterpret_cast<float*>(dst), npix, H * W, W, C, sb, sc, sh, sw);
+  } else {
+    set_error("image_to_nhwc: unsupported dtype %d", dtype);
+    return RSSF_ERR_UNSUPPORTED;
+  }
+  return check_launch("image_to_nhwc");
+}

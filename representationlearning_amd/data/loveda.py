@@ -184,3 +184,94 @@ class DeviceLoader:
             params[:, 0] = np.arange(len(items))
             img, lab = aug.apply(params)
             yield img, dict(cls=lab, fname=[it[1]["fname"] for it in items])
+
+
+class SyntheticTiles:
+    """Stand-in for a LoveDA folder when no dataset is on disk (there is none in this build's environment): `n` procedurally drawn
+    uint8 tiles with blocky raw label ids 0..classes (0 = no-data, like LoveDA's masks), same item format as `LoveDA`.  The tiles go
+    through exactly the path real tiles take: upload as uint8, HBM-resident, augmented by `rssf_input_pipeline`."""
+
+    def __init__(self, n=32, size=1024, classes=6, seed=2333, block=16):
+        self.n, self.size, self.classes, self.seed, self.block = int(n), int(size), int(classes), int(seed), int(block)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        rng = np.random.default_rng(self.seed * 1000003 + idx)
+        S, b = self.size, self.block
+        image = rng.integers(0, 256, (S, S, 3), dtype=np.uint8)
+        m = rng.integers(0, self.classes + 1, ((S + b - 1) // b, (S + b - 1) // b), dtype=np.uint8)
+        mask = np.ascontiguousarray(np.repeat(np.repeat(m, b, 0), b, 1)[:S, :S])
+        return image, dict(cls=mask.astype(np.int64) - 1, raw_mask=mask, fname="synthetic%05d.png" % idx)
+
+
+def epoch_shard(n_tiles, epoch, rank, world, batch_size, seed=2333):
+    """Tile order of one rank for one epoch: ONE permutation per epoch (same seed on every rank), rank r takes every world-th tile,
+    truncated to whole batches (drop_last) - the ranks' shares are disjoint and of equal length."""
+    perm = np.random.default_rng(seed + epoch).permutation(n_tiles)
+    return perm[rank::world][:(n_tiles // world // batch_size) * batch_size]
+
+
+class LoveDALoader:
+    """Training loader (reference `LoveDALoader` with `training=True`, data/loveda.py:97-117: StepDistributedSampler - every rank walks
+    its own 1/world share of one permutation per epoch - batch_size per rank, drop_last; transforms configs/base/loveda.py:18-36).
+
+    MI355X-first: decoded tiles are HBM-RESIDENT uint8 (a 1024 x 1024 x 3 tile is 3 MB; the whole LoveDA training split is 7.9 GB
+    of the 288), uploaded the first time the sampler asks for them (a thread pool decodes the files of a batch) and never again; the
+    whole transform chain of a batch is ONE `rssf_input_pipeline` launch (`DeviceAugment`).  The reference decodes and augments every
+    tile on 2 CPU workers per GPU in every epoch.  Iterating yields (img [B,3,crop,crop] channels-last, dict(cls=int64 labels)) for
+    one epoch; `epoch` advances by itself, so `for ep in range(E): for img, tgt in loader:` reshuffles like the reference."""
+
+    def __init__(self, dataset, batch_size=8, rank=0, world=1, crop=512, p_oneof=0.75, shift_scale_rotate=None, dtype=torch.float32,
+                 device="cuda", seed=2333, mean=LOVEDA_MEAN, std=LOVEDA_STD, max_pixel_value=1.0, decode_threads=8):
+        if len(dataset) < batch_size * world:
+            raise ValueError("LoveDALoader: %d tiles cannot fill one batch of %d on each of %d ranks" % (len(dataset), batch_size, world))
+        self.ds, self.bs, self.rank, self.world, self.seed = dataset, int(batch_size), int(rank), int(world), int(seed)
+        self.device, self.epoch, self.threads = device, 0, int(decode_threads)
+        img0, t0 = dataset[0]
+        H, W = img0.shape[:2]
+        self.store = torch.empty(len(dataset), H, W, 3, device=device, dtype=torch.uint8)
+        self.mstore = torch.empty(len(dataset), H, W, device=device, dtype=torch.uint8)
+        self.have = np.zeros(len(dataset), dtype=bool)
+        self._put(0, img0, t0)
+        self.aug = DeviceAugment(self.store, self.mstore, crop=crop, p_oneof=p_oneof, mean=mean, std=std, max_pixel_value=max_pixel_value,
+                                 dtype=dtype, seed=seed + 7919 * rank, shift_scale_rotate=shift_scale_rotate)
+
+    def _put(self, i, image, tgt):
+        if tuple(image.shape) != tuple(self.store.shape[1:]) or tgt["raw_mask"] is None:
+            raise ValueError("LoveDALoader: tile %d is %s (labelled: %s); the resident store holds labelled %s tiles"
+                             % (i, tuple(image.shape), tgt["raw_mask"] is not None, tuple(self.store.shape[1:])))
+        self.store[i].copy_(torch.from_numpy(np.ascontiguousarray(image)))
+        self.mstore[i].copy_(torch.from_numpy(np.ascontiguousarray(tgt["raw_mask"])))
+        self.have[i] = True
+
+    def __len__(self):
+        return len(self.ds) // self.world // self.bs
+
+    def indices(self, epoch):
+        """This rank's tile order for one epoch: ranks share ONE permutation (seeded by the epoch) and take every world-th tile."""
+        return epoch_shard(len(self.ds), epoch, self.rank, self.world, self.bs, self.seed)
+
+    def resident_fraction(self):
+        return float(self.have.mean())
+
+    def __iter__(self):
+        idx = self.indices(self.epoch)
+        self.epoch += 1
+        for b in range(len(self)):
+            tiles = idx[b * self.bs:(b + 1) * self.bs]
+            missing = [int(i) for i in tiles if not self.have[i]]
+            if missing:
+                if self.threads > 1 and len(missing) > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(min(self.threads, len(missing))) as ex:
+                        items = list(ex.map(self.ds.__getitem__, missing))
+                else:
+                    items = [self.ds[i] for i in missing]
+                for i, (image, tgt) in zip(missing, items):
+                    self._put(i, image, tgt)
+            params = self.aug.draw(self.bs)
+            params[:, 0] = tiles                        # the sampler, not RandomCrop's stream, picks the tiles
+            img, lab = self.aug.apply(params, self.aug.draw_affine(self.bs))
+            yield img, dict(cls=lab)

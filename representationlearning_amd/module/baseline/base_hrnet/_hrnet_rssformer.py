@@ -409,9 +409,14 @@ class HighResolutionNet(nn.Module):
         return nn.Sequential(*mods), num_inchannels
 
     def forward(self, x):
-        if torch.is_autocast_enabled():          # activation dtype policy: bf16 activations, fp32 parameters/statistics
-            x = x.to(torch.get_autocast_dtype("cuda"))
-        x = x.contiguous(memory_format=torch.channels_last)
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        if x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and dt in (torch.float32, torch.bfloat16) \
+                and x.shape[1] <= (8 if dt == torch.bfloat16 else 4):
+            # activation dtype policy (bf16 activations, fp32 parameters / statistics), channels-last layout and the channel padding
+            # of the first convolution in one launch
+            x = nnf.image_to_channels_last(x, dt)
+        else:
+            x = x.to(dt).contiguous(memory_format=torch.channels_last)
         l1 = nnf.bwd_stats_link()                 # bn1's backward statistics ride on conv2's data-gradient launch
         x = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, stats_out=l1)
         x = nnf.conv_bn_act(x, self.conv2, self.bn2, nnf.ACT_RELU, stats_in=l1)

@@ -45,8 +45,9 @@ class GeneralTransformerBlock(nn.Module):
             yt = yt.to(xt.dtype)
         x1 = AG.GatedWindowCrossAttention.apply(xt, yt, self.norm1.weight, self.norm1.bias, *self.attn.gate_params(),
                                                 *self.attn.attn.proj_params(), H, W, self.num_heads)
-        z = AG.LayerNormTokens.apply(x1, self.norm2.weight, self.norm2.bias)
-        x2 = self.mlp(z, H, W, residual=x1)          # x1 + Mlp(LN2(x1)), residual fused into the last BN/GELU pass
+        # LN2 and the skip around the MLP as one node: the two gradients of x1 meet in the LayerNorm-backward launch
+        z, skip = AG.LayerNormTokensRes.apply(x1, self.norm2.weight, self.norm2.bias)
+        x2 = self.mlp(z, H, W, residual=skip)        # x1 + Mlp(LN2(x1)), residual fused into the last BN/GELU pass
         return x2.reshape(B, H, W, C).permute(0, 3, 1, 2)
 
     def extra_repr(self):

@@ -756,9 +756,13 @@ class _ConvBNAct(torch.autograd.Function):
         xh = _nhwc(x)
         dev = x.device
         bias = None
-        if nbias:
-            bias = biases[0] if nbias == 1 else torch.stack(biases).sum(0)      # summed convs: biases add
-            bias = bias.float().contiguous()
+        if nbias == 1:
+            bias = biases[0].float().contiguous()
+        elif nbias:                                    # summed convs: their biases add up to ONE epilogue bias (one launch)
+            bs = [b if (b.dtype == torch.float32 and b.is_contiguous()) else b.float().contiguous() for b in biases]
+            bias = torch.empty_like(bs[0])
+            L.check(L.load().rssf_vec_sum3(L.ptr(bs[0]), L.ptr(bs[1]), L.ptr(bs[2]) if nbias > 2 else None, L.ptr(bias), bias.numel(),
+                                           L.stream()), "rssf_vec_sum3")
         C = spec.cout
         rt = current()
         stats = _zeros(BN_SLOTS * 2 * C, dev, rt) if training else None
@@ -853,9 +857,11 @@ class _ConvBNAct(torch.autograd.Function):
             else:
                 db = _zeros(C, raw.device, rt) if nbias else None
                 _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt, bn=bn, xpre=xpre)
-                for b in p_biases:      # every summed conv's bias sees the same gradient
-                    tb, direct = grad_target(b, rt)
-                    tb += db
+                tbs = [grad_target(b, rt) for b in p_biases]      # every summed conv's bias sees the same gradient: one launch
+                if tbs:
+                    d = [t[0] for t in tbs] + [None, None]
+                    L.check(lib.rssf_vec_add_to3(L.ptr(db), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), C, L.stream()), "rssf_vec_add_to3")
+                for b, (tb, direct) in zip(p_biases, tbs):
                     gbs.append(grad_result(b, tb, direct, rt))
             return gbs
 
@@ -1213,6 +1219,21 @@ def head_upsample_softmax(logits, size, want_probs=True, want_pred=False):
     L.check(L.load().rssf_head_upsample_softmax(L.ptr(lh), L.ptr(probs), L.ptr(pred), B, IH, IW, OH, OW, K, L.dtype_code(lh), L.stream()),
             "rssf_head_upsample_softmax")
     return (None if probs is None else _nchw(probs)), pred
+
+
+def image_to_channels_last(x, dtype):
+    """Network input: fp32 image [B,C,H,W] (NCHW or channels-last memory, C <= 8 / 4) -> logical [B,Cp,H,W] tensor of `dtype` in
+    channels-last memory with the channels zero-padded to the 16-byte vector width (Cp = 8 bf16 / 4 fp32), in ONE launch - the
+    cast, the layout copy and the padding the first convolution needs (forward and weight gradient).  No autograd: the image
+    carries no gradient."""
+    L.require_gpu(x)
+    B, C, H, W = x.shape
+    cp = 8 if dtype == torch.bfloat16 else 4
+    out = torch.empty(B, H, W, cp, device=x.device, dtype=dtype)
+    sb, sc, sh, sw = x.stride()
+    L.check(L.load().rssf_image_to_nhwc(L.ptr(x), L.ptr(out), B, C, H, W, sb, sc, sh, sw, L.dtype_code(out), L.stream()),
+            "rssf_image_to_nhwc")
+    return _nchw(out)
 
 
 def max_pool_3x3_s2(x):

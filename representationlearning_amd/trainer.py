@@ -79,7 +79,8 @@ class GradBuckets:
         for b, mem in enumerate(self.members):
             for i in mem:
                 self.bucket_of[i] = b
-        self.pending = [len(m) for m in self.members]
+        self.live = [len(m) for m in self.members]      # parameters per bucket that DO receive a gradient (see set_live)
+        self.pending = list(self.live)
         self.handles = []
         self.launched = [False] * len(self.members)
         self.index_of = {id(p): i for i, p in enumerate(flat.params)}
@@ -123,9 +124,16 @@ class GradBuckets:
         else:
             self.handles.append(self.comm.allreduce_bucket_async(g))
 
+    def set_live(self, live_ids):
+        """Parameters the loss does not reach (RSSFormer's `headaux`) never fire their hook: counted as pending they kept their
+        bucket - bucket 0, head and neck, the first gradients to be ready - waiting until finish(), i.e. without any overlap
+        (ADVICE r2).  Called before the first backward with the ids of the reachable leaves."""
+        self.live = [sum(1 for i in m if id(self.flat.params[i]) in live_ids) for m in self.members]
+        self.pending = list(self.live)
+
     def begin(self):
         self.compute_stream = torch.cuda.current_stream() if self.flat.grad.is_cuda else None
-        self.pending = [len(m) for m in self.members]
+        self.pending = list(self.live)
         self.launched = [False] * len(self.members)
         self.handles = []
 
@@ -171,6 +179,7 @@ class Trainer:
                  bf16=True, sync_bn=True, nbuckets=6, use_graph=True, deterministic=None):
         self._replayed = 0
         self._replayed_flushed = 0
+        self._steps = 0                  # steps taken by THIS object (`it` may start above 0: a resumed run)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         # RSSF_FORCE_DP=1 exercises the collective plumbing (buckets, SyncBN exchanges) even on one rank (tests)
         dp = self.world > 1 or (dist.is_initialized() and os.environ.get("RSSF_FORCE_DP") == "1")
@@ -250,6 +259,8 @@ class Trainer:
                 if self.sgd_ranges is None:
                     live = reachable_parameters(loss)
                     self.sgd_ranges = self.flat.ranges_of([i for i, p in enumerate(self.flat.params) if id(p) in live])
+                    if self.buckets is not None:
+                        self.buckets.set_live(live)
                 loss.backward()
             finally:
                 nnf.step_end()
@@ -296,7 +307,7 @@ class Trainer:
         """One optimisation step; returns the (detached, on-device) loss."""
         hp = self.hp
         self.lr_dev.fill_(poly_lr(hp["base_lr"], hp["power"], hp["max_iters"], self.it))
-        if self.use_graph and self.it >= self.graph_warmup:
+        if self.use_graph and self._steps >= self.graph_warmup:
             if self.graph is None and not self._capture(img, target):
                 loss = self._eager_step(img, target)
             elif not self._fits_static(img, target):
@@ -323,7 +334,25 @@ class Trainer:
         else:
             loss = self._eager_step(img, target)
         self.it += 1
+        self._steps += 1
         return loss
+
+    def state_dict(self):
+        """What a resumed run needs besides the model's own state_dict: the step counter (poly LR) and the momentum buffer, keyed
+        by parameter name so that it survives a different flat layout."""
+        names = {id(p): k for k, p in self.model.named_parameters()}
+        mom = {}
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            mom[names[id(p)]] = self.flat.mom[o:o + p.numel()].view_as(p).detach().cpu().clone()
+        return dict(it=self.it, momentum=mom)
+
+    def load_state_dict(self, sd):
+        names = {id(p): k for k, p in self.model.named_parameters()}
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            m = sd["momentum"].get(names[id(p)])
+            if m is not None:
+                self.flat.mom[o:o + p.numel()].view_as(p).copy_(m)
+        self.it = int(sd["it"])
 
     def close(self):
         """Destroy the RCCL communicators (before torch.distributed's process group goes away)."""

@@ -105,3 +105,49 @@ def test_shift_scale_rotate_draws():
     assert scale_inv.min() > 1 / 1.2 - 1e-9 and scale_inv.max() < 1 / 0.8 + 1e-9
     xb, yb = aug(8)
     assert xb.shape == (8, 3, 32, 32) and int(yb.min()) >= -1
+
+
+def test_training_loader_feeds_resident_tiles_through_the_device_pipeline():
+    """LoveDALoader (train.py's data path): the sampler's tiles - not random ones - are cropped / flipped / normalised by ONE
+    rssf_input_pipeline launch per batch out of the HBM-resident store; tiles are uploaded once; an epoch has n/world/batch batches;
+    the result equals the oracle's transform chain on the same tile with the same drawn parameters (bit-exact, as above)."""
+    from representationlearning_amd.data.loveda import LoveDALoader, SyntheticTiles, epoch_shard
+    ds = SyntheticTiles(12, 96, classes=6)
+    ld = LoveDALoader(ds, batch_size=4, rank=1, world=2, crop=64, dtype=torch.float32, seed=5, decode_threads=2)
+    assert len(ld) == 1
+    seen = []
+    rng_state = ld.aug.rng.bit_generator.state
+    for img, tgt in ld:
+        assert img.shape == (4, 3, 64, 64) and tgt["cls"].shape == (4, 64, 64) and tgt["cls"].dtype == torch.int64
+        seen.append((img.clone(), tgt["cls"].clone()))
+    assert ld.epoch == 1 and 0 < ld.resident_fraction() <= 5 / 12 + 1e-9
+    tiles = epoch_shard(12, 0, 1, 2, 4, 5)
+    ld.aug.rng.bit_generator.state = rng_state            # redraw the same parameters
+    params = ld.aug.draw(4)
+    params[:, 0] = tiles
+    aff = ld.aug.draw_affine(4)
+    from representationlearning_amd.data import LOVEDA_MEAN, LOVEDA_STD
+    imgs = np.stack([ds[i][0] for i in range(12)])
+    msks = np.stack([ds[i][1]["raw_mask"] for i in range(12)])
+    ri, rl = O.pipeline(imgs, msks, params, 64, LOVEDA_MEAN, LOVEDA_STD, affine=aff)
+    assert torch.equal(seen[0][0].cpu(), torch.from_numpy(ri).permute(0, 3, 1, 2))
+    assert np.array_equal(seen[0][1].cpu().numpy(), rl)
+
+
+def test_train_py_runs_saves_and_resumes(tmp_path):
+    """train.py end to end on synthetic tiles: iterates the loader, logs, evaluates, writes model-<it>.pth (reference keys) +
+    trainer-<it>.pth, and a second invocation resumes at that iteration with the momentum restored."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train.py"), "--model_dir", str(tmp_path), "--batch", "2", "--size", "64", "--synthetic_tiles", "4",
+           "--config_path", "baseline.hrnetw18", "train.log_interval_step", "1", "train.eval_interval_epoch", "1"]
+    r = subprocess.run(cmd + ["--iters", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "iter 5" in r.stdout and "mIoU" in r.stdout and os.path.exists(tmp_path / "model-5.pth")
+    sd = torch.load(tmp_path / "model-5.pth")
+    assert "backbone.hrnet.stage2.0.transformer.attn.attn.q_proj.weight" in sd
+    ts = torch.load(tmp_path / "trainer-5.pth")
+    assert ts["it"] == 5 and float(ts["momentum"]["head.0.weight"].abs().sum()) > 0
+    r = subprocess.run(cmd + ["--iters", "7"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "resumed from" in r.stdout and "iter 6" in r.stdout and "iter 5 " not in r.stdout and os.path.exists(tmp_path / "model-7.pth")

@@ -65,9 +65,10 @@ def test_full_model_fp32(variant, B, S, tag):
     assert np.abs(hist - g["eval_argmax_hist"]).sum() <= 0.005 * hist.sum()
 
 
-def test_large_forward_fp32_and_step_bf16():
-    """Large (w48): fp32 forward vs golden; the fused attention backward for C=48 exists in bf16 only (LDS budget),
-    so the training step is checked in bf16 against the golden loss with the bf16 tolerance."""
+def test_large_step_bf16_small():
+    """Large (w48) bf16 training step at the small golden size: loss in the ballpark of the reference's fp32 golden and finite
+    gradients everywhere (the fp32 forward AND backward of Large are pinned by test_large_fp32_vs_reference_1x256; B = 1 at 64 x 64
+    leaves the deepest branch 4 samples per BatchNorm channel, so bf16 noise is large here by construction)."""
     g = golden("model_large_1x64")
     m = build("large").eval()
     x = seeded_input((1, 3, 64, 64), 7).to(DEV)
@@ -76,7 +77,6 @@ def test_large_forward_fp32_and_step_bf16():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss = m(x, dict(cls=y))["fc_loss"]
     loss.backward()
-    # B=1 at 64x64: the deepest branch normalises over 4 samples -> bf16 noise is large here; ballpark check only
     assert abs(float(loss.detach()) - float(g["loss"])) < 0.1 * abs(float(g["loss"]))
     for k, p in m.named_parameters():
         if not k.startswith("headaux"):

@@ -4,6 +4,7 @@ import os
 import re
 
 import pytest
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -228,3 +229,40 @@ def test_padblock_and_local_permute_methods_match_oracle_partition():
         assert torch.equal(back, t) and torch.equal(O.window_merge(ref, geom), t)
         n_, slot = perm.window_of(B - 1, Hp - 1, Wp - 1, Hp, Wp)
         assert n_ == w.shape[1] - 1 and slot == 48
+
+
+def test_training_loader_epoch_shards_are_disjoint_and_reshuffled():
+    """data/loveda.py:97-117 semantics (StepDistributedSampler + drop_last): per epoch ONE permutation, every rank a disjoint share of
+    equal length in whole batches; another epoch, another order; the same (epoch, seed) on every rank."""
+    from representationlearning_amd.data.loveda import epoch_shard
+    n, world, bs = 103, 4, 8
+    for epoch in (0, 1):
+        shards = [epoch_shard(n, epoch, r, world, bs) for r in range(world)]
+        assert all(len(s) == (n // world // bs) * bs for s in shards)
+        flat = np.concatenate(shards)
+        assert len(set(flat.tolist())) == len(flat)                       # disjoint
+        assert flat.min() >= 0 and flat.max() < n
+    assert not np.array_equal(epoch_shard(n, 0, 0, world, bs), epoch_shard(n, 1, 0, world, bs))
+    assert np.array_equal(epoch_shard(n, 3, 2, world, bs), epoch_shard(n, 3, 2, world, bs))
+    assert len(epoch_shard(16, 0, 0, 1, 16)) == 16
+
+
+def test_synthetic_tiles_look_like_loveda_items():
+    from representationlearning_amd.data.loveda import SyntheticTiles
+    ds = SyntheticTiles(3, 64, classes=6)
+    img, tgt = ds[2]
+    img2, tgt2 = ds[2]
+    assert img.dtype == np.uint8 and img.shape == (64, 64, 3) and np.array_equal(img, img2)
+    assert tgt["raw_mask"].dtype == np.uint8 and tgt["raw_mask"].max() <= 6 and tgt["cls"].min() >= -1
+    assert np.array_equal(tgt["cls"], tgt["raw_mask"].astype(np.int64) - 1)
+
+
+def test_train_checkpoint_discovery(tmp_path):
+    import importlib
+    train = importlib.import_module("train")
+    assert train.latest_checkpoint(str(tmp_path)) is None
+    for k in (5, 40, 12):
+        (tmp_path / ("model-%d.pth" % k)).write_bytes(b"x")
+    (tmp_path / "trainer-40.pth").write_bytes(b"x")
+    step, mp, tp = train.latest_checkpoint(str(tmp_path))
+    assert step == 40 and mp.endswith("model-40.pth") and tp.endswith("trainer-40.pth")

@@ -2,8 +2,12 @@
 """train.py — same surface as the reference's RSSFormer-TIP2023/train.py (:64-80): `seed_torch`, the evaluate callback
 and `python train.py --config_path=baseline.hrnetw32 --model_dir=... [key value ...]` launched one process per GPU
 (`python -m torch.distributed.run --nproc-per-node N train.py ...`).  The external `ever` trainer is replaced by
-representationlearning_amd.trainer (RCCL data parallel, bf16, fused clip+SGD).  No dataset ships with this build:
-without --data_dir it trains on the synthetic LoveDA-shaped tiles of SURVEY.md §8d."""
+representationlearning_amd.trainer (RCCL data parallel, bf16, fused clip+SGD).  The loop iterates `LoveDALoader`
+(data/loveda.py:97-117 semantics: one permutation per epoch shared by the ranks, every rank its 1/world share, drop_last) over
+HBM-resident uint8 tiles augmented on the GPU, evaluates every `train.eval_interval_epoch` epochs, saves every
+`train.save_ckpt_interval_epoch` epochs and at the end, and resumes from the newest checkpoint in --model_dir
+(configs/base/loveda.py:102-111).  No dataset ships with this build: when the config's LoveDA folders do not exist the same
+loaders run over procedurally drawn uint8 tiles."""
 import argparse
 import os
 import random
@@ -47,19 +51,84 @@ def evaluate_cls_fn(model, batches, classes, logger=print, tta_scales=None, viz_
     return out
 
 
+def build_loaders(cfg, args, rank, world, dtype):
+    """(train loader, evaluation loader factory, description).  `--data_dir D` re-roots the config's relative LoveDA folders
+    (configs/base/loveda.py:6-66: ./LoveDA/Train/{Urban,Rural}/images_png ...) under D; when the training folders do not exist - no
+    dataset ships with this build - the same loaders run over procedurally drawn uint8 tiles (data/loveda.py::SyntheticTiles)."""
+    from representationlearning_amd.data.loveda import DeviceLoader, LoveDA, LoveDALoader, SyntheticTiles
+    tp, ep = cfg.data.train.params, cfg.data.test.params
+    root = args.data_dir
+
+    def rooted(dirs):
+        dirs = dirs if isinstance(dirs, (list, tuple)) else [dirs]
+        return [os.path.join(root, d[2:] if d.startswith("./") else d) if root else d for d in dirs]
+
+    timg, tmask = rooted(tp.image_dir), rooted(tp.mask_dir)
+    classes = cfg.model.params.classes
+    if all(os.path.isdir(d) for d in timg):
+        train_ds, what = LoveDA(timg, tmask), "LoveDA tiles under %s" % ", ".join(timg)
+        eimg, emask = rooted(ep.image_dir), rooted(ep.mask_dir)
+        eval_ds = LoveDA(eimg, emask) if all(os.path.isdir(d) for d in eimg) else None
+    else:
+        if root:
+            raise SystemExit("train.py: --data_dir %s holds none of %s" % (root, ", ".join(tp.image_dir)))
+        n = max(args.synthetic_tiles, args.batch * world)
+        train_ds = SyntheticTiles(n, 2 * args.size, classes=classes - 1 if classes == 7 else classes, seed=2333)
+        eval_ds = SyntheticTiles(max(4, ep.batch_size), args.size, classes=classes - 1 if classes == 7 else classes, seed=4666)
+        what = "%d synthetic %dx%d uint8 tiles (no LoveDA folders at %s)" % (n, 2 * args.size, 2 * args.size, ", ".join(timg))
+    loader = LoveDALoader(train_ds, batch_size=args.batch, rank=rank, world=world, crop=args.size, p_oneof=tp.get("p_oneof", 0.75),
+                          shift_scale_rotate=tp.get("shift_scale_rotate"), dtype=dtype, seed=2333)
+
+    def eval_batches():
+        if eval_ds is None:
+            return []
+        return ((img, tgt["cls"]) for img, tgt in DeviceLoader(eval_ds, batch_size=ep.batch_size, dtype=dtype))
+    return loader, eval_batches, what
+
+
+def latest_checkpoint(model_dir):
+    """(step, model path, trainer-state path | None) of the newest `model-<step>.pth` in model_dir, or None."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(model_dir, "model-*.pth")):
+        m = re.search(r"model-(\d+)\.pth$", f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            t = os.path.join(model_dir, "trainer-%s.pth" % m.group(1))
+            best = (int(m.group(1)), f, t if os.path.exists(t) else None)
+    return best
+
+
+def save_checkpoint(model_dir, model, trainer):
+    """`model-<step>.pth` = the model's state_dict with the reference's keys (what eval.py / predict.py load, eval.py:37-38);
+    `trainer-<step>.pth` = momentum + step counter, so that a resumed run continues the poly schedule and the momentum."""
+    from representationlearning_amd.trainer import flush_bn_counters
+    os.makedirs(model_dir, exist_ok=True)
+    flush_bn_counters(trainer)
+    path = os.path.join(model_dir, "model-%d.pth" % trainer.it)
+    torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)
+    torch.save(trainer.state_dict(), os.path.join(model_dir, "trainer-%d.pth" % trainer.it))
+    return path
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config_path", default="baseline.hrnetw32")
     ap.add_argument("--model_dir", default="./log/rssformer")
-    ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (reference: 8, configs/base/loveda.py:39)")
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--data_dir", default=None, help="root of the LoveDA folders the config names (./LoveDA/Train/...); "
+                                                     "default: the config's paths as they are, synthetic tiles if they do not exist")
+    ap.add_argument("--iters", type=int, default=None, help="stop after this many iterations (default: train.num_iters of the config)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: data.train.params.batch_size = 8)")
+    ap.add_argument("--size", type=int, default=None, help="crop size (default: data.train.params.crop = 512)")
+    ap.add_argument("--synthetic_tiles", type=int, default=32, help="number of synthetic tiles when no dataset is on disk")
+    ap.add_argument("--no_resume", action="store_true", help="ignore checkpoints already in --model_dir")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("overrides", nargs="*", help="`a.b.c value` pairs (scripts/train.sh:12-14)")
     args = ap.parse_args()
 
-    from representationlearning_amd import _lib, nnf
-    from representationlearning_amd.configs import config_by_name, synthetic_batch
+    import time
+    from representationlearning_amd import _lib
+    from representationlearning_amd.configs import config_by_name
     from representationlearning_amd.core import registry
     from representationlearning_amd.core.config import AttrDict, apply_overrides
     from representationlearning_amd.trainer import Trainer, init_distributed, shutdown_distributed
@@ -68,25 +137,70 @@ def main():
     seed_torch(2333)
     registry.register_all()
     cfg = apply_overrides(AttrDict.wrap(config_by_name(args.config_path)), args.overrides)
-    model = registry.MODEL[cfg.model.type](cfg.model.params).cuda()
     tr = cfg.train
+    args.batch = args.batch or cfg.data.train.params.batch_size
+    args.size = args.size or cfg.data.train.params.get("crop", 512)
+    num_iters = args.iters if args.iters is not None else tr.num_iters
+    log = print if rank == 0 else (lambda *a, **k: None)
+    model = registry.MODEL[cfg.model.type](cfg.model.params).cuda()
+    resume = None if args.no_resume else latest_checkpoint(args.model_dir)
+    if resume is not None:           # the model BEFORE the trainer re-seats its parameters into the flat buffer
+        sd = torch.load(resume[1], map_location="cpu")
+        model.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()})
     trainer = Trainer(model, base_lr=cfg.learning_rate.params.base_lr, momentum=cfg.optimizer.params.momentum,
                       weight_decay=cfg.optimizer.params.weight_decay, max_norm=cfg.optimizer.grad_clip.max_norm,
                       power=cfg.learning_rate.params.power, max_iters=cfg.learning_rate.params.max_iters, bf16=not args.fp32,
                       sync_bn=tr.sync_bn)
-    img, lab = synthetic_batch(args.batch, args.size, classes=cfg.model.params.classes, seed=2333 + rank)
-    for it in range(args.iters):
-        loss = trainer.step(img, dict(cls=lab))
-        if rank == 0 and (it % tr.log_interval_step == 0 or it == args.iters - 1):
-            print("iter %d  fc_loss %.5f" % (it, float(loss)), flush=True)
+    if resume is not None:
+        if resume[2] is not None:
+            trainer.load_state_dict(torch.load(resume[2], map_location="cpu"))
+        else:
+            trainer.it = resume[0]
+        log("resumed from %s (iteration %d)" % (resume[1], trainer.it))
+    loader, eval_batches, what = build_loaders(cfg, args, rank, world, torch.float32)
+    steps_per_epoch = len(loader)
+    log("data: %s; %d tiles, %d iterations per epoch on each of %d rank(s), batch %d x %dx%d"
+        % (what, len(loader.ds), steps_per_epoch, world, args.batch, args.size, args.size))
+    classes = cfg.model.params.classes
+
+    def evaluate():
+        if rank == 0:
+            evaluate_cls_fn(model, eval_batches(), classes, logger=log)
+
+    loader.epoch = trainer.it // steps_per_epoch
+    t_load = t_step = 0.0
+    n_timed = 0
+    done = trainer.it >= num_iters
+    while not done:
+        epoch = loader.epoch
+        t0 = time.perf_counter()
+        for img, target in loader:
+            t1 = time.perf_counter()
+            loss = trainer.step(img, target)
+            it = trainer.it                       # iterations finished
+            if it % tr.log_interval_step == 0 or it == num_iters or it == 1:
+                lv = float(loss)                  # the only host sync of the loop
+                t2 = time.perf_counter()
+                t_load, t_step, n_timed = t_load + (t1 - t0), t_step + (t2 - t1), n_timed + 1
+                log("iter %d  epoch %d  fc_loss %.5f  lr %.6f" % (it, epoch, lv, float(trainer.lr_dev)), flush=True)
+            if it >= num_iters:
+                done = True
+                break
+            t0 = time.perf_counter()
+        if done:
+            break
+        ep_done = loader.epoch
+        if tr.get("eval_per_epoch", True) and tr.eval_interval_epoch and ep_done % tr.eval_interval_epoch == 0:
+            evaluate()
+        if rank == 0 and tr.save_ckpt_interval_epoch and ep_done % tr.save_ckpt_interval_epoch == 0:
+            log("saved", save_checkpoint(args.model_dir, model, trainer))
+    if n_timed:
+        log("host time per logged iteration: loader (draw + decode-if-new + one rssf_input_pipeline launch) %.2f ms, step enqueue+sync %.2f ms; "
+            "resident tiles %.0f %%" % (1e3 * t_load / n_timed, 1e3 * t_step / n_timed, 100 * loader.resident_fraction()))
     if rank == 0:
-        os.makedirs(args.model_dir, exist_ok=True)
-        from representationlearning_amd.trainer import flush_bn_counters
-        flush_bn_counters(trainer)
-        path = os.path.join(args.model_dir, "model-%d.pth" % trainer.it)
-        torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)   # reference-compatible keys
-        print("saved", path)
-        evaluate_cls_fn(model, [(img, lab)], cfg.model.params.classes)
+        log("saved", save_checkpoint(args.model_dir, model, trainer))
+    if tr.get("eval_after_train", True):
+        evaluate()
     shutdown_distributed(trainer)
 
 
