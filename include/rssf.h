@@ -381,6 +381,24 @@ int rssf_allreduce_bucket(void* buf, int64_t count, int dtype, rssf_comm* comm, 
 int rssf_syncbn_exchange(float* stats, int64_t count, rssf_comm* comm, void* stream);
 int rssf_comm_destroy(rssf_comm* comm);
 
+/* Peer-to-peer SyncBN statistics exchange (csrc/p2p.hip): what nn.SyncBatchNorm's all_gather /
+ * all_reduce of per-layer statistics (modules/ffn_block.py:222-234, configs/base/loveda.py:106-108) costs as ONE single-workgroup
+ * kernel per rank - peer writes into hipIpc-mapped fine-grained windows + flags over xGMI, rank-ordered sum (bit-identical on every
+ * rank), replay-safe inside a captured hipGraph.  The object owns its window (like an RCCL communicator owns its buffers);
+ * `ipc_handle64` = the 64 bytes of its hipIpcMemHandle_t, carried to the peers by the caller's rendezvous; a CHANNEL is an
+ * independent exchange sequence (one per stream that issues exchanges).  `stats` holds, per layer i, an [nslots][item_n[i]] block
+ * at element offset item_off[i] (item_n = 2C): on return slot 0 holds the sum over slots AND ranks, the other slots are zero.
+ * A peer that does not show up within RSSF_P2P_TIMEOUT_MS (default 10 000) sets the error word rssf_p2p_status reports. */
+#define RSSF_P2P_MAX_FLOATS 4096
+#define RSSF_P2P_MAX_ITEMS 8
+typedef struct rssf_p2p rssf_p2p;
+int rssf_p2p_create(rssf_p2p** p2p, int rank, int world, int channels, void* ipc_handle64);
+int rssf_p2p_connect(rssf_p2p* p2p, int peer, const void* ipc_handle64);
+int rssf_p2p_exchange(rssf_p2p* p2p, int channel, float* stats, const int* item_off, const int* item_n, int nitems, int nslots,
+                      void* stream);
+int rssf_p2p_status(rssf_p2p* p2p, int* timed_out);
+int rssf_p2p_destroy(rssf_p2p* p2p);
+
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 /* D[16][16] = A[16][K] * B[16][K]^T through the library's MFMA tile helper (layout self-check). */
 int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, void* stream);

@@ -28,6 +28,7 @@ class WinAttnBwdParams(ctypes.Structure):
 
 
 MAX_TAPS, PACK_CHUNK = 19, 1024      # RSSF_MAX_TAPS, RSSF_PACK_CHUNK
+P2P_MAX_ITEMS, P2P_MAX_FLOATS = 8, 4096      # RSSF_P2P_MAX_ITEMS, RSSF_P2P_MAX_FLOATS
 
 
 class PackJob(ctypes.Structure):       # rssf_pack_job
@@ -105,6 +106,11 @@ SIGNATURES = {
     "rssf_allreduce_bucket": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "rssf_syncbn_exchange": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_comm_destroy": (c_int, [c_void_p]),
+    "rssf_p2p_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    "rssf_p2p_connect": (c_int, [c_void_p, c_int, c_void_p]),
+    "rssf_p2p_exchange": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rssf_p2p_status": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "rssf_p2p_destroy": (c_int, [c_void_p]),
     "rssf_debug_lane_reduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_trread": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_mma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

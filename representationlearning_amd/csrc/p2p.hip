@@ -1,0 +1,186 @@
+// Peer-to-peer SyncBN statistics exchange over xGMI.
+//
+// The reference synchronises every BatchNorm of the step across the data-parallel ranks (nn.SyncBatchNorm in MlpDWBN,
+// modules/ffn_block.py:222-234; train.sync_bn for the other 306, configs/base/loveda.py:106-108): ~660 exchanges of at most a few
+// hundred floats per step, every one of them on the critical path.  Through a collective library each is a launch of a general
+// all-reduce (10-20 us); here it is ONE single-workgroup kernel per rank:
+//     1. fold the layer's slotted {sum, sumsq} (or {sum dz, sum dz*raw}) buffer to [2C] values,
+//     2. store every value TOGETHER WITH THE EPOCH, as one 8-byte word, into the window of EVERY rank (xGMI peer writes into
+//        hipIpc-mapped, fine-grained device memory),
+//     3. spin on the own window until the words of all ranks carry this epoch (no separate flag, no fence: the NCCL "LL" idea),
+//     4. add the contributions in RANK ORDER (every rank forms the same sum: replicas stay bit-identical) and write the total back
+//        into slot 0 of the statistics buffer (the other slots are cleared: the consumers fold all slots).
+// Windows are double-buffered by the parity of a per-channel epoch that lives in device memory and is advanced by the kernel
+// itself, so the launch is replay-safe inside a captured hipGraph; a CHANNEL is an independent sequence of exchanges (one per stream
+// that issues them: kernels of one channel run in stream order, kernels of different channels never touch the same flags).
+// A bounded spin (RSSF_P2P_TIMEOUT_MS, default 10 s) turns a missing peer into an error word instead of a hung GPU.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include "common.hip.h"
+using namespace rssf;
+
+namespace {
+
+constexpr int MAXF = RSSF_P2P_MAX_FLOATS;        // floats of one exchange (sum over its items of 2C)
+constexpr int MAX_WORLD = 16;
+typedef unsigned long long u64;
+
+// window of one rank, per channel: slot[2 parities][world][MAXF] of 8 bytes = {value bits, epoch}
+__host__ __device__ inline size_t chan_slots(int world) { return (size_t)2 * world * MAXF; }
+
+struct ExArgs {
+  u64* win[MAX_WORLD];          // base of every rank's window (this process's mapping), already offset to the channel
+  unsigned* epoch;              // this rank's epoch counter of the channel (device memory)
+  unsigned* err;                // this rank's error word: != 0 after a timed-out wait
+  float* stats;
+  int item_off[RSSF_P2P_MAX_ITEMS], item_n[RSSF_P2P_MAX_ITEMS];   // per layer: offset of its [nslots][n] block in `stats`, n = 2C
+  int nitems, nslots, rank, world;
+  long long timeout_ticks;      // wall_clock64 ticks (100 MHz)
+};
+
+// "LL" exchange: value and epoch travel in ONE 8-byte store, so a reader that sees the epoch it waits for has the value - no flag,
+// no fence, no cache maintenance (a system-scope release / __threadfence_system() writes the L2 back: microseconds on this part,
+// DESIGN.md lesson 2).  Relaxed system-scope atomics on fine-grained memory go to memory / the fabric directly.
+__global__ void __launch_bounds__(256) p2p_exchange_kernel(ExArgs a) {
+  const int tid = threadIdx.x;
+  const unsigned e = __hip_atomic_load(a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;     // uniform: advanced at the end
+  const int par = (int)(e & 1u);
+  int F = 0;
+  for (int i = 0; i < a.nitems; ++i) F += a.item_n[i];
+  const size_t mine = ((size_t)par * a.world + a.rank) * MAXF;
+  const u64* inbox = a.win[a.rank] + (size_t)par * a.world * MAXF;
+  for (int f = tid; f < F; f += 256) {
+    int i = 0, j = f;
+    while (j >= a.item_n[i]) { j -= a.item_n[i]; ++i; }
+    float* blk = a.stats + a.item_off[i] + j;
+    const int n = a.item_n[i];
+    float v = 0.f;
+    for (int s = 0; s < a.nslots; ++s) v += blk[(size_t)s * n];
+    const u64 word = ((u64)e << 32) | (u64)__float_as_uint(v);
+    for (int r = 0; r < a.world; ++r) __hip_atomic_store(a.win[r] + mine + f, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // rank-ordered sum of what the ranks sent (every rank adds in the same order: bit-identical totals)
+    float t = 0.f;
+    const long long t0 = wall_clock64();
+    for (int r = 0; r < a.world; ++r) {
+      u64 w = __hip_atomic_load(inbox + (size_t)r * MAXF + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      while ((unsigned)(w >> 32) != e) {
+        if (wall_clock64() - t0 > a.timeout_ticks) { atomicExch(a.err, 1u + (unsigned)r); break; }
+        __builtin_amdgcn_s_sleep(1);
+        w = __hip_atomic_load(inbox + (size_t)r * MAXF + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      t += __uint_as_float((unsigned)w);
+    }
+    blk[0] = t;
+    for (int s = 1; s < a.nslots; ++s) blk[(size_t)s * n] = 0.f;
+  }
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(a.epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+struct rssf_p2p {
+  int rank, world, channels;
+  u64* window;                   // own window: channels * chan_slots(world) 8-byte slots, fine-grained
+  u64* peer[MAX_WORLD];        // mapped windows (peer[rank] == window)
+  bool opened[MAX_WORLD];
+  unsigned* counters;            // [channels] epochs + [1] error word (ordinary device memory: only this rank's kernels touch it)
+  long long timeout_ticks;
+};
+
+extern "C" int rssf_p2p_create(rssf_p2p** out, int rank, int world, int channels, void* ipc_handle64) {
+  RSSF_REQUIRE(out && ipc_handle64 && world >= 1 && world <= MAX_WORLD && rank >= 0 && rank < world && channels >= 1 && channels <= 16,
+               "p2p_create: bad arguments (rank %d, world %d, channels %d)", rank, world, channels);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI carries the hipIpc handle as 64 opaque bytes");
+  rssf_p2p* h = new (std::nothrow) rssf_p2p();
+  RSSF_REQUIRE(h, "p2p_create: out of memory");
+  memset(h, 0, sizeof(*h));
+  h->rank = rank; h->world = world; h->channels = channels;
+  const size_t bytes = (size_t)channels * chan_slots(world) * sizeof(u64);
+  // fine-grained (uncached) device memory: peers' stores and this rank's loads are coherent INSIDE a running kernel
+  hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&h->window), bytes, hipDeviceMallocUncached);
+  if (e == hipSuccess) e = hipMemset(h->window, 0, bytes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->counters), (channels + 1) * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(h->counters, 0, (channels + 1) * sizeof(unsigned));
+  hipIpcMemHandle_t ih;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&ih, h->window);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    set_error("p2p_create: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    if (h->window) (void)hipFree(h->window);
+    if (h->counters) (void)hipFree(h->counters);
+    delete h;
+    return RSSF_ERR_LAUNCH;
+  }
+  memcpy(ipc_handle64, &ih, 64);
+  h->peer[rank] = h->window;
+  const char* ms = getenv("RSSF_P2P_TIMEOUT_MS");
+  h->timeout_ticks = (long long)(ms ? atoll(ms) : 10000) * 100000LL;       // wall_clock64: 100 MHz
+  *out = h;
+  return RSSF_OK;
+}
+
+extern "C" int rssf_p2p_connect(rssf_p2p* h, int peer, const void* ipc_handle64) {
+  RSSF_REQUIRE(h && ipc_handle64 && peer >= 0 && peer < h->world, "p2p_connect: bad arguments");
+  if (peer == h->rank || h->peer[peer]) return RSSF_OK;
+  hipIpcMemHandle_t ih;
+  memcpy(&ih, ipc_handle64, 64);
+  void* p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) {
+    set_error("p2p_connect: hipIpcOpenMemHandle(rank %d): %s", peer, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return RSSF_ERR_LAUNCH;
+  }
+  h->peer[peer] = reinterpret_cast<u64*>(p);
+  h->opened[peer] = true;
+  return RSSF_OK;
+}
+
+extern "C" int rssf_p2p_exchange(rssf_p2p* h, int channel, float* stats, const int* item_off, const int* item_n, int nitems, int nslots,
+                                 void* stream) {
+  RSSF_REQUIRE(h && stats && item_off && item_n && channel >= 0 && channel < h->channels && nitems >= 1 && nitems <= RSSF_P2P_MAX_ITEMS &&
+                   nslots >= 1,
+               "p2p_exchange: bad arguments (channel %d, items %d, slots %d)", channel, nitems, nslots);
+  ExArgs a;
+  int F = 0;
+  for (int i = 0; i < nitems; ++i) {
+    RSSF_REQUIRE(item_n[i] > 0 && item_off[i] >= 0, "p2p_exchange: bad item %d", i);
+    a.item_off[i] = item_off[i]; a.item_n[i] = item_n[i];
+    F += item_n[i];
+  }
+  RSSF_REQUIRE(F <= MAXF, "p2p_exchange: %d floats exceed the window (%d)", F, MAXF);
+  for (int r = 0; r < h->world; ++r) {
+    RSSF_REQUIRE(h->peer[r], "p2p_exchange: rank %d is not connected", r);
+    a.win[r] = h->peer[r] + (size_t)channel * chan_slots(h->world);
+  }
+  a.epoch = h->counters + channel;
+  a.err = h->counters + h->channels;
+  a.stats = stats; a.nitems = nitems; a.nslots = nslots; a.rank = h->rank; a.world = h->world;
+  a.timeout_ticks = h->timeout_ticks;
+  p2p_exchange_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a);
+  return check_launch("p2p_exchange");
+}
+
+extern "C" int rssf_p2p_status(rssf_p2p* h, int* timed_out) {
+  RSSF_REQUIRE(h && timed_out, "p2p_status: bad arguments");
+  unsigned v = 0;
+  const hipError_t e = hipMemcpy(&v, h->counters + h->channels, sizeof(v), hipMemcpyDeviceToHost);      // synchronises
+  if (e != hipSuccess) { set_error("p2p_status: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
+  *timed_out = (int)v;
+  return RSSF_OK;
+}
+
+extern "C" int rssf_p2p_destroy(rssf_p2p* h) {
+  if (!h) return RSSF_OK;
+  for (int r = 0; r < h->world; ++r)
+    if (h->opened[r] && h->peer[r]) (void)hipIpcCloseMemHandle(h->peer[r]);
+  if (h->window) (void)hipFree(h->window);
+  if (h->counters) (void)hipFree(h->counters);
+  (void)hipGetLastError();
+  delete h;
+  return RSSF_OK;
+}

@@ -202,6 +202,8 @@ class HighResolutionModule(nn.Module):
         rt = nnf.current()
         if not (rt.exchanging() and rt.sync_all_bn and self.training and self.num_branches > 1) or os.environ.get("RSSF_LOCKSTEP", "1") == "0":
             return False
+        if rt.stream_comms and rt.branch_streams and os.environ.get("RSSF_LOCKSTEP") != "force":
+            return False          # every side stream has its own communicator: the branches keep their streams (nnf.parallel_map)
         nblk = len(self.branches[0])
         return all(len(b) == nblk and all(isinstance(m, BasicBlock) and m.downsample is None for m in b) for b in self.branches)
 
@@ -230,7 +232,9 @@ class HighResolutionModule(nn.Module):
         nb, nout = self.num_branches, len(self.fuse_layers)
         x, accs = self._fanout(x)
         up, cur, done = {}, {}, {}                # (i,j) -> 1x1 output / running chain value / finished chain value
-        last_depth = {i: max(i - 1, 1) for i in range(1, nout)}
+        # depth at which `low_i` is complete: the 1x1 / first-stage outputs exist after depth 0, the chain from branch j >= 1 after
+        # depth i - j - 1 (only output 1 of a 2-branch module needs neither: low_1 = x[1])
+        last_depth = {i: max(i - 1, 1 if (i < nb - 1 or i > 1) else 0) for i in range(1, nout)}
         lows, outs = {}, [None] * nout
 
         def low_of(i):
@@ -244,55 +248,68 @@ class HighResolutionModule(nn.Module):
                     low = done[(i, j)] if low is None else low + done[(i, j)]
             return low
 
-        depth = 0
-        while True:
-            items, tags = [], []
-            for i in range(nout):
-                for j in range(nb):
-                    if j > i and depth == 0:
-                        fl = self.fuse_layers[i][j]
-                        items.append(dict(x=x[j], conv=fl[0], bn=fl[1], act=nnf.ACT_NONE, grad_accum=accs[j]))
-                        tags.append(("up", i, j))
-                    elif j < i:
-                        chain = self.fuse_layers[i][j]
-                        length = len(chain)
-                        final0 = j == 0                           # ends in + low_i, ReLU
-                        d = depth
-                        if final0 and depth == last_depth[i] and (length - 1) <= depth:
-                            d = length - 1                        # the (possibly delayed) last convolution of the branch-0 chain
-                        elif final0 and depth >= length - 1:
-                            continue
-                        elif not final0 and depth >= length:
-                            continue
-                        stage = chain[d]
-                        src = x[j] if d == 0 else cur[(i, j)]
-                        acc = accs[j] if d == 0 else None
-                        if final0 and d == length - 1:
-                            if depth != last_depth[i]:
+        def fuse_rest():
+            depth = 0
+            while True:
+                items, tags = [], []
+                for i in range(1, nout):
+                    for j in range(nb):
+                        if j > i and depth == 0:
+                            fl = self.fuse_layers[i][j]
+                            items.append(dict(x=x[j], conv=fl[0], bn=fl[1], act=nnf.ACT_NONE, grad_accum=accs[j]))
+                            tags.append(("up", i, j))
+                        elif j < i:
+                            chain = self.fuse_layers[i][j]
+                            length = len(chain)
+                            final0 = j == 0                           # ends in + low_i, ReLU
+                            d = depth
+                            if final0 and depth == last_depth[i] and (length - 1) <= depth:
+                                d = length - 1                        # the (possibly delayed) last convolution of the branch-0 chain
+                            elif final0 and depth >= length - 1:
                                 continue
-                            if i not in lows:
-                                lows[i] = low_of(i)
-                            items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU, res_pre=lows[i], grad_accum=acc))
-                            tags.append(("out", i, j))
-                        else:
-                            relu = len(stage) > 2
-                            items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU if relu else nnf.ACT_NONE, grad_accum=acc))
-                            tags.append(("last" if d == length - 1 else "mid", i, j))
-            if not items:
-                break
-            res = nnf.conv_bn_act_group(items)
-            for (kind, i, j), t in zip(tags, res):
-                if kind == "up":
-                    up[(i, j)] = t
-                elif kind == "mid":
-                    cur[(i, j)] = t
-                elif kind == "last":
-                    done[(i, j)] = t
-                else:
-                    outs[i] = t
-            depth += 1
-        outs[0] = self.relu(self.transformer(low_of(0), x[0]))
-        return outs
+                            elif not final0 and depth >= length:
+                                continue
+                            stage = chain[d]
+                            src = x[j] if d == 0 else cur[(i, j)]
+                            acc = accs[j] if d == 0 else None
+                            if final0 and d == length - 1:
+                                if depth != last_depth[i]:
+                                    continue
+                                if i not in lows:
+                                    lows[i] = low_of(i)
+                                items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU, res_pre=lows[i], grad_accum=acc))
+                                tags.append(("out", i, j))
+                            else:
+                                relu = len(stage) > 2
+                                items.append(dict(x=src, conv=stage[0], bn=stage[1], act=nnf.ACT_RELU if relu else nnf.ACT_NONE, grad_accum=acc))
+                                tags.append(("last" if d == length - 1 else "mid", i, j))
+                if not items:
+                    break
+                res = nnf.conv_bn_act_group(items)
+                for (kind, i, j), t in zip(tags, res):
+                    if kind == "up":
+                        up[(i, j)] = t
+                    elif kind == "mid":
+                        cur[(i, j)] = t
+                    elif kind == "last":
+                        done[(i, j)] = t
+                    else:
+                        outs[i] = t
+                depth += 1
+            return outs[1:]
+
+        def fuse_zero():
+            # output 0: its 1x1 convolutions (one group, one exchange), the upsampled sum, then the transformer block.  No gradient
+            # accumulator here: these consumers of x[j] run on the main stream, the accumulating ones of outputs 1.. on the side stream
+            its = [dict(x=x[j], conv=self.fuse_layers[0][j][0], bn=self.fuse_layers[0][j][1], act=nnf.ACT_NONE) for j in range(1, nb)]
+            for j, t in zip(range(1, nb), nnf.conv_bn_act_group(its)):
+                up[(0, j)] = t
+            return self.relu(self.transformer(low_of(0), x[0]))
+
+        # as in the single-GPU path the outputs 1.. run beside output 0's transformer block, on a side stream whose SyncBN exchanges
+        # travel on a communicator of their own (nnf.fork_side / Runtime.comm_side); without one, both run on this stream
+        rest, y0 = nnf.fork_side(fuse_rest, fuse_zero, x)
+        return [y0] + list(rest)
 
     def forward(self, x):
         if self.num_branches == 1:

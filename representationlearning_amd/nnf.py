@@ -77,6 +77,14 @@ class Runtime:
         # data-parallel runs, where the branches' SyncBN exchanges must reach the communicator in one fixed order
         self.branch_streams = False
         self.side_streams = {}
+        # data parallel: the items of a lock-step group (nnf.conv_bn_act_group) on parallel streams around the group's ONE SyncBN
+        # exchange, which stays on the step's stream - the branch concurrency of `branch_streams` with a fixed collective order
+        self.group_streams = False
+        self.in_side = 0                 # > 0 while a side-stream function runs (no nested forks: DESIGN lesson 16)
+        # data parallel: one SyncBN communicator PER SIDE STREAM (stream_comms[k] belongs to side_streams[dev][k]); None = the side
+        # streams may not issue exchanges (single communicator: branches and fuse paths then stay on the step's stream, in lock-step)
+        self.stream_comms = None
+        self.comm_active = None          # the communicator exchanges issued NOW go through (set by parallel_map / fork_side)
         self.zero_pool = ZeroPool()
         self.pack_plan = None
         self.wgrad_plan = None
@@ -89,6 +97,11 @@ class Runtime:
 
     def exchanging(self):
         return self.comm is not None and (self.comm.world > 1 or self.force_collectives)
+
+    def exchange_comm(self):
+        """Communicator of the SyncBN exchanges issued at this point of the forward pass: every side stream has its own
+        (collectives of one communicator must be issued in ONE order on every rank; two streams give no such order)."""
+        return self.comm_active if self.comm_active is not None else self.comm
 
 
 _DEFAULT = Runtime()
@@ -154,7 +167,8 @@ def parallel_map(fns, args):
     the fork/join as parallel graph branches."""
     n = len(fns)
     rt = current()
-    if not (rt.branch_streams and n > 1 and args[0].is_cuda):
+    dp = rt.exchanging()
+    if not (rt.branch_streams and n > 1 and args[0].is_cuda) or rt.in_side or (dp and (rt.stream_comms is None or len(rt.stream_comms) < n - 1)):
         return [f(a) for f, a in zip(fns, args)]
     dev = args[0].device
     cur = torch.cuda.current_stream(dev)
@@ -166,8 +180,15 @@ def parallel_map(fns, args):
         s = pool[i - 1]
         s.wait_stream(cur)
         args[i].record_stream(s)
-        with torch.cuda.stream(s):
-            outs[i] = fns[i](args[i])
+        prev = rt.comm_active
+        rt.in_side += 1
+        rt.comm_active = rt.stream_comms[i - 1] if dp else None      # the SyncBN exchanges of this branch: its stream's communicator
+        try:
+            with torch.cuda.stream(s):
+                outs[i] = fns[i](args[i])
+        finally:
+            rt.in_side -= 1
+            rt.comm_active = prev
     outs[0] = fns[0](args[0])
     for i in range(1, n):
         cur.wait_stream(pool[i - 1])
@@ -180,7 +201,7 @@ def fork_side(fn_side, fn_main, tensors):
     stream; joined before returning.  `tensors`: what fn_side reads (they were produced on the current stream)."""
     rt = current()
     ts = [t for t in tensors if t is not None]
-    if not (rt.branch_streams and _FORK_FUSE and ts and ts[0].is_cuda):
+    if not (rt.branch_streams and _FORK_FUSE and ts and ts[0].is_cuda) or (rt.exchanging() and not rt.stream_comms) or rt.in_side:
         return fn_side(), fn_main()
     dev = ts[0].device
     cur = torch.cuda.current_stream(dev)
@@ -191,14 +212,69 @@ def fork_side(fn_side, fn_main, tensors):
     s.wait_stream(cur)
     for t in ts:
         t.record_stream(s)
-    with torch.cuda.stream(s):
-        side = fn_side()
+    prev = rt.comm_active
+    rt.in_side += 1
+    rt.comm_active = rt.stream_comms[0] if rt.exchanging() else None       # pool[0]'s communicator
+    try:
+        with torch.cuda.stream(s):
+            side = fn_side()
+    finally:
+        rt.in_side -= 1
+        rt.comm_active = prev
     main = fn_main()
     cur.wait_stream(s)
     for t in (side if isinstance(side, (list, tuple)) else [side]):
         if t is not None:
             t.record_stream(cur)
     return side, main
+
+
+class _Phases:
+    """Runs the per-item launches of a lock-step group on parallel streams (item 0 on the current one) - `run(i, fn, inputs)`
+    between `join()`s.  Disabled (everything on the current stream) unless the runtime asks for it, inside fork_side's side
+    function (no nested forks) and for groups whose items share a gradient accumulator."""
+
+    def __init__(self, rt, n, device, enabled=True, forked=None):
+        self.streams = None
+        on = (rt.group_streams and enabled and n > 1 and device.type == "cuda" and not rt.in_side) if forked is None else forked
+        if on:
+            self.cur = torch.cuda.current_stream(device)
+            pool = rt.side_streams.setdefault(device, [])
+            while len(pool) < n:
+                pool.append(torch.cuda.Stream(device))
+            self.streams = [self.cur] + pool[1:n]          # pool[0] is fork_side's stream (busy with the fuse outputs 1..)
+            self.used = set()
+            self.made = []
+
+    @property
+    def forked(self):
+        return self.streams is not None
+
+    def run(self, i, fn, inputs=()):
+        if self.streams is None or i == 0:
+            return fn()
+        s = self.streams[i]
+        if i not in self.used:
+            s.wait_stream(self.cur)
+            self.used.add(i)
+        for t in inputs:
+            if t is not None:
+                t.record_stream(s)
+        with torch.cuda.stream(s):
+            out = fn()
+        for t in (out if isinstance(out, (list, tuple)) else [out]):
+            if torch.is_tensor(t):
+                self.made.append(t)
+        return out
+
+    def join(self):
+        if self.streams is None:
+            return
+        for i in sorted(self.used):
+            self.cur.wait_stream(self.streams[i])
+        for t in self.made:                    # allocated on a side stream, used (and possibly freed) on the current one from here on
+            t.record_stream(self.cur)
+        self.used, self.made = set(), []
 
 
 def _ia(vals):
@@ -355,21 +431,38 @@ class PackPlan:
 
 class WgradPlan:
     """Deferred second stage of the split-K weight gradients: the ~330 `wgrad_reduce` launches of a step (5.6 us each, a
-    latency-bound walk over ~9 MB of partials) become ONE `rssf_conv_wgrad_reduce_batch` launch at the end of backward.
+    latency-bound walk over ~9 MB of partials) become a few `rssf_conv_wgrad_reduce_batch` launches.
     Step 1 records the sequence of weight-gradient calls and their workspace sizes; then one arena holds every layer's partials
     at a fixed address (the captured hipGraph needs that anyway), and from step 2 on `_conv_wgrad` launches the first stage
-    only.  The device-side job table is built from the first deferred step and checked against every later one."""
+    only.  `flush()` reduces what has been deferred since the previous flush - ONE launch at the end of backward without data
+    parallelism, one per gradient bucket with it (the trainer flushes before a bucket's all-reduce starts, so that bucket's
+    gradients are final).  Each flush is a SEGMENT [first job, last job) of the step's call sequence with its own device-side job
+    table, built the first time that segment runs and reused while the step keeps its shape."""
 
     def __init__(self):
         self.sizes, self.keys = [], []          # recorded call sequence
         self.recording, self.built = False, False
-        self.cursor = 0
-        self.jobs_host, self.jobs_dev, self.bmap_dev, self.nblocks = [], None, None, 0
-        self.pending = False
+        self.cursor = 0                         # next call of the running step
+        self.flushed = 0                        # first job not yet reduced
+        self.seg_i = 0                          # next segment of the running step
+        self.jobs_host, self.segments = [], []
+        self.seen_dw = set()
 
     def begin(self):
-        self.cursor = 0
-        self.pending = False
+        self.cursor = self.flushed = self.seg_i = 0
+        self.seen_dw = set()
+
+    @property
+    def pending(self):
+        return self.flushed < self.cursor
+
+    def duplicate_target(self, ptrs):
+        """True when one of the gradient buffers `ptrs` is already the target of a deferred job of this step: the batched reduction
+        adds into `dw` without atomics, so two jobs of one launch must not share a target (a weight used twice in a step keeps the
+        immediate, stream-ordered reduction).  Deterministic per step shape: the call sequence stays consistent."""
+        dup = any(q in self.seen_dw for q in ptrs)
+        self.seen_dw.update(ptrs)
+        return dup
 
     def record(self, key, elems):
         self.keys.append(key)
@@ -388,7 +481,7 @@ class WgradPlan:
         """Workspace slice + job struct for the next weight-gradient call of the step, or None if the call sequence changed."""
         i = self.cursor
         if not self.built or i >= len(self.keys) or self.keys[i] != key:
-            self.built = False                       # a different step shape: fall back to immediate reductions for good
+            self.built = False                       # a different step shape: immediate reductions from here on, for good
             return None
         self.cursor += 1
         ws = self.arena[self.offs[i]:self.offs[i] + self.sizes[i]]
@@ -397,26 +490,39 @@ class WgradPlan:
             return ws, self.jobs_host[i], None
         return ws, L.WgradReduceJob(), self.jobs_host[i]
 
-    def flush(self):
-        """Run every pending reduction (one launch)."""
-        if not self.pending:
-            return
+    def _table(self, a, b):
         lib = L.load()
-        if self.jobs_dev is None:
-            if self.cursor != len(self.keys):
-                raise RuntimeError("WgradPlan: %d of %d recorded weight-gradient calls ran in this step" % (self.cursor, len(self.keys)))
-            arr = (L.WgradReduceJob * len(self.jobs_host))(*self.jobs_host)
-            bmap = []
-            for j in range(len(self.jobs_host)):
-                bmap += [(j, b) for b in range(lib.rssf_conv_wgrad_reduce_blocks(ctypes.byref(arr[j])))]
-            dev = self.arena.device
-            self.jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-            self.bmap_dev = torch.tensor(bmap, dtype=torch.int32).reshape(-1, 2).to(dev).contiguous()
-            self.nblocks = len(bmap)
-        if self.nblocks:
-            L.check(lib.rssf_conv_wgrad_reduce_batch(L.ptr(self.jobs_dev), L.ptr(self.bmap_dev), self.nblocks, L.stream()),
-                    "rssf_conv_wgrad_reduce_batch")
-        self.pending = False
+        arr = (L.WgradReduceJob * (b - a))(*self.jobs_host[a:b])
+        bmap = []
+        for j in range(b - a):
+            bmap += [(j, blk) for blk in range(lib.rssf_conv_wgrad_reduce_blocks(ctypes.byref(arr[j])))]
+        dev = self.arena.device
+        jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        bmap_dev = torch.tensor(bmap, dtype=torch.int32).reshape(-1, 2).to(dev).contiguous()
+        return (a, b, jobs_dev, bmap_dev, len(bmap))
+
+    def flush(self):
+        """Reduce every job deferred since the last flush: jobs [flushed, cursor) of the running step, one launch."""
+        a, b = self.flushed, self.cursor
+        if a >= b:
+            return
+        seg = self.segments[self.seg_i] if self.seg_i < len(self.segments) else None
+        if seg is None or seg[0] != a or seg[1] != b:
+            seg = self._table(a, b)                  # first run of this segment (or the flush points moved: rebuilt, not reused)
+            if self.seg_i < len(self.segments):
+                self.segments[self.seg_i] = seg
+            else:
+                self.segments.append(seg)
+        self.seg_i += 1
+        self.flushed = b
+        if seg[4]:
+            L.check(L.load().rssf_conv_wgrad_reduce_batch(L.ptr(seg[2]), L.ptr(seg[3]), seg[4], L.stream()), "rssf_conv_wgrad_reduce_batch")
+
+    def end(self):
+        """End of the step: reduce the rest; a step that issued fewer calls than recorded has changed shape."""
+        self.flush()
+        if self.built and self.cursor != len(self.keys):
+            self.built = False
 
 
 def step_begin(device, plan=None, rt=None, wgrad_plan=None):
@@ -449,7 +555,7 @@ def step_end(rt=None):
     rt.pack_plan = None
     wp = rt.wgrad_plan
     if wp is not None:
-        wp.flush()
+        wp.end()
         if wp.recording:
             wp.recording = False
             if wp.keys:
@@ -712,7 +818,7 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None):
     nws = lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, CO, spec.ntaps)
     plan = (rt or current()).wgrad_plan
     ws = job = ref = None
-    if plan is not None and not padded and tdb is None:
+    if plan is not None and not padded and tdb is None and not plan.duplicate_target([t.data_ptr() for t in dws]):
         key = (id(spec), B, H, W, C, OH, OW, CO, xh.dtype, tuple(t.data_ptr() for t in dws))
         if plan.recording:
             plan.record(key, nws)
@@ -740,7 +846,6 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None):
     if job is not None:
         if ref is not None and bytes(job) != bytes(ref):
             raise RuntimeError("WgradPlan: a deferred weight-gradient reduction changed between steps")
-        plan.pending = True
     if padded:
         for g, t in zip(dws, tgt):
             g += t[:spec.cout, :spec.cin]
@@ -772,8 +877,9 @@ class _ConvBNAct(torch.autograd.Function):
         rows = raw.numel() // C
         n = float(rows)
         exchanged = training and sync and rt.exchanging()
+        ctx.comm = rt.exchange_comm() if exchanged else None
         if exchanged:                  # SyncBN: pooled {sum, sumsq} and sample count over the data-parallel ranks
-            rt.comm.syncbn_exchange_(stats)
+            ctx.comm.syncbn_exchange_(stats, (BN_SLOTS, [(0, 2 * C)]))
             n *= rt.world
         mi = torch.empty(2, C, device=dev, dtype=torch.float32)
         ss = torch.empty(2, C, device=dev, dtype=torch.float32)
@@ -837,7 +943,7 @@ class _ConvBNAct(torch.autograd.Function):
         if exchanged:
             # the input gradient needs the GLOBAL {sum dz, sum dz*raw}; gamma/beta take the data-parallel MEAN of the local
             # sums (torch SyncBatchNorm + DDP), which is the global total / world
-            rt.comm.syncbn_exchange_(sums)
+            ctx.comm.syncbn_exchange_(sums, (BN_BWD_SLOTS, [(0, 2 * C)]))
             pscale = 1.0 / rt.world
         draw = torch.empty_like(raw)
         dres = torch.empty_like(raw) if has_pre else None
@@ -929,37 +1035,48 @@ class _ConvBNActGroup(torch.autograd.Function):
         training = [m[2] for m in metas]
         sizes = [BN_SLOTS * 2 * m[0].cout if tr else 0 for m, tr in zip(metas, training)]
         stats_all = _zeros(sum(sizes), dev, rt) if sum(sizes) else None
+        # items on parallel streams around the ONE exchange (not for groups whose items share a gradient accumulator: its consumers
+        # must stay on one stream)
+        ph = _Phases(rt, n_items, dev, enabled=all((len(m) <= 8 or m[8] is None) for m in metas))
         xs, raws, stats, o = [], [], [], 0
-        for (x, rp, gamma, beta, rm, rv, w), m, sz in zip(it, metas, sizes):
+        for i, ((x, rp, gamma, beta, rm, rv, w), m, sz) in enumerate(zip(it, metas, sizes)):
             xh = _nhwc(x)
             st = stats_all[o:o + sz] if sz else None
             o += sz
             xs.append(xh)
             stats.append(st)
-            raws.append(_conv_forward(m[0], xh, [w], None, st, rt))
+            raws.append(ph.run(i, lambda m=m, xh=xh, w=w, st=st: _conv_forward(m[0], xh, [w], None, st, rt), (xh, st)))
+        ph.join()
         exchanged = stats_all is not None and rt.exchanging() and all(m[5] for m in metas)
+        comm = rt.exchange_comm() if exchanged else None
         if exchanged:
-            rt.comm.syncbn_exchange_(stats_all)
+            comm.syncbn_exchange_(stats_all, (BN_SLOTS, [(sum(sizes[:k]), 2 * m[0].cout) for k, m in enumerate(metas) if sizes[k]]))
         outs, saved, ns = [], [], []
-        for (x, rp, gamma, beta, rm, rv, w), m, xh, raw, st in zip(it, metas, xs, raws, stats):
+        for i, ((x, rp, gamma, beta, rm, rv, w), m, xh, raw, st) in enumerate(zip(it, metas, xs, raws, stats)):
             spec, act, tr, mom, eps = m[:5]
             C = spec.cout
             rows = raw.numel() // C
             n = float(rows) * (rt.world if (exchanged and tr) else 1)
-            mi = torch.empty(2, C, device=dev, dtype=torch.float32)
-            ss = torch.empty(2, C, device=dev, dtype=torch.float32)
             rph = None if rp is None else _nhwc(rp)
             if rph is not None and (rph.dtype != raw.dtype or rph.shape != raw.shape):
                 raise RuntimeError("conv_bn_act_group: residual dtype/shape mismatch")
-            y = torch.empty_like(raw)
-            L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(mi), L.ptr(ss),
-                                               L.ptr(rph), None, L.ptr(y), rows, C, act, n, mom, eps, int(tr), L.dtype_code(raw), L.stream()),
-                    "rssf_bn_finalize_apply")
+
+            def apply(raw=raw, st=st, gamma=gamma, beta=beta, rm=rm, rv=rv, rph=rph, rows=rows, C=C, act=act, n=n, mom=mom, eps=eps, tr=tr):
+                mi = torch.empty(2, C, device=dev, dtype=torch.float32)
+                ss = torch.empty(2, C, device=dev, dtype=torch.float32)
+                y = torch.empty_like(raw)
+                L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(mi), L.ptr(ss),
+                                                   L.ptr(rph), None, L.ptr(y), rows, C, act, n, mom, eps, int(tr), L.dtype_code(raw), L.stream()),
+                        "rssf_bn_finalize_apply")
+                return y, mi, ss
+            y, mi, ss = ph.run(i, apply, (raw, st, rph))
             outs.append(_nchw(y))
             saved += [xh, raw, ss, mi, rph, w]
             ns.append(n)
+        ph.join()
         ctx.save_for_backward(*saved)
         ctx.metas, ctx.ns, ctx.exchanged, ctx.rt = metas, ns, exchanged, rt
+        ctx.comm, ctx.forked = comm, ph.forked
         ctx.gout, ctx.gin = glinks
         if ctx.gout is not None:
             for i, (lk, m) in enumerate(zip(ctx.gout.items, metas)):
@@ -984,6 +1101,7 @@ class _ConvBNActGroup(torch.autograd.Function):
             gout.sums_all, gout.filled = None, 0
             for lk in gout.items:
                 lk.raw = lk.ss = lk.rp = None
+        ph = _Phases(rt, n_items, dev, forked=ctx.forked)          # the same streams as the forward pass of this group
         dyhs, sums, o = [], [], 0
         for i, (m, sz) in enumerate(zip(metas, sizes)):
             xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
@@ -995,19 +1113,24 @@ class _ConvBNActGroup(torch.autograd.Function):
             sm = sums_all[o:o + sz]
             o += sz
             if not fused:
-                dws = None
-                if rt.deterministic:
-                    dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=dev, dtype=torch.float32)
-                L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rph), L.ptr(sm), rows, C, m[1], L.ptr(dws),
-                                               L.dtype_code(raw), L.stream()), "rssf_bn_bwd_reduce")
+                def reduce(dyh=dyh, raw=raw, ss=ss, rph=rph, sm=sm, rows=rows, C=C, act=m[1]):
+                    dws = None
+                    if rt.deterministic:
+                        dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=dev, dtype=torch.float32)
+                    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rph), L.ptr(sm), rows, C, act, L.ptr(dws),
+                                                   L.dtype_code(raw), L.stream()), "rssf_bn_bwd_reduce")
+                ph.run(i, reduce, (dyh, raw, ss, rph, sm))
             dyhs.append(dyh)
             sums.append(sm)
+        ph.join()
         pscale = 1.0
         if ctx.exchanged:
-            rt.comm.syncbn_exchange_(sums_all)
+            ctx.comm.syncbn_exchange_(sums_all, (BN_BWD_SLOTS, [(sum(sizes[:k]), 2 * m[0].cout) for k, m in enumerate(metas)]))
             pscale = 1.0 / rt.world
         grads = []
-        for i, m in enumerate(metas):
+
+        def item_backward(i):
+            m = metas[i]
             spec, act, tr = m[0], m[1], m[2]
             sink, deposit = m[6], m[7]
             xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
@@ -1028,6 +1151,7 @@ class _ConvBNActGroup(torch.autograd.Function):
                 L.check(lib.rssf_bn_bwd_apply(L.ptr(dyhs[i]), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums[i]), L.ptr(rph), L.ptr(draw),
                                               L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), rows, C, act, ctx.ns[i], int(tr), pscale if tr else 1.0,
                                               L.dtype_code(raw), L.stream()), "rssf_bn_bwd_apply")
+            held = dres                     # (also when it travels through a GradLink: the join must see every tensor made here)
             if deposit is not None and dres is not None:
                 deposit.value, dres = dres, None
             addend = None
@@ -1043,15 +1167,21 @@ class _ConvBNActGroup(torch.autograd.Function):
                 gin, bn = ctx.gin, None
                 if gin is not None and gin.items[i].raw is not None and not rt.deterministic:
                     bn = (gin.items[i], gin.slot(i, dev, rt))
-                dx = _nchw(_conv_dgrad(spec, draw, [w], xh.shape, addend, rt, bn=bn))
+                dx = _conv_dgrad(spec, draw, [w], xh.shape, addend, rt, bn=bn)
             else:
                 if addend is not None:
                     raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
                 dx = None
             if not fuse_apply:
                 _conv_wgrad(spec, draw, xh, [tw], None, rt)
-            grads += [dx, None if dres is None else _nchw(dres), grad_result(p_gamma, dgamma, dg_direct, rt),
-                      grad_result(p_beta, dbeta, db_direct, rt), None, None, grad_result(p_w, tw, wd, rt)]
+            return (dx, dres, held, draw, grad_result(p_gamma, dgamma, dg_direct, rt), grad_result(p_beta, dbeta, db_direct, rt),
+                    grad_result(p_w, tw, wd, rt))
+
+        for i in range(n_items):
+            xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
+            dx, dres, _, _, gg, gb, gw = ph.run(i, lambda i=i: item_backward(i), (dyhs[i], sums[i], xh, raw, ss, mi, rph))
+            grads += [None if dx is None else _nchw(dx), None if dres is None else _nchw(dres), gg, gb, None, None, gw]
+        ph.join()
         return (None, None, *grads)
 
 

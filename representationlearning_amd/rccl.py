@@ -56,8 +56,9 @@ class Communicator:
         if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
             raise TypeError("rccl: contiguous fp32 device tensor expected")
 
-    def syncbn_exchange_(self, stats):
-        """In-place sum over ranks of a BatchNorm statistics buffer, on torch's current stream."""
+    def syncbn_exchange_(self, stats, layout=None):
+        """In-place sum over ranks of a BatchNorm statistics buffer, on torch's current stream (`layout`: see P2PChannel; an
+        all-reduce sums the slots of all ranks element-wise, which the consumers' slot fold turns into the same totals)."""
         self._chk(stats)
         self.n_syncbn += 1
         if _SKIP_1RANK and self.world == 1:
@@ -79,6 +80,112 @@ class Communicator:
             self._h = ctypes.c_void_p()
 
 
+class P2PExchange:
+    """The peer-to-peer SyncBN exchange of librssf (`rssf_p2p_*`, csrc/p2p.hip): one window per rank, mapped by every peer through
+    hipIpc; `channel(k)` hands out the communicator-like object of exchange sequence k (one per stream)."""
+
+    def __init__(self, channels):
+        lib = L.load()
+        self.rank, self.world, self.channels = dist.get_rank(), dist.get_world_size(), channels
+        self._lib, self._h = lib, ctypes.c_void_p()
+        mine = ctypes.create_string_buffer(64)
+        err = None
+        if lib.rssf_p2p_create(ctypes.byref(self._h), self.rank, self.world, channels, mine) != 0:
+            err = lib.rssf_last_error().decode()
+        handles = [None] * self.world
+        dist.all_gather_object(handles, None if err else mine.raw)              # every rank joins this, failed or not
+        if err is None and any(h is None for h in handles):
+            err = "a peer could not create its window"
+        if err is None:
+            for r, hb in enumerate(handles):
+                if r != self.rank and lib.rssf_p2p_connect(self._h, r, ctypes.create_string_buffer(hb, 64)) != 0:
+                    err = lib.rssf_last_error().decode()
+                    break
+        self.error = err
+
+    def channel(self, k):
+        return P2PChannel(self, k)
+
+    def timed_out(self):
+        v = ctypes.c_int(0)
+        L.check(self._lib.rssf_p2p_status(self._h, ctypes.byref(v)), "rssf_p2p_status")
+        return v.value
+
+    def destroy(self):
+        if self._h:
+            self._lib.rssf_p2p_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
+class P2PChannel:
+    """Communicator interface (`world`, `rank`, `syncbn_exchange_`) over one channel of a P2PExchange."""
+
+    direct = True
+
+    def __init__(self, ex, k):
+        self.ex, self.k, self.rank, self.world = ex, k, ex.rank, ex.world
+        self.n_syncbn = 0
+
+    def syncbn_exchange_(self, stats, layout=None):
+        """In-place: slot 0 of every layer's block <- sum over slots and ranks, the other slots <- 0 (the consumers fold all slots).
+        layout = (nslots, [(element offset, 2C), ...]); without one the buffer is taken as ONE unslotted item."""
+        Communicator._chk(stats)
+        self.n_syncbn += 1
+        nslots, items = layout if layout is not None else (1, [(0, stats.numel())])
+        lib = self.ex._lib
+        for a in range(0, len(items), L.P2P_MAX_ITEMS):          # (a lock-step group of more than 8 layers: two kernels)
+            part = items[a:a + L.P2P_MAX_ITEMS]
+            offs = (ctypes.c_int * len(part))(*[o for o, _ in part])
+            ns = (ctypes.c_int * len(part))(*[n for _, n in part])
+            L.check(lib.rssf_p2p_exchange(self.ex._h, self.k, L.ptr(stats), offs, ns, len(part), nslots, L.stream()), "rssf_p2p_exchange")
+        return stats
+
+    def destroy(self):
+        pass
+
+
+def create_p2p(channels, reference_comm):
+    """A validated P2PExchange with `channels` channels, or None (all ranks decide together).  The self-test runs one exchange per
+    channel on the hardware it is going to be used on - every rank contributes rank-dependent values in a slotted two-layer layout -
+    and holds the result against an all-reduce of the same numbers through `reference_comm` (RCCL); a time-out, a mismatch or any
+    setup error on any rank sends every rank back to the RCCL exchanges."""
+    if os.environ.get("RSSF_SYNCBN", "p2p") != "p2p":
+        return None
+    ex, why = None, None
+    try:
+        ex = P2PExchange(channels)
+        why = ex.error
+    except Exception as e:                                     # noqa: BLE001
+        why = "%s: %s" % (type(e).__name__, e)
+    if _agree(why is None):
+        try:
+            rank, world = ex.rank, ex.world
+            nslots, c1, c2 = 4, 24, 40
+            base = torch.arange(nslots * (c1 + c2), device="cuda", dtype=torch.float32) * 0.25 + (rank + 1) * 3.0
+            layout = (nslots, [(0, c1), (nslots * c1, c2)])
+            want = torch.cat([base[:nslots * c1].view(nslots, c1).sum(0), base[nslots * c1:].view(nslots, c2).sum(0)]).contiguous()
+            reference_comm.allreduce_bucket_(want)
+            for k in range(channels):
+                for _ in range(3):                              # both window parities, and the epoch carried between launches
+                    got = base.clone()
+                    ex.channel(k).syncbn_exchange_(got, layout)
+                    tot = torch.cat([got[:c1], got[nslots * c1:nslots * c1 + c2]])
+                    rest = torch.cat([got[c1:nslots * c1], got[nslots * c1 + c2:]])
+                    if not (torch.equal(tot, want) and float(rest.abs().sum()) == 0.0):
+                        why = why or "self-test mismatch on channel %d" % k
+            if ex.timed_out():
+                why = "self-test timed out waiting for a peer"
+        except Exception as e:                                 # noqa: BLE001
+            why = "%s: %s" % (type(e).__name__, e)
+        if _agree(why is None):
+            return ex
+    if why:
+        print("[rssf] peer-to-peer SyncBN exchange unavailable (%s); using RCCL all-reduces" % why, flush=True)
+    if ex is not None:
+        ex.destroy()
+    return None
+
+
 class TorchComm:
     """The same interface through torch.distributed (any backend: gloo on CPU hosts / for the 2-ranks-on-one-GPU parity
     test, ProcessGroupNCCL when RSSF_DP_BACKEND=torch).  Eager launches only."""
@@ -90,7 +197,7 @@ class TorchComm:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.n_syncbn = 0
 
-    def syncbn_exchange_(self, stats):
+    def syncbn_exchange_(self, stats, layout=None):
         self.n_syncbn += 1
         dist.all_reduce(stats, group=self.group)
         return stats
@@ -115,20 +222,37 @@ def _agree(flag):
 
 def create(n=1):
     """`n` communicators over the default group (all ranks call this together): direct RCCL ones when possible, else None
-    (RSSF_DP_BACKEND=torch, non-NCCL backend, no GPU, load failure - decided collectively)."""
+    (RSSF_DP_BACKEND=torch, non-NCCL backend, no GPU, load failure - decided collectively).
+    Every step that can fail on ONE rank is followed by an agreement (MIN over ranks of a success flag) before the next collective
+    step starts, so that a failing rank never leaves the others inside a broadcast or an ncclCommInitRank it does not join:
+    library load first, then each communicator after its construction."""
     if (os.environ.get("RSSF_DP_BACKEND", "rccl") != "rccl" or not torch.cuda.is_available() or not dist.is_initialized()
             or dist.get_backend() != "nccl"):
         return None
-    comms, ok = [], True
+    why = None
     try:
-        for _ in range(n):
-            comms.append(Communicator())
-    except Exception as e:                                     # noqa: BLE001 - any failure means "use torch.distributed"
-        print("[rssf] direct RCCL communicator unavailable (%s: %s); using torch.distributed collectives" % (type(e).__name__, e),
-              flush=True)
-        ok = False
-    if not _agree(ok):                                         # all ranks or none
-        for c in comms:
-            c.destroy()
+        L.load()
+        if not os.path.exists(rccl_library_path()):
+            why = "no RCCL library at %s" % rccl_library_path()
+    except Exception as e:                                     # noqa: BLE001
+        why = "%s: %s" % (type(e).__name__, e)
+    if not _agree(why is None):
+        if why:
+            print("[rssf] direct RCCL communicator unavailable (%s); using torch.distributed collectives" % why, flush=True)
         return None
+    comms = []
+    for _ in range(n):
+        c, err = None, None
+        try:
+            c = Communicator()          # rank 0's id failure reaches every rank through the broadcast: all raise together
+        except Exception as e:                                 # noqa: BLE001 - any failure means "use torch.distributed"
+            err = "%s: %s" % (type(e).__name__, e)
+        if c is not None:
+            comms.append(c)
+        if not _agree(err is None):                            # all ranks or none, before the next communicator is built
+            if err:
+                print("[rssf] direct RCCL communicator unavailable (%s); using torch.distributed collectives" % err, flush=True)
+            for k in comms:
+                k.destroy()
+            return None
     return comms

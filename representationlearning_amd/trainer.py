@@ -62,8 +62,11 @@ class GradBuckets:
       joined before the clip (inside a captured step these are parallel branches of the hipGraph),
     * torch.distributed: async_op work handles on the process group's own stream."""
 
-    def __init__(self, flat, comm, nbuckets=6):
+    def __init__(self, flat, comm, nbuckets=6, before_launch=None):
         self.flat, self.comm = flat, comm
+        # called on the compute stream right before a bucket's collective is enqueued: the trainer flushes the deferred split-K
+        # reductions of the weight gradients (nnf.WgradPlan) there, so that the bucket's gradients are final
+        self.before_launch = before_launch
         n = flat.numel
         target = max(1, n // nbuckets)
         self.bounds = []          # (start, end) over the flat buffer, built from the END (last layers first)
@@ -114,6 +117,12 @@ class GradBuckets:
         # the collective after THAT stream leaves it unordered against the backward kernels: a captured step then carries a race
         # that shows up as NaN losses as soon as the replay starts on an idle GPU (tools/dp_nan_probe.py).
         cs = self.compute_stream if (self.compute_stream is not None or not g.is_cuda) else torch.cuda.current_stream()
+        if self.before_launch is not None:
+            if g.is_cuda:
+                with torch.cuda.stream(cs):
+                    self.before_launch()
+            else:
+                self.before_launch()
         if self.comm.direct:
             self.side.wait_stream(cs)
             with torch.cuda.stream(self.side):
@@ -191,13 +200,38 @@ class Trainer:
         # Data path of DP: direct RCCL communicators when possible (collectives enqueued like kernels, so the whole step can
         # still be one hipGraph): one for the SyncBN exchanges on the compute stream, one for the gradient buckets on a side
         # stream.  Else torch.distributed (eager launches; buckets as async work on the process group's stream).
-        self.comm = self.grad_comm = None
+        # Every stream that issues collectives has its OWN communicator (one communicator's collectives must be issued in one order on
+        # every rank, and two streams give none): the SyncBN exchanges of the step's main stream, those of each of the three side
+        # streams (HRNet branches 1..3 / the fuse outputs 1.. beside the transformer block: nnf.parallel_map, nnf.fork_side) and the
+        # gradient buckets on their stream.
+        # The SyncBN exchanges themselves: the peer-to-peer kernel of csrc/p2p.hip (one channel per stream) when its start-up
+        # self-test passes on this node, RCCL all-reduces (one communicator per stream) otherwise.
+        self.comm = self.grad_comm = self.p2p = None
+        self.side_comms, self._rccl = [], []
         if dp:
+            nside = 3 if os.environ.get("RSSF_DP_SIDE_COMMS", "1") != "0" else 0
             comms = rccl.create(2)
-            self.comm, self.grad_comm = comms if comms is not None else (rccl.TorchComm(), rccl.TorchComm())
+            if comms is not None:
+                self._rccl = list(comms)
+                self.comm, self.grad_comm = comms
+                self.p2p = rccl.create_p2p(1 + nside, self.grad_comm)
+                if self.p2p is not None:
+                    self.comm, self.side_comms = self.p2p.channel(0), [self.p2p.channel(1 + k) for k in range(nside)]
+                elif nside:
+                    more = rccl.create(nside)
+                    if more is not None:
+                        self._rccl += more
+                        self.side_comms = list(more)
+            else:
+                self.comm, self.grad_comm = rccl.TorchComm(), rccl.TorchComm()
+                if os.environ.get("RSSF_SYNCBN") == "p2p" and torch.cuda.is_available():
+                    # asked for explicitly: the peer-to-peer exchange does not need RCCL (tests: two ranks on one GPU over gloo)
+                    self.p2p = rccl.create_p2p(1 + nside, self.grad_comm)
+                    if self.p2p is not None:
+                        self.comm, self.side_comms = self.p2p.channel(0), [self.p2p.channel(1 + k) for k in range(nside)]
             self._broadcast_initial_state()
         overlap = os.environ.get("RSSF_GRAD_OVERLAP", "1") != "0"
-        self.buckets = GradBuckets(self.flat, self.grad_comm, nbuckets) if (dp and overlap) else None
+        self.buckets = GradBuckets(self.flat, self.grad_comm, nbuckets, before_launch=self._flush_wgrad) if (dp and overlap) else None
         self.rt.comm = self.comm
         self.rt.sync_all_bn = bool(sync_bn and dp)
         self.rt.force_collectives = dp and self.world == 1
@@ -220,14 +254,26 @@ class Trainer:
         self.graph_warmup = 3
         # HRNet branches on side streams: parallel branches of the captured graph (+1 % at B=16); eager launches are host-bound
         # and the SyncBN exchanges of a DP step must reach the communicator in one fixed order, so both keep a single stream
-        self.rt.branch_streams = self.use_graph and not dp and os.environ.get("RSSF_BRANCH_STREAMS", "1") != "0"
+        self.rt.branch_streams = self.use_graph and os.environ.get("RSSF_BRANCH_STREAMS", "1") != "0"
+        if dp:
+            # data parallel with a communicator per side stream: the same stream layout as the single-GPU step.  With ONE communicator
+            # for all SyncBN exchanges (torch.distributed, RSSF_DP_SIDE_COMMS=0) the HighResolutionModules walk their branches and fuse
+            # paths in lock-step groups on the step's stream instead (one exchange per group, in a fixed order); RSSF_GROUP_STREAMS=1
+            # then runs the items of a group on parallel streams around it (measured slower: two fork/joins per group).
+            self.rt.stream_comms = self.side_comms if (self.side_comms and self.rt.branch_streams) else None
+            self.rt.group_streams = self.rt.branch_streams and self.rt.stream_comms is None and os.environ.get("RSSF_GROUP_STREAMS", "0") == "1"
         self.pack_plan = nnf.PackPlan() if os.environ.get("RSSF_PACK_PLAN", "1") != "0" else None
-        # one batched split-K reduction per step instead of ~330 (nnf.WgradPlan).  With gradient buckets in flight during
-        # backward a bucket's gradients must be final when its parameters report ready, so the reductions stay immediate there.
-        self.wgrad_plan = nnf.WgradPlan() if (self.buckets is None and os.environ.get("RSSF_WGRAD_PLAN", "1") != "0") else None
+        # batched split-K reductions instead of ~330 (nnf.WgradPlan): ONE launch at the end of backward, or - with gradient buckets
+        # in flight during backward - one per bucket, issued right before the bucket's all-reduce (GradBuckets.before_launch)
+        self.wgrad_plan = nnf.WgradPlan() if os.environ.get("RSSF_WGRAD_PLAN", "1") != "0" else None
         self.graph = None
         self._static = None
         self._side = None
+
+    def _flush_wgrad(self):
+        wp = self.rt.wgrad_plan
+        if wp is not None:
+            wp.flush()
 
     def _broadcast_initial_state(self):
         """What DistributedDataParallel does at construction: rank 0's parameters and buffers everywhere."""
@@ -356,9 +402,14 @@ class Trainer:
 
     def close(self):
         """Destroy the RCCL communicators (before torch.distributed's process group goes away)."""
-        for c in {id(c): c for c in (self.comm, self.grad_comm) if c is not None}.values():
+        if self.p2p is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.p2p.destroy()
+        for c in {id(c): c for c in [self.comm, self.grad_comm] + list(self.side_comms) + list(self._rccl) if c is not None}.values():
             c.destroy()
-        self.comm = self.grad_comm = self.rt.comm = None
+        self.comm = self.grad_comm = self.p2p = self.rt.comm = self.rt.stream_comms = None
+        self.side_comms, self._rccl = [], []
 
 
 def init_distributed():

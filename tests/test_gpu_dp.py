@@ -33,11 +33,17 @@ def _inputs():
     return x, y
 
 
-def _worker(rank, port, out_dir, sync_bn):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RSSF_GRAPH="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _worker(rank, port, out_dir, sync_bn, two_gpus=False, p2p=False):
+    """two_gpus: one GPU per rank, NCCL process group, the DIRECT RCCL communicators (one per stream) - what a real node runs.
+    p2p: the SyncBN exchanges through the peer-to-peer kernel (csrc/p2p.hip) instead of torch.distributed."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if p2p:
+        os.environ.update(RSSF_SYNCBN="p2p", RSSF_P2P_TIMEOUT_MS="5000")
+    if not two_gpus:
+        os.environ["RSSF_GRAPH"] = "0"
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank if two_gpus else 0)
+    dist.init_process_group("nccl" if two_gpus else "gloo", rank=rank, world_size=WORLD)
     from oracle.procedural import seeded_state
     from representationlearning_amd.configs import rssformer_config
     from representationlearning_amd.core import registry
@@ -49,8 +55,11 @@ def _worker(rank, port, out_dir, sync_bn):
         sd = {k: (v + 0.01 if v.is_floating_point() else v) for k, v in sd.items()}
     model.load_state_dict(sd)
     model = model.cuda()
-    tr = Trainer(model, bf16=False, sync_bn=sync_bn, base_lr=0.0, weight_decay=0.0, use_graph=False)
-    assert tr.comm is not None and not tr.comm.direct and tr.buckets is not None and tr.world == WORLD
+    tr = Trainer(model, bf16=False, sync_bn=sync_bn, base_lr=0.0, weight_decay=0.0, use_graph=two_gpus)
+    assert tr.comm is not None and tr.comm.direct == (two_gpus or p2p) and tr.buckets is not None and tr.world == WORLD
+    assert (type(tr.comm).__name__ == "P2PChannel") == (p2p or two_gpus), type(tr.comm).__name__
+    if two_gpus:
+        assert len(tr.side_comms) == 3 and tr.rt.stream_comms is not None and tr.use_graph
     x, y = _inputs()
     xs = x[rank * B_LOCAL:(rank + 1) * B_LOCAL].cuda()
     ys = y[rank * B_LOCAL:(rank + 1) * B_LOCAL].cuda()
@@ -65,10 +74,19 @@ def _worker(rank, port, out_dir, sync_bn):
         names = [k for k, p in model.named_parameters() if p.requires_grad]
         out["grads"] = {k: grad[o:o + p.numel()].view_as(p).clone() for k, p, o in zip(names, tr.flat.params, tr.flat.offsets)}
         out["buffers"] = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
+    if two_gpus:
+        # lr = 0 steps repeat the same gradients: run past the warm-up into the captured hipGraph (its parallel branches carry the
+        # collectives of five communicators) and hold the replayed step against the eager one
+        for _ in range(tr.graph_warmup + 1):
+            loss_g = float(tr.step(xs, dict(cls=ys)))
+        assert tr.graph is not None, "the data-parallel step was not captured"
+        g2 = (tr.flat.grad / WORLD).cpu()
+        out["graph_loss"], out["graph_grad_rel"] = loss_g, float((g2 - grad).double().norm() / grad.double().norm())
     # a second step with a real learning rate: replicas must stay bit-identical
     tr.hp["base_lr"] = 0.01
     tr.step(xs, dict(cls=ys))
     out["param_sum_after"] = float(tr.flat.flat.double().sum())
+    out["p2p_timed_out"] = tr.p2p.timed_out() if tr.p2p is not None else 0
     torch.save(out, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     tr.close()
@@ -76,11 +94,11 @@ def _worker(rank, port, out_dir, sync_bn):
 
 
 @functools.lru_cache(maxsize=None)
-def _run_world(sync_bn):
+def _run_world(sync_bn, two_gpus=False, p2p=False):
     ctx = mp.get_context("spawn")
     port = _free_port()
     with tempfile.TemporaryDirectory() as d:
-        procs = [ctx.Process(target=_worker, args=(r, port, d, sync_bn)) for r in range(WORLD)]
+        procs = [ctx.Process(target=_worker, args=(r, port, d, sync_bn, two_gpus, p2p)) for r in range(WORLD)]
         for p in procs:
             p.start()
         for p in procs:
@@ -90,9 +108,20 @@ def _run_world(sync_bn):
 
 
 def test_two_ranks_match_pooled_bn_mean_of_shard_gradients():
+    _check_world(_run_world(sync_bn=True), 280)
+
+
+def test_two_ranks_with_p2p_syncbn_exchange_match_the_same_emulation():
+    """The same two-rank step with every SyncBN exchange (one per layer and direction: 660) going through the peer-to-peer kernel
+    between the two processes - the transport a node uses - instead of torch.distributed."""
+    res = _run_world(True, False, True)
+    assert res[0]["p2p_timed_out"] == 0 and res[1]["p2p_timed_out"] == 0
+    _check_world(res, 700)
+
+
+def _check_world(res, max_exchanges):
     from oracle import rssformer_cpu as O
     from tests.helpers import rel_err, seeded_params
-    res = _run_world(sync_bn=True)
     # replicas agree bit for bit: same all-reduced gradient, same parameters before and after an update
     assert res[0]["grad_sum"] == res[1]["grad_sum"] and res[0]["grad_abs"] == res[1]["grad_abs"]
     assert res[0]["param_sum"] == res[1]["param_sum"] and res[0]["param_sum_after"] == res[1]["param_sum_after"]
@@ -133,7 +162,30 @@ def test_two_ranks_match_pooled_bn_mean_of_shard_gradients():
     assert int(bufs["backbone.hrnet.bn1.num_batches_tracked"]) == 1       # flushed after the first (lr = 0) step
     # SyncBN exchanges of one step: 330 BatchNorm layers x {forward, backward} = 660 one by one; the lock-step walk of the HRNet
     # branches / fuse paths (nnf.conv_bn_act_group) sends the statistics of independent layers together
-    assert res[0]["n_exchanges"] == res[1]["n_exchanges"] and res[0]["n_exchanges"] <= 280, res[0]["n_exchanges"]
+    assert res[0]["n_exchanges"] == res[1]["n_exchanges"] and res[0]["n_exchanges"] <= max_exchanges, res[0]["n_exchanges"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the direct RCCL communicators refuse two ranks on one device)")
+def test_two_gpus_direct_rccl_eager_and_graph_match_emulation():
+    """the direct-RCCL path (one communicator per stream: main, three side streams, gradient buckets) on REAL ranks,
+    eager and hipGraph-replayed, against the same emulation oracle as the one-GPU test above.  Runs wherever two GPUs are visible."""
+    from oracle import rssformer_cpu as O
+    from tests.helpers import rel_err, seeded_params
+    res = _run_world(True, True)
+    assert res[0]["grad_sum"] == res[1]["grad_sum"] and res[0]["param_sum_after"] == res[1]["param_sum_after"]
+    P = seeded_params(O.model_template("base"))
+    x, y = _inputs()
+    xs = [x[r * B_LOCAL:(r + 1) * B_LOCAL] for r in range(WORLD)]
+    ys = [y[r * B_LOCAL:(r + 1) * B_LOCAL] for r in range(WORLD)]
+    mean_loss, shard_losses = O.model_forward_dp(xs, ys, P)
+    mean_loss.backward()
+    for r in range(WORLD):
+        assert abs(res[r]["loss"] - float(shard_losses[r])) < 1e-3 * abs(float(shard_losses[r]))
+        assert abs(res[r]["graph_loss"] - res[r]["loss"]) < 1e-4 * abs(res[r]["loss"])
+        assert res[r]["graph_grad_rel"] < 1e-3, res[r]["graph_grad_rel"]          # atomics order only
+    got = res[0]["grads"]
+    for k in ("neck.fuse_conv.1.weight", "backbone.hrnet.stage4.2.transformer.mlp.norm3.weight", "head.0.weight"):
+        assert rel_err(got[k], P[k].grad) < 2e-2, k
 
 
 def test_two_ranks_without_sync_bn_keep_local_statistics_except_mlp():
@@ -143,3 +195,94 @@ def test_two_ranks_without_sync_bn_keep_local_statistics_except_mlp():
     local = _run_world(sync_bn=False)
     assert local[0]["grad_sum"] == local[1]["grad_sum"]                   # gradients are still averaged
     assert abs(local[0]["loss"] - pooled[0]["loss"]) > 1e-4 * abs(pooled[0]["loss"])
+
+
+def _p2p_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RSSF_P2P_TIMEOUT_MS="4000")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.cuda.set_device(0)
+    from representationlearning_amd import rccl
+    ex = rccl.P2PExchange(2)
+    assert ex.error is None, ex.error
+    nslots, c1, c2 = 16, 32, 128                       # two layers: [16][2*32] and [16][2*128] statistics blocks
+    n1, n2 = 2 * c1, 2 * c2
+    layout = (nslots, [(0, n1), (nslots * n1, n2)])
+    g = torch.Generator().manual_seed(5)
+    base = [torch.randn(nslots * (n1 + n2), generator=g) for _ in range(WORLD)]          # every rank knows every rank's input
+    fold = lambda t: torch.cat([t[:nslots * n1].view(nslots, n1), ], 0).sum(0)
+    want = None
+    for r in range(WORLD):                              # rank-ordered sum of the per-rank slot folds (what the kernel computes)
+        loc = torch.cat([base[r][:nslots * n1].view(nslots, n1).cuda().sum(0), base[r][nslots * n1:].view(nslots, n2).cuda().sum(0)])
+        want = loc if want is None else want + loc
+    out = dict(ok=True, msgs=[])
+
+    def check(buf, what):
+        tot = torch.cat([buf[:n1], buf[nslots * n1:nslots * n1 + n2]])
+        rest = torch.cat([buf[n1:nslots * n1], buf[nslots * n1 + n2:]])
+        if not torch.allclose(tot, want, rtol=1e-5, atol=1e-5) or float(rest.abs().sum()) != 0.0:
+            out["ok"] = False
+            out["msgs"].append("%s: max diff %g" % (what, float((tot - want).abs().max())))
+        return tot.clone()
+
+    mine = base[rank].cuda()
+    ch0, ch1 = ex.channel(0), ex.channel(1)
+    side = torch.cuda.Stream()
+    firsts = []
+    for it in range(5):                                 # eager, both channels in flight on two streams
+        a, b = mine.clone(), mine.clone()
+        side.wait_stream(torch.cuda.current_stream())
+        ch0.syncbn_exchange_(a, layout)
+        with torch.cuda.stream(side):
+            ch1.syncbn_exchange_(b, layout)
+        torch.cuda.current_stream().wait_stream(side)
+        firsts.append(check(a, "eager ch0 #%d" % it))
+        check(b, "eager ch1 #%d" % it)
+    # the same inside a captured graph, replayed: the epoch lives in device memory and advances per replay
+    sa, sb = mine.clone(), mine.clone()
+    src = mine.clone()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            sa.copy_(src); sb.copy_(src)
+            side.wait_stream(torch.cuda.current_stream())
+            ch0.syncbn_exchange_(sa, layout)
+            ch0.syncbn_exchange_(sa, (1, [(0, n1)]))       # a second, unslotted exchange of the totals of layer 1: x WORLD
+            with torch.cuda.stream(side):
+                ch1.syncbn_exchange_(sb, layout)
+            torch.cuda.current_stream().wait_stream(side)
+        for it in range(4):
+            gr.replay()
+            torch.cuda.synchronize()
+            check(sb, "graph ch1 #%d" % it)
+            if not torch.allclose(sa[:n1], WORLD * want[:n1], rtol=1e-5, atol=1e-5):
+                out["ok"] = False
+                out["msgs"].append("graph ch0 #%d" % it)
+    out["timed_out"] = ex.timed_out()
+    out["first"] = firsts[0].cpu()
+    torch.save(out, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    ex.destroy()
+    dist.destroy_process_group()
+
+
+def test_p2p_syncbn_exchange_two_processes():
+    """The peer-to-peer SyncBN exchange (csrc/p2p.hip: hipIpc-mapped windows, value+epoch words, rank-ordered sums) between TWO
+    processes - as on a node, except that both live on the one GPU of the box: eager on two channels / two streams at once, and
+    inside a replayed hipGraph.  Totals equal the slot-folded sum over ranks, the other slots are cleared, both ranks hold
+    bit-identical results, nobody timed out."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_p2p_worker, args=(r, port, d)) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0, "rank process failed (exit code %s)" % p.exitcode
+        res = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=False) for r in range(WORLD)]
+    for r in res:
+        assert r["timed_out"] == 0 and r["ok"], r["msgs"][:5]
+    assert torch.equal(res[0]["first"], res[1]["first"])

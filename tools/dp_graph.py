@@ -13,7 +13,7 @@ registry.register_all()
 torch.manual_seed(0)
 model = registry.MODEL["RSSFormer"](rssformer_config("base")).cuda()
 tr = Trainer(model, base_lr=0.01, max_iters=1000, bf16=True, sync_bn=True)
-print("dp buckets:", tr.buckets is not None, "rccl comm:", tr.comm is not None, "use_graph:", tr.use_graph)
+print("dp buckets:", tr.buckets is not None, "syncbn exchange:", type(tr.comm).__name__, "use_graph:", tr.use_graph)
 img, lab = synthetic_batch(16, 512, seed=1)
 tgt = dict(cls=lab)
 losses = []
@@ -24,6 +24,10 @@ for i in range(12):
 torch.cuda.synchronize()
 print("ms/step %.1f" % ((time.perf_counter() - t0) / 6 * 1e3), "graph captured:", tr.graph is not None)
 print("losses", [round(l, 4) for l in losses])
-print("SyncBN exchanges issued by Python over 12 steps (eager steps + the capture pass):", tr.comm.n_syncbn)
+n0 = tr.comm.n_syncbn
+tr.use_graph = False
+tr._eager_step(img, tgt)
+torch.cuda.synchronize()
+print("SyncBN exchanges per step: main stream %d, side streams %s" % (tr.comm.n_syncbn - n0, [c.n_syncbn // 5 for c in tr.side_comms]))
 tr.close()
 dist.destroy_process_group()
