@@ -18,6 +18,7 @@
 // scatters to its three source convs); measured: per-element atomics from ~1000 blocks cost 300-470 us per call,
 // ~10x the GEMM itself.  (Without a workspace the kernel falls back to atomics.)
 // Optional bias gradient (sum_p dout) for convolutions without a following BatchNorm.
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include "conv.hip.h"
@@ -263,6 +264,137 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
         }
   }
   if (do_bias && tid < TMN && co0 + tid < a.Cout) atomicAdd(a.dbias + co0 + tid, bsum);
+}
+
+// The 128 x 128 (co, ci) tile of the wide layers (MlpDWBN's 17-tap sum: 8 launches of 146 GFLOP per training step) with EIGHT
+// waves and a two-slab pipeline.  The four-wave kernel above keeps one slab in flight per block (register staging of the next
+// slab under the MFMAs of the current one, two barriers per slab) and two blocks per CU: with ~2 us of memory latency under load
+// and ~0.6 us of work per slab it waited out a round trip per slab (measured: 298 us per launch = 19 % of the MFMA peak, the
+// forward kernel of the same FLOPs runs 191 us).  Here a wave owns a 64 x 32 tile (32 accumulator registers instead of 64) and 2
+// staging chunks per operand (instead of 4), which pays for TWO register sets and two LDS buffers: slabs s+1 and s+2 are in
+// flight while slab s computes, one barrier per slab, no branch around a load (exact vmcnt bookkeeping, see conv_fwd.hip).
+__global__ void __launch_bounds__(512) conv_wgrad8_kernel(WgradArgs a) {
+  using T = bf16_t;
+  using MK = MmaK<T>;
+  constexpr int TMN = 128, V = 8, LD = TMN + 16, CPR = TMN / V, CHUNKS = KP * CPR / 512;       // 2 chunks per thread and operand
+  static_assert(CHUNKS * 512 == KP * CPR, "staging covers the slab exactly");
+  __shared__ __attribute__((aligned(16))) T DS[2][KP * LD];
+  __shared__ __attribute__((aligned(16))) T XS[2][KP * LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
+  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);
+  if (q >= (int64_t)a.inner * a.ksplit) return;
+  const unsigned q32 = (unsigned)q;
+  const int range = (int)(q32 / (unsigned)a.inner);
+  int bid = (int)(q32 - (unsigned)range * (unsigned)a.inner);
+  const int cit = bid % a.ctiles_n; bid /= a.ctiles_n;
+  const int cot = bid % a.ctiles_m; bid /= a.ctiles_m;
+  const int tap = a.tap0 + bid;
+  const int co0 = cot * TMN, ci0 = cit * TMN;
+  const int64_t M = (int64_t)a.B * a.OH * a.OW;
+  const int64_t per = ((M + a.ksplit - 1) / a.ksplit + KP - 1) / KP * KP;
+  const int64_t kbeg = (int64_t)range * per, kend = kbeg + per < M ? kbeg + per : M;
+  const int wm = wave >> 2, wn = wave & 3;                   // 2 x 4 waves of 64 (co) x 32 (ci)
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dout), 0, (int)((int64_t)a.B * a.OH * a.OW * a.Cout * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)((int64_t)a.B * a.IH * a.IW * a.Cin * 2), 0x00020000);
+  const int dy = a.taps.dy[tap], dx = a.taps.dx[tap];
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  int srow[CHUNKS], scol[CHUNKS], pix[CHUNKS], pb[CHUNKS], py[CHUNKS], px[CHUNKS];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const int id = tid + c * 512;
+    srow[c] = id / CPR; scol[c] = (id % CPR) * V;
+    pix[c] = (int)kbeg + srow[c];
+    pb[c] = pix[c] / (a.OH * a.OW);
+    const int rem = pix[c] % (a.OH * a.OW);
+    py[c] = rem / a.OW; px[c] = rem % a.OW;
+  }
+  struct Regs { u32x4 d[CHUNKS], x[CHUNKS]; };
+  Regs R0, R1;
+  auto load = [&](Regs& R) {         // the slab the coordinate state points at, then advance the state by one slab
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const bool pv = pix[c] < (int)kend;                                                  // past the range: zeros, never used
+      const int cho = co0 + scol[c], chi = ci0 + scol[c];
+      const int sy = py[c] * a.stride + dy, sx = px[c] * a.stride + dx;
+      const bool dok = pv && cho < a.Cout;
+      const bool xok = pv && sy >= 0 && sy < a.IH && sx >= 0 && sx < a.IW && chi < a.Cin;
+      const unsigned doff = (unsigned)(pix[c] * a.Cout + cho) * 2u;
+      const unsigned xoff = (unsigned)(((pb[c] * a.IH + sy) * a.IW + sx) * a.Cin + chi) * 2u;
+      R.d[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, dok ? doff : OOB, 0, 0));
+      R.x[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xok ? xoff : OOB, 0, 0));
+      pix[c] += KP; px[c] += KP;
+      while (px[c] >= a.OW) { px[c] -= a.OW; ++py[c]; }
+      while (py[c] >= a.OH) { py[c] -= a.OH; ++pb[c]; }
+    }
+  };
+  auto store = [&](const Regs& R, int b) {
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      *reinterpret_cast<u32x4*>(&DS[b][srow[c] * LD + scol[c]]) = R.d[c];
+      *reinterpret_cast<u32x4*>(&XS[b][srow[c] * LD + scol[c]]) = R.x[c];
+    }
+  };
+  auto compute = [&](int b) {
+#pragma unroll
+    for (int ks = 0; ks < KP; ks += MK::KSTEP) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = SlabFrag<T>::load(DS[b], LD, ks, (wm * 4 + i) * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = SlabFrag<T>::load(XS[b], LD, ks, (wn * 2 + j) * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MK::mma(fa[i], fb[j], acc[i][j]);
+    }
+  };
+  // bias gradient (MlpDWBN's convolutions carry a bias, ffn_block.py:219-228): column sums of
+  // the dout slab, by the blocks of the first tap / first ci tile only (block-uniform; LDS reads, no global load in the branch)
+  const bool do_bias = a.dbias && tap == a.tap0 && cit == 0;
+  float bsum = 0.f;
+  auto bias_rows = [&](int b) {
+    const int col = tid & 127, r0 = (tid >> 7) * (KP / 4);
+#pragma unroll
+    for (int k = 0; k < KP / 4; ++k) bsum += ldf(&DS[b][(r0 + k) * LD + col]);
+  };
+  const int nslabs = (int)((kend - kbeg + KP - 1) / KP), nrun = (nslabs + 1) & ~1;
+  load(R0); load(R1);
+  for (int s = 0; s < nrun; s += 2) {
+    store(R0, 0);
+    __syncthreads();               // buffer 0 complete; every wave is done computing out of buffer 1's previous contents
+    load(R0);
+    compute(0);
+    if (do_bias) bias_rows(0);
+    store(R1, 1);
+    __syncthreads();
+    load(R1);
+    compute(1);
+    if (do_bias) bias_rows(1);
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&XS[0][0]);          // [4][128]
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 128 && co0 + tid < a.Cout) atomicAdd(a.dbias + co0 + tid, (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]));
+  }
+  if (!a.partial) return;          // (the dispatcher sends only workspace launches here)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + (wm * 4 + i) * 16 + grp * 4 + r, ci = ci0 + (wn * 2 + j) * 16 + l15;
+        if (co < a.Cout && ci < a.Cin) a.partial[(((int64_t)range * a.ntaps_total + tap) * a.Cout + co) * a.Cin + ci] = acc[i][j][r];
+      }
 }
 
 // second stage of the split-K reduction: dw[torch layout] += sum_k partial[k][tap][co][ci].  A block owns 128 consecutive
@@ -632,7 +764,8 @@ int pick_ksplit(int cout, int cin, int ntaps, int64_t M) {
   const int t = tile_of(cout, cin);
   int64_t par = (int64_t)((cout + t - 1) / t) * ((cin + t - 1) / t);
   if (!taps_in_registers(cout, cin)) par *= ntaps;
-  int64_t ks = (t == 128 ? 512 : 1024) / par;        // measured on MI355X (tools_wgrad_bench.py sweep)
+  static const int blocks128 = getenv("RSSF_WGRAD_KS128") ? atoi(getenv("RSSF_WGRAD_KS128")) : 512;      // tuning sweeps only
+  int64_t ks = (t == 128 ? blocks128 : 1024) / par;  // measured on MI355X (tools/wgrad_bench.py sweep)
   const int64_t maxks = (M + 4 * KP - 1) / (4 * KP);
   if (ks > maxks) ks = maxks;
   if (ks < 1) ks = 1;
@@ -652,7 +785,9 @@ int launch_group(WgradArgs& a, int tap0, int ntap, hipStream_t st) {
     if (vok) conv_wgrad_kernel<T, TMN, (TMN == 32 ? 9 : 1), true><<<grid, 256, 0, st>>>(a);
     else conv_wgrad_kernel<T, TMN, (TMN == 32 ? 9 : 1), false><<<grid, 256, 0, st>>>(a);
   } else {
-    if (vok) conv_wgrad_kernel<T, TMN, 1, true><<<grid, 256, 0, st>>>(a);
+    static const bool wg8 = !(getenv("RSSF_WGRAD8") && getenv("RSSF_WGRAD8")[0] == '0');       // A/B switch (tools/wgrad_bench.py)
+    if (TMN == 128 && sizeof(T) == 2 && vok && a.partial && wg8) conv_wgrad8_kernel<<<grid, 512, 0, st>>>(a);
+    else if (vok) conv_wgrad_kernel<T, TMN, 1, true><<<grid, 256, 0, st>>>(a);
     else conv_wgrad_kernel<T, TMN, 1, false><<<grid, 256, 0, st>>>(a);
   }
   return check_launch("conv_wgrad");
