@@ -388,7 +388,7 @@ int rssf_comm_destroy(rssf_comm* comm);
  * `ipc_handle64` = the 64 bytes of its hipIpcMemHandle_t, carried to the peers by the caller's rendezvous; a CHANNEL is an
  * independent exchange sequence (one per stream that issues exchanges).  `stats` holds, per layer i, an [nslots][item_n[i]] block
  * at element offset item_off[i] (item_n = 2C): on return slot 0 holds the sum over slots AND ranks, the other slots are zero.
- * A peer that does not show up within RSSF_P2P_TIMEOUT_MS (default 10 000) sets the error word rssf_p2p_status reports. */
+ * A peer that does not show up within the time-out (rssf_p2p_set_timeout_ms) sets the error word rssf_p2p_status reports. */
 #define RSSF_P2P_MAX_FLOATS 4096
 #define RSSF_P2P_MAX_ITEMS 8
 typedef struct rssf_p2p rssf_p2p;
@@ -396,6 +396,9 @@ int rssf_p2p_create(rssf_p2p** p2p, int rank, int world, int channels, void* ipc
 int rssf_p2p_connect(rssf_p2p* p2p, int peer, const void* ipc_handle64);
 int rssf_p2p_exchange(rssf_p2p* p2p, int channel, float* stats, const int* item_off, const int* item_n, int nitems, int nslots,
                       void* stream);
+/* bound of the wait for a peer in the exchanges launched from now on; 0 = unbounded (what a collective does).  A new object starts
+ * with RSSF_P2P_TIMEOUT_MS from the environment (default 10 000). */
+int rssf_p2p_set_timeout_ms(rssf_p2p* p2p, int ms);
 int rssf_p2p_status(rssf_p2p* p2p, int* timed_out);
 int rssf_p2p_destroy(rssf_p2p* p2p);
 

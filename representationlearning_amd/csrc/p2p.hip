@@ -13,7 +13,9 @@
 // Windows are double-buffered by the parity of a per-channel epoch that lives in device memory and is advanced by the kernel
 // itself, so the launch is replay-safe inside a captured hipGraph; a CHANNEL is an independent sequence of exchanges (one per stream
 // that issues them: kernels of one channel run in stream order, kernels of different channels never touch the same flags).
-// A bounded spin (RSSF_P2P_TIMEOUT_MS, default 10 s) turns a missing peer into an error word instead of a hung GPU.
+// A bounded spin (rssf_p2p_set_timeout_ms; the start-up self-test and the tests use one) turns a missing peer into an error word
+// instead of a hung GPU; in steady state the wait is unbounded, as a collective's is (a rank may legitimately be minutes late: it
+// evaluates or writes a checkpoint while the others have entered the next step).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(256) p2p_exchange_kernel(ExArgs a) {
     for (int r = 0; r < a.world; ++r) {
       u64 w = __hip_atomic_load(inbox + (size_t)r * MAXF + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       while ((unsigned)(w >> 32) != e) {
-        if (wall_clock64() - t0 > a.timeout_ticks) { atomicExch(a.err, 1u + (unsigned)r); break; }
+        if (a.timeout_ticks > 0 && wall_clock64() - t0 > a.timeout_ticks) { atomicExch(a.err, 1u + (unsigned)r); break; }
         __builtin_amdgcn_s_sleep(1);
         w = __hip_atomic_load(inbox + (size_t)r * MAXF + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -163,6 +165,12 @@ extern "C" int rssf_p2p_exchange(rssf_p2p* h, int channel, float* stats, const i
   a.timeout_ticks = h->timeout_ticks;
   p2p_exchange_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a);
   return check_launch("p2p_exchange");
+}
+
+extern "C" int rssf_p2p_set_timeout_ms(rssf_p2p* h, int ms) {
+  RSSF_REQUIRE(h && ms >= 0, "p2p_set_timeout_ms: bad arguments");
+  h->timeout_ticks = (long long)ms * 100000LL;       // 0: wait for the peers for ever, like a collective library does
+  return RSSF_OK;
 }
 
 extern "C" int rssf_p2p_status(rssf_p2p* h, int* timed_out) {

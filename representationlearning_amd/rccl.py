@@ -106,6 +106,9 @@ class P2PExchange:
     def channel(self, k):
         return P2PChannel(self, k)
 
+    def set_timeout_ms(self, ms):
+        L.check(self._lib.rssf_p2p_set_timeout_ms(self._h, int(ms)), "rssf_p2p_set_timeout_ms")
+
     def timed_out(self):
         v = ctypes.c_int(0)
         L.check(self._lib.rssf_p2p_status(self._h, ctypes.byref(v)), "rssf_p2p_status")
@@ -159,6 +162,7 @@ def create_p2p(channels, reference_comm):
         why = "%s: %s" % (type(e).__name__, e)
     if _agree(why is None):
         try:
+            ex.set_timeout_ms(int(os.environ.get("RSSF_P2P_TIMEOUT_MS", "3000")))      # the self-test must not hang on a broken fabric
             rank, world = ex.rank, ex.world
             nslots, c1, c2 = 4, 24, 40
             base = torch.arange(nslots * (c1 + c2), device="cuda", dtype=torch.float32) * 0.25 + (rank + 1) * 3.0
@@ -178,6 +182,9 @@ def create_p2p(channels, reference_comm):
         except Exception as e:                                 # noqa: BLE001
             why = "%s: %s" % (type(e).__name__, e)
         if _agree(why is None):
+            # steady state: wait for a late rank as long as it takes (it may be evaluating or writing a checkpoint), unless the
+            # environment asks for a bound (tests)
+            ex.set_timeout_ms(int(os.environ.get("RSSF_P2P_TIMEOUT_MS", "0")))
             return ex
     if why:
         print("[rssf] peer-to-peer SyncBN exchange unavailable (%s); using RCCL all-reduces" % why, flush=True)
