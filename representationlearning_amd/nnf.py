@@ -703,6 +703,7 @@ def group_stats_link(n):
     return GroupBwdLink(n) if (_FUSED_BN_STATS and torch.is_grad_enabled() and not current().deterministic) else None
 
 
+_PLAN_BIAS = os.environ.get("RSSF_WGRAD_PLAN_BIAS", "1") != "0"      # A/B switch: deferred split-K reduction also for convolutions with a bias
 _FORK_FUSE = os.environ.get("RSSF_FORK_FUSE", "1") != "0"      # A/B switch: fuse outputs 1.. beside the transformer block (fork_side)
 _DEFER_BN_APPLY = os.environ.get("RSSF_DEFER_BN_APPLY", "1") != "0"      # A/B switch: forward BatchNorm apply inside the consumer's staging
 _FUSED_BN_APPLY = os.environ.get("RSSF_FUSED_BN_APPLY", "1") != "0"      # A/B switch: BatchNorm-backward apply inside the weight-gradient launch
@@ -818,7 +819,8 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None):
     nws = lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, CO, spec.ntaps)
     plan = (rt or current()).wgrad_plan
     ws = job = ref = None
-    if plan is not None and not padded and tdb is None and not plan.duplicate_target([t.data_ptr() for t in dws]):
+    # (a bias gradient does not stand in the way: the first stage adds it straight into its buffer, only the weight partials wait)
+    if plan is not None and not padded and (tdb is None or _PLAN_BIAS) and not plan.duplicate_target([t.data_ptr() for t in dws]):
         key = (id(spec), B, H, W, C, OH, OW, CO, xh.dtype, tuple(t.data_ptr() for t in dws))
         if plan.recording:
             plan.record(key, nws)

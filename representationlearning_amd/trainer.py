@@ -9,6 +9,7 @@ buffer), so gradient exchange is a handful of large flat buckets (xGMI is per-li
 the clip norm is one reduction and the optimizer is one fused HIP launch (csrc/optim.hip).
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -62,8 +63,9 @@ class GradBuckets:
       joined before the clip (inside a captured step these are parallel branches of the hipGraph),
     * torch.distributed: async_op work handles on the process group's own stream."""
 
-    def __init__(self, flat, comm, nbuckets=6, before_launch=None):
+    def __init__(self, flat, comm, nbuckets=6, before_launch=None, side_streams=None):
         self.flat, self.comm = flat, comm
+        self.side_streams = side_streams        # callable -> the streams (besides the compute stream) gradients are produced on
         # called on the compute stream right before a bucket's collective is enqueued: the trainer flushes the deferred split-K
         # reductions of the weight gradients (nnf.WgradPlan) there, so that the bucket's gradients are final
         self.before_launch = before_launch
@@ -88,14 +90,23 @@ class GradBuckets:
         self.launched = [False] * len(self.members)
         self.index_of = {id(p): i for i, p in enumerate(flat.params)}
         self.side = torch.cuda.Stream() if comm.direct else None
+        self.used = set()
         self.compute_stream = None
         # The post-accumulate-grad hook fires once per parameter and backward pass, after the LAST node that uses the parameter
         # has run - also when that node returned None because its kernels accumulated straight into p.grad (nnf's direct
         # gradient accumulation): AccumulateGrad is scheduled for undefined gradients too (tests/test_dp_gloo.py pins this).
         # So the hook alone is the "gradient complete, kernels enqueued" signal; signalling by hand as well counted every
         # parameter twice and launched buckets half-way (caught by tests/test_gpu_dp.py at world 2).
-        for i, p in enumerate(flat.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self.hook_handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
+
+    def close(self):
+        """Remove the hooks (parameters -> hooks -> this object -> parameters is a reference cycle: left alone, the trainer and its
+        captured hipGraph would be released by the cyclic collector at an arbitrary later moment - possibly in the middle of another
+        trainer's graph capture, which crashed the capture / replay of that graph)."""
+        for h in self.hook_handles:
+            h.remove()
+        self.hook_handles = []
+        self.before_launch = None
 
     def _make_hook(self, i):
         def hook(param):
@@ -117,16 +128,31 @@ class GradBuckets:
         # the collective after THAT stream leaves it unordered against the backward kernels: a captured step then carries a race
         # that shows up as NaN losses as soon as the replay starts on an idle GPU (tools/dp_nan_probe.py).
         cs = self.compute_stream if (self.compute_stream is not None or not g.is_cuda) else torch.cuda.current_stream()
-        if self.before_launch is not None:
+        # Gradients of the HRNet branches / fuse paths are produced on SIDE streams (nnf.parallel_map / fork_side): the step's
+        # stream joins them here, so that "after the compute stream" really means "after every kernel that wrote this bucket".
+        if g.is_cuda and self.side_streams is not None:
+            capturing = torch.cuda.is_current_stream_capturing() if cs == torch.cuda.current_stream() else None
+            for s in self.side_streams():
+                if capturing is None:
+                    with torch.cuda.stream(cs):
+                        capturing = torch.cuda.is_current_stream_capturing()
+                with torch.cuda.stream(s):
+                    s_cap = torch.cuda.is_current_stream_capturing()
+                if s_cap == capturing:             # (a stream that is not part of the running capture holds no work of this step)
+                    cs.wait_stream(s)
+        fn = self.before_launch() if self.before_launch is not None else None       # weak reference to the trainer's method
+        if fn is not None:
             if g.is_cuda:
                 with torch.cuda.stream(cs):
-                    self.before_launch()
+                    fn()
             else:
-                self.before_launch()
+                fn()
         if self.comm.direct:
-            self.side.wait_stream(cs)
-            with torch.cuda.stream(self.side):
+            side = self._bucket_stream()
+            side.wait_stream(cs)
+            with torch.cuda.stream(side):
                 self.comm.allreduce_bucket_(g)
+            self.used.add(side)
         elif g.is_cuda:
             with torch.cuda.stream(cs):                 # the process group orders its work after the stream current at the call
                 self.handles.append(self.comm.allreduce_bucket_async(g))
@@ -140,7 +166,17 @@ class GradBuckets:
         self.live = [sum(1 for i in m if id(self.flat.params[i]) in live_ids) for m in self.members]
         self.pending = list(self.live)
 
+    def _bucket_stream(self):
+        """Stream of the bucket all-reduces: the LAST side stream of the step when the step has side streams (its own otherwise).
+        A captured step then has four concurrent branches with or without data parallelism; with a fifth one (a stream of their
+        own) this ROCm's hipGraph runtime crashed in hip::Graph::UpdateStreams when a LATER graph of the process was launched
+        (tests/test_gpu_trainer.py in one process; rocgdb backtrace in DESIGN.md).  The collectives belong to their own
+        communicator, so sharing the stream with that side stream's SyncBN exchanges orders nothing wrongly."""
+        pool = self.side_streams() if self.side_streams is not None else []
+        return pool[-1] if (pool and os.environ.get("RSSF_BUCKET_OWN_STREAM") != "1") else self.side
+
     def begin(self):
+        self.used = set()
         self.compute_stream = torch.cuda.current_stream() if self.flat.grad.is_cuda else None
         self.pending = list(self.live)
         self.launched = [False] * len(self.members)
@@ -152,8 +188,9 @@ class GradBuckets:
             self._launch(b)
         for h in self.handles:
             h.wait()
-        if self.side is not None:
-            (self.compute_stream or torch.cuda.current_stream()).wait_stream(self.side)
+        for side in self.used:
+            (self.compute_stream or torch.cuda.current_stream()).wait_stream(side)
+        self.used = set()
 
 
 def flush_bn_counters(trainer):
@@ -231,7 +268,12 @@ class Trainer:
                         self.comm, self.side_comms = self.p2p.channel(0), [self.p2p.channel(1 + k) for k in range(nside)]
             self._broadcast_initial_state()
         overlap = os.environ.get("RSSF_GRAD_OVERLAP", "1") != "0"
-        self.buckets = GradBuckets(self.flat, self.grad_comm, nbuckets, before_launch=self._flush_wgrad) if (dp and overlap) else None
+        # (a WEAK reference to the bound method: a strong one would tie this trainer - and its captured graph - into the reference
+        # cycle of the gradient hooks, see GradBuckets.close)
+        rt, dev0 = self.rt, self.flat.flat.device            # (not `self`: no reference cycle through the closure)
+        self.buckets = GradBuckets(self.flat, self.grad_comm, nbuckets, before_launch=weakref.WeakMethod(self._flush_wgrad),
+                                   side_streams=lambda: rt.side_streams.get(dev0, []) if rt.branch_streams else []) \
+            if (dp and overlap) else None
         self.rt.comm = self.comm
         self.rt.sync_all_bn = bool(sync_bn and dp)
         self.rt.force_collectives = dp and self.world == 1
@@ -401,7 +443,11 @@ class Trainer:
         self.it = int(sd["it"])
 
     def close(self):
-        """Destroy the RCCL communicators (before torch.distributed's process group goes away)."""
+        """Destroy the RCCL communicators (before torch.distributed's process group goes away) and release the captured step NOW,
+        not whenever the garbage collector gets to it."""
+        if self.buckets is not None:
+            self.buckets.close()
+        self.graph = self._static = self._static_loss = None
         if self.p2p is not None:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
