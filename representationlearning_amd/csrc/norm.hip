@@ -7,7 +7,9 @@ using namespace rssf;
 namespace {
 
 // ---- forward ------------------------------------------------------------------------------------------
-// G lanes cooperate on one row (G*VEC == C); fallback G==0: one thread per row, scalar loop.
+// G lanes (a power of two) serve one row, the first C / VEC of them hold VEC channels each - C = 48 bf16 is six live lanes of
+// eight (Large: the one-thread-per-row fallback took 117 us forward / 868 us backward per launch at 4 x 1024 x 1024);
+// fallback (C not a multiple of VEC, or more than 16 lanes): one thread per row, scalar loop.
 template <typename T, int G>
 __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, T* __restrict__ y,
@@ -16,7 +18,7 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, const
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid / G;
   const int sub = (int)(gid % G);
-  const bool ok = row < rows;
+  const bool ok = row < rows && sub * VEC < C;
   Vec<T> v;
   float s = 0.f;
   if (ok) {
@@ -84,7 +86,8 @@ __global__ void __launch_bounds__(RSSF_LN_BWD_THREADS) ln_bwd_vec(const T* __res
   float* sb = sg + C;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sg[i] = 0.f;
   __syncthreads();
-  const int sub = threadIdx.x % G;
+  const bool live = (int)(threadIdx.x % G) * VEC < C;       // lanes past C / VEC of a group read lane 0's channels and contribute nothing
+  const int sub = live ? threadIdx.x % G : 0;
   float gam[VEC], ag[VEC], ab[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { gam[i] = gamma[sub * VEC + i]; ag[i] = 0.f; ab[i] = 0.f; }
@@ -127,8 +130,9 @@ __global__ void __launch_bounds__(RSSF_LN_BWD_THREADS) ln_bwd_vec(const T* __res
 #pragma unroll
     for (int u = 0; u < RF; ++u) {
       rr[u] = (it + u) * rows_per_pass + row0;
-      ok[u] = (it + u < niter) && rr[u] < rows;
-      qq[u] = ok[u] ? rr[u] : 0;
+      const bool inr = (it + u < niter) && rr[u] < rows;
+      ok[u] = inr && live;
+      qq[u] = inr ? rr[u] : 0;
       vx[u].load(x + qq[u] * C + sub * VEC); vd[u].load(dy + qq[u] * C + sub * VEC);
       if (dx_add) va[u].load(dx_add + qq[u] * C + sub * VEC);
       mm[u] = stats[qq[u] * 2]; ss[u] = stats[qq[u] * 2 + 1];
@@ -141,7 +145,7 @@ __global__ void __launch_bounds__(RSSF_LN_BWD_THREADS) ln_bwd_vec(const T* __res
   for (int o = 32; o >= G; o >>= 1)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { ag[i] += __shfl_xor(ag[i], o, 64); ab[i] += __shfl_xor(ab[i], o, 64); }
-  if ((threadIdx.x & 63) < G) {
+  if ((threadIdx.x & 63) < G && live) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { atomicAdd(&sg[sub * VEC + i], ag[i]); atomicAdd(&sb[sub * VEC + i], ab[i]); }
   }
@@ -189,11 +193,17 @@ __global__ void __launch_bounds__(256) ln_bwd_scalar(const T* __restrict__ dy, c
   }
 }
 
+int lane_group(int n) {            // the smallest power of two >= n lanes (0: more than 16, the scalar kernels run)
+  int g = 1;
+  while (g < n) g <<= 1;
+  return g <= 16 ? g : 0;
+}
+
 template <typename T>
 int ln_bwd_launch(const void* dy, const void* x, const float* stats, const float* gamma, const void* dx_add, void* dx,
                   float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t st) {
   constexpr int VEC = Vec<T>::N;
-  const int G = (C % VEC == 0) ? C / VEC : 0;
+  const int G = (C % VEC == 0) ? lane_group(C / VEC) : 0;
   const size_t sh = 2 * C * sizeof(float);
   const T* a = (const T*)dy; const T* b = (const T*)x; const T* c = (const T*)dx_add; T* d = (T*)dx;
   // 256 blocks: every block ends with 2C same-address global atomics (~40 ns each, serialised per address)
@@ -214,7 +224,7 @@ int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y,
                   float eps, hipStream_t st) {
   constexpr int VEC = Vec<T>::N;
   const T* xp = (const T*)x; T* yp = (T*)y;
-  const int G = (C % VEC == 0) ? C / VEC : 0;
+  const int G = (C % VEC == 0) ? lane_group(C / VEC) : 0;
   auto grid = [&](int g) { return dim3((unsigned)((rows * g + 255) / 256)); };
   switch (G) {
     case 1: ln_fwd_vec<T, 1><<<grid(1), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;

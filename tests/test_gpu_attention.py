@@ -54,7 +54,7 @@ def test_mma_helpers(dtype):
     assert rel_err(d[2], G) < tol
 
 
-@pytest.mark.parametrize("rows,C", [(1000, 32), (777, 18), (64, 48), (4096, 128)])
+@pytest.mark.parametrize("rows,C", [(1000, 32), (777, 18), (64, 48), (4096, 128), (3001, 48), (515, 24), (1030, 96)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layernorm(rows, C, dtype):
     from representationlearning_amd import ops
