@@ -402,6 +402,32 @@ int rssf_p2p_set_timeout_ms(rssf_p2p* p2p, int ms);
 int rssf_p2p_status(rssf_p2p* p2p, int* timed_out);
 int rssf_p2p_destroy(rssf_p2p* p2p);
 
+/* ---- Mix-Transformer (SegFormer MiT) inference operators of the SCD class-activation-map path: BASELINE config 5 as worded
+ *      (SCD-AAAI2023/network/mix_transformer.py:93-131 Attention.forward, :377-388 DWConv, :45-52 Mlp.forward;
+ *      network/TSCD_model.py:66-79; utils/camutils.py:85-113 multi_scale_cam).  Forward only (the reference extracts CAMs under
+ *      no_grad). ---- */
+/* out[b, n, h*d + :] = softmax_m(q[b, n, h] . k[b, m, h] * scale) v[b, m, h]; q [B, N, heads*d], kv [B, M, 2*heads*d] (the
+ * reference's `kv` Linear output: k of head h at channel h*d, v at heads*d + h*d), d = head_dim in {32, 64}.  logits (optional)
+ * [B, heads, N, M] fp32 receives the RAW q.k products (Attention.forward's `attn_`, returned to the caller by the reference). */
+int rssf_mha_fwd(const void* q, const void* kv, void* out, float* logits, int B, int N, int M, int heads, int head_dim, float scale,
+                 int dtype, void* stream);
+/* y = act(depthwise_conv3x3(x) + bias), channels-last [B, H, W, C], w [C][3][3] fp32 (nn.Conv2d(C, C, 3, 1, 1, groups=C)),
+ * act 0 = none, 2 = GELU (exact erf form) */
+int rssf_dwconv3x3(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int act, int dtype,
+                   void* stream);
+/* out[b][p] = sigmoid(bias + sum_h w[h] a0[b][h][p] + w[heads + h] a1[b][h][p]), p < plane: TSCD.forward's
+ * sigmoid(attn_proj(cat(attns[-2:], 1)))[:, 0] on the raw logits of the last two blocks */
+int rssf_attn_proj_sigmoid(const float* a0, const float* a1, const float* w, const float* bias, float* out, int B, int heads,
+                           int64_t plane, void* stream);
+/* F.interpolate(size=(OH, OW), mode='bilinear', align_corners=False), channels-last [B, IH, IW, C] (C = 1 with B = planes for
+ * planar tensors) */
+int rssf_resize_bilinear(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int dtype, void* stream);
+/* one scale of multi_scale_cam: cam [2B, CH, CW, K] channels-last (images, then their horizontal flips) ->
+ * acc[b][k][y][x] (+)= relu(max(up(cam[b])(y, x), up(cam[B + b])(y, W-1-x))), up = align_corners=False bilinear to H x W */
+int rssf_cam_merge(const void* cam, float* acc, int B, int K, int CH, int CW, int H, int W, int accumulate, int dtype, void* stream);
+/* per plane of n elements: x <- (x - min x) / (max x - min x + 1e-5) */
+int rssf_cam_normalize(float* cam, int planes, int64_t n, void* stream);
+
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 /* D[16][16] = A[16][K] * B[16][K]^T through the library's MFMA tile helper (layout self-check). */
 int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, void* stream);

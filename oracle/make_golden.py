@@ -284,6 +284,50 @@ def case_cam():
     sys.path.remove(wc)
 
 
+def case_scd():
+    """BASELINE config 5 as worded: SCD's TSCD(mit_b1, stride [4, 2, 2, 1]) class-activation path on synthetic VOC-sized 321 x 321
+    images (configs/voc_attn_reg.yaml:1-4,28-33; network/TSCD_model.py:66-79; utils/camutils.py:85-113).  timm / mmcv are not
+    vendored: the stubs under oracle/refimport/stubs stand in (mmcv's ConvModule only feeds the decoder output cam_only discards)."""
+    import importlib
+    scd = "/root/reference/SCD-AAAI2023"
+    sys.path.insert(0, scd)
+    for k in [k for k in sys.modules if k in ("network", "utils") or k.startswith(("network.", "utils."))]:
+        del sys.modules[k]
+    tscd_mod = importlib.import_module("network.TSCD_model")
+    from oracle import scd_cpu
+    torch.manual_seed(0)
+    m = tscd_mod.TSCD("mit_b1", num_classes=21, embedding_dim=256, stride=[4, 2, 2, 1], pretrained=False, pooling="gmp").eval()
+    sd = m.state_dict()
+    m.load_state_dict(seeded_state(sd, 777))
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    x = seeded_input((2, 3, 321, 321), 31)
+    xc = torch.cat([x, x.flip(-1)], 0)
+    with torch.no_grad():
+        cam, attn = m(xc, cam_only=True)
+        chk_cam, chk_attn = scd_cpu.tscd_cam_only(xc, P)
+    assert torch.allclose(chk_cam, cam, rtol=1e-4, atol=1e-5), float((chk_cam - cam).abs().max())
+    assert torch.allclose(chk_attn, attn, rtol=1e-4, atol=1e-6), float((chk_attn - attn).abs().max())
+    # multi_scale_cam: the reference's own function (it needs pydensecrf / imageio at import: the one function is taken from the
+    # module source without executing the module's imports of those)
+    import types
+    src = open(os.path.join(scd, "utils", "camutils.py")).read()
+    start = src.index("def multi_scale_cam(")
+    end = src.index("def multi_scale_cam_with_ref_mat(")
+    ns = types.ModuleType("camutils_slice")
+    ns.__dict__.update(torch=torch, F=torch.nn.functional)
+    exec(compile(src[start:end], "camutils.py[multi_scale_cam]", "exec"), ns.__dict__)
+    scales = [1, 0.5, 1.5]
+    msc = ns.multi_scale_cam(m, x, scales)
+    chk = scd_cpu.multi_scale_cam(P, x, scales)
+    assert torch.allclose(chk, msc, rtol=1e-4, atol=1e-5), float((chk - msc).abs().max())
+    save("scd_mitb1_321", cam_s4=npy(cam), attn_sample=npy(attn[:, ::4, ::4]), attn_sum=npy(attn.double().sum((1, 2))),
+         msc_sample=npy(msc[:, :, ::5, ::5]), msc_sum=npy(msc.double().sum((2, 3))), scales=np.array(scales),
+         all_keys=np.array(list(sd.keys())), shapes=np.array([",".join(map(str, v.shape)) for v in sd.values()]))
+    sys.path.remove(scd)
+    for k in [k for k in sys.modules if k in ("network", "utils") or k.startswith(("network.", "utils."))]:
+        del sys.modules[k]
+
+
 def case_state_keys():
     for variant in ("tiny", "base", "large"):
         m = build_model(variant)
@@ -295,7 +339,7 @@ def case_state_keys():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["mhca", "attention", "block", "mlp", "loss", "neck_head", "keys", "models", "eval", "cam"]
+    which = sys.argv[1:] or ["mhca", "attention", "block", "mlp", "loss", "neck_head", "keys", "models", "eval", "cam", "scd"]
     if "eval" in which: case_eval()
     if "mhca" in which: case_mhca()
     if "attention" in which: case_attention()
@@ -305,6 +349,7 @@ if __name__ == "__main__":
     if "neck_head" in which: case_neck_head()
     if "keys" in which: case_state_keys()
     if "cam" in which: case_cam()
+    if "scd" in which: case_scd()
     if "models" in which:
         case_model("tiny", 2, 256, "tiny_2x256")      # BASELINE config 1
         case_model("base", 2, 64, "base_2x64")

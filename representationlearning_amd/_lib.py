@@ -89,6 +89,12 @@ SIGNATURES = {
     "rssf_aux_head_workspace_elems": (c_int64, [c_int, c_int]),
     "rssf_aux_head_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rssf_maxpool3x3s2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rssf_mha_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_int, c_void_p]),
+    "rssf_dwconv3x3": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
+    "rssf_attn_proj_sigmoid": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int64, c_void_p]),
+    "rssf_resize_bilinear": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "rssf_cam_merge": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "rssf_cam_normalize": (c_int, [c_void_p, c_int, c_int64, c_void_p]),
     "rssf_cgfl_loss_fwd": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "rssf_cgfl_loss_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rssf_argmax_confusion": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

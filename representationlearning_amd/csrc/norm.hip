@@ -50,6 +50,50 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, const
   }
 }
 
+// One wave per row, NP 16-byte vectors per lane: the Mix-Transformer widths of the SCD CAM path (C = 320, 512; up to 64 * NP * VEC)
+template <typename T, int NP>
+__global__ void __launch_bounds__(256) ln_fwd_wave(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, T* __restrict__ y,
+                                                   float* __restrict__ stats, int64_t rows, int C, float eps) {
+  constexpr int VEC = Vec<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;                                  // wave-uniform
+  Vec<T> v[NP];
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int c0 = (lane + 64 * p) * VEC;
+    if (c0 < C) {
+      v[p].load(x + row * C + c0);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s += v[p].get(i);
+    }
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    if ((lane + 64 * p) * VEC < C) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { const float d = v[p].get(i) - mean; q += d * d; }
+    }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  if (stats && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  if (y) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int c0 = (lane + 64 * p) * VEC;
+      if (c0 < C) {
+        Vec<T> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o.set(i, (v[p].get(i) - mean) * rstd * gamma[c0 + i] + beta[c0 + i]);
+        o.store(y + row * C + c0);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) ln_fwd_scalar(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -232,7 +276,15 @@ int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y,
     case 4: ln_fwd_vec<T, 4><<<grid(4), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
     case 8: ln_fwd_vec<T, 8><<<grid(8), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
     case 16: ln_fwd_vec<T, 16><<<grid(16), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
-    default: ln_fwd_scalar<T><<<grid(1), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps); break;
+    default: {
+      const int np = (C % VEC == 0) ? (C / VEC + 63) / 64 : 0;      // wide rows: a wave per row
+      const dim3 wg((unsigned)((rows + 3) / 4));
+      if (np == 1) ln_fwd_wave<T, 1><<<wg, 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps);
+      else if (np == 2) ln_fwd_wave<T, 2><<<wg, 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps);
+      else if (np >= 3 && np <= 4) ln_fwd_wave<T, 4><<<wg, 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps);
+      else ln_fwd_scalar<T><<<grid(1), 256, 0, st>>>(xp, gamma, beta, yp, stats, rows, C, eps);
+      break;
+    }
   }
   return check_launch("layernorm_fwd");
 }

@@ -1469,6 +1469,34 @@ def conv_bias(x, conv):
     return _ConvBias.apply(x, spec_of([conv]), conv.weight, conv.bias)
 
 
+class _LinearShape:
+    """What ConvSpec reads of a convolution, for an nn.Linear run as a 1 x 1 convolution over channels-last tokens."""
+
+    def __init__(self, lin):
+        self.in_channels, self.out_channels = lin.in_features, lin.out_features
+        self.stride = self.kernel_size = self.dilation = (1, 1)
+        self.padding = (0, 0)
+        self.groups = 1
+
+
+def conv_nhwc(xh, conv, addend=None):
+    """Inference-only convolution + bias (+ addend) on a channels-last activation [B, H, W, C] -> [B, OH, OW, Cout].  `conv`: an
+    nn.Conv2d (square, ungrouped; more than 19 taps run as chained launches) or an nn.Linear (1 x 1 over the tokens).  No autograd:
+    the CAM extraction paths run under no_grad."""
+    L.require_gpu(xh)
+    if isinstance(conv, nn.Linear):
+        spec = conv.__dict__.get("_rssf_spec")
+        if spec is None:
+            spec = conv.__dict__["_rssf_spec"] = ConvSpec([_LinearShape(conv)])
+        w = conv.weight.detach().view(conv.out_features, conv.in_features, 1, 1)
+    else:
+        spec, w = spec_of([conv]), conv.weight.detach()
+    if addend is not None and spec.parts is not None:
+        raise NotImplementedError("conv_nhwc: an addend on a tap-split convolution")
+    bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
+    return _conv_forward(spec, xh if xh.is_contiguous() else xh.contiguous(), [w], bias, None, current(), addend=addend)
+
+
 def flush_bn_counters(model, extra=0):
     """Materialise the lazily counted `num_batches_tracked` buffers (kept off the hot path: 330 tiny launches).
     `extra`: steps executed by hipGraph replay (no Python ran for them)."""

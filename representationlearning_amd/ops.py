@@ -207,3 +207,76 @@ def debug_mma(a, b):
     L.check(L.load().rssf_debug_mma(L.ptr(a.contiguous()), L.ptr(b.contiguous()), L.ptr(d), K, L.dtype_code(a), L.stream()),
             "rssf_debug_mma")
     return d
+
+
+# ---- Mix-Transformer / CAM inference operators (csrc/mit.hip; reference SCD-AAAI2023/network/mix_transformer.py, utils/camutils.py) ----
+def mha_fwd(q, kv, heads, scale, want_logits=False):
+    """q [B, N, C], kv [B, M, 2C] (k | v, heads-major) -> (softmax(q k^T * scale) v [B, N, C], raw q k^T logits [B, heads, N, M] fp32 or
+    None).  Attention.forward of the reference (mix_transformer.py:93-131), no dropout."""
+    L.require_gpu(q, kv)
+    _tok(q); _tok(kv)
+    B, N, C = q.shape
+    M = kv.shape[1]
+    if kv.shape != (B, M, 2 * C) or kv.dtype != q.dtype or C % heads:
+        raise RuntimeError(f"mha_fwd: q {tuple(q.shape)} {q.dtype} / kv {tuple(kv.shape)} {kv.dtype} / heads {heads}")
+    out = torch.empty_like(q)
+    logits = torch.empty(B, heads, N, M, device=q.device, dtype=torch.float32) if want_logits else None
+    L.check(L.load().rssf_mha_fwd(L.ptr(q), L.ptr(kv), L.ptr(out), L.ptr(logits), B, N, M, heads, C // heads, float(scale),
+                                  L.dtype_code(q), L.stream()), "rssf_mha_fwd")
+    return out, logits
+
+
+def dwconv3x3(x, weight, bias, act=0):
+    """x [B, H, W, C] channels-last -> act(depthwise 3x3 (padding 1) + bias); weight [C, 1, 3, 3]; act 0 none / 2 GELU."""
+    L.require_gpu(x)
+    _tok(x)
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().rssf_dwconv3x3(L.ptr(x), L.ptr(_f32(weight)), L.ptr(None if bias is None else _f32(bias)), L.ptr(y), B, H, W, C, int(act),
+                                    L.dtype_code(x), L.stream()), "rssf_dwconv3x3")
+    return y
+
+
+def attn_proj_sigmoid(a0, a1, weight, bias):
+    """sigmoid(Conv2d(2 * heads, 1, 1)(cat([a0, a1], 1)))[:, 0] for two logit tensors [B, heads, N, M] (TSCD_model.py:73-75)."""
+    L.require_gpu(a0, a1)
+    B, heads = a0.shape[:2]
+    if a0.shape != a1.shape or a0.dtype != torch.float32 or a1.dtype != torch.float32 or weight.numel() != 2 * heads:
+        raise RuntimeError("attn_proj_sigmoid: two fp32 [B, heads, N, M] tensors and a [1, 2 * heads, 1, 1] weight expected")
+    a0, a1 = a0.contiguous(), a1.contiguous()
+    out = torch.empty((B,) + tuple(a0.shape[2:]), device=a0.device, dtype=torch.float32)
+    L.check(L.load().rssf_attn_proj_sigmoid(L.ptr(a0), L.ptr(a1), L.ptr(_f32(weight).reshape(-1)), L.ptr(None if bias is None else _f32(bias)),
+                                            L.ptr(out), B, heads, out[0].numel(), L.stream()), "rssf_attn_proj_sigmoid")
+    return out
+
+
+def resize_bilinear_planar(x, size):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=False) for a contiguous NCHW tensor (every plane on its own)."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty(B, C, size[0], size[1], device=x.device, dtype=x.dtype)
+    L.check(L.load().rssf_resize_bilinear(L.ptr(x), L.ptr(out), B * C, H, W, size[0], size[1], 1, L.dtype_code(x), L.stream()), "rssf_resize_bilinear")
+    return out
+
+
+def cam_merge_(acc, cam, accumulate):
+    """acc [b, K, H, W] fp32 (+)= relu(max(up(cam[:b]), up(cam[b:]).flip(-1))), cam [2b, hc, wc, K] channels-last (camutils.py:93-96)."""
+    L.require_gpu(acc, cam)
+    _tok(cam)
+    b, K, H, W = acc.shape
+    if cam.shape[0] != 2 * b or cam.shape[3] != K or acc.dtype != torch.float32 or not acc.is_contiguous():
+        raise RuntimeError(f"cam_merge: acc {tuple(acc.shape)} {acc.dtype} / cam {tuple(cam.shape)}")
+    L.check(L.load().rssf_cam_merge(L.ptr(cam), L.ptr(acc), b, K, cam.shape[1], cam.shape[2], H, W, int(bool(accumulate)), L.dtype_code(cam),
+                                    L.stream()), "rssf_cam_merge")
+    return acc
+
+
+def cam_normalize_(acc):
+    """per (image, class) plane: (x - min) / (max - min + 1e-5), in place (camutils.py:111-112)."""
+    L.require_gpu(acc)
+    if acc.dtype != torch.float32 or not acc.is_contiguous():
+        raise RuntimeError("cam_normalize: contiguous fp32 tensor expected")
+    b, K, H, W = acc.shape
+    L.check(L.load().rssf_cam_normalize(L.ptr(acc), b * K, H * W, L.stream()), "rssf_cam_normalize")
+    return acc

@@ -1,0 +1,54 @@
+"""SCD's network: Mix-Transformer encoder + class-activation / attention heads (reference: SCD-AAAI2023/network/TSCD_model.py:10-88).
+`forward(x, cam_only=True)` - what `multi_scale_cam` calls (utils/camutils.py:91,103) - runs on librssf kernels: the class
+activation map is the classifier's 1 x 1 weights applied to the stage-4 feature, the attention prediction is
+sigmoid(attn_proj(raw q k^T of the last two blocks)).  Same module tree / `state_dict` as the reference."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import nnf, ops
+from . import mix_transformer
+from .segformer_head import SegFormerHead
+
+
+class TSCD(nn.Module):
+    def __init__(self, backbone, num_classes=None, embedding_dim=256, stride=None, pretrained=None, pooling=None):
+        super().__init__()
+        self.num_classes, self.embedding_dim, self.stride = num_classes, embedding_dim, stride
+        self.feature_strides = [4, 8, 16, 32]
+        self.encoder = getattr(mix_transformer, backbone)(stride=stride)
+        self.in_channels = self.encoder.embed_dims
+        if pretrained:
+            if not isinstance(pretrained, str):
+                raise FileNotFoundError("pretrained=True: pass the path of the ImageNet MiT checkpoint (the reference reads "
+                                        "pretrained/<backbone>.pth, TSCD_model.py:22-26)")
+            sd = torch.load(pretrained, map_location="cpu")
+            for k in ("head.weight", "head.bias"):
+                sd.pop(k, None)
+            self.encoder.load_state_dict(sd)
+        self.pooling = {"gmp": F.adaptive_max_pool2d, "gap": F.adaptive_avg_pool2d}.get(pooling)
+        self.dropout = nn.Dropout2d(0.5)
+        self.decoder = SegFormerHead(feature_strides=self.feature_strides, in_channels=self.in_channels, embedding_dim=embedding_dim,
+                                     num_classes=num_classes)
+        self.attn_proj = nn.Conv2d(16, 1, kernel_size=1, bias=True)
+        nn.init.kaiming_normal_(self.attn_proj.weight, a=math.sqrt(5), mode="fan_out")
+        self.classifier = nn.Conv2d(self.in_channels[3], num_classes - 1, kernel_size=1, bias=False)
+
+    def get_param_groups(self):
+        """[backbone, backbone norms, classification heads, segmentation decoder] (TSCD_model.py:44-62)."""
+        groups = [[], [], [self.classifier.weight, self.attn_proj.weight, self.attn_proj.bias], list(self.decoder.parameters())]
+        for name, p in self.encoder.named_parameters():
+            groups[1 if "norm" in name else 0].append(p)
+        return groups
+
+    def forward(self, x, cam_only=False, seg_detach=True, aux=False):
+        if not cam_only:
+            raise NotImplementedError("TSCD (HIP): the class-activation path (cam_only=True) is what this build covers; the "
+                                      "classification / segmentation outputs of the training forward are not built")
+        feats, attns = self.encoder(x, logits_of_last=2)
+        x4 = feats[3]
+        attn_pred = ops.attn_proj_sigmoid(attns[-2], attns[-1], self.attn_proj.weight.detach(), self.attn_proj.bias.detach())
+        cam_s4 = nnf.conv_nhwc(x4.permute(0, 2, 3, 1), self.classifier).permute(0, 3, 1, 2)
+        return cam_s4, attn_pred

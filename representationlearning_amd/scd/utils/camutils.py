@@ -1,0 +1,49 @@
+"""Multi-scale class-activation maps (reference: SCD-AAAI2023/utils/camutils.py:85-148).  Per scale: one batched forward of the images
+and their horizontal flips, then ONE launch that samples both low-resolution maps at every image pixel (align_corners=False),
+un-flips, takes the maximum, applies the ReLU and adds into the running sum; one launch normalises the planes at the end.  The
+reference builds five full-resolution intermediates per scale for the same result."""
+import torch
+
+from ... import ops
+
+
+def _scales(scales):
+    return [1.0] + [s for s in scales if s != 1.0]          # the reference always evaluates scale 1 first (:89-97), then the others
+
+
+def _cam_pass(model, inputs, s):
+    b, c, h, w = inputs.shape
+    x = inputs if s == 1.0 else ops.resize_bilinear_planar(inputs.float(), (int(s * h), int(s * w)))
+    return model(torch.cat([x, x.flip(-1)], dim=0), cam_only=True)
+
+
+def _merge(acc, cam, first):
+    camh = cam.permute(0, 2, 3, 1)
+    return ops.cam_merge_(acc, camh if camh.is_contiguous() else camh.contiguous(), accumulate=not first)
+
+
+def multi_scale_cam(model, inputs, scales):
+    b, c, h, w = inputs.shape
+    acc = None
+    with torch.no_grad():
+        for i, s in enumerate(_scales(scales)):
+            cam, _ = _cam_pass(model, inputs, s)
+            if acc is None:
+                acc = torch.empty(b, cam.shape[1], h, w, device=inputs.device, dtype=torch.float32)
+            _merge(acc, cam, i == 0)
+        return ops.cam_normalize_(acc)
+
+
+def multi_scale_cam_with_ref_mat(model, inputs, scales):
+    """As multi_scale_cam, also returning the attention prediction `ref_mat[argmax(scales)]` (:115-148; the list is in evaluation
+    order - scale 1 first - and is indexed by the position of the largest entry of `scales`, as the reference does)."""
+    b, c, h, w = inputs.shape
+    acc, ref_mat = None, []
+    with torch.no_grad():
+        for i, s in enumerate(_scales(scales)):
+            cam, ref = _cam_pass(model, inputs, s)
+            ref_mat.append(ref)
+            if acc is None:
+                acc = torch.empty(b, cam.shape[1], h, w, device=inputs.device, dtype=torch.float32)
+            _merge(acc, cam, i == 0)
+        return ops.cam_normalize_(acc), ref_mat[max(range(len(scales)), key=lambda j: scales[j])]
