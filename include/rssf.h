@@ -419,6 +419,10 @@ int rssf_dwconv3x3(const void* x, const float* w, const float* bias, void* y, in
  * sigmoid(attn_proj(cat(attns[-2:], 1)))[:, 0] on the raw logits of the last two blocks */
 int rssf_attn_proj_sigmoid(const float* a0, const float* a1, const float* w, const float* bias, float* out, int B, int heads,
                            int64_t plane, void* stream);
+/* the same prediction straight from the projections of the two blocks (q_s [B, N, heads*d], kv_s [B, M, 2*heads*d]):
+ * out[b][n][m] = sigmoid(bias + sum_{s,h} w[s*heads + h] * q_s[b,n,h,:] . k_s[b,m,h,:]); the per-head logit tensors never exist */
+int rssf_attn_pred(const void* q0, const void* kv0, const void* q1, const void* kv1, const float* w, const float* bias, float* out,
+                   int B, int N, int M, int heads, int head_dim, int dtype, void* stream);
 /* F.interpolate(size=(OH, OW), mode='bilinear', align_corners=False), channels-last [B, IH, IW, C] (C = 1 with B = planes for
  * planar tensors) */
 int rssf_resize_bilinear(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int dtype, void* stream);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "rssf_mha_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_float, c_int, c_void_p]),
     "rssf_dwconv3x3": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p]),
     "rssf_attn_proj_sigmoid": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int64, c_void_p]),
+    "rssf_attn_pred": (c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p]),
     "rssf_resize_bilinear": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rssf_cam_merge": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "rssf_cam_normalize": (c_int, [c_void_p, c_int, c_int64, c_void_p]),

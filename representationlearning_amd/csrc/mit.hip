@@ -7,6 +7,7 @@
 //                           stage 4 of MiT: all 441..961 tokens), optionally the raw q k^T logits (the reference returns them)
 //   rssf_dwconv3x3          depth-wise 3x3 convolution + bias (+ GELU), channels-last
 //   rssf_attn_proj_sigmoid  sigmoid(Conv2d(16 -> 1, 1x1)) over the concatenated logits of the last two blocks
+//   rssf_attn_pred          the same prediction from the q / kv projections of the two blocks, no logit tensors
 //   rssf_resize_bilinear    F.interpolate(mode='bilinear', align_corners=False)
 //   rssf_cam_merge          interpolate the CAMs of an image and of its flip to the image size, max, ReLU, (+=)
 //   rssf_cam_normalize      per-plane (x - min) / (max - min + 1e-5)
@@ -158,49 +159,77 @@ int mha_launch(const void* q, const void* kv, void* out, float* logits, int B, i
 }
 
 // ---- depth-wise 3x3 + bias (+ GELU) -------------------------------------------------------------------------------------------
+// A thread owns VEC channels of a run of DW_SEG pixels of one image row: its 9 x VEC weights and the bias sit in registers, the
+// 3 x 3 window slides along the row (three 16-byte loads per output pixel instead of nine), consecutive threads own consecutive
+// channel vectors of the same pixels (coalesced).  HBM-bound: one read and one write of the activation (the halo rows come from
+// L2); the first form of this kernel - nine loads and 9 x VEC scalar weight loads per output - ran at 0.25 TB/s.
+constexpr int DW_SEG = 16;
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                         T* __restrict__ y, int B, int H, int W, int C, int act) {
-  const int cols = C / VEC;
-  const int64_t total = (int64_t)B * H * W * cols;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % cols);
-    int64_t p = i / cols;
-    const int xx = (int)(p % W); p /= W;
-    const int yy = (int)(p % H);
-    const int b = (int)(p / H);
-    const int c0 = cv * VEC;
-    float acc[VEC];
+  const int cols = C / VEC, segs = (W + DW_SEG - 1) / DW_SEG;
+  const int64_t total = (int64_t)B * H * segs * cols;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int cv = (int)(i % cols);
+  int64_t p = i / cols;
+  const int seg = (int)(p % segs); p /= segs;
+  const int yy = (int)(p % H);
+  const int b = (int)(p / H);
+  const int c0 = cv * VEC, x0 = seg * DW_SEG;
+  float wt[9][VEC], bs[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = bias ? bias[c0 + e] : 0.f;
+  for (int e = 0; e < VEC; ++e) {
+    bs[e] = bias ? bias[c0 + e] : 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = yy + ky - 1;
-      if (iy < 0 || iy >= H) continue;
+    for (int t = 0; t < 9; ++t) wt[t][e] = w[(c0 + e) * 9 + t];
+  }
+  const T* img = x + (int64_t)b * H * W * C + c0;
+  float win[3][3][VEC];                       // [row][column slot][channel]: columns xx-1, xx, xx+1
+  auto load_col = [&](int slot, int ix) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = xx + kx - 1;
-        if (ix < 0 || ix >= W) continue;
-        const T* src = x + (((int64_t)b * H + iy) * W + ix) * C + c0;
-        if constexpr (VEC > 1) {
-          Vec<T> v;
-          v.load(src);
+    for (int r = 0; r < 3; ++r) {
+      const int iy = yy + r - 1;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      if constexpr (VEC > 1) {
+        Vec<T> v;
+        if (ok) v.load(img + ((int64_t)iy * W + ix) * C); else v.clear();
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) acc[e] = fmaf(v.get(e), w[(c0 + e) * 9 + ky * 3 + kx], acc[e]);
-        } else {
-          acc[0] = fmaf(ldf(src), w[c0 * 9 + ky * 3 + kx], acc[0]);
-        }
+        for (int e = 0; e < VEC; ++e) win[r][slot][e] = v.get(e);
+      } else {
+        win[r][slot][0] = ok ? ldf(img + ((int64_t)iy * W + ix) * C) : 0.f;
       }
     }
-    T* dst = y + (((int64_t)b * H + yy) * W + xx) * C + c0;
+  };
+  load_col(0, x0 - 1);
+  load_col(1, x0);
+  T* dst = y + (((int64_t)b * H + yy) * W + x0) * C + c0;
+#pragma unroll
+  for (int k = 0; k < DW_SEG; ++k) {
+    const int xx = x0 + k;
+    if (xx >= W) break;
+    load_col(2, xx + 1);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float a = bs[e];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) a = fmaf(win[r][cidx][e], wt[r * 3 + cidx][e], a);
+      acc[e] = act == ACT_GELU ? gelu_erf(a) : a;
+    }
     if constexpr (VEC > 1) {
       Vec<T> o;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) o.set(e, act == ACT_GELU ? gelu_erf(acc[e]) : acc[e]);
-      o.store(dst);
+      o.set_all(acc);
+      o.store(dst + (int64_t)k * C);
     } else {
-      stf(dst, act == ACT_GELU ? gelu_erf(acc[0]) : acc[0]);
+      stf(dst + (int64_t)k * C, acc[0]);
     }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { win[r][0][e] = win[r][1][e]; win[r][1][e] = win[r][2][e]; }
   }
 }
 
@@ -212,8 +241,9 @@ int grid_of(int64_t total) {
 template <typename T>
 int dwconv_launch(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int act, hipStream_t st) {
   constexpr int V = Vec<T>::N;
-  if (C % V == 0) dwconv3x3_kernel<T, V><<<grid_of((int64_t)B * H * W * (C / V)), 256, 0, st>>>((const T*)x, w, bias, (T*)y, B, H, W, C, act);
-  else dwconv3x3_kernel<T, 1><<<grid_of((int64_t)B * H * W * C), 256, 0, st>>>((const T*)x, w, bias, (T*)y, B, H, W, C, act);
+  const int64_t runs = (int64_t)B * H * ((W + DW_SEG - 1) / DW_SEG);
+  if (C % V == 0) dwconv3x3_kernel<T, V><<<(unsigned)((runs * (C / V) + 255) / 256), 256, 0, st>>>((const T*)x, w, bias, (T*)y, B, H, W, C, act);
+  else dwconv3x3_kernel<T, 1><<<(unsigned)((runs * C + 255) / 256), 256, 0, st>>>((const T*)x, w, bias, (T*)y, B, H, W, C, act);
   return check_launch("dwconv3x3");
 }
 
@@ -231,6 +261,76 @@ __global__ void __launch_bounds__(256) attn_proj_sigmoid_kernel(const float* __r
     }
     out[i] = sigmoidf(acc);
   }
+}
+
+// ---- the attention prediction without the logit tensors -------------------------------------------------------------------------
+// out[b][n][m] = sigmoid(bias + sum over the two blocks s and their heads h of w[s * heads + h] * (q_s[b,n,h,:] . k_s[b,m,h,:])):
+// TSCD.forward's sigmoid(attn_proj(cat(attns[-2:]))) computed from the q / kv projections directly.  The [B, heads, N, M] fp32
+// logits of the two blocks (1.9 GB written and read again at B = 32, 31 x 31 tokens) never exist; per (block, head) the 64-key tile
+// of k is staged once per workgroup, the head's products are formed in fp32 accumulators and folded into the running sum with
+// that head's weight - the arithmetic of the reference (fp32 logits times weights), in another order.
+template <typename T, int D>
+__global__ void __launch_bounds__(256) attn_pred_kernel(const T* __restrict__ q0, const T* __restrict__ kv0, const T* __restrict__ q1,
+                                                        const T* __restrict__ kv1, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int N, int M, int heads) {
+  using MM = Mma<T>;
+  constexpr int VEC = Vec<T>::N, KSTEP = MM::KSTEP, KPL = MM::KPL, NKK = D / KSTEP, LDK = D + (sizeof(T) == 2 ? 8 : 4);
+  __shared__ __attribute__((aligned(16))) T Ks[64 * LDK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, C = heads * D, kc0 = blockIdx.y * 64;
+  const int qa = blockIdx.x * 64 + wave * 16 + n;
+  const int qrow = qa < N ? qa : N - 1;
+  f32x4 tot[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) tot[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int sh = 0; sh < 2 * heads; ++sh) {
+    const int src = sh / heads, h = sh - src * heads;
+    const T* qs = src ? q1 : q0;
+    const T* ks = (src ? kv1 : kv0) + (int64_t)b * M * 2 * C + h * D;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * (D / VEC); i += 256) {
+      const int r = i / (D / VEC), cv = i % (D / VEC);
+      Vec<T> vk;
+      if (kc0 + r < M) vk.load(ks + (int64_t)(kc0 + r) * 2 * C + cv * VEC); else vk.clear();
+      vk.store(Ks + r * LDK + cv * VEC);
+    }
+    typename MM::frag qf[NKK];
+    const T* qp = qs + ((int64_t)b * N + qrow) * C + h * D + g * KPL;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = MM::load(qp + kk * KSTEP);
+    __syncthreads();
+    const float wh = w[sh];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+      const T* ka = Ks + (kt * 16 + n) * LDK + g * KPL;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) s = MM::mma(MM::load(ka + kk * KSTEP), qf[kk], s);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[kt][r] = fmaf(wh, s[r], tot[kt][r]);
+    }
+  }
+  if (qa < N) {
+    const float b0 = bias ? bias[0] : 0.f;
+    float* orow = out + ((int64_t)b * N + qa) * M;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kc0 + kt * 16 + g * 4 + r;
+        if (key < M) orow[key] = sigmoidf(b0 + tot[kt][r]);
+      }
+  }
+}
+
+template <typename T>
+int attn_pred_launch(const void* q0, const void* kv0, const void* q1, const void* kv1, const float* w, const float* bias, float* out, int B, int N,
+                     int M, int heads, int d, hipStream_t st) {
+  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)B);
+  if (d == 64) attn_pred_kernel<T, 64><<<grid, 256, 0, st>>>((const T*)q0, (const T*)kv0, (const T*)q1, (const T*)kv1, w, bias, out, N, M, heads);
+  else if (d == 32) attn_pred_kernel<T, 32><<<grid, 256, 0, st>>>((const T*)q0, (const T*)kv0, (const T*)q1, (const T*)kv1, w, bias, out, N, M, heads);
+  else { set_error("attn_pred: head_dim %d is not built (32 and 64 are)", d); return RSSF_ERR_UNSUPPORTED; }
+  return check_launch("attn_pred");
 }
 
 // ---- half-pixel bilinear sampling (align_corners=False; PyTorch's upsample_bilinear2d with `size=`) ---------------------------
@@ -336,6 +436,17 @@ extern "C" int rssf_attn_proj_sigmoid(const float* a0, const float* a1, const fl
   RSSF_REQUIRE(a0 && a1 && w && out && B > 0 && heads > 0 && plane > 0, "attn_proj_sigmoid: bad arguments");
   attn_proj_sigmoid_kernel<<<grid_of((int64_t)B * plane), 256, 0, (hipStream_t)stream>>>(a0, a1, w, bias, out, B, heads, plane);
   return check_launch("attn_proj_sigmoid");
+}
+
+extern "C" int rssf_attn_pred(const void* q0, const void* kv0, const void* q1, const void* kv1, const float* w, const float* bias, float* out,
+                             int B, int N, int M, int heads, int head_dim, int dtype, void* stream) {
+  RSSF_REQUIRE(q0 && kv0 && q1 && kv1 && w && out && B > 0 && N > 0 && M > 0 && heads > 0 && B <= 65535 && (M + 63) / 64 <= 65535,
+               "attn_pred: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return attn_pred_launch<float>(q0, kv0, q1, kv1, w, bias, out, B, N, M, heads, head_dim, st);
+  if (dtype == RSSF_BF16) return attn_pred_launch<bf16_t>(q0, kv0, q1, kv1, w, bias, out, B, N, M, heads, head_dim, st);
+  set_error("attn_pred: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
 }
 
 extern "C" int rssf_resize_bilinear(const void* in, void* out, int B, int IH, int IW, int OH, int OW, int C, int dtype, void* stream) {

@@ -250,6 +250,24 @@ def attn_proj_sigmoid(a0, a1, weight, bias):
     return out
 
 
+def attn_pred(q0, kv0, q1, kv1, weight, bias, heads):
+    """sigmoid(Conv2d(2 * heads, 1, 1)(cat([q0 k0^T, q1 k1^T], 1)))[:, 0] from the projections themselves (q_s [B, N, C], kv_s
+    [B, M, 2C]): the attention prediction of TSCD.forward (TSCD_model.py:73-75) without materialising the logits."""
+    L.require_gpu(q0, kv0, q1, kv1)
+    for t in (q0, kv0, q1, kv1):
+        _tok(t)
+    B, N, C = q0.shape
+    M = kv0.shape[1]
+    if q1.shape != q0.shape or kv0.shape != (B, M, 2 * C) or kv1.shape != kv0.shape or weight.numel() != 2 * heads or C % heads \
+            or len({q0.dtype, q1.dtype, kv0.dtype, kv1.dtype}) != 1:
+        raise RuntimeError("attn_pred: q [B, N, C] / kv [B, M, 2C] of two blocks in one dtype and a [1, 2 * heads, 1, 1] weight expected")
+    out = torch.empty(B, N, M, device=q0.device, dtype=torch.float32)
+    L.check(L.load().rssf_attn_pred(L.ptr(q0), L.ptr(kv0), L.ptr(q1), L.ptr(kv1), L.ptr(_f32(weight).reshape(-1)),
+                                    L.ptr(None if bias is None else _f32(bias)), L.ptr(out), B, N, M, heads, C // heads, L.dtype_code(q0), L.stream()),
+            "rssf_attn_pred")
+    return out
+
+
 def resize_bilinear_planar(x, size):
     """F.interpolate(x, size=size, mode='bilinear', align_corners=False) for a contiguous NCHW tensor (every plane on its own)."""
     L.require_gpu(x)

@@ -1,7 +1,7 @@
 """SCD's network: Mix-Transformer encoder + class-activation / attention heads (reference: SCD-AAAI2023/network/TSCD_model.py:10-88).
 `forward(x, cam_only=True)` - what `multi_scale_cam` calls (utils/camutils.py:91,103) - runs on librssf kernels: the class
 activation map is the classifier's 1 x 1 weights applied to the stage-4 feature, the attention prediction is
-sigmoid(attn_proj(raw q k^T of the last two blocks)).  Same module tree / `state_dict` as the reference."""
+sigmoid(attn_proj(raw q k^T of the last two blocks)), formed by `rssf_attn_pred` without the logit tensors.  Same module tree / `state_dict` as the reference."""
 import math
 
 import torch
@@ -47,8 +47,10 @@ class TSCD(nn.Module):
         if not cam_only:
             raise NotImplementedError("TSCD (HIP): the class-activation path (cam_only=True) is what this build covers; the "
                                       "classification / segmentation outputs of the training forward are not built")
-        feats, attns = self.encoder(x, logits_of_last=2)
+        feats, qkv = self.encoder(x, last=2, want="qkv")
         x4 = feats[3]
-        attn_pred = ops.attn_proj_sigmoid(attns[-2], attns[-1], self.attn_proj.weight.detach(), self.attn_proj.bias.detach())
+        # sigmoid(attn_proj(cat(attns[-2:], 1)))[:, 0] from the projections of the last two blocks: the logit tensors are not formed
+        attn_pred = ops.attn_pred(*qkv[-2], *qkv[-1], self.attn_proj.weight.detach(), self.attn_proj.bias.detach(),
+                                  self.encoder.block4[-1].attn.num_heads)
         cam_s4 = nnf.conv_nhwc(x4.permute(0, 2, 3, 1), self.classifier).permute(0, 3, 1, 2)
         return cam_s4, attn_pred

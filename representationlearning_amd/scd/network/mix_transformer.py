@@ -82,20 +82,23 @@ class Attention(nn.Module):
             self.norm = nn.LayerNorm(dim)
         self.apply(_init)
 
-    def forward(self, xh, residual=None, want_logits=False):
-        """xh: LayerNorm'ed tokens [B, H, W, C].  Returns (proj(attention) (+ residual), raw q k^T [B, heads, N, M] or None).
-        The reference also hands back a pooled copy of the logits for the spatially reduced stages (:119-129); nothing on the
-        CAM path reads those, so they are not formed (want_logits is honoured for sr_ratio == 1 only)."""
+    def forward(self, xh, residual=None, want=None):
+        """xh: LayerNorm'ed tokens [B, H, W, C].  Returns (proj(attention) (+ residual), extra): extra = the raw q k^T products
+        [B, heads, N, M] for want == "logits" (what the reference hands back when sr_ratio == 1, :119-131), the projections
+        (q [B, N, C], kv [B, M, 2C]) for want == "qkv" (all TSCD's attention head needs), else None.  The reference also returns a
+        pooled copy of the logits for the spatially reduced stages (:121-124); nothing on the CAM path reads those, they are not
+        formed."""
         B, H, W, C = xh.shape
         q = nnf.conv_nhwc(xh, self.q)
         src = xh
         if self.sr_ratio > 1:
             src = _layer_norm(nnf.conv_nhwc(xh, self.sr), self.norm)
         kv = nnf.conv_nhwc(src, self.kv)
-        if want_logits and self.sr_ratio > 1:
+        if want == "logits" and self.sr_ratio > 1:
             raise NotImplementedError("Attention (HIP): the pooled attention maps of the spatially reduced stages are not built")
-        o, logits = ops.mha_fwd(q.view(B, H * W, C), kv.view(B, -1, 2 * C), self.num_heads, self.scale, want_logits)
-        return nnf.conv_nhwc(o.view(B, H, W, C), self.proj, addend=residual), logits
+        q, kv = q.view(B, H * W, C), kv.view(B, -1, 2 * C)
+        o, logits = ops.mha_fwd(q, kv, self.num_heads, self.scale, want == "logits")
+        return nnf.conv_nhwc(o.view(B, H, W, C), self.proj, addend=residual), (q, kv) if want == "qkv" else logits
 
 
 class Block(nn.Module):
@@ -111,10 +114,10 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.apply(_init)
 
-    def forward(self, xh, want_logits=False):
+    def forward(self, xh, want=None):
         if self.training:
             raise NotImplementedError("Block (HIP): inference only - call .eval() (the CAM extraction of the reference runs under no_grad)")
-        xh, logits = self.attn(_layer_norm(xh, self.norm1), residual=xh, want_logits=want_logits)
+        xh, logits = self.attn(_layer_norm(xh, self.norm1), residual=xh, want=want)
         return self.mlp(_layer_norm(xh, self.norm2), residual=xh), logits
 
 
@@ -153,9 +156,10 @@ class MixVisionTransformer(nn.Module):
             setattr(self, f"norm{i + 1}", norm_layer(embed_dims[i]))
         self.apply(_init)
 
-    def forward_features(self, x, logits_of_last=0):
-        """x: image batch [B, 3, H, W] fp32 (any memory format).  Returns (the four stage outputs as channels-last NCHW views, the
-        raw attention logits of the last `logits_of_last` blocks - None for the earlier ones)."""
+    def forward_features(self, x, last=0, want="logits"):
+        """x: image batch [B, 3, H, W] fp32 (any memory format).  Returns (the four stage outputs as channels-last NCHW views, one
+        entry per block: for the last `last` blocks what `want` names - "logits": the raw attention products the reference returns,
+        "qkv": the (q, kv) projections - and None for the earlier ones)."""
         if self.training:
             raise NotImplementedError("MixVisionTransformer (HIP): inference only - call .eval()")
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else torch.float32
@@ -165,15 +169,15 @@ class MixVisionTransformer(nn.Module):
         for i in range(4):
             xh = getattr(self, f"patch_embed{i + 1}")(xh)
             for blk in getattr(self, f"block{i + 1}"):
-                xh, a = blk(xh, want_logits=k >= nblocks - logits_of_last)
+                xh, a = blk(xh, want=want if k >= nblocks - last else None)
                 attns.append(a)
                 k += 1
             xh = _layer_norm(xh, getattr(self, f"norm{i + 1}"))
             outs.append(xh.permute(0, 3, 1, 2))
         return outs, attns
 
-    def forward(self, x, logits_of_last=0):
-        return self.forward_features(x, logits_of_last)
+    def forward(self, x, last=0, want="logits"):
+        return self.forward_features(x, last, want)
 
 
 def _variant(embed_dims, depths):
