@@ -567,7 +567,10 @@ def _zeros(n, device, rt=None):
     return (rt or current()).zero_pool.zeros(n, device)
 
 
-def _pack(spec, weights, transpose, dtype, device, rt=None):
+def _pack(spec, weights, transpose, dtype, device, rt=None, cache=False):
+    """cache: keep the packed copy ON the spec until a weight's version counter or address changes.  Only for paths whose
+    parameters are never written behind autograd's back (the inference-only CAM networks): the trainer's fused SGD kernel updates
+    the flat parameter buffer through raw pointers, which no version counter sees - training / evaluation go through PackPlan."""
     key = (id(spec), bool(transpose), dtype)
     plan = (rt or current()).pack_plan
     if plan is not None:
@@ -575,6 +578,11 @@ def _pack(spec, weights, transpose, dtype, device, rt=None):
         if v is not None:
             return v
         plan.record(key, spec, weights, transpose, dtype)
+    elif cache:
+        tag = tuple((w.data_ptr(), w._version) for w in weights)
+        hit = spec.__dict__.setdefault("_packed", {}).get((bool(transpose), dtype, device))
+        if hit is not None and hit[0] == tag:
+            return hit[1]
     lib = L.load()
     code = L.RSSF_BF16 if dtype == torch.bfloat16 else L.RSSF_F32
     rows, cols = (spec.cin, spec.cout) if transpose else (spec.cout, spec.cin)
@@ -583,6 +591,8 @@ def _pack(spec, weights, transpose, dtype, device, rt=None):
     w = [wt if wt.is_contiguous() else wt.contiguous() for wt in weights] + [None, None]
     L.check(lib.rssf_conv_pack(L.ptr(w[0]), L.ptr(w[1]), L.ptr(w[2]), _ia(spec.ksizes), len(weights), _ia(spec.src), _ia(spec.kpos),
                                spec.c_alias, spec.ntaps, spec.cout, spec.cin, int(transpose), L.ptr(out), code, L.stream()), "rssf_conv_pack")
+    if cache and plan is None and not torch.cuda.is_current_stream_capturing():      # (a buffer born inside a capture belongs to the graph)
+        spec._packed[(bool(transpose), dtype, device)] = (tag, out)
     return out
 
 
@@ -594,18 +604,18 @@ def _pad_channels(t):
     return t if c % v == 0 else torch.nn.functional.pad(t, (0, v - c % v))
 
 
-def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None, preact=None):
+def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None, preact=None, cache_pack=False):
     if spec.parts is not None:                      # > 19 taps: partial sums chained through the epilogue's addend (inference)
         if stats is not None:
             raise NotImplementedError("librssf conv: fused statistics are not available for tap-split convolutions")
         out = None
         for k, part in enumerate(spec.parts):
-            out = _conv_forward(part, xh, weights, bias if k == 0 else None, None, rt, addend=out)
+            out = _conv_forward(part, xh, weights, bias if k == 0 else None, None, rt, addend=out, cache_pack=cache_pack)
         return out
     xh = _pad_channels(xh)
     B, H, W, C = xh.shape
     OH, OW = spec.out_hw(H, W)
-    wpk = _pack(spec, weights, False, xh.dtype, xh.device, rt)
+    wpk = _pack(spec, weights, False, xh.dtype, xh.device, rt, cache=cache_pack)
     out = torch.empty(B, OH, OW, spec.cout, device=xh.device, dtype=xh.dtype)
     lib = L.load()
     ws = None
@@ -1482,7 +1492,7 @@ class _LinearShape:
 def conv_nhwc(xh, conv, addend=None):
     """Inference-only convolution + bias (+ addend) on a channels-last activation [B, H, W, C] -> [B, OH, OW, Cout].  `conv`: an
     nn.Conv2d (square, ungrouped; more than 19 taps run as chained launches) or an nn.Linear (1 x 1 over the tokens).  No autograd:
-    the CAM extraction paths run under no_grad."""
+    the CAM extraction paths run under no_grad - where the packed weights are then kept until a parameter changes (`_pack`)."""
     L.require_gpu(xh)
     if isinstance(conv, nn.Linear):
         spec = conv.__dict__.get("_rssf_spec")
@@ -1494,7 +1504,8 @@ def conv_nhwc(xh, conv, addend=None):
     if addend is not None and spec.parts is not None:
         raise NotImplementedError("conv_nhwc: an addend on a tap-split convolution")
     bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
-    return _conv_forward(spec, xh if xh.is_contiguous() else xh.contiguous(), [w], bias, None, current(), addend=addend)
+    return _conv_forward(spec, xh if xh.is_contiguous() else xh.contiguous(), [w], bias, None, current(), addend=addend,
+                         cache_pack=not torch.is_grad_enabled())
 
 
 def flush_bn_counters(model, extra=0):

@@ -17,8 +17,8 @@ flops = [0.0]
 _fwd, _mha = nnf._conv_forward, ops.mha_fwd
 
 
-def counted(spec, xh, weights, bias, stats, rt=None, addend=None, preact=None):
-    out = _fwd(spec, xh, weights, bias, stats, rt, addend=addend, preact=preact)
+def counted(spec, xh, weights, bias, stats, rt=None, addend=None, preact=None, cache_pack=False):
+    out = _fwd(spec, xh, weights, bias, stats, rt, addend=addend, preact=preact, cache_pack=cache_pack)
     if spec.parts is None:
         flops[0] += 2.0 * out.numel() * spec.cin * spec.ntaps
     return out
