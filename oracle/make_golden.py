@@ -320,7 +320,17 @@ def case_scd():
     msc = ns.multi_scale_cam(m, x, scales)
     chk = scd_cpu.multi_scale_cam(P, x, scales)
     assert torch.allclose(chk, msc, rtol=1e-4, atol=1e-5), float((chk - msc).abs().max())
-    save("scd_mitb1_321", cam_s4=npy(cam), attn_sample=npy(attn[:, ::4, ::4]), attn_sum=npy(attn.double().sum((1, 2))),
+    with torch.no_grad():
+        cls, seg, attns, pred = m(x)                       # the full forward at inference (eval: dropout off, running statistics)
+        o_cls, o_seg, o_attns, o_pred = scd_cpu.tscd_full(x, P)
+    for a_, b_ in [(o_cls, cls), (o_seg, seg), (o_pred, pred)] + list(zip(o_attns, attns)):
+        assert a_.shape == b_.shape and torch.allclose(a_, b_, rtol=1e-4, atol=1e-5), float((a_ - b_).abs().max())
+    full = dict(full_cls=npy(cls), full_seg_sample=npy(seg[:, :, ::3, ::3]), full_pred_sample=npy(pred[:, ::4, ::4]))
+    for i, a_ in enumerate(attns):
+        full[f"full_attn{i}_shape"] = np.array(a_.shape)
+        st = 3 if a_.shape[-1] <= 100 else 7
+        full[f"full_attn{i}_sample"] = npy(a_[:, :, ::st, ::st])
+    save("scd_mitb1_321", **full, cam_s4=npy(cam), attn_sample=npy(attn[:, ::4, ::4]), attn_sum=npy(attn.double().sum((1, 2))),
          msc_sample=npy(msc[:, :, ::5, ::5]), msc_sum=npy(msc.double().sum((2, 3))), scales=np.array(scales),
          all_keys=np.array(list(sd.keys())), shapes=np.array([",".join(map(str, v.shape)) for v in sd.values()]))
     sys.path.remove(scd)

@@ -57,7 +57,7 @@ def block(x, H, W, P, pre, heads, sr):
     return x + mlp(_ln(x, P, pre + "norm2.", 1e-6), H, W, P, pre + "mlp."), raw
 
 
-def encoder(x, P, backbone="mit_b1", stride=(4, 2, 2, 1), pre="encoder."):
+def encoder(x, P, backbone="mit_b1", stride=(4, 2, 2, 1), pre="encoder.", pooled_attn=False):
     """MixVisionTransformer.forward_features (:330-372): the four stage outputs [B, C, H, W] and the raw attention products of
     the sr_ratio == 1 blocks (None for the others: the reference returns pooled copies nothing on the CAM path reads)."""
     cfg = MIT[backbone]
@@ -70,7 +70,10 @@ def encoder(x, P, backbone="mit_b1", stride=(4, 2, 2, 1), pre="encoder."):
         x = _ln(x.flatten(2).transpose(1, 2), P, pe + "norm.", 1e-5)
         for j in range(cfg["depths"][i]):
             x, raw = block(x, H, W, P, f"{pre}block{i + 1}.{j}.", HEADS[i], SR[i])
-            raws.append(raw if SR[i] == 1 else None)
+            if SR[i] > 1 and pooled_attn:                                   # attn_copy of the reduced stages (:119-129)
+                Bq, hd, _, M = raw.shape
+                raw = F.avg_pool3d(raw.reshape(Bq, hd, H, W, M), kernel_size=(SR[i], SR[i], 1), stride=(SR[i], SR[i], 1)).reshape(-1, hd, M, M)
+            raws.append(raw if (SR[i] == 1 or pooled_attn) else None)
         x = _ln(x, P, f"{pre}norm{i + 1}.", 1e-6)
         x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
         outs.append(x)
@@ -83,6 +86,27 @@ def tscd_cam_only(x, P, backbone="mit_b1", stride=(4, 2, 2, 1)):
     attn_cat = torch.cat(raws[-2:], dim=1)
     attn_pred = torch.sigmoid(F.conv2d(attn_cat, P["attn_proj.weight"], P["attn_proj.bias"]))[:, 0]
     return F.conv2d(feats[3], P["classifier.weight"]), attn_pred
+
+
+def tscd_full(x, P, backbone="mit_b1", stride=(4, 2, 2, 1), pooling="gmp"):
+    """TSCD.forward(x) at inference (TSCD_model.py:66-88): (class scores, segmentation logits, the attention products of every block -
+    pooled over sr x sr query patches where sr_ratio > 1, mix_transformer.py:119-129 -, the attention prediction)."""
+    feats, attns = encoder(x, P, backbone, stride, pooled_attn=True)
+    c1, c2, c3, c4 = feats
+    n = x.shape[0]
+    ups = []
+    for name, c in (("c4", c4), ("c3", c3), ("c2", c2), ("c1", c1)):                # SegFormerHead.forward (segformer_head.py:58-81)
+        t = F.linear(c.flatten(2).transpose(1, 2), P[f"decoder.linear_{name}.proj.weight"], P[f"decoder.linear_{name}.proj.bias"])
+        t = t.permute(0, 2, 1).reshape(n, -1, c.shape[2], c.shape[3])
+        ups.append(t if name == "c1" else F.interpolate(t, size=c1.shape[2:], mode="bilinear", align_corners=False))
+    f = F.conv2d(torch.cat(ups, 1), P["decoder.linear_fuse.conv.weight"])
+    f = F.relu(F.batch_norm(f, P["decoder.linear_fuse.bn.running_mean"], P["decoder.linear_fuse.bn.running_var"],
+                            P["decoder.linear_fuse.bn.weight"], P["decoder.linear_fuse.bn.bias"], False, 0.0, 1e-5))
+    seg = F.conv2d(f, P["decoder.linear_pred.weight"], P["decoder.linear_pred.bias"])
+    pool = F.adaptive_max_pool2d if pooling == "gmp" else F.adaptive_avg_pool2d
+    cls = F.conv2d(pool(c4, (1, 1)), P["classifier.weight"]).view(-1, P["classifier.weight"].shape[0])
+    pred = torch.sigmoid(F.conv2d(torch.cat(attns[-2:], 1), P["attn_proj.weight"], P["attn_proj.bias"]))[:, 0]
+    return cls, seg, attns, pred
 
 
 def multi_scale_cam(P, inputs, scales, backbone="mit_b1", stride=(4, 2, 2, 1)):

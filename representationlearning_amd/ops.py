@@ -278,6 +278,16 @@ def resize_bilinear_planar(x, size):
     return out
 
 
+def resize_bilinear_nhwc(xh, size):
+    """F.interpolate(size=size, mode='bilinear', align_corners=False) of a channels-last activation [B, H, W, C]."""
+    L.require_gpu(xh)
+    _tok(xh)
+    B, H, W, C = xh.shape
+    out = torch.empty(B, size[0], size[1], C, device=xh.device, dtype=xh.dtype)
+    L.check(L.load().rssf_resize_bilinear(L.ptr(xh), L.ptr(out), B, H, W, size[0], size[1], C, L.dtype_code(xh), L.stream()), "rssf_resize_bilinear")
+    return out
+
+
 def cam_merge_(acc, cam, accumulate):
     """acc [b, K, H, W] fp32 (+)= relu(max(up(cam[:b]), up(cam[b:]).flip(-1))), cam [2b, hc, wc, K] channels-last (camutils.py:93-96)."""
     L.require_gpu(acc, cam)

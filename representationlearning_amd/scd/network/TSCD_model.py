@@ -1,5 +1,6 @@
-"""SCD's network: Mix-Transformer encoder + class-activation / attention heads (reference: SCD-AAAI2023/network/TSCD_model.py:10-88).
-`forward(x, cam_only=True)` - what `multi_scale_cam` calls (utils/camutils.py:91,103) - runs on librssf kernels: the class
+"""SCD's network: Mix-Transformer encoder + class-activation / attention heads + SegFormer decoder (reference:
+SCD-AAAI2023/network/TSCD_model.py:10-88), inference.  `forward(x, cam_only=True)` - what `multi_scale_cam` calls
+(utils/camutils.py:91,103) - and the full forward (class scores, segmentation logits, attention maps) run on librssf kernels: the class
 activation map is the classifier's 1 x 1 weights applied to the stage-4 feature, the attention prediction is
 sigmoid(attn_proj(raw q k^T of the last two blocks)), formed by `rssf_attn_pred` without the logit tensors.  Same module tree / `state_dict` as the reference."""
 import math
@@ -43,14 +44,27 @@ class TSCD(nn.Module):
             groups[1 if "norm" in name else 0].append(p)
         return groups
 
-    def forward(self, x, cam_only=False, seg_detach=True, aux=False):
-        if not cam_only:
-            raise NotImplementedError("TSCD (HIP): the class-activation path (cam_only=True) is what this build covers; the "
-                                      "classification / segmentation outputs of the training forward are not built")
-        feats, qkv = self.encoder(x, last=2, want="qkv")
-        x4 = feats[3]
+    def _attn_pred(self, qkv):
         # sigmoid(attn_proj(cat(attns[-2:], 1)))[:, 0] from the projections of the last two blocks: the logit tensors are not formed
-        attn_pred = ops.attn_pred(*qkv[-2], *qkv[-1], self.attn_proj.weight.detach(), self.attn_proj.bias.detach(),
-                                  self.encoder.block4[-1].attn.num_heads)
-        cam_s4 = nnf.conv_nhwc(x4.permute(0, 2, 3, 1), self.classifier).permute(0, 3, 1, 2)
-        return cam_s4, attn_pred
+        return ops.attn_pred(*qkv[-2], *qkv[-1], self.attn_proj.weight.detach(), self.attn_proj.bias.detach(),
+                             self.encoder.block4[-1].attn.num_heads)
+
+    def forward(self, x, cam_only=False, seg_detach=True, aux=False):
+        if self.training or torch.is_grad_enabled():
+            raise NotImplementedError("TSCD (HIP): inference only - .eval() under torch.no_grad() (the class-activation extraction of "
+                                      "the reference; its training step is not built)")
+        if cam_only:
+            feats, qkv = self.encoder(x, last=2, want="qkv")
+            cam_s4 = nnf.conv_nhwc(feats[3].permute(0, 2, 3, 1), self.classifier).permute(0, 3, 1, 2)
+            return cam_s4, self._attn_pred(qkv)
+        # the full forward (TSCD_model.py:68-88): image-level class scores from the pooled stage-4 feature, the segmentation logits,
+        # every block's attention products (pooled for the spatially reduced stages) and the attention prediction
+        feats, attns = self.encoder(x, last=None, want="logits")
+        seg = self.decoder(feats)
+        if self.pooling is None:
+            raise ValueError("TSCD: pooling='gmp' or 'gap' is needed for the classification output")
+        pooled = self.pooling(feats[3].float(), (1, 1)).to(feats[3].dtype).permute(0, 2, 3, 1).contiguous()
+        cls_x4 = nnf.conv_nhwc(pooled, self.classifier).reshape(-1, self.num_classes - 1)
+        if aux:
+            return cls_x4, seg, attns
+        return cls_x4, seg, attns, ops.attn_proj_sigmoid(attns[-2], attns[-1], self.attn_proj.weight.detach(), self.attn_proj.bias.detach())

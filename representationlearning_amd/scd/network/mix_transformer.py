@@ -85,20 +85,24 @@ class Attention(nn.Module):
     def forward(self, xh, residual=None, want=None):
         """xh: LayerNorm'ed tokens [B, H, W, C].  Returns (proj(attention) (+ residual), extra): extra = the raw q k^T products
         [B, heads, N, M] for want == "logits" (what the reference hands back when sr_ratio == 1, :119-131), the projections
-        (q [B, N, C], kv [B, M, 2C]) for want == "qkv" (all TSCD's attention head needs), else None.  The reference also returns a
-        pooled copy of the logits for the spatially reduced stages (:121-124); nothing on the CAM path reads those, they are not
-        formed."""
+        (q [B, N, C], kv [B, M, 2C]) for want == "qkv" (all TSCD's attention head needs), else None.  For the spatially reduced
+        stages "logits" is the reference's pooled copy [B, heads, M, M] (:121-129)."""
         B, H, W, C = xh.shape
         q = nnf.conv_nhwc(xh, self.q)
         src = xh
         if self.sr_ratio > 1:
             src = _layer_norm(nnf.conv_nhwc(xh, self.sr), self.norm)
         kv = nnf.conv_nhwc(src, self.kv)
-        if want == "logits" and self.sr_ratio > 1:
-            raise NotImplementedError("Attention (HIP): the pooled attention maps of the spatially reduced stages are not built")
-        q, kv = q.view(B, H * W, C), kv.view(B, -1, 2 * C)
-        o, logits = ops.mha_fwd(q, kv, self.num_heads, self.scale, want == "logits")
-        return nnf.conv_nhwc(o.view(B, H, W, C), self.proj, addend=residual), (q, kv) if want == "qkv" else logits
+        qt, kv = q.view(B, H * W, C), kv.view(B, -1, 2 * C)
+        pooled = want == "logits" and self.sr_ratio > 1
+        o, logits = ops.mha_fwd(qt, kv, self.num_heads, self.scale, want == "logits" and not pooled)
+        if pooled:
+            # avg_pool3d(raw logits as [B, heads, H, W, M], (sr, sr, 1)) (:121-124) = the products of the POOLED queries with the
+            # same keys (the mean over a patch of q.k is (mean q).k): the [B, heads, N, M] tensor is never formed
+            qp = torch.nn.functional.avg_pool2d(q.permute(0, 3, 1, 2).float(), self.sr_ratio, self.sr_ratio).permute(0, 2, 3, 1)
+            qp = qp.reshape(B, -1, C).to(q.dtype).contiguous()
+            logits = ops.mha_fwd(qp, kv, self.num_heads, self.scale, True)[1].reshape(-1, self.num_heads, kv.shape[1], kv.shape[1])
+        return nnf.conv_nhwc(o.view(B, H, W, C), self.proj, addend=residual), (qt, kv) if want == "qkv" else logits
 
 
 class Block(nn.Module):
@@ -158,13 +162,14 @@ class MixVisionTransformer(nn.Module):
 
     def forward_features(self, x, last=0, want="logits"):
         """x: image batch [B, 3, H, W] fp32 (any memory format).  Returns (the four stage outputs as channels-last NCHW views, one
-        entry per block: for the last `last` blocks what `want` names - "logits": the raw attention products the reference returns,
-        "qkv": the (q, kv) projections - and None for the earlier ones)."""
+        entry per block: for the last `last` blocks (None = all, what the reference returns) what `want` names - "logits": the
+        attention products as the reference hands them back, "qkv": the (q, kv) projections - and None for the earlier ones)."""
         if self.training:
             raise NotImplementedError("MixVisionTransformer (HIP): inference only - call .eval()")
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else torch.float32
         xh = nnf.image_to_channels_last(x.float(), dtype).permute(0, 2, 3, 1)
         nblocks, k = sum(self.depths), 0
+        last = nblocks if last is None else last
         outs, attns = [], []
         for i in range(4):
             xh = getattr(self, f"patch_embed{i + 1}")(xh)

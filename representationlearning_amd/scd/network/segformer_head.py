@@ -1,9 +1,13 @@
-"""Parameter tree of the SegFormer decoder the SCD model carries (reference: SCD-AAAI2023/network/segformer_head.py:12-81; its
-`linear_fuse` is an mmcv ConvModule = Conv2d(bias=False) + SyncBN + ReLU registered as `conv` / `bn` / `activate`).
+"""SegFormer all-MLP decoder of the SCD model, inference (reference: SCD-AAAI2023/network/segformer_head.py:12-81; its `linear_fuse`
+is an mmcv ConvModule = Conv2d(bias=False) + SyncBN + ReLU registered as `conv` / `bn` / `activate`).
 
-`TSCD(..., cam_only=True)` evaluates the decoder and discards the result (TSCD_model.py:71,77-79): the CAM path does not need it, so
-only the parameters exist here - checkpoints of the reference load unchanged - and calling it says so."""
+`TSCD(..., cam_only=True)` evaluates the decoder and discards the result (TSCD_model.py:71,77-79), so the CAM path skips it; the
+full forward runs it on librssf launches: four 1 x 1 projections, three align_corners=False up-samplings to the stride-4 grid,
+concat, 1 x 1 convolution + BatchNorm (running statistics) + ReLU, 1 x 1 prediction."""
+import torch
 import torch.nn as nn
+
+from ... import nnf, ops
 
 
 class MLP(nn.Module):
@@ -31,4 +35,14 @@ class SegFormerHead(nn.Module):
         self.linear_pred = nn.Conv2d(embedding_dim, num_classes, kernel_size=1)
 
     def forward(self, feats):
-        raise NotImplementedError("SegFormerHead (HIP): the segmentation decoder is outside the CAM path this build covers")
+        """feats: the four stage outputs (channels-last NCHW views).  Returns the class logits [B, num_classes, H/4, W/4]."""
+        if self.training:
+            raise NotImplementedError("SegFormerHead (HIP): inference only - call .eval()")
+        hs = [f.permute(0, 2, 3, 1) for f in feats]
+        size = hs[0].shape[1:3]
+        parts = []
+        for i in (4, 3, 2, 1):                                                  # the reference concatenates [_c4, _c3, _c2, _c1]
+            t = nnf.conv_nhwc(hs[i - 1], getattr(self, f"linear_c{i}").proj)
+            parts.append(t if i == 1 else ops.resize_bilinear_nhwc(t, size))
+        fused = nnf.conv_bn_act(torch.cat(parts, dim=3).permute(0, 3, 1, 2), self.linear_fuse.conv, self.linear_fuse.bn, nnf.ACT_RELU)
+        return nnf.conv_nhwc(fused.permute(0, 2, 3, 1), self.linear_pred).permute(0, 3, 1, 2)       # Dropout2d: identity at inference

@@ -285,6 +285,13 @@ def test_scd_cam_oracle_vs_reference_golden():
     assert rel_err(cam, g["cam_s4"]) < TOL and rel_err(attn[:, ::4, ::4], g["attn_sample"]) < TOL
     assert rel_err(attn.double().sum((1, 2)), g["attn_sum"]) < TOL
     assert rel_err(msc[:, :, ::5, ::5], g["msc_sample"]) < TOL and rel_err(msc.double().sum((2, 3)), g["msc_sum"]) < TOL
+    with torch.no_grad():
+        cls, seg, attns, pred = scd_cpu.tscd_full(x, P)
+    assert rel_err(cls, g["full_cls"]) < TOL and rel_err(seg[:, :, ::3, ::3], g["full_seg_sample"]) < TOL
+    assert rel_err(pred[:, ::4, ::4], g["full_pred_sample"]) < TOL
+    for i, a in enumerate(attns):
+        st = 3 if a.shape[-1] <= 100 else 7
+        assert tuple(a.shape) == tuple(g[f"full_attn{i}_shape"]) and rel_err(a[:, :, ::st, ::st], g[f"full_attn{i}_sample"]) < TOL
 
 
 def test_scd_state_dict_matches_reference():
