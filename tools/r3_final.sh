@@ -17,6 +17,7 @@ tools/hbm_traffic.sh ${tag}_hbm_step python bench.py --steps 1 --warmup 1 --no-c
 for v in "A=1" "RSSF_SYNCBN=rccl"; do echo "== forced 1-rank data parallel, $v" >> $o/dp_forced_1rank.txt; env $v timeout 400 python tools/dp_graph.py 2>&1 | grep "ms/step\|SyncBN\|dp buckets" >> $o/dp_forced_1rank.txt; done
 timeout 600 python bench.py --variant large --size 1024 --batch 4 --steps 10 --warmup 3 --no-cpu-baseline > $o/bench_large.json 2>/dev/null
 timeout 300 python tools/cam_bench.py > $o/cam.json 2>/dev/null
+timeout 300 python tools/scd_cam_bench.py > $o/scd_cam.json 2>/dev/null
 timeout 300 python tools/loader_bench.py > $o/loader.txt 2>&1
 timeout 300 python tools/input_bench.py >> $o/loader.txt 2>&1
 find gpurun_out -name "*kernel_trace.csv" -size +10M -delete; find gpurun_out -name "*.db" -size +10M -delete
