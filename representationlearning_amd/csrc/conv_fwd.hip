@@ -637,7 +637,8 @@ struct BnBwdStats {            // see HaloArgs::bn_* (conv.hip.h)
   const void* raw; const void* res; const float* ss; float* sums; int act;
 };
 bool halo_path(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype) {
-  return dtype == RSSF_BF16 && (int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx);
+  static const int maxc = getenv("RSSF_HALO_MAXC") ? atoi(getenv("RSSF_HALO_MAXC")) : (1 << 30);      // tuning sweeps only (tools/conv3x3_bench.py)
+  return dtype == RSSF_BF16 && Cin <= maxc && (int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx);
 }
 struct PreAct {              // see HaloArgs::pre_* (conv.hip.h)
   const float* stats; const float* gamma; const float* beta; float* rmean; float* rvar; float* mi; float* ss;
