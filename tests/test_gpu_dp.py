@@ -197,10 +197,10 @@ def test_two_ranks_without_sync_bn_keep_local_statistics_except_mlp():
     assert abs(local[0]["loss"] - pooled[0]["loss"]) > 1e-4 * abs(pooled[0]["loss"])
 
 
-def _p2p_worker(rank, port, out_dir):
+def _p2p_worker(rank, port, out_dir, world=WORLD):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RSSF_P2P_TIMEOUT_MS="4000")
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from representationlearning_amd import rccl
     ex = rccl.P2PExchange(2)
@@ -209,10 +209,10 @@ def _p2p_worker(rank, port, out_dir):
     n1, n2 = 2 * c1, 2 * c2
     layout = (nslots, [(0, n1), (nslots * n1, n2)])
     g = torch.Generator().manual_seed(5)
-    base = [torch.randn(nslots * (n1 + n2), generator=g) for _ in range(WORLD)]          # every rank knows every rank's input
+    base = [torch.randn(nslots * (n1 + n2), generator=g) for _ in range(world)]          # every rank knows every rank's input
     fold = lambda t: torch.cat([t[:nslots * n1].view(nslots, n1), ], 0).sum(0)
     want = None
-    for r in range(WORLD):                              # rank-ordered sum of the per-rank slot folds (what the kernel computes)
+    for r in range(world):                              # rank-ordered sum of the per-rank slot folds (what the kernel computes)
         loc = torch.cat([base[r][:nslots * n1].view(nslots, n1).cuda().sum(0), base[r][nslots * n1:].view(nslots, n2).cuda().sum(0)])
         want = loc if want is None else want + loc
     out = dict(ok=True, msgs=[])
@@ -249,7 +249,7 @@ def _p2p_worker(rank, port, out_dir):
             sa.copy_(src); sb.copy_(src)
             side.wait_stream(torch.cuda.current_stream())
             ch0.syncbn_exchange_(sa, layout)
-            ch0.syncbn_exchange_(sa, (1, [(0, n1)]))       # a second, unslotted exchange of the totals of layer 1: x WORLD
+            ch0.syncbn_exchange_(sa, (1, [(0, n1)]))       # a second, unslotted exchange of the totals of layer 1: x world
             with torch.cuda.stream(side):
                 ch1.syncbn_exchange_(sb, layout)
             torch.cuda.current_stream().wait_stream(side)
@@ -257,7 +257,7 @@ def _p2p_worker(rank, port, out_dir):
             gr.replay()
             torch.cuda.synchronize()
             check(sb, "graph ch1 #%d" % it)
-            if not torch.allclose(sa[:n1], WORLD * want[:n1], rtol=1e-5, atol=1e-5):
+            if not torch.allclose(sa[:n1], world * want[:n1], rtol=1e-5, atol=1e-5):
                 out["ok"] = False
                 out["msgs"].append("graph ch0 #%d" % it)
     out["timed_out"] = ex.timed_out()
@@ -268,21 +268,23 @@ def _p2p_worker(rank, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_p2p_syncbn_exchange_two_processes():
-    """The peer-to-peer SyncBN exchange (csrc/p2p.hip: hipIpc-mapped windows, value+epoch words, rank-ordered sums) between TWO
-    processes - as on a node, except that both live on the one GPU of the box: eager on two channels / two streams at once, and
-    inside a replayed hipGraph.  Totals equal the slot-folded sum over ranks, the other slots are cleared, both ranks hold
-    bit-identical results, nobody timed out."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_p2p_syncbn_exchange_two_processes(world):
+    """The peer-to-peer SyncBN exchange (csrc/p2p.hip: hipIpc-mapped windows, value+epoch words, rank-ordered sums) between 2, 4
+    and 8 processes - as on a node, except that all live on the one GPU of the box: eager on two channels / two streams at once,
+    and inside a replayed hipGraph.  Totals equal the slot-folded sum over ranks, the other slots are cleared, all ranks hold
+    bit-identical results, nobody timed out.  (World 8 is the node the driver's scaling run uses.)"""
     ctx = mp.get_context("spawn")
     port = _free_port()
     with tempfile.TemporaryDirectory() as d:
-        procs = [ctx.Process(target=_p2p_worker, args=(r, port, d)) for r in range(WORLD)]
+        procs = [ctx.Process(target=_p2p_worker, args=(r, port, d, world)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
-            p.join(300)
+            p.join(600)
             assert p.exitcode == 0, "rank process failed (exit code %s)" % p.exitcode
-        res = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=False) for r in range(WORLD)]
+        res = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=False) for r in range(world)]
     for r in res:
         assert r["timed_out"] == 0 and r["ok"], r["msgs"][:5]
-    assert torch.equal(res[0]["first"], res[1]["first"])
+    for r in res[1:]:
+        assert torch.equal(res[0]["first"], r["first"])
