@@ -332,9 +332,10 @@ def main():
                        "sync_bn": (not args.no_sync_bn) and world > 1,
                        "step_launch": "hipGraph replay" if trainer.graph is not None else "eager",
                        "collectives": None if world == 1 else (
-                           "SyncBN: %s, one channel / communicator per stream (main + %d side); gradients: RCCL all-reduce of 6 flat "
-                           "buckets on their own stream" % ("peer-to-peer kernel over hipIpc windows" if trainer.p2p is not None
-                                                            else "RCCL all-reduce", len(trainer.side_comms))
+                           "SyncBN: %s, one channel / communicator per stream (main + %d side); gradients: %s" % (
+                               "peer-to-peer kernel over hipIpc windows" if trainer.p2p is not None else "RCCL all-reduce", len(trainer.side_comms),
+                               "RCCL all-reduce of 6 flat buckets beside backward" if getattr(trainer.grad_comm, "direct", False)
+                               else "torch.distributed (bucketed, hook-driven)")
                            if getattr(trainer.comm, "direct", False) else "torch.distributed (bucketed, hook-driven)")},
             "final_loss": round(final_loss, 5),
             "whole_step_mfma_frac": round(value * flop_img / (world * MFMA_BF16_PEAK), 5),

@@ -128,6 +128,10 @@ class GradBuckets:
         # the collective after THAT stream leaves it unordered against the backward kernels: a captured step then carries a race
         # that shows up as NaN losses as soon as the replay starts on an idle GPU (tools/dp_nan_probe.py).
         cs = self.compute_stream if (self.compute_stream is not None or not g.is_cuda) else torch.cuda.current_stream()
+        if os.environ.get("RSSF_TEST_FAIL_CAPTURE") == "1" and g.is_cuda and b == len(self.members) // 2:
+            with torch.cuda.stream(cs):                 # test hook: an error in the middle of a CAPTURED backward (side streams forked)
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("injected failure inside the captured step (RSSF_TEST_FAIL_CAPTURE)")
         # Gradients of the HRNet branches / fuse paths are produced on SIDE streams (nnf.parallel_map / fork_side): the step's
         # stream joins them here, so that "after the compute stream" really means "after every kernel that wrote this bucket".
         if g.is_cuda and self.side_streams is not None:
@@ -292,7 +296,9 @@ class Trainer:
         # replayed.  In DP this needs the direct RCCL communicators (collectives issued through torch.distributed cannot be
         # captured: its watchdog thread polls their events).  RSSF_GRAPH=1 forces graphs, RSSF_GRAPH=0 disables them.
         env = os.environ.get("RSSF_GRAPH")
-        self.use_graph = (env == "1") or (env != "0" and use_graph and (not dp or self.comm.direct))
+        # (BOTH communicators: the peer-to-peer SyncBN exchange can also run beside torch.distributed gradient buckets - two ranks
+        # on one GPU over gloo - and those cannot be captured)
+        self.use_graph = (env == "1") or (env != "0" and use_graph and (not dp or (self.comm.direct and self.grad_comm.direct)))
         self.graph_warmup = 3
         # HRNet branches on side streams: parallel branches of the captured graph (+1 % at B=16); eager launches are host-bound
         # and the SyncBN exchanges of a DP step must reach the communicator in one fixed order, so both keep a single stream
@@ -374,10 +380,21 @@ class Trainer:
             # thread_local: the NCCL watchdog thread keeps polling events of earlier collectives, which a global-mode
             # capture forbids ("operation not permitted when stream is capturing")
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._static_loss = self._eager_step(*self._static)
+                try:
+                    self._static_loss = self._eager_step(*self._static)
+                finally:
+                    # An exception in the middle of the step (a collective that cannot be captured, an allocation failure, ...)
+                    # leaves the side streams it had forked into INSIDE the capture: ending the capture then fails with
+                    # hipErrorStreamCaptureUnjoined and, on this ROCm, those streams STAY in capture mode - the eager steps that
+                    # follow die on their first synchronising call ("operation not permitted when stream is capturing";
+                    # found with bench.py on two ranks over gloo).  Join every stream of this step that is still capturing
+                    # back into the capture's stream, so that the capture ends cleanly whatever happened.
+                    self._join_capturing_streams()
         except Exception as e:       # fall back to eager launches, loudly
             print("[rssf] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), flush=True)
             self.use_graph = False
+            self.rt.branch_streams = False       # (eager launches are host-bound: one stream, as without graphs)
+            self._static = None
             torch.cuda.synchronize()
             return False
         finally:
@@ -385,6 +402,21 @@ class Trainer:
                 m._rssf_steps = k
         self.graph = g
         return True
+
+    def _join_capturing_streams(self):
+        cur = torch.cuda.current_stream()
+        if not torch.cuda.is_current_stream_capturing():
+            return
+        pool = [st for lst in self.rt.side_streams.values() for st in lst]
+        if self.buckets is not None and getattr(self.buckets, "side", None) is not None:
+            pool.append(self.buckets.side)
+        for st in pool:
+            if st == cur:
+                continue
+            with torch.cuda.stream(st):
+                capturing = torch.cuda.is_current_stream_capturing()
+            if capturing:
+                cur.wait_stream(st)
 
     def _fits_static(self, img, target):
         s_img, s_tgt = self._static
@@ -463,12 +495,16 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RSSF_ONE_GPU=1 (test hook): every rank on device 0 over gloo - the multi-process plumbing of bench.py / train.py on a one-GPU
+    # box (RCCL refuses two ranks on one device; the SyncBN exchange is then torch.distributed's or, with RSSF_SYNCBN=p2p, the
+    # peer-to-peer kernel).  Says nothing about speed.
+    one_gpu = os.environ.get("RSSF_ONE_GPU") == "1"
     if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(0 if one_gpu else local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() and not one_gpu else "gloo", rank=rank, world_size=world)
     return rank, local, world
 
 
