@@ -21,6 +21,9 @@ using namespace rssf;
 using namespace rssf::wa;
 
 // tuning knobs (defaults = the measured best on MI355X; tools/attn_variants.sh builds the alternatives)
+#ifndef RSSF_FWD_PIPE
+#define RSSF_FWD_PIPE 1            // bf16: next window's loads one window ahead + raw-x tile in LDS (0: two tiles per wave, three workgroups per CU)
+#endif
 #ifndef RSSF_FWD_OCC
 #define RSSF_FWD_OCC 2             // waves per SIMD the register allocator makes room for (bf16)
 #endif
@@ -40,7 +43,7 @@ template <typename T, typename DM> struct FwdLayout {
   static constexpr size_t SHARED_OFF = (sizeof(T) * W_ELEMS + sizeof(float) * F_ELEMS + 15) / 16 * 16;
   // bf16: a third tile per wave keeps the RAW x tokens for the residual (they are in registers when the tile is staged; re-reading
   // them from global cost 9 MB of fabric traffic per launch on top of the L2 hits)
-  static constexpr int NREG = sizeof(T) == 2 ? 3 : 2;
+  static constexpr int NREG = (sizeof(T) == 2 && RSSF_FWD_PIPE) ? 3 : 2;
   static constexpr size_t WAVE_BYTES = sizeof(T) * NREG * REGION;
   // waves per workgroup: as many (<= 4) as fit the 160 KiB LDS of one CU
   static constexpr int WAVES = (SHARED_OFF + 4 * WAVE_BYTES <= 160 * 1024) ? 4 : (SHARED_OFF + 2 * WAVE_BYTES <= 160 * 1024) ? 2 : 1;
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
   constexpr int LDX = LY::LDX, LDW = LY::LDW, LDO = LY::LDO;
   constexpr int C = DM::C, CP = DM::CP, CV = DM::CV, MT = DM::MT, CT = DM::CT, TPH = DM::TPH, D = DM::D;
   constexpr int LW = WIN * WIN;                      // live tokens of a window (the entry point checked window == 7)
-  constexpr bool PIPE = CONTIG && sizeof(T) == 2 && (C % Vec<T>::N) == 0;      // next window's global loads issued one window ahead
+  constexpr bool PIPE = RSSF_FWD_PIPE && CONTIG && sizeof(T) == 2 && (C % Vec<T>::N) == 0;      // next window's global loads issued one window ahead
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // ---- workgroup-shared: weights as T (MFMA operands), biases / LN affine fp32 ---------------------------------
   T* sWq = reinterpret_cast<T*>(smem_raw);           // [CV][LDW]  virtual rows, k = real input channel
