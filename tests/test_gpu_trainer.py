@@ -145,34 +145,42 @@ def test_dp_plumbing_on_one_rank_matches_plain_path(backend):
     assert rel_err(g_dp.cpu(), g_plain.cpu()) < 1e-5, rel_err(g_dp.cpu(), g_plain.cpu())
 
 
-def test_failed_capture_falls_back_to_working_eager_steps(capfd):
-    """An exception in the middle of the captured step (injected inside a gradient bucket's launch: side streams forked, nothing
-    joined) must end the capture cleanly: the trainer says so, drops the graph and keeps training with eager launches on healthy
-    streams - same losses as a trainer that never tried to capture."""
+def _failed_capture_worker():
+    import contextlib
+    import io
     from representationlearning_amd.trainer import Trainer
     t0 = Trainer(_mk(1), bf16=False, base_lr=0.0, weight_decay=0.0, use_graph=False, deterministic=True)
     plain = _run(t0, steps=2)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RSSF_FORCE_DP="1", RSSF_DP_BACKEND="rccl", RSSF_GRAPH="1",
                       RSSF_TEST_FAIL_CAPTURE="1")
     dist.init_process_group("nccl", rank=0, world_size=1)
-    tr = None
-    try:
-        tr = Trainer(_mk(1), bf16=False, sync_bn=True, base_lr=0.0, weight_decay=0.0, deterministic=True)
-        assert tr.use_graph and tr.rt.branch_streams
+    out = io.StringIO()
+    tr = Trainer(_mk(1), bf16=False, sync_bn=True, base_lr=0.0, weight_decay=0.0, deterministic=True)
+    assert tr.use_graph and tr.rt.branch_streams
+    with contextlib.redirect_stdout(out):
         dp = _run(tr, steps=7)                     # 3 warm-up, the failed capture + its eager step, 3 more eager steps
-        assert tr.graph is None and not tr.use_graph and not tr.rt.branch_streams
-        torch.cuda.synchronize()
-        x = torch.empty(1 << 28, device="cuda")    # a fresh allocation and a synchronising call still work (no stream is stuck capturing)
-        del x
-        assert not torch.cuda.is_current_stream_capturing()
-    finally:
-        if tr is not None:
-            tr.close()
-        dist.destroy_process_group()
-        for k in ("RSSF_FORCE_DP", "RSSF_DP_BACKEND", "RSSF_GRAPH", "RSSF_TEST_FAIL_CAPTURE"):
-            os.environ.pop(k)
-    assert "hipGraph capture failed" in capfd.readouterr().out
+    assert tr.graph is None and not tr.use_graph and not tr.rt.branch_streams
+    torch.cuda.synchronize()
+    x = torch.empty(1 << 28, device="cuda")        # a fresh allocation and a synchronising call still work (no stream is stuck capturing)
+    del x
+    assert not torch.cuda.is_current_stream_capturing()
+    assert "hipGraph capture failed" in out.getvalue(), out.getvalue()
     assert max(abs(a - plain[0]) for a in dp) < 1e-6 * abs(plain[0]), (plain, dp)
+    tr.close()
+    dist.destroy_process_group()
+
+
+def test_failed_capture_falls_back_to_working_eager_steps():
+    """An exception in the middle of the captured step (injected inside a gradient bucket's launch: side streams forked, nothing
+    joined) must end the capture cleanly: the trainer says so, drops the graph and keeps training with eager launches on healthy
+    streams - same losses as a trainer that never tried to capture.  In a process of its own: a graph that was captured with
+    parallel branches and thrown away unlaunched is one more way into the hip::Graph::UpdateStreams crash of a LATER graph launch
+    (DESIGN lesson 27) - seen when this ran inside the full suite; a trainer whose capture failed launches no graph again."""
+    import torch.multiprocessing as mp
+    p = mp.get_context("spawn").Process(target=_failed_capture_worker)
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
 
 
 def test_graph_replay_matches_eager():
