@@ -108,6 +108,119 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const T* __restrict__
   }
 }
 
+// ---- few-channel tensors (the 6-class logits of the head, x 4 up-sampling of hrnet_aux.py:80): ONE thread per pixel -------------
+// The vector kernels above need C % VEC == 0; their scalar instantiation spends a full set of coordinate / index arithmetic on
+// every single element (16 x 512 x 512 x 6: 120 us forward, 94 us backward = 0.4 TB/s).  Here a thread computes the coordinates
+// once and walks the pixel's channels in 4-byte units (two bf16 or one fp32 channel).
+template <typename T> struct PxUnit;
+template <> struct PxUnit<float> {
+  static constexpr int CH = 1;
+  typedef float raw;
+  static __device__ __forceinline__ void get(raw r, float* v) { v[0] = r; }
+  static __device__ __forceinline__ raw put(const float* v) { return v[0]; }
+};
+template <> struct PxUnit<bf16_t> {
+  static constexpr int CH = 2;
+  typedef uint32_t raw;
+  static __device__ __forceinline__ void get(raw r, float* v) { v[0] = __uint_as_float(r << 16); v[1] = __uint_as_float(r & 0xffff0000u); }
+  static __device__ __forceinline__ raw put(const float* v) { return f2bf2(v[0], v[1]); }
+};
+constexpr int PX_MAXU = 8;           // up to 8 units per pixel (8 fp32 / 16 bf16 channels)
+
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_fwd_px_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int IH, int IW, int OH, int OW,
+                                                              int C, int ldw, float sy, float sx) {
+  using U = PxUnit<T>;
+  typedef typename U::raw raw;
+  const int nu = C / U::CH;
+  const int64_t total = (int64_t)B * OH * OW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const float fy = src_coord(oy, sy), fx = src_coord(ox, sx);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < IH ? y0 + 1 : IH - 1, x1 = x0 + 1 < IW ? x0 + 1 : IW - 1;
+    const float wy = fy - y0, wx = fx - x0;
+    const T* base = in + (int64_t)b * IH * IW * C;
+    const raw* p00 = reinterpret_cast<const raw*>(base + ((int64_t)y0 * IW + x0) * C);
+    const raw* p01 = reinterpret_cast<const raw*>(base + ((int64_t)y0 * IW + x1) * C);
+    const raw* p10 = reinterpret_cast<const raw*>(base + ((int64_t)y1 * IW + x0) * C);
+    const raw* p11 = reinterpret_cast<const raw*>(base + ((int64_t)y1 * IW + x1) * C);
+    raw* dst = reinterpret_cast<raw*>(out + (((int64_t)b * OH + oy) * OW + ox) * ldw);
+    const float w00 = (1.f - wy) * (1.f - wx), w01 = (1.f - wy) * wx, w10 = wy * (1.f - wx), w11 = wy * wx;
+#pragma unroll
+    for (int u = 0; u < PX_MAXU; ++u) {
+      if (u >= nu) break;
+      float a[U::CH], bq[U::CH], c[U::CH], d[U::CH], o[U::CH];
+      U::get(p00[u], a); U::get(p01[u], bq); U::get(p10[u], c); U::get(p11[u], d);
+#pragma unroll
+      for (int e = 0; e < U::CH; ++e) o[e] = w00 * a[e] + w01 * bq[e] + w10 * c[e] + w11 * d[e];
+      dst[u] = U::put(o);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_bwd_px_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int IH, int IW, int OH, int OW,
+                                                              int C, int ldw, float sy, float sx) {
+  using U = PxUnit<T>;
+  typedef typename U::raw raw;
+  const int nu = C / U::CH;
+  const int64_t total = (int64_t)B * IH * IW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t p = i;
+    const int ix = (int)(p % IW); p /= IW;
+    const int iy = (int)(p % IH);
+    const int b = (int)(p / IH);
+    int oy_lo = 0, oy_hi = OH - 1, ox_lo = 0, ox_hi = OW - 1;
+    if (sy > 0.f) {
+      oy_lo = (int)floorf((iy - 1) / sy); oy_hi = (int)ceilf((iy + 1) / sy);
+      if (oy_lo < 0) oy_lo = 0;
+      if (oy_hi > OH - 1) oy_hi = OH - 1;
+    }
+    if (sx > 0.f) {
+      ox_lo = (int)floorf((ix - 1) / sx); ox_hi = (int)ceilf((ix + 1) / sx);
+      if (ox_lo < 0) ox_lo = 0;
+      if (ox_hi > OW - 1) ox_hi = OW - 1;
+    }
+    float acc[PX_MAXU * U::CH];
+#pragma unroll
+    for (int e = 0; e < PX_MAXU * U::CH; ++e) acc[e] = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float fy = src_coord(oy, sy);
+      const int y0 = (int)fy, y1 = y0 + 1 < IH ? y0 + 1 : IH - 1;
+      const float wy = fy - y0;
+      const float cy = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+      if (cy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float fx = src_coord(ox, sx);
+        const int x0 = (int)fx, x1 = x0 + 1 < IW ? x0 + 1 : IW - 1;
+        const float wx = fx - x0;
+        const float cx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+        if (cx == 0.f) continue;
+        const raw* src = reinterpret_cast<const raw*>(dout + (((int64_t)b * OH + oy) * OW + ox) * ldw);
+        const float w = cy * cx;
+#pragma unroll
+        for (int u = 0; u < PX_MAXU; ++u) {
+          if (u >= nu) break;
+          float v[U::CH];
+          U::get(src[u], v);
+#pragma unroll
+          for (int e = 0; e < U::CH; ++e) acc[u * U::CH + e] += w * v[e];
+        }
+      }
+    }
+    raw* dst = reinterpret_cast<raw*>(din + (((int64_t)b * IH + iy) * IW + ix) * C);
+#pragma unroll
+    for (int u = 0; u < PX_MAXU; ++u) {
+      if (u >= nu) break;
+      dst[u] = U::put(acc + u * U::CH);
+    }
+  }
+}
+
 // out = (acc ? acc : 0) + nearest_up(in, s)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) nearest_add_fwd_kernel(const T* __restrict__ acc, const T* __restrict__ in, T* __restrict__ out, int B,
@@ -184,6 +297,13 @@ int bilinear_launch(const void* in, void* out, int B, int IH, int IW, int OH, in
   const float sy = ac_scale(IH, OH), sx = ac_scale(IW, OW);
   const bool vec = C % V == 0;
   const int64_t px = (int64_t)B * (backward ? IH * IW : OH * OW);
+  constexpr int UCH = PxUnit<T>::CH;
+  if (!vec && C % UCH == 0 && ldw % UCH == 0 && C / UCH <= PX_MAXU) {        // few channels: one thread per pixel
+    const int gp = grid_for(px);
+    if (!backward) bilinear_fwd_px_kernel<T><<<gp, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
+    else bilinear_bwd_px_kernel<T><<<gp, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
+    return check_launch(backward ? "upsample_bilinear_bwd" : "upsample_bilinear_fwd");
+  }
   const int g = grid_for(px * (vec ? C / V : C));
   if (!backward) {
     if (vec) bilinear_fwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);

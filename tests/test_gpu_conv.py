@@ -368,7 +368,8 @@ def test_conv_base_shape_linearity_bf16():
     assert rel_err((ya + yb).cpu(), yab.cpu()) < 2e-2
 
 
-@pytest.mark.parametrize("B,C,IH,IW,OH,OW", [(2, 64, 6, 5, 12, 10), (1, 256, 2, 1, 16, 8), (2, 6, 8, 8, 32, 32), (1, 18, 5, 7, 20, 28)])
+@pytest.mark.parametrize("B,C,IH,IW,OH,OW", [(2, 64, 6, 5, 12, 10), (1, 256, 2, 1, 16, 8), (2, 6, 8, 8, 32, 32), (1, 18, 5, 7, 20, 28),
+                                                    (2, 2, 5, 5, 17, 13), (1, 7, 4, 6, 9, 11), (1, 6, 64, 64, 256, 256), (3, 16, 3, 3, 3, 3)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upsample_bilinear(B, C, IH, IW, OH, OW, dtype):
     from representationlearning_amd import nnf
