@@ -468,6 +468,28 @@ def test_cgfl_loss_vs_golden(tag, dtype):
     assert aux.grad is None
 
 
+@pytest.mark.parametrize("K", [2, 5, 6, 7, 9])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cgfl_loss_class_counts_vs_oracle(K, dtype):
+    """The loss kernels at other class counts than the goldens' six: the compile-time instantiations (6, 7 = LoveDA) and the run-time
+    form, against the CPU oracle on the values the kernel reads."""
+    from oracle import rssformer_cpu as O
+    from representationlearning_amd import nnf
+    torch.manual_seed(K)
+    lg = (torch.randn(2, K, 9, 13) * 2.0).to(dtype)
+    y = torch.randint(-1, K, (2, 9, 13))
+    aux = torch.randn(2, 7)
+    lr = lg.float().clone().requires_grad_()
+    want = O.cgfl_loss(lr, y, aux)
+    want.backward()
+    ld = lg.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    loss = nnf.cgfl_loss(ld, y.to(DEV), aux.to(DEV))
+    loss.backward()
+    f32 = dtype == torch.float32
+    assert abs(float(loss.detach()) - float(want.detach())) < (2e-6 if f32 else 5e-3) * max(1.0, abs(float(want.detach())))
+    assert rel_err(ld.grad.float().cpu(), lr.grad) < (1e-5 if f32 else 1e-2)
+
+
 def test_cgfl_loss_full_size_properties():
     """BASELINE config-2 size (16 x 6 x 512 x 512): finite, gradient sums to zero over classes, zero on ignored pixels."""
     from representationlearning_amd import nnf
