@@ -268,6 +268,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
         _cpu_baseline_child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
         return
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a five-line version banner to the C stdout of every rank at its
+    # first communicator (flushed at exit), so file descriptor 1 is pointed at stderr for the run and the line goes to a private
+    # copy of the real stdout
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -297,6 +303,12 @@ def main():
     img, lab = synthetic_batch(args.batch, args.size, seed=2333 + rank)
     target = dict(cls=lab)
 
+    # building the step: the trainer runs `graph_warmup` eager steps and captures the whole step into a hipGraph on the next one.
+    # That is set-up (like compiling), done before the W warm-up steps so that a small --warmup does not put the capture inside the
+    # timed region; the count is reported in config.graph_init_steps.
+    init_steps = trainer.graph_warmup + 1 if trainer.use_graph else 0
+    for _ in range(init_steps):
+        trainer.step(img, target)
     for _ in range(args.warmup):
         loss = trainer.step(img, target)
     if world > 1:
@@ -330,7 +342,7 @@ def main():
                                    "fwd+CGFL loss+bwd+clip+SGD, random-init weights" % (args.variant, args.batch, args.size, args.size),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "sync_bn": (not args.no_sync_bn) and world > 1,
-                       "step_launch": "hipGraph replay" if trainer.graph is not None else "eager",
+                       "step_launch": "hipGraph replay" if trainer.graph is not None else "eager", "graph_init_steps": init_steps,
                        "collectives": None if world == 1 else (
                            "SyncBN: %s, one channel / communicator per stream (main + %d side); gradients: %s" % (
                                "peer-to-peer kernel over hipIpc windows" if trainer.p2p is not None else "RCCL all-reduce", len(trainer.side_comms),
@@ -347,7 +359,8 @@ def main():
         if world == 1:
             line["roofline_kernels"] = measure_dominant_kernels(args.batch, args.size, C=c0)
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
-        print(json.dumps(line), flush=True)
+        result_out.write(json.dumps(line) + "\n")
+        result_out.flush()
     if world > 1:
         dist.barrier()
         trainer.close()
