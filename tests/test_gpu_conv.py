@@ -41,6 +41,8 @@ CONVS = [  # ci, co, k, stride, pad, dil, bias, B, H, W
     (48, 96, 3, 1, 1, 1, True, 3, 21, 37),          # halo kernel: ragged tiles, partial channel chunk, bias
     (64, 128, 3, 1, 1, 1, False, 4, 64, 128),       # halo kernel: 64-wide channel tile
     (480, 6, 1, 1, 0, 1, True, 1, 16, 16),          # the head's shape: 6 output channels (gradient padded to 8)
+    (128, 128, 3, 1, 1, 1, False, 16, 32, 32),      # halo kernel at branch 2 of a Base step (8-row tiles, 4 channel chunks)
+    (160, 160, 3, 1, 1, 1, True, 2, 12, 20),        # ... five channel chunks, 4-row tiles, bias
 ]
 
 
@@ -193,6 +195,7 @@ def test_grad_accum_matches_autograd_sum(order):
     (3, 1, 32, 32, 24, 20, 1, False, torch.bfloat16),      # halo kernel
     (3, 1, 64, 64, 17, 33, 1, True, torch.bfloat16),       # halo kernel, ragged edges, residual before the activation
     (3, 1, 128, 128, 16, 16, 2, False, torch.bfloat16),    # halo kernel, GELU
+    (3, 1, 256, 256, 16, 16, 1, True, torch.bfloat16),     # halo kernel, 8 channel chunks, residual before the activation
     (1, 1, 128, 32, 20, 24, 2, False, torch.bfloat16),     # 1x1 (MlpDWBN fc2's data gradient: 128-wide statistics)
     (1, 1, 32, 128, 20, 24, 0, True, torch.bfloat16),      # 1x1, no activation, residual
     (3, 2, 64, 64, 24, 24, 1, False, torch.bfloat16),      # stride 2 (the stem's conv2): strided data gradient
@@ -287,7 +290,7 @@ def test_conv_wgrad_bnapply_equals_apply_then_wgrad(k, cin, cout, H, W, act, res
             assert torch.equal(a_, b_), name
 
 
-@pytest.mark.parametrize("cin,cout,H,W,act", [(32, 32, 24, 20, 1), (64, 64, 17, 33, 1), (32, 64, 16, 16, 2), (128, 128, 9, 16, 0)])
+@pytest.mark.parametrize("cin,cout,H,W,act", [(32, 32, 24, 20, 1), (64, 64, 17, 33, 1), (32, 64, 16, 16, 2), (128, 128, 9, 16, 0), (256, 256, 16, 16, 1), (160, 32, 11, 9, 2)])
 def test_conv_preact_input_equals_apply_then_conv(cin, cout, H, W, act):
     """rssf_conv_gather_preact / rssf_conv_wgrad_bnapply(in_scale_shift): the producer's BatchNorm + activation applied while the
     consumer stages the RAW tensor, against rssf_bn_apply followed by the plain launches - bit-identical output, fused forward
