@@ -267,6 +267,61 @@ int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift,
                       const void* res_pre, void* draw, void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act,
                       double n, int training, float param_grad_scale, int dtype, void* stream);
 
+/* ---- Grouped launches: the parallel branches of a HighResolutionModule (_hrnet_rssformer.py:216-246 BasicBlock, :410-423
+ *      `x[i] = self.branches[i](x[i])`) run the SAME step at the same moment on independent tensors - 128^2 x 32, 64^2 x 64,
+ *      32^2 x 128, 16^2 x 256 for Base.  Each of those launches is bound by the latency chain of its blocks, not by a roofline;
+ *      the entry points below take the n problems of such a step and run them as ONE grid (blocks of the long-chain problems
+ *      first, the others fill their bubbles; one launch ramp and tail instead of n).  Results per problem are those of the
+ *      single-problem entry point named with each struct (same kernels' block bodies).  n > RSSF_GROUP_MAX, mixed kinds or
+ *      shapes without a grouped kernel run problem by problem through those entry points - always valid, never faster. */
+#define RSSF_GROUP_MAX 4
+/* rssf_conv_gather_add / _bnbwd / _preact of a 3x3, stride-1, "same" convolution (taps in forward order; mirrored = 1:
+ * data-gradient order, i.e. dy/dx negated, wpk the transposed pack).  Unused optional parts are NULL. */
+typedef struct rssf_conv3x3_item {
+  const void* in; const void* wpk; void* out;
+  float* stats;                                        /* [RSSF_BN_SLOTS][2][Cout] of the following BatchNorm, or NULL */
+  const void* addend;                                  /* added to out, or NULL */
+  const void* bn_raw; const void* bn_res; const float* bn_ss; float* bn_sums;   /* rssf_conv_gather_bnbwd (bn_sums != NULL) */
+  const float* pre_stats; const float* pre_gamma; const float* pre_beta;        /* rssf_conv_gather_preact (pre_ss != NULL) */
+  float* pre_running_mean; float* pre_running_var; float* pre_mean_invstd; float* pre_ss;
+  double pre_n;
+  float pre_momentum, pre_eps;
+  int pre_training, pre_act, bn_act;
+  int B, H, W, Cin, Cout;
+} rssf_conv3x3_item;
+int rssf_conv3x3_group(const rssf_conv3x3_item* items, int n, int mirrored, int dtype, void* stream);
+/* rssf_conv_wgrad / rssf_conv_wgrad_bnapply of a bias-free 3x3, stride-1, "same" convolution (bn_dy != NULL: the fused
+ * BatchNorm-backward apply, `draw` is then an OUTPUT and `dout` is ignored; in_ss != NULL: pre-activation input operand).
+ * workspace: rssf_conv_wgrad_workspace_elems(..., 9) floats per item; defer_reduce as in rssf_conv_wgrad. */
+typedef struct rssf_wgrad3x3_item {
+  const void* dout; const void* in; float* dw; float* workspace; struct rssf_wgrad_reduce_job* defer_reduce;
+  const void* bn_dy; const void* bn_raw; const float* bn_ss; const float* bn_mi; const float* bn_sums; const void* bn_res;
+  void* draw; void* dres; float* dgamma; float* dbeta;
+  const float* in_ss;
+  double bn_n;
+  float pscale;
+  int bn_act, bn_training, in_act;
+  int B, H, W, Cin, Cout;
+} rssf_wgrad3x3_item;
+int rssf_conv3x3_wgrad_group(const rssf_wgrad3x3_item* items, int n, int dtype, void* stream);
+/* rssf_bn_finalize_apply per item */
+typedef struct rssf_bn_apply_item {
+  const void* raw; const float* stats; const float* gamma; const float* beta; float* running_mean; float* running_var;
+  float* mean_invstd; float* scale_shift; const void* res_pre; const void* res_post; void* y;
+  int64_t rows;
+  double n;
+  float momentum, eps;
+  int C, act, training;
+} rssf_bn_apply_item;
+int rssf_bn_finalize_apply_group(const rssf_bn_apply_item* items, int n, int dtype, void* stream);
+/* rssf_bn_bwd_reduce per item (slotted atomics; the deterministic workspace form is not grouped) */
+typedef struct rssf_bn_reduce_item {
+  const void* dy; const void* raw; const float* scale_shift; const void* res_pre; float* sums;
+  int64_t rows;
+  int C, act;
+} rssf_bn_reduce_item;
+int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n, int dtype, void* stream);
+
 /* ---- Device input pipeline: RandomCrop -> OneOf(HorizontalFlip, VerticalFlip, RandomRotate90) ->
  *      ShiftScaleRotate -> Normalize -> ToTensor and the LoveDA `mask - 1` shift (configs/base/loveda.py:18-36,
  *      data/loveda.py:82-91) as one gather over a device-resident uint8 dataset img [nsrc][SH][SW][3], mask [nsrc][SH][SW]

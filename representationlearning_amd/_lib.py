@@ -42,6 +42,33 @@ class WgradReduceJob(ctypes.Structure):       # rssf_wgrad_reduce_job
         ("src_of_tap", c_int * MAX_TAPS), ("kpos_of_tap", c_int * MAX_TAPS), ("alias_of_tap", (c_int * 4) * MAX_TAPS)]
 
 
+GROUP_MAX = 4      # RSSF_GROUP_MAX
+c_double = ctypes.c_double
+
+
+class Conv3x3Item(ctypes.Structure):       # rssf_conv3x3_item
+    _fields_ = [(n, c_void_p) for n in ("in_", "wpk", "out", "stats", "addend", "bn_raw", "bn_res", "bn_ss", "bn_sums", "pre_stats", "pre_gamma",
+                                        "pre_beta", "pre_running_mean", "pre_running_var", "pre_mean_invstd", "pre_ss")] + [
+        ("pre_n", c_double), ("pre_momentum", c_float), ("pre_eps", c_float)] + [
+        (n, c_int) for n in ("pre_training", "pre_act", "bn_act", "B", "H", "W", "Cin", "Cout")]
+
+
+class Wgrad3x3Item(ctypes.Structure):       # rssf_wgrad3x3_item
+    _fields_ = [(n, c_void_p) for n in ("dout", "in_", "dw", "workspace", "defer_reduce", "bn_dy", "bn_raw", "bn_ss", "bn_mi", "bn_sums", "bn_res",
+                                        "draw", "dres", "dgamma", "dbeta", "in_ss")] + [
+        ("bn_n", c_double), ("pscale", c_float)] + [(n, c_int) for n in ("bn_act", "bn_training", "in_act", "B", "H", "W", "Cin", "Cout")]
+
+
+class BnApplyItem(ctypes.Structure):       # rssf_bn_apply_item
+    _fields_ = [(n, c_void_p) for n in ("raw", "stats", "gamma", "beta", "running_mean", "running_var", "mean_invstd", "scale_shift", "res_pre",
+                                        "res_post", "y")] + [
+        ("rows", c_int64), ("n", c_double), ("momentum", c_float), ("eps", c_float), ("C", c_int), ("act", c_int), ("training", c_int)]
+
+
+class BnReduceItem(ctypes.Structure):       # rssf_bn_reduce_item
+    _fields_ = [(n, c_void_p) for n in ("dy", "raw", "scale_shift", "res_pre", "sums")] + [("rows", c_int64), ("C", c_int), ("act", c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/rssf.h declares must appear here (tests check it)
 SIGNATURES = {
     "rssf_version": (ctypes.c_char_p, []),
@@ -75,6 +102,10 @@ SIGNATURES = {
     "rssf_conv_gather_preact": (c_int, [c_void_p] * 8 + [ctypes.c_double, c_float, c_float, c_int, c_int] + [c_void_p] * 5 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_reduce_blocks": (c_int, [c_void_p]),
     "rssf_conv_wgrad_reduce_batch": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv3x3_group": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rssf_conv3x3_wgrad_group": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "rssf_bn_finalize_apply_group": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "rssf_bn_bwd_reduce_group": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),
     "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),

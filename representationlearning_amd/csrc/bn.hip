@@ -99,24 +99,26 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ raw
 // bn_finalize + bn_apply in one launch (330 BatchNorm layers per step: one launch and ~4 us of latency less each).  Every
 // block folds the statistics slots of ITS channels into scale/shift (cooperatively, through LDS, under the first row's
 // loads); block row 0 also publishes mean/invstd, scale/shift and the running statistics for the backward pass.
+// (a __device__ body with explicit block coordinates: bn_finapply_kernel runs it for one layer, bn_finapply_group_kernel for the
+// layers of a lock-step group in ONE grid - rssf_bn_finalize_apply_group)
 template <typename T, int VEC>
-__global__ void __launch_bounds__(256) bn_finapply_kernel(const T* __restrict__ raw, const float* __restrict__ stats,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
-                                                          const T* __restrict__ res_pre, const T* __restrict__ res_post, T* __restrict__ y,
-                                                          int64_t rows, int C, int act, float n, float momentum, float eps, int training) {
-  extern __shared__ float lds[];                          // scale/shift [2][nch]
+__device__ __forceinline__ void bn_finapply_block(const T* __restrict__ raw, const float* __restrict__ stats,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                  float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                  const T* __restrict__ res_pre, const T* __restrict__ res_post, T* __restrict__ y,
+                                                  int64_t rows, int C, int act, float n, float momentum, float eps, int training,
+                                                  const unsigned bx, const unsigned by, const unsigned gx, float* lds) {
   const int allcols = C / VEC;
-  const int colbase = blockIdx.y * 256;
+  const int colbase = by * 256;
   const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
   const int nch = cols * VEC, ch0 = colbase * VEC;
   const int rpb = 256 / cols;
   const int col = threadIdx.x % cols, rlocal = threadIdx.x / cols;
   const bool active = rlocal < rpb;
   const int c0 = (colbase + col) * VEC;
-  const int64_t stride = (int64_t)gridDim.x * rpb;
-  int64_t r = (int64_t)blockIdx.x * rpb + rlocal;
+  const int64_t stride = (int64_t)gx * rpb;
+  int64_t r = (int64_t)bx * rpb + rlocal;
   Vec<T> v, rp, rq;
   bool have = active && r < rows;
   if constexpr (VEC > 1) {
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(256) bn_finapply_kernel(const T* __restrict__ 
     const float invstd = rsqrtf(var + eps);
     const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
     scsh[i] = sc; scsh[nch + i] = sh;
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
       mean_invstd[c] = mean; mean_invstd[C + c] = invstd;
       scale_shift[c] = sc; scale_shift[C + c] = sh;
       if (training && running_mean) {
@@ -193,21 +195,54 @@ __global__ void __launch_bounds__(256) bn_finapply_kernel(const T* __restrict__ 
   }
 }
 
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bn_finapply_kernel(const T* __restrict__ raw, const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                          const T* __restrict__ res_pre, const T* __restrict__ res_post, T* __restrict__ y,
+                                                          int64_t rows, int C, int act, float n, float momentum, float eps, int training) {
+  extern __shared__ float lds[];                          // scale/shift [2][nch]
+  bn_finapply_block<T, VEC>(raw, stats, gamma, beta, running_mean, running_var, mean_invstd, scale_shift, res_pre, res_post, y, rows, C, act, n,
+                            momentum, eps, training, blockIdx.x, blockIdx.y, gridDim.x, lds);
+}
+// the layers of a lock-step group in one grid: item i owns blocks [start[i], start[i+1]) laid out as its own (gx, gy) grid
+struct FinApplyItem {
+  const void* raw; const float* stats; const float* gamma; const float* beta; float* rm; float* rv; float* mi; float* ss;
+  const void* rp; const void* rq; void* y;
+  int64_t rows;
+  int C, act, training, gx;
+  float n, momentum, eps;
+};
+struct FinApplyGroup { FinApplyItem it[RSSF_GROUP_MAX]; int start[RSSF_GROUP_MAX + 1]; int n; };
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bn_finapply_group_kernel(FinApplyGroup g) {
+  extern __shared__ float lds[];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
+    if (k < g.n && blockIdx.x >= (unsigned)g.start[k]) i = k;
+  const FinApplyItem& a = g.it[i];
+  const unsigned r = blockIdx.x - (unsigned)g.start[i], gx = (unsigned)a.gx;
+  bn_finapply_block<T, VEC>((const T*)a.raw, a.stats, a.gamma, a.beta, a.rm, a.rv, a.mi, a.ss, (const T*)a.rp, (const T*)a.rq, (T*)a.y, a.rows, a.C, a.act,
+                            a.n, a.momentum, a.eps, a.training, r % gx, r / gx, gx, lds);
+}
+
 // s[0][c] += sum dz ; s[1][c] += sum dz*raw ; thread owns a fixed vector column and strides over rows.
 // DET (deterministic mode): no shuffle/atomic folding - every thread parks its partials in LDS ([row group][2][channels of
 // this column block]), they are summed in row-group order and the block's totals go to det_ws[block][2][C] with plain stores;
 // cv::stats_fold_kernel then adds the blocks in order into slot 0 of `sums`.
 template <typename T, int VEC, bool DET>
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
-                                                            const T* __restrict__ res_pre, float* __restrict__ sums, int64_t rows, int C,
-                                                            int act, float* __restrict__ det_ws) {
-  extern __shared__ float sacc[];                         // [2][C]  (DET: [256 / cols][2][cols * VEC])
+__device__ __forceinline__ void bn_bwd_reduce_block(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
+                                                    const T* __restrict__ res_pre, float* __restrict__ sums, int64_t rows, int C,
+                                                    int act, float* __restrict__ det_ws, const unsigned bx, const unsigned by,
+                                                    const unsigned gx, float* sacc) {
   if constexpr (!DET) {
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sacc[i] = 0.f;
     __syncthreads();
   }
   const int allcols = C / VEC;
-  const int colbase = blockIdx.y * 256;                   // column blocks of <= 256 vector columns
+  const int colbase = by * 256;                           // column blocks of <= 256 vector columns
   const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
   const int rpb = blockDim.x / cols;                      // rows handled per block per pass (>= 1)
   const int col = threadIdx.x % cols, rlocal = threadIdx.x / cols;
@@ -220,7 +255,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
-    const int64_t stride = (int64_t)gridDim.x * rpb;
+    const int64_t stride = (int64_t)gx * rpb;
     auto body = [&](const Vec<T>& vd, const Vec<T>& vr, const Vec<T>& vp) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -231,7 +266,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
         a1[e] += dz; a2[e] += dz * x;
       }
     };
-    int64_t r = (int64_t)blockIdx.x * rpb + rlocal;
+    int64_t r = (int64_t)bx * rpb + rlocal;
     if constexpr (VEC > 1) {
       for (; r + stride < rows; r += 2 * stride) {          // two rows in flight per thread
         const int64_t o0 = r * C + c0, o1 = (r + stride) * C + c0;
@@ -265,7 +300,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
       for (int e = 0; e < VEC; ++e) { sacc[(rlocal * 2) * nch + col * VEC + e] = a1[e]; sacc[(rlocal * 2 + 1) * nch + col * VEC + e] = a2[e]; }
     }
     __syncthreads();
-    float* part = det_ws + (size_t)blockIdx.x * 2 * C;
+    float* part = det_ws + (size_t)bx * 2 * C;
     for (int i = threadIdx.x; i < 2 * nch; i += blockDim.x) {
       const int half = i / nch, ch = i % nch;
       float t = 0.f;
@@ -287,12 +322,33 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
     for (int e = 0; e < VEC; ++e) { atomicAdd(&sacc[c0 + e], a1[e]); atomicAdd(&sacc[C + c0 + e], a2[e]); }
   }
   __syncthreads();
-  float* slot = sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * C;
+  float* slot = sums + (size_t)(bx % RSSF_BN_BWD_SLOTS) * 2 * C;
   for (int i = threadIdx.x; i < cols * VEC; i += blockDim.x) {
     const int c = colbase * VEC + i;
     atomicAdd(&slot[c], sacc[c]);
     atomicAdd(&slot[C + c], sacc[C + c]);
   }
+}
+
+template <typename T, int VEC, bool DET>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
+                                                            const T* __restrict__ res_pre, float* __restrict__ sums, int64_t rows, int C,
+                                                            int act, float* __restrict__ det_ws) {
+  extern __shared__ float sacc[];                         // [2][C]  (DET: [256 / cols][2][cols * VEC])
+  bn_bwd_reduce_block<T, VEC, DET>(dy, raw, ss, res_pre, sums, rows, C, act, det_ws, blockIdx.x, blockIdx.y, gridDim.x, sacc);
+}
+struct ReduceItem { const void* dy; const void* raw; const float* ss; const void* rp; float* sums; int64_t rows; int C, act, gx; };
+struct ReduceGroup { ReduceItem it[RSSF_GROUP_MAX]; int start[RSSF_GROUP_MAX + 1]; int n; };
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_group_kernel(ReduceGroup g) {
+  extern __shared__ float sacc[];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
+    if (k < g.n && blockIdx.x >= (unsigned)g.start[k]) i = k;
+  const ReduceItem& a = g.it[i];
+  const unsigned r = blockIdx.x - (unsigned)g.start[i], gx = (unsigned)a.gx;
+  bn_bwd_reduce_block<T, VEC, false>((const T*)a.dy, (const T*)a.raw, a.ss, (const T*)a.rp, a.sums, a.rows, a.C, a.act, nullptr, r % gx, r / gx, gx, sacc);
 }
 
 // draw = scale*(dz - k1 - xhat*k2) (training) or scale*dz (eval);  dres (optional) = dz.   Same thread layout as
@@ -538,4 +594,91 @@ extern "C" int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* s
                                     training, param_grad_scale, st);
   set_error("bn_bwd_apply: unsupported dtype %d", dtype);
   return RSSF_ERR_UNSUPPORTED;
+}
+
+// ---- grouped BatchNorm passes (rssf.h "Grouped launches") ---------------------------------------------------------------------
+namespace {
+template <typename T>
+int finapply_group_launch(const rssf_bn_apply_item* items, int n, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  FinApplyGroup g;
+  g.n = n;
+  int blocks = 0, maxc = 0;
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_apply_item& it = items[i];
+    const dim3 grid = grid2d(it.rows, it.C, V);
+    g.it[i] = {it.raw, it.stats, it.gamma, it.beta, it.running_mean, it.running_var, it.mean_invstd, it.scale_shift, it.res_pre, it.res_post, it.y,
+               it.rows, it.C, it.act, it.training, (int)grid.x, (float)it.n, it.momentum, it.eps};
+    g.start[i] = blocks;
+    blocks += (int)(grid.x * grid.y);
+    const int nch = (it.C / V < 256 ? it.C / V : 256) * V;
+    if (nch > maxc) maxc = nch;
+  }
+  for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = blocks;
+  bn_finapply_group_kernel<T, V><<<(unsigned)blocks, 256, 2 * maxc * sizeof(float), st>>>(g);
+  return check_launch("bn_finalize_apply_group");
+}
+template <typename T>
+int reduce_group_launch(const rssf_bn_reduce_item* items, int n, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  ReduceGroup g;
+  g.n = n;
+  int blocks = 0, maxc = 0;
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_reduce_item& it = items[i];
+    const int cols = it.C / V, cblocks = (cols + 255) / 256, rpb = 256 / (cols < 256 ? cols : 256);
+    int64_t gx = (it.rows + 4 * rpb - 1) / (4 * rpb);
+    if (gx > REDUCE_MAX_BLOCKS) gx = REDUCE_MAX_BLOCKS;
+    g.it[i] = {it.dy, it.raw, it.scale_shift, it.res_pre, it.sums, it.rows, it.C, it.act, (int)gx};
+    g.start[i] = blocks;
+    blocks += (int)gx * cblocks;
+    if (it.C > maxc) maxc = it.C;
+  }
+  for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = blocks;
+  bn_bwd_reduce_group_kernel<T, V><<<(unsigned)blocks, 256, 2 * maxc * sizeof(float), st>>>(g);
+  return check_launch("bn_bwd_reduce_group");
+}
+const bool g_group_enabled = !(getenv("RSSF_GROUP_KERNELS") && getenv("RSSF_GROUP_KERNELS")[0] == '0');      // A/B switch (tools/group_bench.py)
+}  // namespace
+
+extern "C" int rssf_bn_finalize_apply_group(const rssf_bn_apply_item* items, int n, int dtype, void* stream) {
+  RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_finalize_apply_group: bad arguments");
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_apply_item& it = items[i];
+    RSSF_REQUIRE(it.raw && it.gamma && it.beta && it.mean_invstd && it.scale_shift && it.y && it.rows > 0 && it.C > 0 && it.act >= 0 && it.act <= 2,
+                 "bn_finalize_apply_group: bad item %d", i);
+    RSSF_REQUIRE(it.training ? (it.stats != nullptr && it.n >= 1) : (it.running_mean && it.running_var),
+                 "bn_finalize_apply_group: missing statistics (item %d)", i);
+    grouped = grouped && (it.C % V) == 0;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (grouped) return dtype == RSSF_BF16 ? finapply_group_launch<bf16_t>(items, n, st) : finapply_group_launch<float>(items, n, st);
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_apply_item& it = items[i];
+    const int rc = rssf_bn_finalize_apply(it.raw, it.stats, it.gamma, it.beta, it.running_mean, it.running_var, it.mean_invstd, it.scale_shift,
+                                          it.res_pre, it.res_post, it.y, it.rows, it.C, it.act, it.n, it.momentum, it.eps, it.training, dtype, stream);
+    if (rc) return rc;
+  }
+  return RSSF_OK;
+}
+
+extern "C" int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n, int dtype, void* stream) {
+  RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_bwd_reduce_group: bad arguments");
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_reduce_item& it = items[i];
+    RSSF_REQUIRE(it.dy && it.raw && it.scale_shift && it.sums && it.rows > 0 && it.C > 0 && it.act >= 0 && it.act <= 2, "bn_bwd_reduce_group: bad item %d", i);
+    grouped = grouped && (it.C % V) == 0;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (grouped) return dtype == RSSF_BF16 ? reduce_group_launch<bf16_t>(items, n, st) : reduce_group_launch<float>(items, n, st);
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_reduce_item& it = items[i];
+    const int rc = rssf_bn_bwd_reduce(it.dy, it.raw, it.scale_shift, it.res_pre, it.sums, it.rows, it.C, it.act, nullptr, dtype, stream);
+    if (rc) return rc;
+  }
+  return RSSF_OK;
 }

@@ -79,6 +79,7 @@ struct HaloArgs {
 
 bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_halo(HaloArgs a, hipStream_t st);
+int launch_halo_group(HaloArgs* items, int n, hipStream_t st);      // n <= RSSF_GROUP_MAX problems as one grid
 int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st);
 
 template <typename T> struct LdsPad;

@@ -11,6 +11,7 @@
 // chunk's global loads issued before the MFMAs of the current one (register double buffering).  Epilogue:
 // + bias, per-channel sum / sum-of-squares partials for the following BatchNorm (fused statistics: the
 // activation is not re-read for the mean/var pass), tile transposed through LDS for 16-byte coalesced stores.
+#include <string.h>
 #include <type_traits>
 #include "conv.hip.h"
 using namespace rssf;
@@ -644,6 +645,22 @@ struct PreAct {              // see HaloArgs::pre_* (conv.hip.h)
   const float* stats; const float* gamma; const float* beta; float* rmean; float* rvar; float* mi; float* ss;
   float n, momentum, eps; int training, act;
 };
+HaloArgs make_halo(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, float* stats_ws,
+                   const BnBwdStats* bn, const PreAct* pre, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, const int* dy, const int* dx) {
+  HaloArgs h;
+  memset(&h, 0, sizeof(h));
+  if (pre) {
+    h.pre_stats = pre->stats; h.pre_gamma = pre->gamma; h.pre_beta = pre->beta; h.pre_rmean = pre->rmean; h.pre_rvar = pre->rvar;
+    h.pre_mi = pre->mi; h.pre_ss = pre->ss; h.pre_n = pre->n; h.pre_momentum = pre->momentum; h.pre_eps = pre->eps;
+    h.pre_training = pre->training; h.pre_act = pre->act;
+  }
+  h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats; h.stats_ws = stats_ws;
+  h.addend = (const bf16_t*)addend;
+  if (bn) { h.bn_raw = (const bf16_t*)bn->raw; h.bn_res = (const bf16_t*)bn->res; h.bn_ss = bn->ss; h.bn_sums = bn->sums; h.bn_act = bn->act; }
+  h.B = B; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout; h.CinP = CinP; h.CoutP = CoutP;
+  for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
+  return h;
+}
 int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, float* stats_ws,
                      const BnBwdStats* bn, const PreAct* pre, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
                      const int* dy, const int* dx, int dtype, void* stream) {
@@ -664,20 +681,8 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
   a.CinP = (Cin + bk - 1) / bk * bk;
   hipStream_t st = (hipStream_t)stream;
   if (halo_path(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype)) {
-    HaloArgs h;
-    h.pre_ss = nullptr; h.pre_act = 0;
-    if (pre) {
-      h.pre_stats = pre->stats; h.pre_gamma = pre->gamma; h.pre_beta = pre->beta; h.pre_rmean = pre->rmean; h.pre_rvar = pre->rvar;
-      h.pre_mi = pre->mi; h.pre_ss = pre->ss; h.pre_n = pre->n; h.pre_momentum = pre->momentum; h.pre_eps = pre->eps;
-      h.pre_training = pre->training; h.pre_act = pre->act;
-    }
-    h.in = (const bf16_t*)in; h.wpk = (const bf16_t*)wpk; h.out = (bf16_t*)out; h.bias = bias; h.stats = stats; h.stats_ws = a.stats_ws;
-    h.addend = (const bf16_t*)addend;
     const bool fused = bn && (Cout % 8) == 0;               // the 16-byte-row epilogue carries the statistics
-    h.bn_raw = fused ? (const bf16_t*)bn->raw : nullptr; h.bn_res = fused ? (const bf16_t*)bn->res : nullptr;
-    h.bn_ss = fused ? bn->ss : nullptr; h.bn_sums = fused ? bn->sums : nullptr; h.bn_act = fused ? bn->act : 0;
-    h.B = B; h.H = IH; h.W = IW; h.Cin = Cin; h.Cout = Cout; h.CinP = a.CinP; h.CoutP = a.CoutP;
-    for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
+    const HaloArgs h = make_halo(in, wpk, out, bias, stats, addend, a.stats_ws, fused ? bn : nullptr, pre, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, dy, dx);
     const int rc = launch_halo(h, st);
     if (rc || !bn || fused) return rc;
     return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
@@ -731,4 +736,47 @@ extern "C" int rssf_conv_gather_preact(const void* in_raw, const float* pre_stat
                       pre_momentum, pre_eps, pre_training, pre_act};
   return conv_gather_impl(in_raw, wpk, out, bias, stats, nullptr, stats_ws, nullptr, &pre, B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx,
                           dtype, stream);
+}
+
+// ---- grouped 3x3 launches (rssf.h "Grouped launches") ----------------------------------------------------------------------
+extern "C" int rssf_conv3x3_group(const rssf_conv3x3_item* items, int n, int mirrored, int dtype, void* stream) {
+  RSSF_REQUIRE(items && n >= 1 && (mirrored == 0 || mirrored == 1), "conv3x3_group: bad arguments");
+  int dy[9], dx[9];
+  for (int t = 0; t < 9; ++t) { dy[t] = (mirrored ? -1 : 1) * (t / 3 - 1); dx[t] = (mirrored ? -1 : 1) * (t % 3 - 1); }
+  static const bool enabled = !(getenv("RSSF_GROUP_KERNELS") && getenv("RSSF_GROUP_KERNELS")[0] == '0');      // A/B switch (tools/group_bench.py)
+  bool grouped = enabled && n >= 2 && n <= RSSF_GROUP_MAX && dtype == RSSF_BF16;
+  for (int i = 0; i < n; ++i) {
+    const rssf_conv3x3_item& it = items[i];
+    RSSF_REQUIRE(it.in && it.wpk && it.out && it.B > 0 && it.H > 0 && it.W > 0 && it.Cin > 0 && it.Cout > 0, "conv3x3_group: bad item %d", i);
+    RSSF_REQUIRE(!it.bn_sums || (it.bn_raw && it.bn_ss && it.bn_act >= 0 && it.bn_act <= 2), "conv3x3_group: bad BatchNorm arguments (item %d)", i);
+    RSSF_REQUIRE(!it.pre_ss || (it.pre_gamma && it.pre_beta && it.pre_mean_invstd && it.pre_act >= 0 && it.pre_act <= 2 && !it.addend && !it.bn_sums &&
+                                (it.pre_training ? (it.pre_stats != nullptr && it.pre_n >= 1) : (it.pre_running_mean && it.pre_running_var))),
+                 "conv3x3_group: bad pre-activation arguments (item %d)", i);
+    grouped = grouped && (it.Cout % 8) == 0 && halo_path(it.B, it.H, it.W, it.Cin, it.H, it.W, it.Cout, 1, 1, 9, dy, dx, dtype) &&
+              (int64_t)it.B * it.H * it.W * it.Cin < ((int64_t)1 << 30) && (it.pre_ss != nullptr) == (items[0].pre_ss != nullptr) &&
+              (!it.pre_ss || (!mirrored && it.Cin <= 256));
+  }
+  if (grouped) {
+    HaloArgs hs[RSSF_GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+      const rssf_conv3x3_item& it = items[i];
+      const BnBwdStats bn = {it.bn_raw, it.bn_res, it.bn_ss, it.bn_sums, it.bn_act};
+      const PreAct pre = {it.pre_stats, it.pre_gamma, it.pre_beta, it.pre_running_mean, it.pre_running_var, it.pre_mean_invstd, it.pre_ss,
+                          (float)it.pre_n, it.pre_momentum, it.pre_eps, it.pre_training, it.pre_act};
+      const int bnt = pick_bn(it.Cout);
+      hs[i] = make_halo(it.in, it.wpk, it.out, nullptr, it.stats, it.addend, nullptr, it.bn_sums ? &bn : nullptr, it.pre_ss ? &pre : nullptr, it.B,
+                        it.H, it.W, it.Cin, it.Cout, (it.Cin + 31) / 32 * 32, (it.Cout + bnt - 1) / bnt * bnt, dy, dx);
+    }
+    return launch_halo_group(hs, n, (hipStream_t)stream);
+  }
+  for (int i = 0; i < n; ++i) {
+    const rssf_conv3x3_item& it = items[i];
+    const BnBwdStats bn = {it.bn_raw, it.bn_res, it.bn_ss, it.bn_sums, it.bn_act};
+    const PreAct pre = {it.pre_stats, it.pre_gamma, it.pre_beta, it.pre_running_mean, it.pre_running_var, it.pre_mean_invstd, it.pre_ss,
+                        (float)it.pre_n, it.pre_momentum, it.pre_eps, it.pre_training, it.pre_act};
+    const int rc = conv_gather_impl(it.in, it.wpk, it.out, nullptr, it.stats, it.addend, nullptr, it.bn_sums ? &bn : nullptr,
+                                    it.pre_ss ? &pre : nullptr, it.B, it.H, it.W, it.Cin, it.H, it.W, it.Cout, 1, 1, 9, dy, dx, dtype, stream);
+    if (rc) return rc;
+  }
+  return RSSF_OK;
 }

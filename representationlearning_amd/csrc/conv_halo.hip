@@ -25,8 +25,10 @@ constexpr int TW = 16, KC = 32, LDK = KC + 8;             // 80-byte LDS rows: c
 // MIRROR: the nine taps in data-gradient order (offset of tap t = -(t/3 - 1, t%3 - 1)) instead of forward order; the offsets
 // are compile-time, so a tap only changes the IMMEDIATE offset of the A-operand LDS reads (with run-time dy/dx every tap cost
 // two scalar loads and ~6 VALU of address arithmetic per fragment in an issue-bound kernel).
-template <int TH, int BN, bool MIRROR, bool PRE = false>
-__global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
+// One block's work: logical tile q of problem a.  A __device__ function so that the single-problem kernel and the grouped kernel
+// (several independent problems in ONE launch, conv3x3_halo_group_kernel below) share it.
+template <int TH, int BN, bool MIRROR, bool PRE>
+__device__ __forceinline__ void halo_block(const HaloArgs& a, const unsigned q) {
   constexpr int MI = TH / 4, NI = BN / 16, HP = (TH + 2) * (TW + 2), BMP = TH * TW;
   constexpr int A_ELEMS = HP * LDK, B_ELEMS = 9 * BN * LDK, LDC = BN + 8;
   constexpr int A_LOADS = (HP * 4 + 255) / 256, B_LOADS = (9 * BN * 4 + 255) / 256;
@@ -37,11 +39,9 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   bf16_t* Bs = lds + A_ELEMS;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
-  const int64_t q64 = xcd_logical(blockIdx.x, a.xcd_per);
-  if (q64 >= a.total) return;
   // 32-bit unsigned tile arithmetic (launch_halo keeps the block count below 2^31): the 64-bit scalar divisions were a serial
   // ~150-instruction chain in front of the first global load of every block
-  const unsigned q = (unsigned)q64, ntn = (unsigned)a.ntiles_n, ntx = (unsigned)a.tiles_x, nty = (unsigned)a.tiles_y;
+  const unsigned ntn = (unsigned)a.ntiles_n, ntx = (unsigned)a.tiles_x, nty = (unsigned)a.tiles_y;
   unsigned t = q / ntn;
   const int tile_id = (int)t;
   const int n0 = (int)(q - t * ntn) * BN;
@@ -337,6 +337,40 @@ __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   }
 }
 
+template <int TH, int BN, bool MIRROR, bool PRE = false>
+__global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
+  const int64_t q64 = xcd_logical(blockIdx.x, a.xcd_per);
+  if (q64 >= a.total) return;
+  halo_block<TH, BN, MIRROR, PRE>(a, (unsigned)q64);
+}
+
+// GROUPED launch: up to RSSF_GROUP_MAX independent problems (the parallel branches of a HighResolutionModule run the same
+// BasicBlock step at 128^2 x 32, 64^2 x 64, 32^2 x 128, 16^2 x 256: _hrnet_rssformer.py:216-246, 410-423) as ONE grid.  Each of
+// these launches is bound by the latency chain of its blocks (load -> LDS -> 9 taps -> epilogue, DESIGN.md lesson 32), not by a
+// roofline: side by side in one grid the blocks of the four problems fill each other's bubbles and the launch ramp / tail is paid
+// once.  Block b: XCD b & 7 (the hardware's round-robin), index b >> 3; problem i owns the indices [start[i], start[i+1]) and maps
+// them XCD-major onto its own tiles exactly as the single-problem kernel does (neighbouring tiles of one problem share an L2).
+// The host orders the problems by DESCENDING channel count: the long chains (8 chunks at 256 channels) start first, the short
+// 32-channel blocks fill the tail.  One tile shape (8 x 16 pixels x 32 output channels) for every problem: the LDS footprint of a
+// launch is static, the 64-column shape would halve the resident blocks of all problems.
+struct HaloGroupArgs {
+  HaloArgs it[RSSF_GROUP_MAX];
+  int start[RSSF_GROUP_MAX + 1];
+  int n;
+};
+template <bool MIRROR, bool PRE>
+__global__ void __launch_bounds__(256) conv3x3_halo_group_kernel(HaloGroupArgs g) {
+  const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
+    if (k < g.n && idx >= (unsigned)g.start[k]) i = k;
+  const HaloArgs& a = g.it[i];
+  const int64_t q = (int64_t)xcd * a.xcd_per + (idx - (unsigned)g.start[i]);
+  if (q >= a.total) return;
+  halo_block<8, 32, MIRROR, PRE>(a, (unsigned)q);
+}
+
 }  // namespace
 
 // true when the halo kernel covers this call (bf16 only; the caller checked the dtype)
@@ -356,18 +390,55 @@ bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, in
   return tap_order(dy, dx) != 0;
 }
 
+static int tile_problem(HaloArgs& a, int th, int bn) {
+  a.tiles_x = (a.W + TW - 1) / TW;
+  a.tiles_y = (a.H + th - 1) / th;
+  a.ntiles_n = (a.Cout + bn - 1) / bn;
+  a.total = (int64_t)a.B * a.tiles_y * a.tiles_x * a.ntiles_n;
+  if (a.total >= ((int64_t)1 << 31)) { set_error("conv3x3_halo: %lld tiles exceed the 32-bit tile arithmetic", (long long)a.total); return RSSF_ERR_UNSUPPORTED; }
+  a.xcd_per = xcd_per(a.total);
+  return RSSF_OK;
+}
+
+// n <= RSSF_GROUP_MAX problems in one grid (see conv3x3_halo_group_kernel); all forward-order or all mirrored, all with or all
+// without a pre-activation input.  Deterministic-mode statistics workspaces are not served here (the caller launches one by one).
+int launch_halo_group(HaloArgs* items, int n, hipStream_t st) {
+  if (n < 1 || n > RSSF_GROUP_MAX) { set_error("conv3x3_halo_group: %d problems (1..%d)", n, RSSF_GROUP_MAX); return RSSF_ERR_BAD_ARG; }
+  const bool mirror = tap_order(items[0].dy, items[0].dx) < 0, pre = items[0].pre_ss != nullptr;
+  int order[RSSF_GROUP_MAX];
+  for (int i = 0; i < n; ++i) order[i] = i;
+  for (int i = 1; i < n; ++i)                                   // descending input channels (= chunks per block): long chains first
+    for (int j = i; j > 0 && items[order[j]].Cin > items[order[j - 1]].Cin; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  HaloGroupArgs g;
+  g.n = n;
+  int idx = 0;
+  for (int k = 0; k < n; ++k) {
+    HaloArgs& a = items[order[k]];
+    if ((tap_order(a.dy, a.dx) < 0) != mirror || (a.pre_ss != nullptr) != pre || a.stats_ws) {
+      set_error("conv3x3_halo_group: the problems of one launch must share tap order and input kind");
+      return RSSF_ERR_BAD_ARG;
+    }
+    if (pre && (mirror || a.Cin > 256)) { set_error("conv3x3_halo_group: a pre-activation input is a forward-launch feature (<= 256 channels)"); return RSSF_ERR_UNSUPPORTED; }
+    if (const int rc = tile_problem(a, 8, 32)) return rc;
+    g.it[k] = a;
+    g.start[k] = idx;
+    idx += a.xcd_per;
+  }
+  for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = idx;
+  const dim3 grid((unsigned)idx * 8);
+  if (mirror) conv3x3_halo_group_kernel<true, false><<<grid, 256, 0, st>>>(g);
+  else if (pre) conv3x3_halo_group_kernel<false, true><<<grid, 256, 0, st>>>(g);
+  else conv3x3_halo_group_kernel<false, false><<<grid, 256, 0, st>>>(g);
+  return check_launch("conv3x3_halo_group");
+}
+
 int launch_halo(HaloArgs a, hipStream_t st) {
   const int tx = (a.W + TW - 1) / TW;
   const int64_t tiles8 = (int64_t)a.B * ((a.H + 7) / 8) * tx;
   int th = 8, bn = 32;
   if (a.Cout >= 64 && tiles8 * ((a.Cout + 63) / 64) >= 512) bn = 64;
   else if (tiles8 * ((a.Cout + 31) / 32) < 512) th = 4;
-  a.tiles_x = tx;
-  a.tiles_y = (a.H + th - 1) / th;
-  a.ntiles_n = (a.Cout + bn - 1) / bn;
-  a.total = (int64_t)a.B * a.tiles_y * a.tiles_x * a.ntiles_n;
-  if (a.total >= ((int64_t)1 << 31)) { set_error("conv3x3_halo: %lld tiles exceed the 32-bit tile arithmetic", (long long)a.total); return RSSF_ERR_UNSUPPORTED; }
-  a.xcd_per = xcd_per(a.total);
+  if (const int rc = tile_problem(a, th, bn)) return rc;
   dim3 grid((unsigned)a.xcd_per * 8);
   const bool mirror = tap_order(a.dy, a.dx) < 0;
   if (a.pre_ss && (mirror || a.Cin > 256)) { set_error("conv3x3_halo: a pre-activation input is a forward-launch feature (<= 256 channels)"); return RSSF_ERR_UNSUPPORTED; }

@@ -512,8 +512,8 @@ constexpr int HTH = 8, HTW = 16, HHP = (HTH + 2) * (HTW + 2), HNPX = HTH * HTW, 
 constexpr int HWG_THREADS = 512;
 // FUSE / RES are template parameters: a run-time branch around the staging loads would make the compiler drain vmcnt at the join,
 // i.e. wait for a tile's loads where they are issued instead of one tile later (measured: 16 -> 27 us per launch)
-template <bool FUSE, bool RES, bool XPRE = false>
-__global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
+template <bool FUSE, bool RES, bool XPRE>
+__device__ __forceinline__ void wgrad_halo_block(const WgradHaloArgs& a, const int64_t q) {
   constexpr int NT_ = HWG_THREADS;
   constexpr int X_LOADS = (HHP * 4 + NT_ - 1) / NT_, D_LOADS = HNPX * 4 / NT_;
   constexpr int STAGE_ELEMS = (HHP + HNPX) * HLD;
@@ -521,8 +521,6 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
   __shared__ __attribute__((aligned(16))) bf16_t lds_raw[STAGE_ELEMS];
   bf16_t* XH = lds_raw;
   bf16_t* DS = lds_raw + HHP * HLD;
-  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);       // the (co, ci) tiles of one pixel range share an XCD's L2
-  if (q >= a.total) return;
   const unsigned q32 = (unsigned)q;                         // bounded by the grid size: 32-bit divisions
   const int range = (int)(q32 / (unsigned)a.npairs), pair = (int)(q32 - (unsigned)range * (unsigned)a.npairs);
   const int co0 = (pair / a.ptiles_n) * HCT, ci0 = (pair % a.ptiles_n) * HCT;
@@ -538,9 +536,11 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
 
   // ---- fused BatchNorm-backward apply: per-channel constants of this block's 32 output channels through LDS -----------------
   constexpr bool fuse = FUSE;
-  __shared__ float sbn[4][HCT];                               // scale, shift, cb, cc (bn_bwd_apply_kernel's names)
+  __shared__ __attribute__((aligned(16))) float sbn[4][HCT];                               // scale, shift, cb, cc (bn_bwd_apply_kernel's names)
   static_assert(D_LOADS == 1, "a thread stages ONE 8-channel chunk of the dout tile: its constants are fixed");
-  float bsc[8], bsh[8], bcb[8], bcc[8];
+  // (the constants of a thread's 8 channels are READ BACK from LDS where a tile is staged - eight 16-byte reads per tile - instead
+  // of living in 32 + 16 registers: with them the fused variants needed 166..186 VGPRs = ONE resident block per CU; at <= 128 two
+  // blocks share a CU, which is what lets the problems of a grouped launch overlap, see conv3x3_wgrad_halo_group_kernel)
   if (fuse) {
     if (tid < HCT) {
       const int c = co0 + tid;
@@ -557,32 +557,32 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
       }
       sbn[0][tid] = sc; sbn[1][tid] = sh; sbn[2][tid] = cb; sbn[3][tid] = cc;
     }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int lc = (tid & 3) * 8 + e;
-      bsc[e] = sbn[0][lc]; bsh[e] = sbn[1][lc]; bcb[e] = sbn[2][lc]; bcc[e] = sbn[3][lc];
-    }
   }
   const bool writer = fuse && ci0 == 0;                       // the (co, ci = 0) blocks own the global copy of draw / dres
-  // XPRE: scale / shift of this thread's 8 input channels (its channel group inside the 32-channel tile is fixed: tid & 3)
-  float xsc[8], xsh[8];
+  // XPRE: scale / shift of the block's 32 input channels (a thread's channel group inside the tile is fixed: tid & 3)
+  __shared__ __attribute__((aligned(16))) float sxs[2][HCT];
   if constexpr (XPRE) {
-    const int c0 = ci0 + (tid & 3) * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool cok = c0 + e < a.Cin;
-      xsc[e] = cok ? a.x_ss[c0 + e] : 0.f;
-      xsh[e] = cok ? a.x_ss[a.Cin + c0 + e] : 0.f;
+    if (tid >= 64 && tid < 64 + HCT) {
+      const int c = ci0 + tid - 64;
+      const bool cok = c < a.Cin;
+      sxs[0][tid - 64] = cok ? a.x_ss[c] : 0.f;
+      sxs[1][tid - 64] = cok ? a.x_ss[a.Cin + c] : 0.f;
     }
   }
+  if (fuse || XPRE) __syncthreads();
+  const int cg8 = (tid & 3) * 8;                              // this thread's 8 channels inside a 32-channel tile
 
   Vec<bf16_t> rx[X_LOADS], rd[D_LOADS], rr[D_LOADS], rq[D_LOADS], vdk[D_LOADS], vzk[D_LOADS];
-  bool xok[X_LOADS], dok[D_LOADS];
-  int64_t doff[D_LOADS];
-  unsigned soff[D_LOADS];
-  constexpr unsigned SOOB = 0x80000000u;                    // >= num_records (the entry point keeps the tensors below 2^31 bytes)
-  const int dbytes = (int)((int64_t)a.B * a.H * a.W * a.Cout * 2);
+  // every load is a hardware-bounds-checked buffer load with a 32-bit byte offset (the entry point keeps the tensors below 2^31
+  // bytes): a halo pixel outside the image / a channel chunk past the tensor gets the out-of-range offset and loads zeros - no
+  // 64-bit address pairs, no validity flags held across the tile (VGPRs are what limits this kernel to one block per CU)
+  constexpr unsigned SOOB = 0x80000000u;                    // >= num_records
+  unsigned xoff[X_LOADS], doff[D_LOADS], soff[D_LOADS];
+  const int dbytes = (int)((int64_t)a.B * a.H * a.W * a.Cout * 2), xbytes = (int)((int64_t)a.B * a.H * a.W * a.Cin * 2);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.in), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(fuse ? a.bn_dy : a.dout), 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rraw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(fuse ? a.bn_raw : a.dout), 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(fuse && RES ? a.bn_res : a.dout), 0, dbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdraw = __builtin_amdgcn_make_buffer_rsrc(fuse ? a.draw_out : const_cast<bf16_t*>(a.dout), 0, dbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdres = __builtin_amdgcn_make_buffer_rsrc(fuse && a.dres_out ? a.dres_out : (fuse ? a.draw_out : const_cast<bf16_t*>(a.dout)), 0, dbytes, 0x00020000);
   auto load_tile = [&](int t) {
@@ -592,27 +592,33 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
     for (int i = 0; i < X_LOADS; ++i) {
       const int idx = tid + i * NT_, p = idx >> 2, ch = ci0 + (idx & 3) * 8;
       const int gy = y0 - 1 + p / (HTW + 2), gx = x0 - 1 + p % (HTW + 2);
-      xok[i] = idx < HHP * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ch < a.Cin;
-      rx[i].load(a.in + (xok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cin + ch : 0));
+      const bool ok = idx < HHP * 4 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ch < a.Cin;
+      xoff[i] = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.Cin + ch) * 2) : SOOB;
+      rx[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xoff[i], 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < D_LOADS; ++i) {
       const int idx = tid + i * NT_, p = idx >> 2, ch = co0 + (idx & 3) * 8;
       const int gy = y0 + p / HTW, gx = x0 + p % HTW;
-      dok[i] = gy < a.H && gx < a.W && ch < a.Cout;
-      doff[i] = dok[i] ? (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + ch : 0;
+      const bool ok = gy < a.H && gx < a.W && ch < a.Cout;
+      doff[i] = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.Cout + ch) * 2) : SOOB;
+      rd[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, doff[i], 0, 0));
       if constexpr (fuse) {
-        rd[i].load(a.bn_dy + doff[i]);
-        rr[i].load(a.bn_raw + doff[i]);
-        if constexpr (RES) rq[i].load(a.bn_res + doff[i]);
-      } else {
-        rd[i].load(a.dout + doff[i]);
+        rr[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rraw, doff[i], 0, 0));
+        if constexpr (RES) rq[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, doff[i], 0, 0));
       }
     }
   };
   // draw / dz of one staged chunk (see WgradHaloArgs): block-uniform activation, one specialised loop runs
   auto apply_chunk = [&](auto ACT, int i, Vec<bf16_t>& vdraw, Vec<bf16_t>& vdz) {
-    float o1[8], o2[8];
+    float o1[8], o2[8], bsc[8], bsh[8], bcb[8], bcc[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sbn[0][cg8 + 4 * h]), v1 = *reinterpret_cast<const f32x4*>(&sbn[1][cg8 + 4 * h]);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(&sbn[2][cg8 + 4 * h]), v3 = *reinterpret_cast<const f32x4*>(&sbn[3][cg8 + 4 * h]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bsc[4 * h + e] = v0[e]; bsh[4 * h + e] = v1[e]; bcb[4 * h + e] = v2[e]; bcc[4 * h + e] = v3[e]; }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float x = rr[i].get(e);
@@ -631,6 +637,13 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
       const int idx = tid + i * NT_;
       Vec<bf16_t> v = rx[i];
       if constexpr (XPRE) {
+        float xsc[8], xsh[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sxs[0][cg8 + 4 * h]), v1 = *reinterpret_cast<const f32x4*>(&sxs[1][cg8 + 4 * h]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xsc[4 * h + e] = v0[e]; xsh[4 * h + e] = v1[e]; }
+        }
         auto apply = [&](auto ACT) {
           float o[8];
 #pragma unroll
@@ -644,7 +657,7 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
         else if (a.x_act == 2) apply(std::integral_constant<int, 2>{});
         else apply(std::integral_constant<int, 0>{});
       }
-      if (!xok[i]) v.raw = {0, 0, 0, 0};
+      if constexpr (XPRE) { if (xoff[i] == SOOB) v.raw = {0, 0, 0, 0}; }      // (plain operand: an out-of-range load returned zeros)
       if (idx < HHP * 4) v.store(XH + (idx >> 2) * HLD + (idx & 3) * 8);
     }
 #pragma unroll
@@ -656,9 +669,9 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
         else if (a.bn_act == 2) apply_chunk(std::integral_constant<int, 2>{}, i, v, vzk[i]);
         else apply_chunk(std::integral_constant<int, 0>{}, i, v, vzk[i]);
         vdk[i] = v;
-        soff[i] = (writer && dok[i]) ? (unsigned)(doff[i] * 2) : SOOB;
+        soff[i] = writer ? doff[i] : SOOB;
+        if (doff[i] == SOOB) v.raw = {0, 0, 0, 0};             // (draw of an out-of-range pixel is the constant term, not zero)
       }
-      if (!dok[i]) v.raw = {0, 0, 0, 0};
       v.store(DS + (idx >> 2) * HLD + (idx & 3) * 8);
     }
   };
@@ -676,8 +689,11 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
   // this lane's transpose-read base rows: dout tile row (pixel) / halo row of tap (0,0) for the 32-pixel k-step 0
   const int i4 = l15 >> 2, c4 = (l15 & 3) * 4;
   // K-slot map of a 32-pixel step (see SlabFrag): first read = pixels 4g..4g+3 of image row 2ks, second = same of row 2ks+1
-  const bf16_t* dbase = DS + (grp * 4 + i4) * HLD + wm * 16 + c4;
-  const bf16_t* xbase = XH + ((HTW + 2) + grp * 4 + 1 + i4) * HLD + wn * 16 + c4;
+  // (the wave group's K-steps 2wg, 2wg + 1 are folded into the base rows; the taps are in the standard order - halo_wgrad_eligible -
+  // so every tap / K-step is an IMMEDIATE offset of the transpose reads: with run-time dy / dx the compiler hoisted 18 address
+  // registers out of the tile loop)
+  const bf16_t* dbase = DS + (grp * 4 + i4 + 2 * wg * 32) * HLD + wm * 16 + c4;
+  const bf16_t* xbase = XH + ((HTW + 2) * (1 + 4 * wg) + grp * 4 + 1 + i4) * HLD + wn * 16 + c4;
   auto tr8 = [&](const bf16_t* p, int hi_rows) {   // 8 K values of this lane's column: two transpose reads `hi_rows` rows apart
     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
     const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + hi_rows * HLD));
@@ -694,11 +710,10 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
     if constexpr (fuse) flush_stores();
 #pragma unroll
     for (int kk = 0; kk < HNPX / 64; ++kk) {                  // 32 pixels = image rows 2ks, 2ks+1 of the tile
-      const int ks = 2 * wg + kk;
-      const bf16x8 fa = tr8(dbase + ks * 32 * HLD, HTW);
+      const bf16x8 fa = tr8(dbase + kk * 32 * HLD, HTW);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const bf16x8 fb = tr8(xbase + ((2 * ks + a.dy[tap]) * (HTW + 2) + a.dx[tap]) * HLD, HTW + 2);
+        const bf16x8 fb = tr8(xbase + ((2 * kk + tap / 3 - 1) * (HTW + 2) + tap % 3 - 1) * HLD, HTW + 2);
         acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[tap], 0, 0, 0);
       }
     }
@@ -731,6 +746,35 @@ __global__ void __launch_bounds__(HWG_THREADS) conv3x3_wgrad_halo_kernel(WgradHa
   }
 }
 
+// two resident blocks per CU (<= 128 VGPRs): a block alone keeps ONE tile's loads in flight under its MFMAs, i.e. it runs at the
+// latency of its loads; the second block - of the same problem, or of another problem of a grouped launch - fills that time
+template <bool FUSE, bool RES, bool XPRE = false>
+__global__ void __launch_bounds__(HWG_THREADS, 4) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
+  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);       // the (co, ci) tiles of one pixel range share an XCD's L2
+  if (q >= a.total) return;
+  wgrad_halo_block<FUSE, RES, XPRE>(a, q);
+}
+// GROUPED launch (rssf_conv3x3_wgrad_group, see conv3x3_halo_group_kernel in conv_halo.hip): problem i owns the block indices
+// [start[i], start[i+1]) of every XCD.  Every problem's blocks do the same amount of work (a run of tiles_per_block spatial tiles of
+// one 32 x 32 channel pair), whatever its resolution.
+struct WgradHaloGroupArgs {
+  WgradHaloArgs it[RSSF_GROUP_MAX];
+  int start[RSSF_GROUP_MAX + 1];
+  int n;
+};
+template <bool FUSE, bool RES, bool XPRE>
+__global__ void __launch_bounds__(HWG_THREADS, 4) conv3x3_wgrad_halo_group_kernel(WgradHaloGroupArgs g) {
+  const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
+    if (k < g.n && idx >= (unsigned)g.start[k]) i = k;
+  const WgradHaloArgs& a = g.it[i];
+  const int64_t q = (int64_t)xcd * a.xcd_per + (idx - (unsigned)g.start[i]);
+  if (q >= a.total) return;
+  wgrad_halo_block<FUSE, RES, XPRE>(a, q);
+}
+
 // spatial tiles per block: 8 when that still yields >= 256 blocks, fewer for small problems
 int halo_tiles_per_block(int64_t ntiles, int npairs) {
   int tpb = 8;
@@ -746,7 +790,7 @@ int halo_ksplit(int B, int H, int W, int Cout, int Cin) {
 bool halo_wgrad_eligible(int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, int nsrc, const int* dy, const int* dx) {
   if (stride != 1 || IH != OH || IW != OW || ntaps != 9 || nsrc != 1 || (Cin % 8) != 0 || (Cout % 8) != 0) return false;
   for (int t = 0; t < 9; ++t)
-    if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1) return false;
+    if (dy[t] != t / 3 - 1 || dx[t] != t % 3 - 1) return false;       // the kernel's tap offsets are compile-time
   return true;
 }
 
@@ -830,6 +874,29 @@ struct BnApply {               // arguments of rssf_bn_bwd_apply (see WgradHaloA
   float* dgamma; float* dbeta; double n; int act, training; float pscale;
 };
 struct XPreAct { const float* ss; int act; };
+// arguments of the halo-tiled kernel for one problem; ksplit_out = partial planes the second stage has to fold
+WgradHaloArgs make_wgrad_halo(const void* dout, const void* in, float* workspace, int B, int H, int W, int Cin, int Cout, const BnApply* bn,
+                              const XPreAct* xpre, int& ksplit_out) {
+  WgradHaloArgs h;
+  memset(&h, 0, sizeof(h));
+  h.dout = (const bf16_t*)dout; h.in = (const bf16_t*)in; h.partial = workspace;
+  h.B = B; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout;
+  h.tiles_y = (H + HTH - 1) / HTH; h.tiles_x = (W + HTW - 1) / HTW; h.ntiles = B * h.tiles_y * h.tiles_x;
+  h.ptiles_n = (Cin + HCT - 1) / HCT; h.npairs = ((Cout + HCT - 1) / HCT) * h.ptiles_n;
+  h.tiles_per_block = halo_tiles_per_block(h.ntiles, h.npairs);
+  ksplit_out = (h.ntiles + h.tiles_per_block - 1) / h.tiles_per_block;
+  h.total = (int64_t)ksplit_out * h.npairs;
+  h.xcd_per = xcd_per(h.total);
+  for (int t = 0; t < 9; ++t) { h.dy[t] = t / 3 - 1; h.dx[t] = t % 3 - 1; }
+  if (bn) {                  // the BatchNorm-backward apply rides in this kernel's staging of the output-gradient tile
+    h.bn_dy = (const bf16_t*)bn->dy; h.bn_raw = (const bf16_t*)bn->raw; h.bn_res = (const bf16_t*)bn->res;
+    h.bn_ss = bn->ss; h.bn_mi = bn->mi; h.bn_sums = bn->sums;
+    h.draw_out = (bf16_t*)bn->draw; h.dres_out = (bf16_t*)bn->dres; h.dgamma = bn->dgamma; h.dbeta = bn->dbeta;
+    h.bn_n = (float)bn->n; h.bn_pscale = bn->pscale; h.bn_act = bn->act; h.bn_training = bn->training;
+  }
+  h.x_ss = xpre ? xpre->ss : nullptr; h.x_act = xpre ? xpre->act : 0;
+  return h;
+}
 int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
                     int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
                     float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
@@ -857,25 +924,8 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
   a.ksplit = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RSSF_BF16 && workspace && !dbias && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx)) {
-    WgradHaloArgs h;
-    h.dout = (const bf16_t*)dout; h.in = (const bf16_t*)in; h.partial = workspace;
-    h.B = B; h.H = IH; h.W = IW; h.Cin = Cin; h.Cout = Cout;
-    h.tiles_y = (IH + HTH - 1) / HTH; h.tiles_x = (IW + HTW - 1) / HTW; h.ntiles = B * h.tiles_y * h.tiles_x;
-    h.ptiles_n = (Cin + HCT - 1) / HCT; h.npairs = ((Cout + HCT - 1) / HCT) * h.ptiles_n;
-    h.tiles_per_block = halo_tiles_per_block(h.ntiles, h.npairs);
-    a.ksplit = (h.ntiles + h.tiles_per_block - 1) / h.tiles_per_block;
-    h.total = (int64_t)a.ksplit * h.npairs;
-    h.xcd_per = xcd_per(h.total);
-    for (int t = 0; t < 9; ++t) { h.dy[t] = dy[t]; h.dx[t] = dx[t]; }
-    h.bn_dy = nullptr;
-    if (bn) {                  // the BatchNorm-backward apply rides in this kernel's staging of the output-gradient tile
-      h.bn_dy = (const bf16_t*)bn->dy; h.bn_raw = (const bf16_t*)bn->raw; h.bn_res = (const bf16_t*)bn->res;
-      h.bn_ss = bn->ss; h.bn_mi = bn->mi; h.bn_sums = bn->sums;
-      h.draw_out = (bf16_t*)bn->draw; h.dres_out = (bf16_t*)bn->dres; h.dgamma = bn->dgamma; h.dbeta = bn->dbeta;
-      h.bn_n = (float)bn->n; h.bn_pscale = bn->pscale; h.bn_act = bn->act; h.bn_training = bn->training;
-    }
+    const WgradHaloArgs h = make_wgrad_halo(dout, in, workspace, B, IH, IW, Cin, Cout, bn, xpre, a.ksplit);
     const dim3 hgrid((unsigned)h.xcd_per * 8);
-    h.x_ss = xpre ? xpre->ss : nullptr; h.x_act = xpre ? xpre->act : 0;
     if (xpre) {
       if (!bn) conv3x3_wgrad_halo_kernel<false, false, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
       else if (bn->res) conv3x3_wgrad_halo_kernel<true, true, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
@@ -942,4 +992,76 @@ extern "C" int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, c
 extern "C" int rssf_conv_wgrad_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, int nsrc,
                                                 const int* dy, const int* dx, int has_bias, int dtype) {
   return dtype == RSSF_BF16 && !has_bias && dy && dx && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx) ? 1 : 0;
+}
+
+// ---- grouped 3x3 weight gradients (rssf.h "Grouped launches") ----------------------------------------------------------------
+extern "C" int rssf_conv3x3_wgrad_group(const rssf_wgrad3x3_item* items, int n, int dtype, void* stream) {
+  RSSF_REQUIRE(items && n >= 1, "conv3x3_wgrad_group: bad arguments");
+  int dy[9], dx[9];
+  for (int t = 0; t < 9; ++t) { dy[t] = t / 3 - 1; dx[t] = t % 3 - 1; }
+  static const int ks9[1] = {3}, src9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, kpos9[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+  static const bool enabled = !(getenv("RSSF_GROUP_KERNELS") && getenv("RSSF_GROUP_KERNELS")[0] == '0');      // A/B switch (tools/group_bench.py)
+  bool grouped = enabled && n >= 2 && n <= RSSF_GROUP_MAX && dtype == RSSF_BF16;
+  for (int i = 0; i < n; ++i) {
+    const rssf_wgrad3x3_item& it = items[i];
+    RSSF_REQUIRE(it.in && it.dw && it.B > 0 && it.H > 0 && it.W > 0 && it.Cin > 0 && it.Cout > 0 && (it.bn_dy ? it.draw != nullptr : it.dout != nullptr),
+                 "conv3x3_wgrad_group: bad item %d", i);
+    RSSF_REQUIRE(!it.bn_dy || (it.bn_raw && it.bn_ss && it.bn_mi && it.bn_sums && it.bn_act >= 0 && it.bn_act <= 2 && (it.dgamma == nullptr) == (it.dbeta == nullptr)),
+                 "conv3x3_wgrad_group: bad BatchNorm arguments (item %d)", i);
+    RSSF_REQUIRE(!it.in_ss || it.bn_dy, "conv3x3_wgrad_group: a pre-activation input operand needs the fused apply (item %d)", i);
+    grouped = grouped && it.workspace && halo_wgrad_eligible(it.H, it.W, it.Cin, it.H, it.W, it.Cout, 1, 9, 1, dy, dx) &&
+              (int64_t)it.B * it.H * it.W * it.Cout < ((int64_t)1 << 30) && (int64_t)it.B * it.H * it.W * it.Cin < ((int64_t)1 << 30) &&
+              (it.bn_dy != nullptr) == (items[0].bn_dy != nullptr) && (it.bn_res != nullptr) == (items[0].bn_res != nullptr) &&
+              (it.in_ss != nullptr) == (items[0].in_ss != nullptr);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (grouped) {
+    WgradHaloGroupArgs g;
+    g.n = n;
+    int idx = 0;
+    WgradArgs ra[RSSF_GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+      const rssf_wgrad3x3_item& it = items[i];
+      const BnApply bn = {it.bn_dy, it.bn_raw, it.bn_ss, it.bn_mi, it.bn_sums, it.bn_res, it.draw, it.dres, it.dgamma, it.dbeta, it.bn_n, it.bn_act,
+                          it.bn_training, it.pscale};
+      const XPreAct xp = {it.in_ss, it.in_act};
+      int ksplit = 1;
+      g.it[i] = make_wgrad_halo(it.bn_dy ? it.draw : it.dout, it.in, it.workspace, it.B, it.H, it.W, it.Cin, it.Cout, it.bn_dy ? &bn : nullptr,
+                                it.in_ss ? &xp : nullptr, ksplit);
+      g.start[i] = idx;
+      idx += g.it[i].xcd_per;
+      WgradArgs& a = ra[i];                          // what the second stage needs to know (make_job)
+      memset(&a, 0, sizeof(a));
+      a.partial = it.workspace; a.dw[0] = it.dw; a.ks[0] = 3; a.ks[1] = a.ks[2] = 1;
+      a.ntaps_total = 9; a.Cout = it.Cout; a.Cin = it.Cin; a.ksplit = ksplit;
+      for (int t = 0; t < MAX_TAPS; ++t) { a.src_of_tap[t] = 0; a.kpos_of_tap[t] = t < 9 ? t : 0; for (int e = 0; e < 4; ++e) a.alias[t][e] = -1; }
+    }
+    for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = idx;
+    const dim3 grid((unsigned)idx * 8);
+    const bool fuse = items[0].bn_dy != nullptr, res = items[0].bn_res != nullptr, xp = items[0].in_ss != nullptr;
+    if (xp) {
+      if (!fuse) conv3x3_wgrad_halo_group_kernel<false, false, true><<<grid, HWG_THREADS, 0, st>>>(g);
+      else if (res) conv3x3_wgrad_halo_group_kernel<true, true, true><<<grid, HWG_THREADS, 0, st>>>(g);
+      else conv3x3_wgrad_halo_group_kernel<true, false, true><<<grid, HWG_THREADS, 0, st>>>(g);
+    } else {
+      if (!fuse) conv3x3_wgrad_halo_group_kernel<false, false, false><<<grid, HWG_THREADS, 0, st>>>(g);
+      else if (res) conv3x3_wgrad_halo_group_kernel<true, true, false><<<grid, HWG_THREADS, 0, st>>>(g);
+      else conv3x3_wgrad_halo_group_kernel<true, false, false><<<grid, HWG_THREADS, 0, st>>>(g);
+    }
+    if (int rc = check_launch("conv3x3_wgrad_halo_group")) return rc;
+    for (int i = 0; i < n; ++i)
+      if (int rc = finish_reduce(ra[i], items[i].defer_reduce, st)) return rc;
+    return RSSF_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    const rssf_wgrad3x3_item& it = items[i];
+    const BnApply bn = {it.bn_dy, it.bn_raw, it.bn_ss, it.bn_mi, it.bn_sums, it.bn_res, it.draw, it.dres, it.dgamma, it.dbeta, it.bn_n, it.bn_act,
+                        it.bn_training, it.pscale};
+    const XPreAct xp = {it.in_ss, it.in_act};
+    const int rc = conv_wgrad_impl(it.bn_dy ? it.draw : it.dout, it.in, it.dw, nullptr, nullptr, ks9, 1, src9, kpos9, nullptr, nullptr, it.workspace, it.B,
+                                   it.H, it.W, it.Cin, it.H, it.W, it.Cout, 1, 9, dy, dx, it.defer_reduce, it.bn_dy ? &bn : nullptr,
+                                   it.in_ss ? &xp : nullptr, dtype, stream);
+    if (rc) return rc;
+  }
+  return RSSF_OK;
 }

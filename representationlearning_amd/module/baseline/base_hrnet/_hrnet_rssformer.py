@@ -197,13 +197,12 @@ class HighResolutionModule(nn.Module):
         return self.num_inchannels
 
     def _lockstep_ok(self):
-        """Data parallel with SyncBN on every BatchNorm: walk the branches block by block so that the BatchNorm statistics of all
-        branches (and of all fuse paths of one depth) travel in ONE collective (nnf.conv_bn_act_group)."""
-        rt = nnf.current()
-        if not (rt.exchanging() and rt.sync_all_bn and self.training and self.num_branches > 1) or os.environ.get("RSSF_LOCKSTEP", "1") == "0":
+        """Walk the branches block by block (all branches of a module run the same BasicBlock step on independent tensors): every
+        phase of a step - convolutions, BatchNorm passes, weight / data gradients - is then ONE grouped launch over the branches
+        (nnf.conv_bn_act_group) instead of one latency-bound launch per branch on its own stream, and under data parallelism the
+        BatchNorm statistics of all branches (and of all fuse paths of one depth) travel in ONE collective on one communicator."""
+        if self.num_branches < 2 or os.environ.get("RSSF_LOCKSTEP", "1") == "0":
             return False
-        if rt.stream_comms and rt.branch_streams and os.environ.get("RSSF_LOCKSTEP") != "force":
-            return False          # every side stream has its own communicator: the branches keep their streams (nnf.parallel_map)
         nblk = len(self.branches[0])
         return all(len(b) == nblk and all(isinstance(m, BasicBlock) and m.downsample is None for m in b) for b in self.branches)
 
@@ -216,7 +215,9 @@ class HighResolutionModule(nn.Module):
             blks = [self.branches[i][k] for i in range(nb)]
             links = [nnf.residual_link(xs[i], xs[i]) for i in range(nb)]
             g1 = nnf.group_stats_link(nb)
-            mid = nnf.conv_bn_act_group([dict(x=xs[i], conv=blks[i].conv1, bn=blks[i].bn1, act=nnf.ACT_RELU, grad_sink=links[i])
+            # relu(bn1(conv1(x))) has ONE consumer, conv2: where conv2's kernels can apply bn1 + ReLU on load it is never written
+            defer = [g1 is not None and nnf.can_defer_apply(xs[i], blks[i].conv1, blks[i].conv2) for i in range(nb)]
+            mid = nnf.conv_bn_act_group([dict(x=xs[i], conv=blks[i].conv1, bn=blks[i].bn1, act=nnf.ACT_RELU, grad_sink=links[i], defer_apply=defer[i])
                                          for i in range(nb)], stats_out=g1, stats_in=prev if all(l is not None for l in links) else None)
             g2 = nnf.group_stats_link(nb) if k + 1 < nblk else None
             xs = nnf.conv_bn_act_group([dict(x=mid[i], conv=blks[i].conv2, bn=blks[i].bn2, act=nnf.ACT_RELU, res_pre=xs[i],

@@ -713,6 +713,7 @@ def group_stats_link(n):
     return GroupBwdLink(n) if (_FUSED_BN_STATS and torch.is_grad_enabled() and not current().deterministic) else None
 
 
+_GROUP_LAUNCH = os.environ.get("RSSF_GROUP_LAUNCH", "1") != "0"      # A/B switch: the phases of a lock-step group as grouped launches
 _PLAN_BIAS = os.environ.get("RSSF_WGRAD_PLAN_BIAS", "1") != "0"      # A/B switch: deferred split-K reduction also for convolutions with a bias
 _FORK_FUSE = os.environ.get("RSSF_FORK_FUSE", "1") != "0"      # A/B switch: fuse outputs 1.. beside the transformer block (fork_side)
 _DEFER_BN_APPLY = os.environ.get("RSSF_DEFER_BN_APPLY", "1") != "0"      # A/B switch: forward BatchNorm apply inside the consumer's staging
@@ -1024,15 +1025,39 @@ class _ConvBNAct(torch.autograd.Function):
                 grad_result(p_beta, dbeta, db_direct, rt), None, None, None, None, None, None, None, None, None, None, *gws, *gbs)
 
 
+def _is_plain3x3(spec):
+    """3x3 / stride 1 / padding 1 / single bias-free source in the standard tap order: what the grouped 3x3 entry points take."""
+    return (spec.parts is None and spec.ntaps == 9 and spec.stride == 1 and len(spec.ksizes) == 1 and spec.ksizes[0] == 3
+            and spec.dy == [t // 3 - 1 for t in range(9)] and spec.dx == [t % 3 - 1 for t in range(9)])
+
+
+def _chunks(idx):
+    """Runs of at most RSSF_GROUP_MAX item indices (one grouped launch each)."""
+    return [idx[k:k + L.GROUP_MAX] for k in range(0, len(idx), L.GROUP_MAX)]
+
+
+def _group_conv3x3(entries, mirrored, code):
+    """entries: dicts of rssf_conv3x3_item fields (tensors or None, scalars) -> grouped launches of <= RSSF_GROUP_MAX problems."""
+    lib = L.load()
+    for ch in _chunks(list(range(len(entries)))):
+        arr = (L.Conv3x3Item * len(ch))()
+        for k, i in enumerate(ch):
+            it, e = arr[k], entries[i]
+            for name, v in e.items():
+                setattr(it, name, v.data_ptr() if torch.is_tensor(v) else (0 if v is None else v))
+        L.check(lib.rssf_conv3x3_group(ctypes.cast(arr, ctypes.c_void_p), len(ch), int(mirrored), code, L.stream()), "rssf_conv3x3_group")
+
+
 class _ConvBNActGroup(torch.autograd.Function):
-    """N INDEPENDENT Conv2d -> BatchNorm2d -> act (+ residual before the activation) layers as one autograd node with ONE SyncBN
-    exchange per direction: the convolutions of all items are launched, their statistics buffers - carved out of one contiguous
-    allocation - are summed over the ranks by a single collective, then every item is normalised; backward mirrors it (all
-    reductions, one exchange, all applies / data gradients / weight gradients).  Used in data-parallel runs for the parallel
-    branches and fuse paths of a HighResolutionModule: the ~660 per-layer exchanges of a step, all of them on the critical path,
-    become ~250 (representationlearning_amd/module/.../_hrnet_rssformer.py::HighResolutionModule._forward_lockstep).
+    """N INDEPENDENT Conv2d -> BatchNorm2d -> act (+ residual before the activation) layers as one autograd node: the parallel
+    branches of a HighResolutionModule run the same BasicBlock step at the same moment (_hrnet_rssformer.py:216-246, 410-423),
+    so do the fuse paths of one depth (:361-405).  Every phase of the node is ONE grouped launch where a grouped kernel exists
+    (rssf.h "Grouped launches": 3x3 / stride-1 convolutions forward, data gradient and weight gradient with the fused
+    BatchNorm-backward apply, the BatchNorm finalize+apply and backward-statistics passes) - the launches of the branches are
+    latency-bound one by one and fill each other's bubbles in one grid - and there is ONE SyncBN exchange per direction: the
+    statistics buffers are carved out of one contiguous allocation and summed over the ranks by a single collective.
     Per item (7 tensor slots): x, res_pre, gamma, beta, running_mean, running_var, weight.  Single bias-free convolutions only
-    (every HRNet convolution); meta = (spec, act, training, momentum, eps, sync, sink link, deposit link, GradAccum)."""
+    (every HRNet convolution); meta = (spec, act, training, momentum, eps, sync, sink link, deposit link, GradAccum, defer)."""
 
     SLOTS = 7
 
@@ -1044,26 +1069,49 @@ class _ConvBNActGroup(torch.autograd.Function):
         it = [flat[i * 7:(i + 1) * 7] for i in range(n_items)]
         L.require_gpu(*[t[0] for t in it])
         dev = it[0][0].device
+        gout, gin = glinks
         training = [m[2] for m in metas]
         sizes = [BN_SLOTS * 2 * m[0].cout if tr else 0 for m, tr in zip(metas, training)]
         stats_all = _zeros(sum(sizes), dev, rt) if sum(sizes) else None
-        # items on parallel streams around the ONE exchange (not for groups whose items share a gradient accumulator: its consumers
-        # must stay on one stream)
-        ph = _Phases(rt, n_items, dev, enabled=all((len(m) <= 8 or m[8] is None) for m in metas))
-        xs, raws, stats, o = [], [], [], 0
+        xs, stats, pres, o = [], [], [], 0
         for i, ((x, rp, gamma, beta, rm, rv, w), m, sz) in enumerate(zip(it, metas, sizes)):
-            xh = _nhwc(x)
-            st = stats_all[o:o + sz] if sz else None
+            xs.append(_nhwc(x))
+            stats.append(stats_all[o:o + sz] if sz else None)
             o += sz
-            xs.append(xh)
-            stats.append(st)
-            raws.append(ph.run(i, lambda m=m, xh=xh, w=w, st=st: _conv_forward(m[0], xh, [w], None, st, rt), (xh, st)))
-        ph.join()
+            si = gin.items[i] if gin is not None else None
+            pres.append((si.pre, si.act, si.ss) if (si is not None and si.deferred) else None)     # x_i is the producer's RAW output
+        # ---- convolutions: one grouped launch for the plain 3x3 items, the others one by one
+        bf16 = all(xh.dtype == torch.bfloat16 for xh in xs)
+        g3 = [i for i in range(n_items) if bf16 and _GROUP_LAUNCH and not rt.deterministic and _is_plain3x3(metas[i][0])
+              and xs[i].shape[3] == metas[i][0].cin and metas[i][0].cin % 8 == 0 and metas[i][0].cout % 8 == 0]
+        raws = [None] * n_items
+        for kind in (False, True):                          # plain inputs, then pre-activation inputs (two kernels)
+            sel = [i for i in g3 if (pres[i] is not None) == kind]
+            if len(sel) < 2:
+                continue
+            entries = []
+            for i in sel:
+                spec, xh = metas[i][0], xs[i]
+                B, H, W, C = xh.shape
+                raws[i] = torch.empty(B, H, W, spec.cout, device=dev, dtype=xh.dtype)
+                e = dict(in_=xh, wpk=_pack(spec, [it[i][6]], False, xh.dtype, dev, rt), out=raws[i], stats=stats[i], B=B, H=H, W=W, Cin=C, Cout=spec.cout)
+                if kind:
+                    (pst, pga, pbe, prm, prv, pmi, pss, pn, pmom, peps, ptr), pact, _ = pres[i]
+                    e.update(pre_stats=pst, pre_gamma=pga, pre_beta=pbe, pre_running_mean=prm, pre_running_var=prv, pre_mean_invstd=pmi, pre_ss=pss,
+                             pre_n=pn, pre_momentum=pmom, pre_eps=peps, pre_training=int(ptr), pre_act=pact)
+                entries.append(e)
+            _group_conv3x3(entries, False, L.RSSF_BF16)
+        for i in range(n_items):
+            if raws[i] is None:
+                raws[i] = _conv_forward(metas[i][0], xs[i], [it[i][6]], None, stats[i], rt,
+                                        preact=None if pres[i] is None else (pres[i][0], pres[i][1]))
+        # ---- ONE exchange
         exchanged = stats_all is not None and rt.exchanging() and all(m[5] for m in metas)
         comm = rt.exchange_comm() if exchanged else None
         if exchanged:
             comm.syncbn_exchange_(stats_all, (BN_SLOTS, [(sum(sizes[:k]), 2 * m[0].cout) for k, m in enumerate(metas) if sizes[k]]))
-        outs, saved, ns = [], [], []
+        # ---- finalize + apply: one grouped launch (an item whose only consumer applies on load keeps its raw output)
+        outs, saved, ns, defers, todo = [], [], [], [], []
         for i, ((x, rp, gamma, beta, rm, rv, w), m, xh, raw, st) in enumerate(zip(it, metas, xs, raws, stats)):
             spec, act, tr, mom, eps = m[:5]
             C = spec.cout
@@ -1072,28 +1120,40 @@ class _ConvBNActGroup(torch.autograd.Function):
             rph = None if rp is None else _nhwc(rp)
             if rph is not None and (rph.dtype != raw.dtype or rph.shape != raw.shape):
                 raise RuntimeError("conv_bn_act_group: residual dtype/shape mismatch")
-
-            def apply(raw=raw, st=st, gamma=gamma, beta=beta, rm=rm, rv=rv, rph=rph, rows=rows, C=C, act=act, n=n, mom=mom, eps=eps, tr=tr):
-                mi = torch.empty(2, C, device=dev, dtype=torch.float32)
-                ss = torch.empty(2, C, device=dev, dtype=torch.float32)
+            mi = torch.empty(2, C, device=dev, dtype=torch.float32)
+            ss = torch.empty(2, C, device=dev, dtype=torch.float32)
+            defer = bool(len(m) > 9 and m[9] and gout is not None and rph is None)
+            if defer:
+                y = raw
+            else:
                 y = torch.empty_like(raw)
-                L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(mi), L.ptr(ss),
-                                                   L.ptr(rph), None, L.ptr(y), rows, C, act, n, mom, eps, int(tr), L.dtype_code(raw), L.stream()),
-                        "rssf_bn_finalize_apply")
-                return y, mi, ss
-            y, mi, ss = ph.run(i, apply, (raw, st, rph))
+                todo.append(dict(raw=raw, stats=st, gamma=gamma, beta=beta, running_mean=rm, running_var=rv, mean_invstd=mi, scale_shift=ss,
+                                 res_pre=rph, res_post=None, y=y, rows=rows, n=n, momentum=mom, eps=eps, C=C, act=act, training=int(tr)))
             outs.append(_nchw(y))
             saved += [xh, raw, ss, mi, rph, w]
             ns.append(n)
-        ph.join()
+            defers.append(defer)
+        code = L.dtype_code(raws[0])
+        same = all(r.dtype == raws[0].dtype for r in raws)
+        for ch in (_chunks(list(range(len(todo)))) if (same and _GROUP_LAUNCH) else [[k] for k in range(len(todo))]):
+            arr = (L.BnApplyItem * len(ch))()
+            for k, j in enumerate(ch):
+                for name, v in todo[j].items():
+                    setattr(arr[k], name, v.data_ptr() if torch.is_tensor(v) else (0 if v is None else v))
+            L.check(lib.rssf_bn_finalize_apply_group(ctypes.cast(arr, ctypes.c_void_p), len(ch), L.dtype_code(todo[ch[0]]["raw"]), L.stream()),
+                    "rssf_bn_finalize_apply_group")
         ctx.save_for_backward(*saved)
         ctx.metas, ctx.ns, ctx.exchanged, ctx.rt = metas, ns, exchanged, rt
-        ctx.comm, ctx.forked = comm, ph.forked
-        ctx.gout, ctx.gin = glinks
-        if ctx.gout is not None:
-            for i, (lk, m) in enumerate(zip(ctx.gout.items, metas)):
+        ctx.comm = comm
+        ctx.gout, ctx.gin = gout, gin
+        ctx.xpres = [None if p is None else (p[2], p[1]) for p in pres]      # (scale/shift, act) of a pre-activation input operand
+        if gout is not None:
+            for i, (lk, m) in enumerate(zip(gout.items, metas)):
                 xh_, raw_, ss_, mi_, rph_, w_ = saved[i * 6:(i + 1) * 6]
                 lk.raw, lk.ss, lk.rp, lk.act, lk.C, lk.sums = raw_, ss_, rph_, m[1], m[0].cout, None
+                lk.deferred = defers[i]
+                tr = m[2]
+                lk.pre = (stats[i], it[i][2], it[i][3], it[i][4], it[i][5], mi_, ss_, ns[i], m[3], m[4], tr) if defers[i] else None
         ctx.params = [(t[2], t[3], t[6]) for t in it]
         ctx.x_req = [t[0].requires_grad for t in it]
         ctx.has_pre = [t[1] is not None for t in it]
@@ -1112,60 +1172,98 @@ class _ConvBNActGroup(torch.autograd.Function):
         if gout is not None:
             gout.sums_all, gout.filled = None, 0
             for lk in gout.items:
-                lk.raw = lk.ss = lk.rp = None
-        ph = _Phases(rt, n_items, dev, forked=ctx.forked)          # the same streams as the forward pass of this group
+                lk.raw = lk.ss = lk.rp = lk.pre = None
         dyhs, sums, o = [], [], 0
         for i, (m, sz) in enumerate(zip(metas, sizes)):
-            xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
+            raw = sv[i * 6 + 1]
             dyh = _nhwc(dys[i])
             if dyh.dtype != raw.dtype:
                 dyh = dyh.to(raw.dtype)
-            C = m[0].cout
-            rows = raw.numel() // C
-            sm = sums_all[o:o + sz]
+            dyhs.append(dyh)
+            sums.append(sums_all[o:o + sz])
             o += sz
-            if not fused:
-                def reduce(dyh=dyh, raw=raw, ss=ss, rph=rph, sm=sm, rows=rows, C=C, act=m[1]):
+        same = all(sv[i * 6 + 1].dtype == sv[1].dtype for i in range(n_items))
+        if not fused:
+            if rt.deterministic or not (same and _GROUP_LAUNCH):
+                for i, m in enumerate(metas):
+                    xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
+                    C = m[0].cout
+                    rows = raw.numel() // C
                     dws = None
                     if rt.deterministic:
                         dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=dev, dtype=torch.float32)
-                    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rph), L.ptr(sm), rows, C, act, L.ptr(dws),
+                    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyhs[i]), L.ptr(raw), L.ptr(ss), L.ptr(rph), L.ptr(sums[i]), rows, C, m[1], L.ptr(dws),
                                                    L.dtype_code(raw), L.stream()), "rssf_bn_bwd_reduce")
-                ph.run(i, reduce, (dyh, raw, ss, rph, sm))
-            dyhs.append(dyh)
-            sums.append(sm)
-        ph.join()
+            else:
+                for ch in _chunks(list(range(n_items))):
+                    arr = (L.BnReduceItem * len(ch))()
+                    for k, i in enumerate(ch):
+                        xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
+                        C = metas[i][0].cout
+                        q = arr[k]
+                        q.dy, q.raw, q.scale_shift, q.res_pre, q.sums = dyhs[i].data_ptr(), raw.data_ptr(), ss.data_ptr(), (0 if rph is None else rph.data_ptr()), sums[i].data_ptr()
+                        q.rows, q.C, q.act = raw.numel() // C, C, metas[i][1]
+                    L.check(lib.rssf_bn_bwd_reduce_group(ctypes.cast(arr, ctypes.c_void_p), len(ch), L.dtype_code(sv[1]), L.stream()), "rssf_bn_bwd_reduce_group")
         pscale = 1.0
         if ctx.exchanged:
             ctx.comm.syncbn_exchange_(sums_all, (BN_BWD_SLOTS, [(sum(sizes[:k]), 2 * m[0].cout) for k, m in enumerate(metas)]))
             pscale = 1.0 / rt.world
-        grads = []
-
-        def item_backward(i):
-            m = metas[i]
+        # ---- per item: gradient buffers; then the weight gradients (with the fused BatchNorm-backward apply) and the data gradients,
+        #      each phase ONE grouped launch for the plain 3x3 items
+        st = []
+        for i, m in enumerate(metas):
             spec, act, tr = m[0], m[1], m[2]
-            sink, deposit = m[6], m[7]
             xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
             p_gamma, p_beta, p_w = ctx.params[i]
-            C = spec.cout
-            rows = raw.numel() // C
-            draw = torch.empty_like(raw)
-            dres = torch.empty_like(raw) if ctx.has_pre[i] else None
-            dgamma, dg_direct = grad_target(p_gamma, rt)
-            dbeta, db_direct = grad_target(p_beta, rt)
-            tw, wd = grad_target(p_w, rt)
+            d = dict(spec=spec, act=act, tr=tr, xh=xh, raw=raw, ss=ss, mi=mi, rph=rph, w=w, C=spec.cout, rows=raw.numel() // spec.cout)
+            d["draw"] = torch.empty_like(raw)
+            d["dres"] = torch.empty_like(raw) if ctx.has_pre[i] else None
+            d["dgamma"], d["dg_direct"] = grad_target(p_gamma, rt)
+            d["dbeta"], d["db_direct"] = grad_target(p_beta, rt)
+            d["tw"], d["wd"] = grad_target(p_w, rt)
             vch = 8 if raw.dtype == torch.bfloat16 else 4
-            fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0      # see _ConvBNAct.backward
-            if fuse_apply:
-                _conv_wgrad(spec, draw, xh, [tw], None, rt,
-                            bn=(dyhs[i], raw, ss, mi, sums[i], rph, dres, dgamma, dbeta, act, ctx.ns[i], tr, pscale if tr else 1.0))
+            d["fuse_apply"] = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0      # see _ConvBNAct.backward
+            d["xpre"] = ctx.xpres[i]
+            if d["xpre"] is not None and not d["fuse_apply"]:
+                raise RuntimeError("conv_bn_act_group: a pre-activation input needs the fused weight-gradient path")
+            d["g3"] = (_GROUP_LAUNCH and raw.dtype == torch.bfloat16 and not rt.deterministic and _is_plain3x3(spec) and d["fuse_apply"]
+                       and xh.shape[3] == spec.cin)
+            st.append(d)
+        # weight gradients
+        grouped_w = set()
+        for res_kind in (False, True):
+            for pre_kind in (False, True):
+                sel = [i for i in range(n_items) if st[i]["g3"] and (st[i]["rph"] is not None) == res_kind and (st[i]["xpre"] is not None) == pre_kind]
+                if len(sel) < 2:
+                    continue
+                for ch in _chunks(sel):
+                    if len(ch) < 2:
+                        continue
+                    if not _group_wgrad3x3([st[i] for i in ch], [dyhs[i] for i in ch], [sums[i] for i in ch], [ctx.ns[i] for i in ch], pscale, rt):
+                        continue
+                    grouped_w.update(ch)
+        for i in range(n_items):
+            d = st[i]
+            if i in grouped_w:
+                continue
+            if d["fuse_apply"]:
+                _conv_wgrad(d["spec"], d["draw"], d["xh"], [d["tw"]], None, rt,
+                            bn=(dyhs[i], d["raw"], d["ss"], d["mi"], sums[i], d["rph"], d["dres"], d["dgamma"], d["dbeta"], d["act"], ctx.ns[i], d["tr"],
+                                pscale if d["tr"] else 1.0), xpre=d["xpre"])
             else:
-                L.check(lib.rssf_bn_bwd_apply(L.ptr(dyhs[i]), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums[i]), L.ptr(rph), L.ptr(draw),
-                                              L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), rows, C, act, ctx.ns[i], int(tr), pscale if tr else 1.0,
-                                              L.dtype_code(raw), L.stream()), "rssf_bn_bwd_apply")
-            held = dres                     # (also when it travels through a GradLink: the join must see every tensor made here)
-            if deposit is not None and dres is not None:
-                deposit.value, dres = dres, None
+                L.check(lib.rssf_bn_bwd_apply(L.ptr(dyhs[i]), L.ptr(d["raw"]), L.ptr(d["ss"]), L.ptr(d["mi"]), L.ptr(sums[i]), L.ptr(d["rph"]), L.ptr(d["draw"]),
+                                              L.ptr(d["dres"]), L.ptr(d["dgamma"]), L.ptr(d["dbeta"]), d["rows"], d["C"], d["act"], ctx.ns[i], int(d["tr"]),
+                                              pscale if d["tr"] else 1.0, L.dtype_code(d["raw"]), L.stream()), "rssf_bn_bwd_apply")
+        # data gradients
+        dxs = [None] * n_items
+        entries, owners = [], []
+        for i, m in enumerate(metas):
+            d = st[i]
+            spec, sink, deposit = d["spec"], m[6], m[7]
+            if deposit is not None and d["dres"] is not None:
+                deposit.value, d["dres_out"] = d["dres"], None
+            else:
+                d["dres_out"] = d["dres"]
             addend = None
             if sink is not None:
                 addend, sink.value = sink.value, None
@@ -1173,28 +1271,92 @@ class _ConvBNActGroup(torch.autograd.Function):
             if ctx.x_req[i] and accum is not None:
                 if addend is not None:
                     raise RuntimeError("GradAccum: a convolution cannot be both the sink of a residual link and an accumulating consumer")
-                _accumulate_dgrad(accum, spec, draw, [w], xh.shape, rt)
-                dx = None
+                _accumulate_dgrad(accum, spec, d["draw"], [d["w"]], d["xh"].shape, rt)
             elif ctx.x_req[i]:
                 gin, bn = ctx.gin, None
                 if gin is not None and gin.items[i].raw is not None and not rt.deterministic:
                     bn = (gin.items[i], gin.slot(i, dev, rt))
-                dx = _conv_dgrad(spec, draw, [w], xh.shape, addend, rt, bn=bn)
-            else:
-                if addend is not None:
-                    raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
-                dx = None
-            if not fuse_apply:
-                _conv_wgrad(spec, draw, xh, [tw], None, rt)
-            return (dx, dres, held, draw, grad_result(p_gamma, dgamma, dg_direct, rt), grad_result(p_beta, dbeta, db_direct, rt),
-                    grad_result(p_w, tw, wd, rt))
-
+                B, H, W, C = d["xh"].shape
+                if (_GROUP_LAUNCH and d["raw"].dtype == torch.bfloat16 and _is_plain3x3(spec) and C == spec.cin and C % 8 == 0 and spec.cout % 8 == 0
+                        and (addend is None or (addend.shape == d["xh"].shape and addend.dtype == d["xh"].dtype and addend.is_contiguous()))):
+                    dx = torch.empty(B, H, W, C, device=dev, dtype=d["raw"].dtype)
+                    e = dict(in_=d["draw"], wpk=_pack(spec, [d["w"]], True, d["raw"].dtype, dev, rt), out=dx, addend=addend, B=B, H=H, W=W, Cin=spec.cout, Cout=C)
+                    if bn is not None:
+                        link, sm = bn
+                        if link.raw.shape != dx.shape or link.raw.dtype != dx.dtype or link.C != C:
+                            raise RuntimeError("GroupBwdLink: the producer's output is not this convolution's input")
+                        e.update(bn_raw=link.raw, bn_res=link.rp, bn_ss=link.ss, bn_sums=sm, bn_act=link.act)
+                    entries.append(e)
+                    owners.append(i)
+                    dxs[i] = dx
+                else:
+                    dxs[i] = _conv_dgrad(spec, d["draw"], [d["w"]], d["xh"].shape, addend, rt, bn=bn)
+            elif addend is not None:
+                raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
+        if entries:
+            _group_conv3x3(entries, True, L.RSSF_BF16)         # (a single entry runs through the one-problem kernels inside the entry point)
+        grads = []
         for i in range(n_items):
-            xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
-            dx, dres, _, _, gg, gb, gw = ph.run(i, lambda i=i: item_backward(i), (dyhs[i], sums[i], xh, raw, ss, mi, rph))
-            grads += [None if dx is None else _nchw(dx), None if dres is None else _nchw(dres), gg, gb, None, None, gw]
-        ph.join()
+            d = st[i]
+            if not d["fuse_apply"]:
+                _conv_wgrad(d["spec"], d["draw"], d["xh"], [d["tw"]], None, rt)
+            p_gamma, p_beta, p_w = ctx.params[i]
+            grads += [None if dxs[i] is None else _nchw(dxs[i]), None if d["dres_out"] is None else _nchw(d["dres_out"]),
+                      grad_result(p_gamma, d["dgamma"], d["dg_direct"], rt), grad_result(p_beta, d["dbeta"], d["db_direct"], rt), None, None,
+                      grad_result(p_w, d["tw"], d["wd"], rt)]
         return (None, None, *grads)
+
+
+def _group_wgrad3x3(items, dyhs, sums, ns, pscale, rt):
+    """Weight gradients (+ fused BatchNorm-backward apply) of <= RSSF_GROUP_MAX plain 3x3 layers as one launch, under the step's
+    WgradPlan (the split-K partials of every item wait for the plan's batched reduction).  False: the plan could not serve the
+    items (call sequence changed, a gradient buffer already has a deferred job) - the caller launches them one by one."""
+    lib = L.load()
+    plan = rt.wgrad_plan
+    n = len(items)
+    keys = []
+    for d in items:
+        xh, spec = d["xh"], d["spec"]
+        B, H, W, C = xh.shape
+        keys.append((id(spec), B, H, W, C, H, W, spec.cout, xh.dtype, (d["tw"].data_ptr(),)))
+    # all-or-nothing: the plan's cursor only moves when every item of the launch gets its slot
+    if plan is not None:
+        if plan.recording or not plan.built:
+            return False                 # the recording step (and a plan that fell back for good) takes the calls one by one
+        i0 = plan.cursor
+        if i0 + n > len(plan.keys) or any(plan.keys[i0 + k] != keys[k] for k in range(n)):
+            return False
+        if any(plan.duplicate_target([d["tw"].data_ptr()]) for d in items):
+            raise RuntimeError("WgradPlan: a grouped weight gradient targets a buffer that already has a deferred job in this step")
+    arr = (L.Wgrad3x3Item * n)()
+    jobs, refs, held = [], [], []
+    for k, d in enumerate(items):
+        xh, spec = d["xh"], d["spec"]
+        B, H, W, C = xh.shape
+        if plan is not None:
+            ws, job, ref = plan.slot(keys[k])
+        else:                            # no plan (a model run outside a Trainer): own workspace, immediate second stage
+            ws = torch.empty(lib.rssf_conv_wgrad_workspace_elems(B, H, W, C, spec.cout, 9), device=xh.device, dtype=torch.float32)
+            job = ref = None
+        jobs.append(job)
+        refs.append(ref)
+        held.append(ws)
+        q = arr[k]
+        q.dout, q.in_, q.dw, q.workspace = 0, xh.data_ptr(), d["tw"].data_ptr(), ws.data_ptr()
+        q.defer_reduce = 0 if job is None else ctypes.addressof(job)
+        q.bn_dy, q.bn_raw, q.bn_ss, q.bn_mi, q.bn_sums = dyhs[k].data_ptr(), d["raw"].data_ptr(), d["ss"].data_ptr(), d["mi"].data_ptr(), sums[k].data_ptr()
+        q.bn_res = 0 if d["rph"] is None else d["rph"].data_ptr()
+        q.draw, q.dres = d["draw"].data_ptr(), (0 if d["dres"] is None else d["dres"].data_ptr())
+        q.dgamma, q.dbeta = d["dgamma"].data_ptr(), d["dbeta"].data_ptr()
+        q.in_ss, q.in_act = (0, 0) if d["xpre"] is None else (d["xpre"][0].data_ptr(), d["xpre"][1])
+        q.bn_n, q.pscale = ns[k], (pscale if d["tr"] else 1.0)
+        q.bn_act, q.bn_training = d["act"], int(d["tr"])
+        q.B, q.H, q.W, q.Cin, q.Cout = B, H, W, C, spec.cout
+    L.check(lib.rssf_conv3x3_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), n, L.RSSF_BF16, L.stream()), "rssf_conv3x3_wgrad_group")
+    for job, ref in zip(jobs, refs):
+        if job is not None and ref is not None and bytes(job) != bytes(ref):
+            raise RuntimeError("WgradPlan: a deferred weight-gradient reduction changed between steps")
+    return True
 
 
 def conv_bn_act_group(items, stats_out=None, stats_in=None):
@@ -1205,7 +1367,8 @@ def conv_bn_act_group(items, stats_out=None, stats_in=None):
         d = items[0]
         return [conv_bn_act(d["x"], d["conv"], d["bn"], d.get("act", ACT_NONE), res_pre=d.get("res_pre"), grad_sink=d.get("grad_sink"),
                             grad_deposit=d.get("grad_deposit"), grad_accum=d.get("grad_accum"),
-                            stats_out=None if stats_out is None else stats_out.items[0], stats_in=None if stats_in is None else stats_in.items[0])]
+                            stats_out=None if stats_out is None else stats_out.items[0], stats_in=None if stats_in is None else stats_in.items[0],
+                            defer_apply=bool(d.get("defer_apply", False)))]
     rt = current()
     metas, flat = [], []
     for d in items:
@@ -1217,7 +1380,7 @@ def conv_bn_act_group(items, stats_out=None, stats_in=None):
             bn._rssf_steps = getattr(bn, "_rssf_steps", 0) + 1
         sync = isinstance(bn, nn.SyncBatchNorm) or rt.sync_all_bn
         metas.append((spec_of([conv]), d.get("act", ACT_NONE), training, 0.1 if bn.momentum is None else bn.momentum, bn.eps, sync,
-                      d.get("grad_sink"), d.get("grad_deposit"), d.get("grad_accum")))
+                      d.get("grad_sink"), d.get("grad_deposit"), d.get("grad_accum"), bool(d.get("defer_apply", False))))
         flat += [d["x"], d.get("res_pre"), bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight]
     return list(_ConvBNActGroup.apply(metas, (stats_out, stats_in), *flat))
 

@@ -250,7 +250,9 @@ class Trainer:
         self.comm = self.grad_comm = self.p2p = None
         self.side_comms, self._rccl = [], []
         if dp:
-            nside = 3 if os.environ.get("RSSF_DP_SIDE_COMMS", "1") != "0" else 0
+            # side streams that issue exchanges: with the lock-step walk of the HighResolutionModules (the default) only the fuse
+            # outputs 1.. run beside the main stream (nnf.fork_side); the branch-by-branch walk (RSSF_LOCKSTEP=0) uses three
+            nside = 0 if os.environ.get("RSSF_DP_SIDE_COMMS", "1") == "0" else (3 if os.environ.get("RSSF_LOCKSTEP", "1") == "0" else 1)
             comms = rccl.create(2)
             if comms is not None:
                 self._rccl = list(comms)
@@ -403,6 +405,26 @@ class Trainer:
         self.graph = g
         return True
 
+    def _agree_on_capture(self, ok):
+        """Data parallel: the captured and the eager step issue DIFFERENT exchange sequences (the eager fall-back gives up the side
+        stream and with it that stream's communicator), so a capture that failed on one rank only - an allocation failure, say -
+        would leave the ranks in different collectives: all ranks keep the graph, or none does (MIN over the ranks, outside the
+        capture)."""
+        if self.world <= 1 or not dist.is_initialized():
+            return ok
+        dev = self.flat.flat.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return True
+        if ok:
+            print("[rssf] another rank failed to capture the step; all ranks continue with eager launches", flush=True)
+            self.graph = self._static = None
+            self.use_graph = False
+            self.rt.branch_streams = False
+            torch.cuda.synchronize()
+        return False
+
     def _join_capturing_streams(self):
         cur = torch.cuda.current_stream()
         if not torch.cuda.is_current_stream_capturing():
@@ -428,7 +450,7 @@ class Trainer:
         hp = self.hp
         self.lr_dev.fill_(poly_lr(hp["base_lr"], hp["power"], hp["max_iters"], self.it))
         if self.use_graph and self._steps >= self.graph_warmup:
-            if self.graph is None and not self._capture(img, target):
+            if self.graph is None and not self._agree_on_capture(self._capture(img, target)):
                 loss = self._eager_step(img, target)
             elif not self._fits_static(img, target):
                 loss = self._eager_step(img, target)       # e.g. a last partial batch: the captured step has fixed shapes

@@ -1,0 +1,282 @@
+"""GPU parity of the GROUPED launches (rssf.h "Grouped launches": the phases of the parallel HRNet branches as one grid each)
+against the one-problem entry points they stand for, through the C ABI, and of the lock-step HighResolutionModule walk that uses
+them against the branch-by-branch walk (reference: _hrnet_rssformer.py:216-246 BasicBlock, :410-437 HighResolutionModule.forward)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _lib():
+    from representationlearning_amd import _lib as L
+    return L, L.load()
+
+
+def _stream():
+    from representationlearning_amd import _lib as L
+    return L.stream()
+
+
+# (B, H, W, C): the four branches of a Base step at reduced size, ragged maps, channel counts that are not multiples of 32
+GROUPS = [
+    [(2, 32, 32, 32), (2, 16, 16, 64), (2, 8, 8, 128), (2, 4, 4, 256)],
+    [(1, 21, 37, 48), (3, 9, 11, 96)],
+    [(2, 17, 13, 32), (1, 16, 16, 64), (2, 10, 10, 40)],
+    [(16, 16, 16, 256), (4, 64, 64, 32), (4, 32, 32, 64), (4, 16, 16, 128)],
+]
+
+
+def _pack(w, transpose):
+    """bf16 MFMA-layout copy of a [Co, Ci, 3, 3] fp32 weight through rssf_conv_pack (the layout the kernels read)."""
+    L, lib = _lib()
+    co, ci = w.shape[:2]
+    rows, cols = (ci, co) if transpose else (co, ci)
+    n = lib.rssf_conv_packed_elems(9, rows, cols, L.RSSF_BF16)
+    out = torch.empty(n, device=DEV, dtype=BF)
+    ia = lambda v: (ctypes.c_int * len(v))(*v)
+    L.check(lib.rssf_conv_pack(L.ptr(w), None, None, ia([3]), 1, ia([0] * 9), ia(list(range(9))), None, 9, co, ci, int(transpose), L.ptr(out),
+                               L.RSSF_BF16, _stream()), "pack")
+    return out
+
+
+def _fill(item, **kw):
+    for k, v in kw.items():
+        setattr(item, k, v.data_ptr() if torch.is_tensor(v) else (0 if v is None else v))
+
+
+def _problem(shape, seed):
+    B, H, W, C = shape
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, H, W, C, generator=g).to(DEV, BF)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+    return x, w
+
+
+@pytest.mark.parametrize("shapes", GROUPS)
+@pytest.mark.parametrize("mirrored", [0, 1])
+def test_conv3x3_group_equals_single_launches(shapes, mirrored):
+    """forward (statistics epilogue) and data-gradient (addend + fused BatchNorm-backward statistics) launches"""
+    L, lib = _lib()
+    n = len(shapes)
+    probs = [_problem(s, 11 + i) for i, s in enumerate(shapes)]
+    wpk = [_pack(w, bool(mirrored)) for _, w in probs]
+    res = {}
+    for mode in ("group", "single"):
+        outs, stats, sums, keep = [], [], [], []
+        arr = (L.Conv3x3Item * n)()
+        for i, ((x, w), s) in enumerate(zip(probs, shapes)):
+            B, H, W, C = s
+            out = torch.zeros(B, H, W, C, device=DEV, dtype=BF)
+            kw = dict(in_=x, wpk=wpk[i], out=out, B=B, H=H, W=W, Cin=C, Cout=C)
+            if not mirrored:
+                st = torch.zeros(16 * 2 * C, device=DEV)
+                kw.update(stats=st)
+                stats.append(st)
+            else:
+                g = torch.Generator(device="cpu").manual_seed(77 + i)
+                add = torch.randn(B, H, W, C, generator=g).to(DEV, BF)
+                raw = torch.randn(B, H, W, C, generator=g).to(DEV, BF)
+                rp = torch.randn(B, H, W, C, generator=g).to(DEV, BF) if i % 2 == 0 else None
+                ss = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1]).to(DEV).contiguous()
+                sm = torch.zeros(8 * 2 * C, device=DEV)
+                kw.update(addend=add, bn_raw=raw, bn_res=rp, bn_ss=ss, bn_sums=sm, bn_act=1 if i % 3 else 2)
+                sums.append(sm)
+                keep += [add, raw, rp, ss]
+            _fill(arr[i], **kw)
+            outs.append(out)
+        if mode == "group":
+            L.check(lib.rssf_conv3x3_group(ctypes.cast(arr, ctypes.c_void_p), n, mirrored, L.RSSF_BF16, _stream()), "group")
+        else:
+            for i in range(n):
+                one = (L.Conv3x3Item * 1)(arr[i])
+                L.check(lib.rssf_conv3x3_group(ctypes.cast(one, ctypes.c_void_p), 1, mirrored, L.RSSF_BF16, _stream()), "single")
+        torch.cuda.synchronize()
+        res[mode] = (outs, [t.view(16, -1).sum(0) for t in stats], [t.view(8, -1).sum(0) for t in sums])
+    for a, b in zip(res["group"][0], res["single"][0]):
+        assert torch.equal(a, b)                      # same block body, same accumulation order: bit-identical outputs
+    for k in (1, 2):
+        for a, b in zip(res["group"][k], res["single"][k]):
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-4 * float(b.abs().max()) + 1e-6)      # slotted atomics: order differs
+
+
+@pytest.mark.parametrize("shapes", GROUPS[:3])
+def test_conv3x3_group_preact_equals_single(shapes):
+    """pre-activation inputs: the producer's BatchNorm finalize + apply on load (rssf_conv_gather_preact per problem)"""
+    L, lib = _lib()
+    n = len(shapes)
+    res = {}
+    for mode in ("group", "single"):
+        arr = (L.Conv3x3Item * n)()
+        outs, pubs, keep = [], [], []
+        for i, s in enumerate(shapes):
+            B, H, W, C = s
+            x, w = _problem(s, 31 + i)
+            g = torch.Generator(device="cpu").manual_seed(5 + i)
+            pst = torch.zeros(16, 2, C)
+            pst[:, 0] = torch.randn(16, C, generator=g) * 3
+            pst[:, 1] = torch.rand(16, C, generator=g) * 40 + 20
+            pst = pst.to(DEV).contiguous()
+            gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            mi, ss = torch.zeros(2, C, device=DEV), torch.zeros(2, C, device=DEV)
+            out = torch.zeros(B, H, W, C, device=DEV, dtype=BF)
+            st = torch.zeros(16 * 2 * C, device=DEV)
+            wp = _pack(w, False)
+            _fill(arr[i], in_=x, wpk=wp, out=out, stats=st, pre_stats=pst, pre_gamma=gamma, pre_beta=beta, pre_running_mean=rm, pre_running_var=rv,
+                  pre_mean_invstd=mi, pre_ss=ss, pre_n=float(B * H * W), pre_momentum=0.1, pre_eps=1e-5, pre_training=1, pre_act=1, B=B, H=H, W=W,
+                  Cin=C, Cout=C)
+            outs.append(out)
+            pubs += [mi, ss, rm, rv]
+            keep += [x, wp, pst, gamma, beta, st]
+        if mode == "group":
+            L.check(lib.rssf_conv3x3_group(ctypes.cast(arr, ctypes.c_void_p), n, 0, L.RSSF_BF16, _stream()), "group")
+        else:
+            for i in range(n):
+                one = (L.Conv3x3Item * 1)(arr[i])
+                L.check(lib.rssf_conv3x3_group(ctypes.cast(one, ctypes.c_void_p), 1, 0, L.RSSF_BF16, _stream()), "single")
+        torch.cuda.synchronize()
+        res[mode] = (outs, pubs)
+    for a, b in zip(res["group"][0], res["single"][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["group"][1], res["single"][1]):
+        assert torch.equal(a, b)                      # published mean / invstd / scale / shift / running statistics
+
+
+@pytest.mark.parametrize("shapes", GROUPS)
+@pytest.mark.parametrize("res,xpre", [(False, False), (True, False), (False, True), (True, True)])
+def test_wgrad3x3_group_equals_single_launches(shapes, res, xpre):
+    """weight gradient with the fused BatchNorm-backward apply (draw / dres / parameter gradients) and the split-K partials"""
+    L, lib = _lib()
+    n = len(shapes)
+    out = {}
+    for mode in ("group", "single"):
+        arr = (L.Wgrad3x3Item * n)()
+        rec, keep = [], []
+        for i, s in enumerate(shapes):
+            B, H, W, C = s
+            g = torch.Generator(device="cpu").manual_seed(91 + i)
+            mk = lambda: torch.randn(B, H, W, C, generator=g).to(DEV, BF)
+            x, dy, raw, rp = mk(), mk(), mk(), (mk() if res else None)
+            ss = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1]).to(DEV).contiguous()
+            mi = torch.stack([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).to(DEV).contiguous()
+            sums = torch.zeros(8, 2, C)
+            sums[0] = torch.randn(2, C, generator=g) * 5
+            sums = sums.to(DEV).contiguous()
+            xss = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1]).to(DEV).contiguous() if xpre else None
+            draw, dres = torch.zeros_like(dy), (torch.zeros_like(dy) if res else None)
+            dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            dw = torch.zeros(C, C, 3, 3, device=DEV)
+            ws = torch.zeros(lib.rssf_conv_wgrad_workspace_elems(B, H, W, C, C, 9), device=DEV)
+            _fill(arr[i], in_=x, dw=dw, workspace=ws, defer_reduce=None, bn_dy=dy, bn_raw=raw, bn_ss=ss, bn_mi=mi, bn_sums=sums, bn_res=rp, draw=draw,
+                  dres=dres, dgamma=dgamma, dbeta=dbeta, in_ss=xss, bn_n=float(B * H * W), pscale=1.0, bn_act=1, bn_training=1, in_act=1 if xpre else 0,
+                  B=B, H=H, W=W, Cin=C, Cout=C)
+            rec += [draw, dres, dgamma, dbeta, dw]
+            keep += [x, dy, raw, rp, ss, mi, sums, xss, ws]
+        if mode == "group":
+            L.check(lib.rssf_conv3x3_wgrad_group(ctypes.cast(arr, ctypes.c_void_p), n, L.RSSF_BF16, _stream()), "group")
+        else:
+            for i in range(n):
+                one = (L.Wgrad3x3Item * 1)(arr[i])
+                L.check(lib.rssf_conv3x3_wgrad_group(ctypes.cast(one, ctypes.c_void_p), 1, L.RSSF_BF16, _stream()), "single")
+        torch.cuda.synchronize()
+        out[mode] = rec
+    for a, b in zip(out["group"], out["single"]):
+        if a is not None:
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+def test_bn_group_passes_equal_single_launches(dtype):
+    """finalize + apply and the backward statistics of four layers in one grid each"""
+    L, lib = _lib()
+    shapes = [(2 * 32 * 32, 32), (2 * 16 * 16, 64), (333, 128), (57, 256)]
+    n = len(shapes)
+    code = L.RSSF_BF16 if dtype == BF else L.RSSF_F32
+    res = {}
+    for mode in ("group", "single"):
+        fa, ra = (L.BnApplyItem * n)(), (L.BnReduceItem * n)()
+        rec, keep = [], []
+        for i, (rows, C) in enumerate(shapes):
+            g = torch.Generator(device="cpu").manual_seed(3 + i)
+            raw = torch.randn(rows, C, generator=g).to(DEV, dtype)
+            rp = torch.randn(rows, C, generator=g).to(DEV, dtype) if i % 2 else None
+            dy = torch.randn(rows, C, generator=g).to(DEV, dtype)
+            st = torch.zeros(16, 2, C)
+            st[:, 0] = torch.randn(16, C, generator=g)
+            st[:, 1] = torch.rand(16, C, generator=g) * rows / 8 + 1
+            st = st.to(DEV).contiguous()
+            gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            mi, ss = torch.zeros(2, C, device=DEV), torch.zeros(2, C, device=DEV)
+            y = torch.zeros(rows, C, device=DEV, dtype=dtype)
+            sums = torch.zeros(8 * 2 * C, device=DEV)
+            _fill(fa[i], raw=raw, stats=st, gamma=gamma, beta=beta, running_mean=rm, running_var=rv, mean_invstd=mi, scale_shift=ss, res_pre=rp,
+                  res_post=None, y=y, rows=rows, n=float(rows), momentum=0.1, eps=1e-5, C=C, act=1 + i % 2, training=1)
+            _fill(ra[i], dy=dy, raw=raw, scale_shift=ss, res_pre=rp, sums=sums, rows=rows, C=C, act=1 + i % 2)
+            rec += [y, mi, ss, rm, rv, sums]
+            keep += [raw, rp, dy, st, gamma, beta]
+        if mode == "group":
+            L.check(lib.rssf_bn_finalize_apply_group(ctypes.cast(fa, ctypes.c_void_p), n, code, _stream()), "fa")
+            L.check(lib.rssf_bn_bwd_reduce_group(ctypes.cast(ra, ctypes.c_void_p), n, code, _stream()), "ra")
+        else:
+            for i in range(n):
+                L.check(lib.rssf_bn_finalize_apply_group(ctypes.cast((L.BnApplyItem * 1)(fa[i]), ctypes.c_void_p), 1, code, _stream()), "fa1")
+                L.check(lib.rssf_bn_bwd_reduce_group(ctypes.cast((L.BnReduceItem * 1)(ra[i]), ctypes.c_void_p), 1, code, _stream()), "ra1")
+        torch.cuda.synchronize()
+        res[mode] = rec
+    for k, (a, b) in enumerate(zip(res["group"], res["single"])):
+        if k % 6 == 5:
+            a, b = a.view(8, -1).sum(0), b.view(8, -1).sum(0)
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * float(b.abs().max()) + 1e-6)
+        else:
+            assert torch.equal(a, b)
+
+
+def _hr_module(nb, widths, seed):
+    from representationlearning_amd.module.baseline.base_hrnet import _hrnet_rssformer as H
+    torch.manual_seed(seed)
+    m = H.HighResolutionModule(nb, H.BasicBlock, (2,) * nb, list(widths), widths, "SUM")
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.2)
+    return m.to(DEV).train()
+
+
+@pytest.mark.parametrize("nb,widths,size", [(2, (32, 64), 28), (4, (32, 64, 128, 256), 32), (3, (48, 96, 192), 28)])
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+def test_lockstep_module_equals_branchwise_module(monkeypatch, nb, widths, size, dtype):
+    """HighResolutionModule forward + backward: the lock-step walk with grouped launches (and the deferred BatchNorm apply inside
+    the groups) against the branch-by-branch walk on the same parameters and inputs."""
+    from representationlearning_amd import nnf
+    res = {}
+    for mode in ("lockstep", "branch"):
+        monkeypatch.setenv("RSSF_LOCKSTEP", "1" if mode == "lockstep" else "0")
+        m = _hr_module(nb, widths, 3)
+        g = torch.Generator(device="cpu").manual_seed(9)
+        xs = [torch.randn(2, widths[i], size >> i, size >> i, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+              for i in range(nb)]
+        with nnf.use(nnf.Runtime()):
+            ys = m(xs)
+            loss = sum((y.float() * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum() for y in ys)
+            loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = ([y.detach().float() for y in ys], [x.grad.float() for x in xs],
+                     {k: p.grad.float().clone() for k, p in m.named_parameters() if p.grad is not None and "transformer" not in k},
+                     {k: b.clone() for k, b in m.named_buffers() if "running" in k and "transformer" not in k})
+    tol = 4e-2 if dtype == BF else 2e-4      # (bf16: the two walks differ in summation order of the statistics, 12 BatchNorm layers deep)
+    for a, b in zip(res["lockstep"][0], res["branch"][0]):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+    for a, b in zip(res["lockstep"][1], res["branch"][1]):
+        assert float((a - b).norm()) <= 2 * tol * float(b.norm())
+    for k, b in res["branch"][2].items():
+        a = res["lockstep"][2][k]
+        assert float((a - b).norm()) <= 2 * tol * float(b.norm()) + 1e-6, k
+    for k, b in res["branch"][3].items():      # running statistics (bf16: of activations that differ in the last bit here and there)
+        assert torch.allclose(res["lockstep"][3][k], b, rtol=1e-4 if dtype != BF else 5e-3, atol=1e-5 if dtype != BF else 2e-4), k
