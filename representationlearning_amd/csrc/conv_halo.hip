@@ -20,7 +20,10 @@ namespace cv {
 
 namespace {
 
-constexpr int TW = 16, KC = 32, LDK = KC + 8;             // 80-byte LDS rows: conflict-free ds_read_b128
+#ifndef RSSF_HALO_LDK_PAD
+#define RSSF_HALO_LDK_PAD 8
+#endif
+constexpr int TW = 16, KC = 32, LDK = KC + RSSF_HALO_LDK_PAD;      // 80-byte LDS rows (2-way conflicts on the non-contiguous 16-lane groups of ds_read_b128; 96-byte rows are conflict-free but cost a resident block per CU: measured equal, round 4)
 
 // MIRROR: the nine taps in data-gradient order (offset of tap t = -(t/3 - 1, t%3 - 1)) instead of forward order; the offsets
 // are compile-time, so a tap only changes the IMMEDIATE offset of the A-operand LDS reads (with run-time dy/dx every tap cost
@@ -358,7 +361,7 @@ struct HaloGroupArgs {
   int start[RSSF_GROUP_MAX + 1];
   int n;
 };
-template <bool MIRROR, bool PRE>
+template <bool MIRROR, bool PRE, int TH = 8>
 __global__ void __launch_bounds__(256) conv3x3_halo_group_kernel(HaloGroupArgs g) {
   const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
   int i = 0;
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(256) conv3x3_halo_group_kernel(HaloGroupArgs g
   const HaloArgs& a = g.it[i];
   const int64_t q = (int64_t)xcd * a.xcd_per + (idx - (unsigned)g.start[i]);
   if (q >= a.total) return;
-  halo_block<8, 32, MIRROR, PRE>(a, (unsigned)q);
+  halo_block<TH, 32, MIRROR, PRE>(a, (unsigned)q);
 }
 
 }  // namespace
@@ -412,6 +415,7 @@ int launch_halo_group(HaloArgs* items, int n, hipStream_t st) {
   HaloGroupArgs g;
   g.n = n;
   int idx = 0;
+  static const int gth = getenv("RSSF_GROUP_TH") ? atoi(getenv("RSSF_GROUP_TH")) : 8;      // tuning sweeps only (tools/group_bench.py)
   for (int k = 0; k < n; ++k) {
     HaloArgs& a = items[order[k]];
     if ((tap_order(a.dy, a.dx) < 0) != mirror || (a.pre_ss != nullptr) != pre || a.stats_ws) {
@@ -419,13 +423,18 @@ int launch_halo_group(HaloArgs* items, int n, hipStream_t st) {
       return RSSF_ERR_BAD_ARG;
     }
     if (pre && (mirror || a.Cin > 256)) { set_error("conv3x3_halo_group: a pre-activation input is a forward-launch feature (<= 256 channels)"); return RSSF_ERR_UNSUPPORTED; }
-    if (const int rc = tile_problem(a, 8, 32)) return rc;
+    if (const int rc = tile_problem(a, gth, 32)) return rc;
     g.it[k] = a;
     g.start[k] = idx;
     idx += a.xcd_per;
   }
   for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = idx;
   const dim3 grid((unsigned)idx * 8);
+  if (gth == 16) {
+    if (mirror) conv3x3_halo_group_kernel<true, false, 16><<<grid, 256, 0, st>>>(g);
+    else if (pre) conv3x3_halo_group_kernel<false, true, 16><<<grid, 256, 0, st>>>(g);
+    else conv3x3_halo_group_kernel<false, false, 16><<<grid, 256, 0, st>>>(g);
+  } else
   if (mirror) conv3x3_halo_group_kernel<true, false><<<grid, 256, 0, st>>>(g);
   else if (pre) conv3x3_halo_group_kernel<false, true><<<grid, 256, 0, st>>>(g);
   else conv3x3_halo_group_kernel<false, false><<<grid, 256, 0, st>>>(g);

@@ -206,13 +206,17 @@ class HighResolutionModule(nn.Module):
         nblk = len(self.branches[0])
         return all(len(b) == nblk and all(isinstance(m, BasicBlock) and m.downsample is None for m in b) for b in self.branches)
 
-    def _branches_lockstep(self, xs):
+    def _branches_lockstep(self, xs, which=None):
+        """The branches `which` (default: all) block by block as groups; xs: their inputs, in that order."""
         xs = list(xs)
-        nb = self.num_branches
-        nblk = len(self.branches[0])
+        which = list(range(self.num_branches)) if which is None else list(which)
+        nb = len(xs)
+        if nb == 1:
+            return [self.branches[which[0]](xs[0])]
+        nblk = len(self.branches[which[0]])
         prev = None                               # GroupBwdLink of the previous block's bn2 group (see run_blocks / nnf.BnBwdLink)
         for k in range(nblk):
-            blks = [self.branches[i][k] for i in range(nb)]
+            blks = [self.branches[i][k] for i in which]
             links = [nnf.residual_link(xs[i], xs[i]) for i in range(nb)]
             g1 = nnf.group_stats_link(nb)
             # relu(bn1(conv1(x))) has ONE consumer, conv2: where conv2's kernels can apply bn1 + ReLU on load it is never written
@@ -316,7 +320,24 @@ class HighResolutionModule(nn.Module):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
         if self._lockstep_ok():
-            return self._fuse_lockstep(self._branches_lockstep(x[:self.num_branches]))
+            nb = self.num_branches
+            split = os.environ.get("RSSF_LOCKSTEP_SPLIT", "0,1")
+            if ";" in split:                       # per branch count: "<2 branches>;<3 branches>;<4 branches>"
+                split = (split.split(";") + ["all"] * 3)[nb - 2]
+            if split not in ("", "all"):
+                # the branches named in RSSF_LOCKSTEP_SPLIT on the step's stream, the others as lock-step groups beside them
+                main = sorted({int(v) for v in split.split(",") if int(v) < nb})
+                side = [i for i in range(nb) if i not in main]
+                if main and side:
+                    ys_side, ys_main = nnf.fork_side(lambda: self._branches_lockstep([x[i] for i in side], side),
+                                                     lambda: self._branches_lockstep([x[i] for i in main], main), [x[i] for i in side])
+                    ys = [None] * nb
+                    for i, y in zip(main, ys_main):
+                        ys[i] = y
+                    for i, y in zip(side, ys_side):
+                        ys[i] = y
+                    return self._fuse_lockstep(ys)
+            return self._fuse_lockstep(self._branches_lockstep(x[:nb]))
         x = nnf.parallel_map(list(self.branches), x[:self.num_branches])       # BlockChains of BasicBlocks, one stream each
         x, accs = self._fanout(x)
 

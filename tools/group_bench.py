@@ -20,6 +20,10 @@ RING = 3
 DEV, BF = "cuda", torch.bfloat16
 lib = L.load()
 SHAPES = [(16, 128, 128, 32), (16, 64, 64, 64), (16, 32, 32, 128), (16, 16, 16, 256)][:NB]
+if os.environ.get("GB_CH"):          # e.g. GB_CH=32,32,32,32: the channel counts of the problems (map side = 4096 / C)
+    SHAPES = [(16, 4096 // int(c), 4096 // int(c), int(c)) for c in os.environ["GB_CH"].split(",")]
+    NB = len(SHAPES)
+ONLY = os.environ.get("GB_ONLY", "")          # substring filter on the phase names
 
 
 def timeit(fn, sets):
@@ -112,6 +116,8 @@ def report(name, tg, ts):
 
 st = L.stream
 for mirrored, name in ((0, "3x3 forward + statistics"), (1, "3x3 data gradient + bn-bwd stats")):
+    if ONLY and ONLY not in name:
+        continue
     sets = conv_sets(mirrored)
     g = timeit(lambda s: L.check(lib.rssf_conv3x3_group(ctypes.cast(s[0], ctypes.c_void_p), NB, mirrored, L.RSSF_BF16, st()), "g"), sets)
 
@@ -121,6 +127,8 @@ for mirrored, name in ((0, "3x3 forward + statistics"), (1, "3x3 data gradient +
     report(name, g, timeit(single, sets))
     del sets
 for res in (False, True):
+    if ONLY and ONLY not in "weight gradient":
+        continue
     sets = wgrad_sets(res)
     g = timeit(lambda s: L.check(lib.rssf_conv3x3_wgrad_group(ctypes.cast(s[0], ctypes.c_void_p), NB, L.RSSF_BF16, st()), "g"), sets)
 
@@ -129,6 +137,8 @@ for res in (False, True):
             L.check(lib.rssf_conv3x3_wgrad_group(ctypes.addressof(s[0]) + i * ctypes.sizeof(L.Wgrad3x3Item), 1, L.RSSF_BF16, st()), "s")
     report("3x3 weight gradient + bn apply" + (" + res" if res else ""), g, timeit(single, sets))
     del sets
+if ONLY and ONLY not in "bn":
+    sys.exit(0)
 sets = bn_sets()
 g = timeit(lambda s: L.check(lib.rssf_bn_finalize_apply_group(ctypes.cast(s[0], ctypes.c_void_p), NB, L.RSSF_BF16, st()), "g"), sets)
 
