@@ -324,7 +324,8 @@ class HighResolutionModule(nn.Module):
             split = os.environ.get("RSSF_LOCKSTEP_SPLIT", "0,1")
             if ";" in split:                       # per branch count: "<2 branches>;<3 branches>;<4 branches>"
                 split = (split.split(";") + ["all"] * 3)[nb - 2]
-            if split not in ("", "all"):
+            # (one stream only - eager launches, a single SyncBN communicator: all branches in ONE group, the fewest launches / exchanges)
+            if split not in ("", "all") and nnf.can_fork_side(x[0]):
                 # the branches named in RSSF_LOCKSTEP_SPLIT on the step's stream, the others as lock-step groups beside them
                 main = sorted({int(v) for v in split.split(",") if int(v) < nb})
                 side = [i for i in range(nb) if i not in main]

@@ -196,6 +196,13 @@ def parallel_map(fns, args):
     return outs
 
 
+def can_fork_side(t):
+    """True when fork_side() would really run its side function on a side stream (branch streams on, not already inside a side
+    function, and - under data parallelism - a communicator of its own for that stream)."""
+    rt = current()
+    return bool(rt.branch_streams and _FORK_FUSE and t is not None and t.is_cuda and not rt.in_side and not (rt.exchanging() and not rt.stream_comms))
+
+
 def fork_side(fn_side, fn_main, tensors):
     """(fn_side(), fn_main()): fn_side on a side stream when branch streams are enabled, concurrently with fn_main on the current
     stream; joined before returning.  `tensors`: what fn_side reads (they were produced on the current stream)."""
