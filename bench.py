@@ -45,19 +45,22 @@ ATTN_SOURCES = ("representationlearning_amd/csrc/win_attn_fwd.hip", "representat
 
 
 def _profiled_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed counter pass (profiles/r02_hbm_traffic.json, written by
+    """HBM-side bytes per launch of `kernel` from the committed counter pass (the newest profiles/rNN_hbm_traffic.json whose source stamp matches, written by
     tools/hbm_traffic.sh + tools/hbm_traffic_json.py: rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum in a
     run of its own, reads doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read inside this process.
     The file is stamped with the hash of the kernel's sources: a number measured on OTHER code is reported as null, not stale."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
-            d = json.load(f)
-        if d.get("source_sha16") != _source_sha16(*ATTN_SOURCES):
-            return None
-        e = d[kernel]
-        return int(e["read_bytes"] + e["write_bytes"])
-    except (OSError, KeyError, ValueError):
-        return None
+    import glob
+    sha = _source_sha16(*ATTN_SOURCES)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):      # newest round first
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("source_sha16") == sha:
+                e = d[kernel]
+                return int(e["read_bytes"] + e["write_bytes"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def _time_us(fn, iters, warm=3):
@@ -343,6 +346,8 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "sync_bn": (not args.no_sync_bn) and world > 1,
                        "step_launch": "hipGraph replay" if trainer.graph is not None else "eager", "graph_init_steps": init_steps,
+                       "rccl_nranks": (trainer.grad_comm.nranks() if hasattr(trainer.grad_comm, "nranks") else None) if world > 1 else None,
+                       "p2p_self_test": None if world == 1 else ("passed" if trainer.p2p is not None else "not run / failed: RCCL exchanges"),
                        "collectives": None if world == 1 else (
                            "SyncBN: %s, one channel / communicator per stream (main + %d side); gradients: %s" % (
                                "peer-to-peer kernel over hipIpc windows" if trainer.p2p is not None else "RCCL all-reduce", len(trainer.side_comms),

@@ -244,7 +244,10 @@ int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, const int* b
 int rssf_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float* mean_invstd, float* scale_shift, int C, double n, float momentum, float eps, int training,
                      void* stream);
-/* y = act(raw*scale + shift + res_pre) + res_post   (res_* optional, same shape as raw) */
+/* y = act(raw*scale + shift + res_pre) + res_post   (res_* optional, same shape as raw).
+ * act | RSSF_ACT_POST_RELU: y = relu(act(..) + res_post) - `self.relu(self.transformer(..))` of HighResolutionModule.forward
+ * (_hrnet_rssformer.py:435) inside the last BatchNorm pass of MlpDWBN; its backward: rssf_bn_bwd_reduce_post / _apply_post */
+#define RSSF_ACT_POST_RELU 16
 int rssf_bn_apply(const void* raw, const float* scale_shift, const void* res_pre, const void* res_post, void* y,
                   int64_t rows, int C, int act, int dtype, void* stream);
 /* rssf_bn_finalize followed by rssf_bn_apply as ONE launch (same arguments, same results) */
@@ -321,6 +324,16 @@ typedef struct rssf_bn_reduce_item {
   int C, act;
 } rssf_bn_reduce_item;
 int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n, int dtype, void* stream);
+
+/* rssf_bn_bwd_reduce / rssf_bn_bwd_apply of a layer run forward with res_post (and possibly RSSF_ACT_POST_RELU in `act`): the
+ * gradient that enters the activation is g = dy where y > 0 (all of dy without the flag); dpost (optional) = g is the gradient of
+ * res_post.  det_ws as in rssf_bn_bwd_reduce. */
+int rssf_bn_bwd_reduce_post(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, const void* res_post,
+                            float* sums, int64_t rows, int C, int act, float* det_ws, int dtype, void* stream);
+int rssf_bn_bwd_apply_post(const void* dy, const void* raw, const float* scale_shift, const float* mean_invstd, const float* sums,
+                           const void* res_pre, const void* res_post, void* draw, void* dres, void* dpost, float* dgamma,
+                           float* dbeta, int64_t rows, int C, int act, double n, int training, float param_grad_scale, int dtype,
+                           void* stream);
 
 /* ---- Device input pipeline: RandomCrop -> OneOf(HorizontalFlip, VerticalFlip, RandomRotate90) ->
  *      ShiftScaleRotate -> Normalize -> ToTensor and the LoveDA `mask - 1` shift (configs/base/loveda.py:18-36,
@@ -402,6 +415,9 @@ int rssf_zero_f32(float* p, int64_t n, void* stream);
  * (reference modules/ffn_block.py:226-228, 250-257); d0 (d1, d2) += src: their common bias gradient.  fp32, c / d1 / d2 may be null. */
 int rssf_vec_sum3(const float* a, const float* b, const float* c, float* out, int n, void* stream);
 int rssf_vec_add_to3(const float* src, float* d0, float* d1, float* d2, int n, void* stream);
+/* out = a + b over n elements of `dtype` (out may alias a or b; 16-byte aligned): `fuse(x)` running sums of
+ * HighResolutionModule.forward (_hrnet_rssformer.py:424-435) and gradient sums no convolution epilogue carries */
+int rssf_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 /* fp32 image [B,C,H,W] given by its element strides (NCHW or channels-last memory) -> channels-last [B,H,W,Cp] of `dtype`, channels
  * zero-padded to the 16-byte vector (Cp = 8 bf16 / 4 fp32): the network input of HighResolutionNet.forward
  * (_hrnet_rssformer.py:605-613) in one launch. */
@@ -428,6 +444,7 @@ int rssf_comm_unique_id(void* id128, const char* rccl_path);
 int rssf_comm_init(rssf_comm** comm, int rank, int world, const void* id128, const char* rccl_path);
 int rssf_comm_rank(const rssf_comm* comm);
 int rssf_comm_world(const rssf_comm* comm);
+int rssf_comm_nranks(const rssf_comm* comm);     /* ncclCommCount: the rank count RCCL itself reports for the communicator (0: none, -1: error) */
 /* in-place sum over ranks of one flat gradient bucket (`count` elements of `dtype`); the 1/world factor of the mean is
  * folded into rssf_sgd_step's grad_scale */
 int rssf_allreduce_bucket(void* buf, int64_t count, int dtype, rssf_comm* comm, void* stream);

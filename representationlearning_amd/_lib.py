@@ -111,6 +111,8 @@ SIGNATURES = {
     "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_reduce_workspace_elems": (c_int64, [c_int64, c_int]),
     "rssf_bn_bwd_reduce": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "rssf_bn_bwd_reduce_post": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "rssf_bn_bwd_apply_post": (c_int, [c_void_p] * 12 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_float, c_int, c_void_p]),
     "rssf_bn_bwd_apply": (c_int, [c_void_p] * 10 + [c_int64, c_int, c_int, ctypes.c_double, c_int, c_float, c_int, c_void_p]),
     "rssf_input_pipeline": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "rssf_upsample_bilinear": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
@@ -133,6 +135,7 @@ SIGNATURES = {
     "rssf_zero_f32": (c_int, [c_void_p, c_int64, c_void_p]),
     "rssf_vec_sum3": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "rssf_vec_add_to3": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
+    "rssf_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rssf_image_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_int64] * 4 + [c_int, c_void_p]),
     "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p, c_float, c_float,
@@ -141,6 +144,7 @@ SIGNATURES = {
     "rssf_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, ctypes.c_char_p]),
     "rssf_comm_rank": (c_int, [c_void_p]),
     "rssf_comm_world": (c_int, [c_void_p]),
+    "rssf_comm_nranks": (c_int, [c_void_p]),
     "rssf_allreduce_bucket": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "rssf_syncbn_exchange": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_comm_destroy": (c_int, [c_void_p]),

@@ -8,6 +8,16 @@ import torch
 from . import nnf, ops
 
 
+def _gate_kernels(k1, k2):
+    """[2 (stream), 2 (mean, max), 7, 7] view of the two SpatialAttention kernels (multihead_isa_pool_attention.py:30-31).  Under the
+    trainer both parameters are neighbours in the flat fp32 buffer: a strided view, no torch.stack copy per block and step."""
+    a, b = k1[0], k2[0]
+    if (a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and b.data_ptr() == a.data_ptr() + a.numel() * 4):
+        return torch.as_strided(a.detach(), (2,) + tuple(a.shape), (a.numel(),) + tuple(a.stride()), a.storage_offset())
+    return torch.stack([a, b]).contiguous()
+
+
 class GatedWindowCrossAttention(torch.autograd.Function):
     """out = x + Attn(LN1(x), LN1(y)) for one GeneralTransformerBlock (modules/MTFM.py:107), i.e.
     norm1 on both streams -> InterlacedPoolAttention2 (saliency gate, 7x7 windows, Mhca) -> residual.
@@ -23,7 +33,7 @@ class GatedWindowCrossAttention(torch.autograd.Function):
         _, sx = ops.layernorm_fwd(x, ln_g, ln_b, want_y=False)
         _, sy = ops.layernorm_fwd(y, ln_g, ln_b, want_y=False)
         pooled, argmax = ops.gate_pool_fwd(x, y, sx, sy, ln_g, ln_b)
-        kk = torch.stack([k1[0], k2[0]]).contiguous()              # [2(stream), 2(mean,max), 7, 7]
+        kk = _gate_kernels(k1, k2)                                   # [2(stream), 2(mean,max), 7, 7]
         wl2 = wl.reshape(2, 2).contiguous()
         gsig, omega, _ = ops.gate_weights_fwd(pooled, kk, wl2, bl, H, W)
         w = dict(wq=wq, bq=bq, wk=wk, bk=bk, wv=wv, bv=bv, wo=wo, bo=bo)

@@ -19,12 +19,17 @@ namespace {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
+// act = activation (bits 0..1) | RSSF_ACT_POST_RELU: y = relu(act(z) + res_post) - the ReLU that closes a HighResolutionModule's
+// transformer output (_hrnet_rssformer.py:435) rides in the last BatchNorm pass of MlpDWBN
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  return act == ACT_RELU ? fmaxf(z, 0.f) : act == ACT_GELU ? gelu_erf(z) : z;
+  const int a = act & 3;
+  return a == ACT_RELU ? fmaxf(z, 0.f) : a == ACT_GELU ? gelu_erf(z) : z;
 }
 __device__ __forceinline__ float act_bwd(float z, int act) {
-  return act == ACT_RELU ? (z > 0.f ? 1.f : 0.f) : act == ACT_GELU ? gelu_erf_grad(z) : 1.f;
+  const int a = act & 3;
+  return a == ACT_RELU ? (z > 0.f ? 1.f : 0.f) : a == ACT_GELU ? gelu_erf_grad(z) : 1.f;
 }
+__host__ __device__ __forceinline__ bool act_ok(int act) { return (act & ~RSSF_ACT_POST_RELU) >= 0 && (act & ~RSSF_ACT_POST_RELU) <= 2; }
 
 // stats [2][C] = {sum, sumsq} over n samples  ->  mean/invstd, scale/shift; running stats updated in place.
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -82,6 +87,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ raw
         if (res_pre) z += rp.get(e);
         float t = act_fwd(z, act);
         if (res_post) t += rq.get(e);
+        if (act & RSSF_ACT_POST_RELU) t = fmaxf(t, 0.f);
         ov[e] = t;
       }
       o.set_all(ov);
@@ -91,6 +97,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ raw
       if (res_pre) z += ldf(res_pre + off);
       float t = act_fwd(z, act);
       if (res_post) t += ldf(res_post + off);
+      if (act & RSSF_ACT_POST_RELU) t = fmaxf(t, 0.f);
       stf(y + off, t);
     }
   }
@@ -176,6 +183,7 @@ __device__ __forceinline__ void bn_finapply_block(const T* __restrict__ raw, con
         if (res_pre) z += rp.get(e);
         float t = act_fwd(z, act);
         if (res_post) t += rq.get(e);
+        if (act & RSSF_ACT_POST_RELU) t = fmaxf(t, 0.f);
         ov[e] = t;
       }
       Vec<T> o;
@@ -190,6 +198,7 @@ __device__ __forceinline__ void bn_finapply_block(const T* __restrict__ raw, con
       if (res_pre) z += ldf(res_pre + off);
       float t = act_fwd(z, act);
       if (res_post) t += ldf(res_post + off);
+      if (act & RSSF_ACT_POST_RELU) t = fmaxf(t, 0.f);
       stf(y + off, t);
     }
   }
@@ -236,7 +245,7 @@ template <typename T, int VEC, bool DET>
 __device__ __forceinline__ void bn_bwd_reduce_block(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
                                                     const T* __restrict__ res_pre, float* __restrict__ sums, int64_t rows, int C,
                                                     int act, float* __restrict__ det_ws, const unsigned bx, const unsigned by,
-                                                    const unsigned gx, float* sacc) {
+                                                    const unsigned gx, float* sacc, const T* __restrict__ res_post = nullptr) {
   if constexpr (!DET) {
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) sacc[i] = 0.f;
     __syncthreads();
@@ -256,13 +265,16 @@ __device__ __forceinline__ void bn_bwd_reduce_block(const T* __restrict__ dy, co
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
     const int64_t stride = (int64_t)gx * rpb;
-    auto body = [&](const Vec<T>& vd, const Vec<T>& vr, const Vec<T>& vp) {
+    const bool post = (act & RSSF_ACT_POST_RELU) != 0;         // y = relu(act(z) + res_post): the gradient passes where y > 0
+    auto body = [&](const Vec<T>& vd, const Vec<T>& vr, const Vec<T>& vp, const Vec<T>& vq) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float x = vr.get(e);
         float z = fmaf(x, sc[e], sh[e]);
         if (res_pre) z += vp.get(e);
-        const float dz = vd.get(e) * act_bwd(z, act);
+        float g = vd.get(e);
+        if (post && !(act_fwd(z, act) + (res_post ? vq.get(e) : 0.f) > 0.f)) g = 0.f;
+        const float dz = g * act_bwd(z, act);
         a1[e] += dz; a2[e] += dz * x;
       }
     };
@@ -270,17 +282,19 @@ __device__ __forceinline__ void bn_bwd_reduce_block(const T* __restrict__ dy, co
     if constexpr (VEC > 1) {
       for (; r + stride < rows; r += 2 * stride) {          // two rows in flight per thread
         const int64_t o0 = r * C + c0, o1 = (r + stride) * C + c0;
-        Vec<T> d0, r0, p0, d1, r1, p1;
+        Vec<T> d0, r0, p0, q0, d1, r1, p1, q1;
         d0.load(dy + o0); r0.load(raw + o0); d1.load(dy + o1); r1.load(raw + o1);
         if (res_pre) { p0.load(res_pre + o0); p1.load(res_pre + o1); }
-        body(d0, r0, p0); body(d1, r1, p1);
+        if (res_post) { q0.load(res_post + o0); q1.load(res_post + o1); }
+        body(d0, r0, p0, q0); body(d1, r1, p1, q1);
       }
       for (; r < rows; r += stride) {
         const int64_t o0 = r * C + c0;
-        Vec<T> d0, r0, p0;
+        Vec<T> d0, r0, p0, q0;
         d0.load(dy + o0); r0.load(raw + o0);
         if (res_pre) p0.load(res_pre + o0);
-        body(d0, r0, p0);
+        if (res_post) q0.load(res_post + o0);
+        body(d0, r0, p0, q0);
       }
     } else {
       for (; r < rows; r += stride) {
@@ -288,7 +302,9 @@ __device__ __forceinline__ void bn_bwd_reduce_block(const T* __restrict__ dy, co
         const float x = ldf(raw + off);
         float z = x * sc[0] + sh[0];
         if (res_pre) z += ldf(res_pre + off);
-        const float dz = ldf(dy + off) * act_bwd(z, act);
+        float g = ldf(dy + off);
+        if (post && !(act_fwd(z, act) + (res_post ? ldf(res_post + off) : 0.f) > 0.f)) g = 0.f;
+        const float dz = g * act_bwd(z, act);
         a1[0] += dz; a2[0] += dz * x;
       }
     }
@@ -333,9 +349,9 @@ __device__ __forceinline__ void bn_bwd_reduce_block(const T* __restrict__ dy, co
 template <typename T, int VEC, bool DET>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
                                                             const T* __restrict__ res_pre, float* __restrict__ sums, int64_t rows, int C,
-                                                            int act, float* __restrict__ det_ws) {
+                                                            int act, float* __restrict__ det_ws, const T* __restrict__ res_post) {
   extern __shared__ float sacc[];                         // [2][C]  (DET: [256 / cols][2][cols * VEC])
-  bn_bwd_reduce_block<T, VEC, DET>(dy, raw, ss, res_pre, sums, rows, C, act, det_ws, blockIdx.x, blockIdx.y, gridDim.x, sacc);
+  bn_bwd_reduce_block<T, VEC, DET>(dy, raw, ss, res_pre, sums, rows, C, act, det_ws, blockIdx.x, blockIdx.y, gridDim.x, sacc, res_post);
 }
 struct ReduceItem { const void* dy; const void* raw; const float* ss; const void* rp; float* sums; int64_t rows; int C, act, gx; };
 struct ReduceGroup { ReduceItem it[RSSF_GROUP_MAX]; int start[RSSF_GROUP_MAX + 1]; int n; };
@@ -358,7 +374,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mi, const float* __restrict__ sums,
                                                            const T* __restrict__ res_pre, T* __restrict__ draw, T* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
-                                                           int act, float n, int training, float pscale) {
+                                                           int act, float n, int training, float pscale, const T* __restrict__ res_post,
+                                                           T* __restrict__ dpost) {
   const int allcols = C / VEC;
   const int colbase = blockIdx.y * 256;
   const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
@@ -370,12 +387,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
   int64_t r = (int64_t)blockIdx.x * rpb + rlocal;
   // the first row's operands and the per-channel constants are requested before the slot totals are folded, so that
   // the fold's load -> LDS -> barrier chain overlaps with them (each thread only sees a handful of rows)
-  Vec<T> vd, vr, vp;
+  Vec<T> vd, vr, vp, vq;
+  const bool post = (act & RSSF_ACT_POST_RELU) != 0;        // y = relu(act(z) + res_post): dpost = dy where y > 0, and dz from that
   bool have = active && r < rows;
   if constexpr (VEC > 1) {
     if (have) {
       vd.load(dy + r * C + c0); vr.load(raw + r * C + c0);
       if (res_pre) vp.load(res_pre + r * C + c0);
+      if (res_post) vq.load(res_post + r * C + c0);
     }
   }
   float sc[VEC], sh[VEC], mean[VEC], istd[VEC], k1[VEC], k2[VEC], cb[VEC], cc[VEC];
@@ -411,18 +430,22 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     while (have) {
       const int64_t off = r * C + c0, rn = r + stride;
       const bool have_next = rn < rows;
-      Vec<T> nd, nr, np;
+      Vec<T> nd, nr, np, nq;
       if (have_next) {
         nd.load(dy + rn * C + c0); nr.load(raw + rn * C + c0);
         if (res_pre) np.load(res_pre + rn * C + c0);
+        if (res_post) nq.load(res_post + rn * C + c0);
       }
-      float o1[VEC], o2[VEC];
+      float o1[VEC], o2[VEC], o3[VEC];
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float x = vr.get(e);
         float z = fmaf(x, sc[e], sh[e]);                       // explicit: the fused forms (conv_wgrad.hip, conv_halo.hip) round alike
         if (res_pre) z += vp.get(e);
-        const float dz = vd.get(e) * act_bwd(z, act);
+        float g = vd.get(e);
+        if (post && !(act_fwd(z, act) + (res_post ? vq.get(e) : 0.f) > 0.f)) g = 0.f;
+        o3[e] = g;
+        const float dz = g * act_bwd(z, act);
         o2[e] = dz;
         o1[e] = training ? fmaf(sc[e], dz, fmaf(cb[e], x, cc[e])) : sc[e] * dz;
       }
@@ -430,7 +453,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
       w1.set_all(o1); w2.set_all(o2);
       w1.store(draw + off);
       if (dres) w2.store(dres + off);
-      vd = nd; vr = nr; vp = np; r = rn; have = have_next;
+      if (dpost) { Vec<T> w3; w3.set_all(o3); w3.store(dpost + off); }
+      vd = nd; vr = nr; vp = np; vq = nq; r = rn; have = have_next;
     }
   } else {
     for (; r < rows; r += stride) {
@@ -438,9 +462,12 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
       const float x = ldf(raw + off);
       float z = fmaf(x, sc[0], sh[0]);
       if (res_pre) z += ldf(res_pre + off);
-      const float dz = ldf(dy + off) * act_bwd(z, act);
+      float g = ldf(dy + off);
+      if (post && !(act_fwd(z, act) + (res_post ? ldf(res_post + off) : 0.f) > 0.f)) g = 0.f;
+      const float dz = g * act_bwd(z, act);
       stf(draw + off, training ? sc[0] * (dz - k1[0] - (x - mean[0]) * istd[0] * k2[0]) : sc[0] * dz);
       if (dres) stf(dres + off, dz);
+      if (dpost) stf(dpost + off, g);
     }
   }
 }
@@ -486,7 +513,7 @@ constexpr int REDUCE_MAX_BLOCKS = 512;
 
 template <typename T>
 int reduce_launch(const void* dy, const void* raw, const float* ss, const void* rp, float* sums, int64_t rows, int C, int act, float* det_ws,
-                  hipStream_t st) {
+                  hipStream_t st, const void* rq = nullptr) {
   constexpr int V = Vec<T>::N;
   const size_t sh = 2 * C * sizeof(float);
   const int vec = (C % V == 0) ? V : 1;
@@ -499,16 +526,16 @@ int reduce_launch(const void* dy, const void* raw, const float* ss, const void* 
   if (det_ws) {
     const size_t shd = (size_t)rpb * 2 * (cols < 256 ? cols : 256) * vec * sizeof(float);
     if (vec == V)
-      bn_bwd_reduce_kernel<T, V, true><<<grid, 256, shd, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, det_ws);
+      bn_bwd_reduce_kernel<T, V, true><<<grid, 256, shd, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, det_ws, (const T*)rq);
     else
-      bn_bwd_reduce_kernel<T, 1, true><<<grid, 256, shd, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, det_ws);
+      bn_bwd_reduce_kernel<T, 1, true><<<grid, 256, shd, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, det_ws, (const T*)rq);
     const int rc = check_launch("bn_bwd_reduce(det)");
     return rc ? rc : rssf::cv::launch_stats_fold(det_ws, blocks, C, sums, st);
   }
   if (vec == V)
-    bn_bwd_reduce_kernel<T, V, false><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, nullptr);
+    bn_bwd_reduce_kernel<T, V, false><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, nullptr, (const T*)rq);
   else
-    bn_bwd_reduce_kernel<T, 1, false><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, nullptr);
+    bn_bwd_reduce_kernel<T, 1, false><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, (const T*)rp, sums, rows, C, act, nullptr, (const T*)rq);
   return check_launch("bn_bwd_reduce");
 }
 
@@ -516,16 +543,16 @@ int reduce_launch(const void* dy, const void* raw, const float* ss, const void* 
 template <typename T>
 int bwd_apply_launch(const void* dy, const void* raw, const float* ss, const float* mi, const float* sums, const void* rp, void* draw,
                      void* dres, float* dgamma, float* dbeta, int64_t rows, int C, int act, float n, int training, float pscale,
-                     hipStream_t st) {
+                     hipStream_t st, const void* rq = nullptr, void* dpost = nullptr) {
   constexpr int V = Vec<T>::N;
   const dim3 grid = grid2d(rows, C, (C % V == 0) ? V : 1);
   const size_t sh = 2 * sizeof(float) * (C < 256 * V ? C : 256 * V);
   if (C % V == 0)
     bn_bwd_apply_kernel<T, V><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, dgamma,
-                                                    dbeta, rows, C, act, n, training, pscale);
+                                                    dbeta, rows, C, act, n, training, pscale, (const T*)rq, (T*)dpost);
   else
     bn_bwd_apply_kernel<T, 1><<<grid, 256, sh, st>>>((const T*)dy, (const T*)raw, ss, mi, sums, (const T*)rp, (T*)draw, (T*)dres, dgamma,
-                                                    dbeta, rows, C, act, n, training, pscale);
+                                                    dbeta, rows, C, act, n, training, pscale, (const T*)rq, (T*)dpost);
   return check_launch("bn_bwd_apply");
 }
 }  // namespace
@@ -542,7 +569,7 @@ extern "C" int rssf_bn_finalize(const float* stats, const float* gamma, const fl
 
 extern "C" int rssf_bn_apply(const void* raw, const float* scale_shift, const void* res_pre, const void* res_post, void* y, int64_t rows,
                              int C, int act, int dtype, void* stream) {
-  RSSF_REQUIRE(raw && scale_shift && y && rows > 0 && C > 0 && act >= 0 && act <= 2, "bn_apply: bad arguments");
+  RSSF_REQUIRE(raw && scale_shift && y && rows > 0 && C > 0 && act_ok(act), "bn_apply: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RSSF_F32) return apply_launch<float>(raw, scale_shift, res_pre, res_post, y, rows, C, act, st);
   if (dtype == RSSF_BF16) return apply_launch<bf16_t>(raw, scale_shift, res_pre, res_post, y, rows, C, act, st);
@@ -554,7 +581,7 @@ extern "C" int rssf_bn_finalize_apply(const void* raw, const float* stats, const
                                       float* running_var, float* mean_invstd, float* scale_shift, const void* res_pre,
                                       const void* res_post, void* y, int64_t rows, int C, int act, double n, float momentum, float eps,
                                       int training, int dtype, void* stream) {
-  RSSF_REQUIRE(raw && gamma && beta && mean_invstd && scale_shift && y && rows > 0 && C > 0 && act >= 0 && act <= 2,
+  RSSF_REQUIRE(raw && gamma && beta && mean_invstd && scale_shift && y && rows > 0 && C > 0 && act_ok(act),
                "bn_finalize_apply: bad arguments");
   RSSF_REQUIRE(training ? (stats != nullptr && n >= 1) : (running_mean && running_var), "bn_finalize_apply: missing statistics");
   hipStream_t st = (hipStream_t)stream;
@@ -577,6 +604,33 @@ extern "C" int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* 
   if (dtype == RSSF_F32) return reduce_launch<float>(dy, raw, scale_shift, res_pre, sums, rows, C, act, det_ws, st);
   if (dtype == RSSF_BF16) return reduce_launch<bf16_t>(dy, raw, scale_shift, res_pre, sums, rows, C, act, det_ws, st);
   set_error("bn_bwd_reduce: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}
+
+extern "C" int rssf_bn_bwd_reduce_post(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, const void* res_post,
+                                       float* sums, int64_t rows, int C, int act, float* det_ws, int dtype, void* stream) {
+  RSSF_REQUIRE(dy && raw && scale_shift && sums && rows > 0 && C > 0 && act_ok(act), "bn_bwd_reduce_post: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return reduce_launch<float>(dy, raw, scale_shift, res_pre, sums, rows, C, act, det_ws, st, res_post);
+  if (dtype == RSSF_BF16) return reduce_launch<bf16_t>(dy, raw, scale_shift, res_pre, sums, rows, C, act, det_ws, st, res_post);
+  set_error("bn_bwd_reduce_post: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}
+
+extern "C" int rssf_bn_bwd_apply_post(const void* dy, const void* raw, const float* scale_shift, const float* mean_invstd, const float* sums,
+                                      const void* res_pre, const void* res_post, void* draw, void* dres, void* dpost, float* dgamma,
+                                      float* dbeta, int64_t rows, int C, int act, double n, int training, float param_grad_scale, int dtype,
+                                      void* stream) {
+  RSSF_REQUIRE(dy && raw && scale_shift && mean_invstd && sums && draw && rows > 0 && C > 0 && act_ok(act), "bn_bwd_apply_post: bad arguments");
+  RSSF_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_apply_post: dgamma and dbeta go together");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32)
+    return bwd_apply_launch<float>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, dgamma, dbeta, rows, C, act, (float)n,
+                                   training, param_grad_scale, st, res_post, dpost);
+  if (dtype == RSSF_BF16)
+    return bwd_apply_launch<bf16_t>(dy, raw, scale_shift, mean_invstd, sums, res_pre, draw, dres, dgamma, dbeta, rows, C, act, (float)n,
+                                    training, param_grad_scale, st, res_post, dpost);
+  set_error("bn_bwd_apply_post: unsupported dtype %d", dtype);
   return RSSF_ERR_UNSUPPORTED;
 }
 
@@ -647,7 +701,7 @@ extern "C" int rssf_bn_finalize_apply_group(const rssf_bn_apply_item* items, int
   bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
   for (int i = 0; i < n; ++i) {
     const rssf_bn_apply_item& it = items[i];
-    RSSF_REQUIRE(it.raw && it.gamma && it.beta && it.mean_invstd && it.scale_shift && it.y && it.rows > 0 && it.C > 0 && it.act >= 0 && it.act <= 2,
+    RSSF_REQUIRE(it.raw && it.gamma && it.beta && it.mean_invstd && it.scale_shift && it.y && it.rows > 0 && it.C > 0 && act_ok(it.act),
                  "bn_finalize_apply_group: bad item %d", i);
     RSSF_REQUIRE(it.training ? (it.stats != nullptr && it.n >= 1) : (it.running_mean && it.running_var),
                  "bn_finalize_apply_group: missing statistics (item %d)", i);

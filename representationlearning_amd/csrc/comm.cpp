@@ -30,6 +30,7 @@ struct Rccl {
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(const void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   char why[256] = "";
 };
@@ -54,6 +55,7 @@ void bind(const char* path) {
   g_rccl.CommInitRank = (int (*)(void**, int, UniqueId, int))sym("ncclCommInitRank");
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+  g_rccl.CommCount = (int (*)(const void*, int*))sym("ncclCommCount");
   g_rccl.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
   if (!ok) g_rccl.handle = nullptr;
 }
@@ -110,6 +112,18 @@ extern "C" int rssf_comm_init(rssf_comm** comm, int rank, int world, const void*
 
 extern "C" int rssf_comm_rank(const rssf_comm* c) { return c ? c->rank : -1; }
 extern "C" int rssf_comm_world(const rssf_comm* c) { return c ? c->world : 0; }
+
+// what RCCL ITSELF says the communicator spans (ncclCommCount), not what the caller passed to rssf_comm_init: bench.py prints it
+// so that a multi-GPU line can be checked against "RCCL saw N ranks"
+extern "C" int rssf_comm_nranks(const rssf_comm* c) {
+  if (!c || !c->nccl) return 0;
+  const Rccl* r = rccl(nullptr);
+  if (!r) return 0;
+  int n = 0;
+  const int rc = r->CommCount(c->nccl, &n);
+  if (rc) { fail(r, rc, "ncclCommCount"); return -1; }
+  return n;
+}
 
 extern "C" int rssf_allreduce_bucket(void* buf, int64_t count, int dtype, rssf_comm* c, void* stream) {
   if (!c || !buf || count <= 0) { rssf::set_error("rssf_allreduce_bucket: bad arguments"); return RSSF_ERR_BAD_ARG; }

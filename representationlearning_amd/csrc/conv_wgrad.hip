@@ -776,9 +776,9 @@ __global__ void __launch_bounds__(HWG_THREADS, 4) conv3x3_wgrad_halo_group_kerne
 }
 
 // spatial tiles per block: 8 when that still yields >= 256 blocks, fewer for small problems
-int halo_tiles_per_block(int64_t ntiles, int npairs) {
-  int tpb = 8;
-  while (tpb > 1 && ((ntiles + tpb - 1) / tpb) * npairs < 256) tpb >>= 1;
+int halo_tiles_per_block(int64_t ntiles, int npairs, int max_tpb = 8, int min_blocks = 256) {
+  int tpb = max_tpb;
+  while (tpb > 1 && ((ntiles + tpb - 1) / tpb) * npairs < min_blocks) tpb >>= 1;
   return tpb;
 }
 int halo_ksplit(int B, int H, int W, int Cout, int Cin) {
@@ -876,14 +876,14 @@ struct BnApply {               // arguments of rssf_bn_bwd_apply (see WgradHaloA
 struct XPreAct { const float* ss; int act; };
 // arguments of the halo-tiled kernel for one problem; ksplit_out = partial planes the second stage has to fold
 WgradHaloArgs make_wgrad_halo(const void* dout, const void* in, float* workspace, int B, int H, int W, int Cin, int Cout, const BnApply* bn,
-                              const XPreAct* xpre, int& ksplit_out) {
+                              const XPreAct* xpre, int& ksplit_out, int max_tpb = 8, int min_blocks = 256) {
   WgradHaloArgs h;
   memset(&h, 0, sizeof(h));
   h.dout = (const bf16_t*)dout; h.in = (const bf16_t*)in; h.partial = workspace;
   h.B = B; h.H = H; h.W = W; h.Cin = Cin; h.Cout = Cout;
   h.tiles_y = (H + HTH - 1) / HTH; h.tiles_x = (W + HTW - 1) / HTW; h.ntiles = B * h.tiles_y * h.tiles_x;
   h.ptiles_n = (Cin + HCT - 1) / HCT; h.npairs = ((Cout + HCT - 1) / HCT) * h.ptiles_n;
-  h.tiles_per_block = halo_tiles_per_block(h.ntiles, h.npairs);
+  h.tiles_per_block = halo_tiles_per_block(h.ntiles, h.npairs, max_tpb, min_blocks);
   ksplit_out = (h.ntiles + h.tiles_per_block - 1) / h.tiles_per_block;
   h.total = (int64_t)ksplit_out * h.npairs;
   h.xcd_per = xcd_per(h.total);
@@ -1026,8 +1026,12 @@ extern "C" int rssf_conv3x3_wgrad_group(const rssf_wgrad3x3_item* items, int n, 
                           it.bn_training, it.pscale};
       const XPreAct xp = {it.in_ss, it.in_act};
       int ksplit = 1;
+      // the problems of a group fill the chip TOGETHER: each may run longer tile runs per block (fewer split-K partial planes for
+      // the second stage to fold: 3.5 GB per step with runs of 8) as long as it keeps >= gmin blocks
+      static const int gtpb = getenv("RSSF_GROUP_WGRAD_TPB") ? atoi(getenv("RSSF_GROUP_WGRAD_TPB")) : 16;
+      static const int gmin = getenv("RSSF_GROUP_WGRAD_MINBLK") ? atoi(getenv("RSSF_GROUP_WGRAD_MINBLK")) : 128;
       g.it[i] = make_wgrad_halo(it.bn_dy ? it.draw : it.dout, it.in, it.workspace, it.B, it.H, it.W, it.Cin, it.Cout, it.bn_dy ? &bn : nullptr,
-                                it.in_ss ? &xp : nullptr, ksplit);
+                                it.in_ss ? &xp : nullptr, ksplit, n >= 2 ? gtpb : 8, n >= 2 ? gmin : 256);
       g.start[i] = idx;
       idx += g.it[i].xcd_per;
       WgradArgs& a = ra[i];                          // what the second stage needs to know (make_job)

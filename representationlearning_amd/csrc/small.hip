@@ -26,6 +26,27 @@ __global__ void __launch_bounds__(256) vec_add_to3_kernel(const float* __restric
   if (d2) d2[i] += v;
 }
 
+// out = a + b over n elements (out may be a or b): the few sums of the step that no convolution / BatchNorm epilogue carries - the
+// running sums of a HighResolutionModule's fuse outputs (_hrnet_rssformer.py:424-435) and the gradient of a tensor that has both
+// convolution and non-convolution consumers (nnf._Fanout) - as the library's own launch: the training step holds no framework kernel
+template <typename T>
+__global__ void __launch_bounds__(256) add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t nvec, int64_t n) {
+  constexpr int V = Vec<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    Vec<T> x, y, o;
+    x.load(a + i * V); y.load(b + i * V);
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = x.get(e) + y.get(e);
+    o.set_all(v);
+    o.store(out + i * V);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - nvec * V)) {             // tail shorter than one vector
+    const int64_t i = nvec * V + threadIdx.x;
+    stf(out + i, ldf(a + i) + ldf(b + i));
+  }
+}
+
 // one thread per output pixel: C strided reads (coalesced across the threads of a row for NCHW sources), one 16-byte store
 template <typename T>
 __global__ void __launch_bounds__(256) image_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t npix, int HW, int W,
@@ -75,4 +96,19 @@ extern "C" int rssf_image_to_nhwc(const float* src, void* dst, int B, int C, int
     return RSSF_ERR_UNSUPPORTED;
   }
   return check_launch("image_to_nhwc");
+}
+
+extern "C" int rssf_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+  RSSF_REQUIRE(a && b && out && n > 0, "add: bad arguments");
+  RSSF_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "add: operands must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  const int64_t nvec = n / V;
+  int64_t blocks = (nvec + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (dtype == RSSF_BF16) add_kernel<bf16_t><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, nvec, n);
+  else if (dtype == RSSF_F32) add_kernel<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)a, (const float*)b, (float*)out, nvec, n);
+  else { set_error("add: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  return check_launch("add");
 }

@@ -193,6 +193,12 @@ class HighResolutionModule(nn.Module):
             rows.append(nn.ModuleList(row))
         return nn.ModuleList(rows)
 
+    def _transformer_relu(self, low, high):
+        """relu(transformer(low, high)) (:430-435): the ReLU rides in the block's last BatchNorm pass (no clamp / mask launches)."""
+        if isinstance(self.transformer, GeneralTransformerBlock) and isinstance(self.relu, nn.ReLU):
+            return self.transformer(low, high, post_relu=True)
+        return self.relu(self.transformer(low, high))
+
     def get_num_inchannels(self):
         return self.num_inchannels
 
@@ -246,11 +252,11 @@ class HighResolutionModule(nn.Module):
             low = None
             for j in range(1, nb):
                 if j == i:
-                    low = x[j] if low is None else low + x[j]
+                    low = x[j] if low is None else nnf.add(low, x[j])
                 elif j > i:
                     low = nnf.upsample_nearest_add(low, up[(i, j)], int(self.fuse_layers[i][j][2].scale_factor))
                 else:
-                    low = done[(i, j)] if low is None else low + done[(i, j)]
+                    low = done[(i, j)] if low is None else nnf.add(low, done[(i, j)])
             return low
 
         def fuse_rest():
@@ -309,7 +315,7 @@ class HighResolutionModule(nn.Module):
             its = [dict(x=x[j], conv=self.fuse_layers[0][j][0], bn=self.fuse_layers[0][j][1], act=nnf.ACT_NONE) for j in range(1, nb)]
             for j, t in zip(range(1, nb), nnf.conv_bn_act_group(its)):
                 up[(0, j)] = t
-            return self.relu(self.transformer(low_of(0), x[0]))
+            return self._transformer_relu(low_of(0), x[0])
 
         # as in the single-GPU path the outputs 1.. run beside output 0's transformer block, on a side stream whose SyncBN exchanges
         # travel on a communicator of their own (nnf.fork_side / Runtime.comm_side); without one, both run on this stream
@@ -346,16 +352,16 @@ class HighResolutionModule(nn.Module):
             low = None
             for j in range(1, self.num_branches):
                 if j == i:
-                    low = x[j] if low is None else low + x[j]
+                    low = x[j] if low is None else nnf.add(low, x[j])
                 elif j > i:      # 1x1 conv + BN, then nearest upsample fused with the running sum
                     fl = self.fuse_layers[i][j]
                     t = nnf.conv_bn_act(x[j], fl[0], fl[1], grad_accum=accs[j] if i > 0 else None)
                     low = nnf.upsample_nearest_add(low, t, int(fl[2].scale_factor))
                 else:
                     t = nnf.run_sequential(self.fuse_layers[i][j], x[j], grad_accum=accs[j])
-                    low = t if low is None else low + t
+                    low = t if low is None else nnf.add(low, t)
             if i == 0:
-                return self.relu(self.transformer(low, x[0]))     # residual comes from `low`; x[0] only feeds K/V (:430-431)
+                return self._transformer_relu(low, x[0])     # residual comes from `low`; x[0] only feeds K/V (:430-431)
             # relu(fuse[i][0](x[0]) + low) (:432-435): sum and ReLU ride in the last down-sampling conv's BatchNorm pass
             return nnf.run_sequential(self.fuse_layers[i][0], x[0], res_pre=low, act_last=nnf.ACT_RELU, grad_accum=accs[0])
 

@@ -34,7 +34,9 @@ class GeneralTransformerBlock(nn.Module):
         self.mlp = MlpDWBN(in_features=self.dim, hidden_features=int(self.dim * mlp_ratio), out_features=self.out_dim,
                            act_layer=act_layer, dw_act_layer=act_layer, drop=drop)
 
-    def forward(self, x, y, mask=None):
+    def forward(self, x, y, mask=None, post_relu=False):
+        """post_relu: relu() of the block's output inside the MLP's last BatchNorm pass (what HighResolutionModule.forward applies to
+        it, _hrnet_rssformer.py:435) - no separate clamp launch forward, no mask launch backward."""
         B, C, H, W = x.shape
         xt = x.permute(0, 2, 3, 1).reshape(B, H * W, C)          # free when x is channels-last
         yt = y.permute(0, 2, 3, 1).reshape(B, H * W, C)
@@ -47,7 +49,7 @@ class GeneralTransformerBlock(nn.Module):
                                                 *self.attn.attn.proj_params(), H, W, self.num_heads)
         # LN2 and the skip around the MLP as one node: the two gradients of x1 meet in the LayerNorm-backward launch
         z, skip = AG.LayerNormTokensRes.apply(x1, self.norm2.weight, self.norm2.bias)
-        x2 = self.mlp(z, H, W, residual=skip)        # x1 + Mlp(LN2(x1)), residual fused into the last BN/GELU pass
+        x2 = self.mlp(z, H, W, residual=skip, post_relu=post_relu)        # x1 + Mlp(LN2(x1)), residual fused into the last BN/GELU pass
         return x2.reshape(B, H, W, C).permute(0, 3, 1, 2)
 
     def extra_repr(self):

@@ -27,8 +27,9 @@ class MlpDWBN(nn.Module):
         self.act3 = act_layer()
         self.norm3 = nn.SyncBatchNorm(out_features)
 
-    def forward_nhwc(self, t, residual=None):
-        """t: logical NCHW tensor in channels_last memory; residual (optional) is added AFTER the last GELU."""
+    def forward_nhwc(self, t, residual=None, post_relu=False):
+        """t: logical NCHW tensor in channels_last memory; residual (optional) is added AFTER the last GELU; post_relu: a ReLU on that
+        sum (the one HighResolutionModule.forward puts behind the transformer block, _hrnet_rssformer.py:435) in the same pass."""
         for a in (self.act1, self.act2, self.act3):
             if not isinstance(a, nn.GELU):
                 raise NotImplementedError("MlpDWBN (HIP): GELU activations only (the RSSFormer configuration)")
@@ -36,9 +37,9 @@ class MlpDWBN(nn.Module):
         l1, l2 = nnf.bwd_stats_link(), nnf.bwd_stats_link()
         t = nnf.conv_bn_act(t, self.fc1, self.norm1, nnf.ACT_GELU, stats_out=l1)
         t = nnf.conv_bn_act(t, [self.dw, self.dw6, self.dw12], self.norm2, nnf.ACT_GELU, stats_out=l2, stats_in=l1)
-        return nnf.conv_bn_act(t, self.fc2, self.norm3, nnf.ACT_GELU, res_post=residual, stats_in=l2)
+        return nnf.conv_bn_act(t, self.fc2, self.norm3, nnf.ACT_GELU, res_post=residual, stats_in=l2, post_relu=post_relu)
 
-    def forward(self, x, H, W, residual=None):
+    def forward(self, x, H, W, residual=None, post_relu=False):
         if x.dim() != 3:
             raise RuntimeError("Unsupported input shape: {}".format(x.shape))
         B, N, C = x.shape
@@ -46,4 +47,4 @@ class MlpDWBN(nn.Module):
             raise RuntimeError("MlpDWBN (HIP): class-token inputs are not on the RSSFormer path")
         t = x.reshape(B, H, W, C).permute(0, 3, 1, 2)          # channels-last view, no copy
         r = None if residual is None else residual.reshape(B, H, W, -1).permute(0, 3, 1, 2)
-        return self.forward_nhwc(t, r).permute(0, 2, 3, 1).reshape(B, N, -1)
+        return self.forward_nhwc(t, r, post_relu).permute(0, 2, 3, 1).reshape(B, N, -1)

@@ -19,6 +19,7 @@ import torch.nn as nn
 from . import _lib as L
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT_POST_RELU = 16                        # RSSF_ACT_POST_RELU: y = relu(act(z) + res_post)
 BN_SLOTS, BN_BWD_SLOTS = 16, 8            # RSSF_BN_SLOTS / RSSF_BN_BWD_SLOTS of include/rssf.h
 
 
@@ -750,6 +751,44 @@ class GradAccum:
         self.stream = None          # stream the consumers accumulate on (the fan-out node may run on another one)
 
 
+def _dense(t):
+    """every element of the storage range exactly once (any dimension order): an element-wise kernel may walk it linearly"""
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)) or t.permute(
+        *sorted(range(t.dim()), key=lambda d: -t.stride(d))).is_contiguous()
+
+
+def _add_into(t, g):
+    """t += g in place with the library's own launch (same dtype, both dense in the same memory order), else torch's."""
+    if (t.is_cuda and g.dtype == t.dtype and t.dtype in (torch.float32, torch.bfloat16) and g.shape == t.shape and g.stride() == t.stride()
+            and _dense(t) and t.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0):
+        L.check(L.load().rssf_add(L.ptr(t), L.ptr(g), L.ptr(t), t.numel(), L.dtype_code(t), L.stream()), "rssf_add")
+        return t
+    return t.add_(g.to(t.dtype))
+
+
+class _Add(torch.autograd.Function):
+    """a + b of two activations of one shape / dtype / memory order (the running sums of a HighResolutionModule's fuse outputs,
+    _hrnet_rssformer.py:424-435); the gradient goes to both unchanged."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        L.check(L.load().rssf_add(L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.dtype_code(a), L.stream()), "rssf_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    """a + b; the library's launch where both operands are dense GPU tensors of one shape, dtype and memory order."""
+    if (a.is_cuda and a.dtype == b.dtype and a.dtype in (torch.float32, torch.bfloat16) and a.shape == b.shape and a.stride() == b.stride()
+            and _dense(a) and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        return _Add.apply(a, b)
+    return a + b
+
+
 class _Fanout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, acc):
@@ -768,7 +807,7 @@ class _Fanout(torch.autograd.Function):
                 cur.wait_stream(ctx.acc.stream)
                 buf.record_stream(cur)
         t = _nchw(buf)
-        return (t if g is None else t.add_(g.to(t.dtype))), None
+        return (t if g is None else _add_into(t, g)), None
 
 
 def fanout(x, n_conv_consumers):
@@ -919,6 +958,9 @@ class _ConvBNAct(torch.autograd.Function):
             L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi), L.ptr(ss),
                                                L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, n, momentum, eps, int(training), L.dtype_code(raw),
                                                L.stream()), "rssf_bn_finalize_apply")
+        if act & ACT_POST_RELU and (defer or (len(links) > 3 and links[3] is not None)):
+            raise RuntimeError("conv_bn_act: a ReLU behind res_post belongs to a layer without a BatchNorm-statistics link")
+        ctx.rq = rq if (act & ACT_POST_RELU) else None          # (held by the node: the residual stream is alive until the block's backward anyway)
         ctx.save_for_backward(xh, raw, ss, mi, rp, *weights)
         ctx.meta = (spec, act, training, n, exchanged, nbias, len(weights), res_pre is not None, res_post is not None, x.requires_grad)
         ctx.rt = rt
@@ -952,7 +994,16 @@ class _ConvBNAct(torch.autograd.Function):
         sums = None
         if so is not None:               # the consumer's data-gradient launch already summed {dz, dz*raw} (BnBwdLink)
             sums, so.raw, so.ss, so.rp, so.sums = so.sums, None, None, None, None
-        if sums is None:
+        post = bool(act & ACT_POST_RELU)       # y = relu(act(z) + res_post): the kernels mask dy where y <= 0 and hand back d(res_post)
+        rq = ctx.rq
+        if sums is None and post:
+            sums = _zeros(BN_BWD_SLOTS * 2 * C, raw.device, rt)
+            dws = None
+            if rt.deterministic:
+                dws = torch.empty(lib.rssf_bn_bwd_reduce_workspace_elems(rows, C), device=raw.device, dtype=torch.float32)
+            L.check(lib.rssf_bn_bwd_reduce_post(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(rq), L.ptr(sums), rows, C, act, L.ptr(dws),
+                                                L.dtype_code(raw), L.stream()), "rssf_bn_bwd_reduce_post")
+        elif sums is None:
             sums = _zeros(BN_BWD_SLOTS * 2 * C, raw.device, rt)
             dws = None
             if rt.deterministic:
@@ -994,11 +1045,17 @@ class _ConvBNAct(torch.autograd.Function):
         # the BatchNorm-backward apply rides in the weight-gradient launch where a kernel for that exists (rssf_conv_wgrad_bnapply:
         # the entry point falls back to the two launches itself); channel counts the kernels would see padded keep the two calls
         vch = 8 if raw.dtype == torch.bfloat16 else 4
-        fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0
+        fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0 and not post
         if xpre is not None and not fuse_apply:
             raise RuntimeError("conv_bn_act: a pre-activation input needs the fused weight-gradient path (can_defer_apply)")
+        dpost = None
         if fuse_apply:
             gbs = weight_grads((dyh, raw, ss, mi, sums, rp, dres, dgamma, dbeta, act, n, training, pscale))
+        elif post:
+            dpost = torch.empty_like(raw) if has_post else None
+            L.check(lib.rssf_bn_bwd_apply_post(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(rq), L.ptr(draw), L.ptr(dres),
+                                               L.ptr(dpost), L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), pscale, L.dtype_code(raw),
+                                               L.stream()), "rssf_bn_bwd_apply_post")
         else:
             L.check(lib.rssf_bn_bwd_apply(L.ptr(dyh), L.ptr(raw), L.ptr(ss), L.ptr(mi), L.ptr(sums), L.ptr(rp), L.ptr(draw), L.ptr(dres),
                                           L.ptr(dgamma), L.ptr(dbeta), rows, C, act, n, int(training), pscale, L.dtype_code(raw), L.stream()),
@@ -1028,7 +1085,8 @@ class _ConvBNAct(torch.autograd.Function):
         if not fuse_apply:
             gbs = weight_grads(None)
         gws = [grad_result(w, t[0], t[1], rt) for w, t in zip(p_weights, wt)]
-        return (dx, None if dres is None else _nchw(dres), dy if has_post else None, grad_result(p_gamma, dgamma, dg_direct, rt),
+        return (dx, None if dres is None else _nchw(dres), (dy if dpost is None else _nchw(dpost)) if has_post else None,
+                grad_result(p_gamma, dgamma, dg_direct, rt),
                 grad_result(p_beta, dbeta, db_direct, rt), None, None, None, None, None, None, None, None, None, None, *gws, *gbs)
 
 
@@ -1619,7 +1677,7 @@ def cgfl_loss(logits, labels, aux, ignore_index=-1):
 
 
 def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_sink=None, grad_deposit=None, grad_accum=None,
-                stats_out=None, stats_in=None, defer_apply=False):
+                stats_out=None, stats_in=None, defer_apply=False, post_relu=False):
     """convs: one nn.Conv2d or a list of up to 3 summed convs; bn: nn.BatchNorm2d / nn.SyncBatchNorm.
     grad_sink / grad_deposit: GradLink of a residual block (see GradLink); grad_accum: GradAccum of a multi-consumer input;
     stats_out / stats_in: BnBwdLink of this layer / of the layer that produced x (see BnBwdLink); defer_apply (needs stats_out): return
@@ -1636,6 +1694,8 @@ def conv_bn_act(x, convs, bn, act=ACT_NONE, res_pre=None, res_post=None, grad_si
     if biases and len(biases) != len(convs):
         raise NotImplementedError("conv_bn_act: either all or none of the summed convs carry a bias")
     mom = 0.1 if bn.momentum is None else bn.momentum
+    if post_relu:           # relu(act(bn(conv(x))) + res_post) in the layer's own BatchNorm pass (see ACT_POST_RELU)
+        act = act | ACT_POST_RELU
     return _ConvBNAct.apply(x, res_pre, res_post, bn.weight, bn.bias, bn.running_mean, bn.running_var, spec, act, training, mom, bn.eps,
                             sync, len(biases), (grad_sink, grad_deposit, grad_accum, stats_out, stats_in, bool(defer_apply)), *weights, *biases)
 

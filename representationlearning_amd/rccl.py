@@ -51,6 +51,10 @@ class Communicator:
         self._lib = lib
         self.n_syncbn = 0           # exchanges issued so far (reported by bench.py / checked by the DP tests)
 
+    def nranks(self):
+        """The rank count RCCL itself reports for this communicator (ncclCommCount)."""
+        return int(self._lib.rssf_comm_nranks(self._h))
+
     @staticmethod
     def _chk(t):
         if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:

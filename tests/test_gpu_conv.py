@@ -532,3 +532,38 @@ def test_lane_reductions_without_lds():
     assert out[7].long().tolist() == torch.cat([ar[1], br[1], ar[3], br[3]]).tolist()
     assert out[8].long().tolist() == torch.cat([a[:32], b[:32]]).tolist()
     assert out[9].long().tolist() == torch.cat([a[32:], b[32:]]).tolist()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [1, 2])
+def test_conv_bn_act_post_relu_and_add(dtype, act):
+    """relu(act(bn(conv(x))) + res_post) as ONE BatchNorm pass (RSSF_ACT_POST_RELU: HighResolutionModule's `relu(transformer(..))`,
+    _hrnet_rssformer.py:435, inside MlpDWBN's last layer) and its backward (rssf_bn_bwd_reduce_post / _apply_post: dy masked where
+    the output is <= 0, d(res_post) handed back), and rssf_add, against plain torch on the same values."""
+    from representationlearning_amd import nnf
+    conv, bn = _mk_conv(64, 32, 1, bias=True), _mk_bn(32)
+    conv_r, bn_r = _mk_conv(64, 32, 1, bias=True), _mk_bn(32)
+    conv, bn = conv.to(DEV), bn.to(DEV).train()
+    bn_r.train()
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 12, 10).to(dtype).float()
+    r = torch.randn(2, 32, 12, 10).to(dtype).float()
+    w = torch.randn(2, 32, 12, 10)
+    xr, rr = x.clone().requires_grad_(), r.clone().requires_grad_()
+    z = bn_r(conv_r(xr))
+    yr = F.relu((F.relu(z) if act == 1 else F.gelu(z)) + rr)
+    (yr * w).sum().backward()
+    xg = x.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    rg = r.to(DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    yg = nnf.conv_bn_act(xg, conv, bn, act, res_post=rg, post_relu=True)
+    (yg.float() * w.to(DEV)).sum().backward()
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(yg.detach().float().cpu(), yr.detach()) < tol
+    assert float((yg.detach() < 0).sum()) == 0
+    assert rel_err(xg.grad.float().cpu(), xr.grad) < 3 * tol
+    assert rel_err(rg.grad.float().cpu(), rr.grad) < tol
+    assert rel_err(conv.weight.grad.cpu(), conv_r.weight.grad) < 3 * tol
+    assert rel_err(bn.weight.grad.cpu(), bn_r.weight.grad) < 3 * tol and rel_err(bn.bias.grad.cpu(), bn_r.bias.grad) < 3 * tol
+    a, b = xg.detach(), torch.randn_like(xg)
+    s = nnf.add(a, b)
+    assert torch.equal(s, (a.float() + b.float()).to(dtype)) and s.stride() == a.stride()

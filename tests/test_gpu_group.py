@@ -185,8 +185,12 @@ def test_wgrad3x3_group_equals_single_launches(shapes, res, xpre):
                 L.check(lib.rssf_conv3x3_wgrad_group(ctypes.cast(one, ctypes.c_void_p), 1, L.RSSF_BF16, _stream()), "single")
         torch.cuda.synchronize()
         out[mode] = rec
-    for a, b in zip(out["group"], out["single"]):
-        if a is not None:
+    for k, (a, b) in enumerate(zip(out["group"], out["single"])):
+        if a is None:
+            continue
+        if k % 5 == 4:       # dw: a grouped launch may run longer tile runs per block (fewer split-K partials): another summation order
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+        else:
             assert torch.equal(a, b)
 
 
