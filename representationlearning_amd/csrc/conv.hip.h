@@ -80,6 +80,11 @@ struct HaloArgs {
 bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_halo(HaloArgs a, hipStream_t st);
 int launch_halo_group(HaloArgs* items, int n, hipStream_t st);      // n <= RSSF_GROUP_MAX problems as one grid
+// dilated two-ring tap sets on their pixel lattice (conv_lattice.hip): MlpDWBN's fused 17-tap sum, forward and data gradient (bf16)
+bool lattice_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
+int launch_lattice(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, const void* bn_raw,
+                   const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP,
+                   int CoutP, int ntaps, const int* dy, const int* dx, hipStream_t st);
 int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st);
 
 template <typename T> struct LdsPad;

@@ -1,0 +1,102 @@
+"""The lattice kernel of MlpDWBN's fused {1x1 + 3x3 dil 6 + 3x3 dil 12} convolution (csrc/conv_lattice.hip; reference
+ffn_block.py:226-228, 250-257) against the generic gather kernel on the same operands and against torch fp32 convolutions:
+forward with bias + fused BatchNorm statistics, data gradient with addend and with the producer's BatchNorm-backward statistics,
+on ragged maps (lattice classes of different sizes, several tiles per class) and at the benchmark geometry."""
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _convs(C, seed):
+    torch.manual_seed(seed)
+    return [nn.Conv2d(C, C, 1, 1).to(DEV), nn.Conv2d(C, C, 3, 1, padding=6, dilation=6).to(DEV),
+            nn.Conv2d(C, C, 3, 1, padding=12, dilation=12).to(DEV)]
+
+
+class _Switch:
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("RSSF_LATTICE")
+        os.environ["RSSF_LATTICE"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("RSSF_LATTICE", None)
+        else:
+            os.environ["RSSF_LATTICE"] = self.old
+
+
+SHAPES = [(1, 30, 26), (2, 67, 70), (1, 133, 140), (3, 6, 5), (2, 128, 128)]
+
+
+@pytest.mark.parametrize("B,H,W", SHAPES)
+def test_lattice_forward_matches_gather_and_torch(B, H, W):
+    from representationlearning_amd import nnf
+    from representationlearning_amd import _lib as L
+    C = 128
+    convs = _convs(C, 3)
+    spec = nnf.spec_of(convs)
+    weights = [c.weight.detach() for c in convs]
+    bias = sum(c.bias.detach() for c in convs).float().contiguous()
+    x = torch.randn(B, H, W, C, device=DEV).bfloat16()
+    nslots = nnf.BN_SLOTS
+    outs, stats = [], []
+    for on in (False, True):
+        with _Switch(on):
+            st = torch.zeros(nslots * 2 * C, device=DEV)
+            outs.append(nnf._conv_forward(spec, x, weights, bias, st))
+            stats.append(st.view(nslots, 2, C).sum(0))
+    torch.cuda.synchronize()
+    ref = sum(F.conv2d(x.permute(0, 3, 1, 2).float(), c.weight.detach().bfloat16().float(), None, 1, c.padding, c.dilation) for c in convs)
+    ref = (ref + bias.view(1, C, 1, 1)).permute(0, 2, 3, 1)
+    assert rel_err(outs[1].float().cpu(), ref.cpu()) < 6e-3            # bf16 output rounding (2^-9 relative, rms ~ 2e-3)
+    assert rel_err(outs[1].float().cpu(), outs[0].float().cpu()) < 3e-3   # same fp32 sums in another order, then the same rounding
+    assert rel_err(stats[1].cpu(), stats[0].cpu()) < 1e-4
+    n = B * H * W
+    assert rel_err(stats[1][0].cpu() / n, ref.reshape(-1, C).mean(0).cpu()) < 2e-2 or float(ref.mean().abs()) < 1e-3
+    assert rel_err(stats[1][1].cpu() / n, (ref.reshape(-1, C) ** 2).mean(0).cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,W", SHAPES)
+@pytest.mark.parametrize("act", [0, 2])
+def test_lattice_dgrad_matches_gather_and_torch(B, H, W, act):
+    """Data gradient (mirrored taps, transposed slabs) with an addend and the fused BatchNorm-backward statistics of the producer."""
+    from representationlearning_amd import nnf
+    from representationlearning_amd import _lib as L
+    C = 128
+    convs = _convs(C, 4)
+    spec = nnf.spec_of(convs)
+    weights = [c.weight.detach() for c in convs]
+    dout = torch.randn(B, H, W, C, device=DEV).bfloat16()
+    addend = torch.randn(B, H, W, C, device=DEV).bfloat16()
+    raw = torch.randn(B, H, W, C, device=DEV).bfloat16()
+    link = nnf.BnBwdLink()
+    link.raw, link.rp, link.act, link.C = raw, None, act, C
+    link.ss = torch.stack([torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.3]).contiguous()
+    res, sums = [], []
+    for on in (False, True):
+        with _Switch(on):
+            sm = torch.zeros(nnf.BN_BWD_SLOTS * 2 * C, device=DEV)
+            res.append(nnf._conv_dgrad(spec, dout, weights, (B, H, W, C), addend, bn=(link, sm)).clone())
+            sums.append(sm.view(nnf.BN_BWD_SLOTS, 2, C).sum(0))
+            res.append(nnf._conv_dgrad(spec, dout, weights, (B, H, W, C), None).clone())
+    torch.cuda.synchronize()
+    xr = torch.zeros(B, C, H, W, device=DEV, requires_grad=True)
+    y = sum(F.conv2d(xr, c.weight.detach().bfloat16().float(), None, 1, c.padding, c.dilation) for c in convs)
+    y.backward(dout.permute(0, 3, 1, 2).float())
+    ref = xr.grad.permute(0, 2, 3, 1)
+    assert rel_err(res[3].float().cpu(), ref.cpu()) < 6e-3
+    assert rel_err(res[3].float().cpu(), res[1].float().cpu()) < 3e-3
+    assert rel_err(res[2].float().cpu(), (ref + addend.float()).cpu()) < 6e-3
+    assert rel_err(res[2].float().cpu(), res[0].float().cpu()) < 3e-3
+    assert rel_err(sums[1].cpu(), sums[0].cpu()) < 2e-3                 # statistics of bf16 values that differ in the last bit here and there
