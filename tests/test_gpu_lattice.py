@@ -39,6 +39,22 @@ class _Switch:
 SHAPES = [(1, 30, 26), (2, 67, 70), (1, 133, 140), (3, 6, 5), (2, 128, 128)]
 
 
+@pytest.fixture(params=["whole", "quarter-tail"], autouse=True)
+def _tail_mode(request):
+    """Every case twice: as whole workgroups, and with a pretended 16-CU chip so that the remainder past the last full round takes the
+    quarter-workgroup path (32 output channels per workgroup) that the benchmark geometry uses for its last 64 of 576 tiles."""
+    old = os.environ.get("RSSF_LATTICE_CUS")
+    if request.param == "quarter-tail":
+        os.environ["RSSF_LATTICE_CUS"] = "16"
+    else:
+        os.environ.pop("RSSF_LATTICE_CUS", None)
+    yield
+    if old is None:
+        os.environ.pop("RSSF_LATTICE_CUS", None)
+    else:
+        os.environ["RSSF_LATTICE_CUS"] = old
+
+
 @pytest.mark.parametrize("B,H,W", SHAPES)
 def test_lattice_forward_matches_gather_and_torch(B, H, W):
     from representationlearning_amd import nnf
