@@ -130,10 +130,10 @@ int rssf_conv_pack(const float* w0, const float* w1, const float* w2, const int*
  * sums their weights into tap t's slab and the weight gradient writes tap t's gradient to each of them, so that a sum of
  * convolutions runs with one tap per DISTINCT offset (17 instead of 19 for the MLP). */
 /* Batched packing: ONE launch re-packs every convolution of the model (both layouts) after an optimizer step.
- * `jobs` is a DEVICE array of rssf_pack_job; `block_map` a DEVICE array of nblocks {job index, chunk index} pairs, one
- * per 1024-element chunk of each job's output (chunks of a job: ceil(packed_elems / 1024)). */
+ * `jobs` is a DEVICE array of rssf_pack_job; `block_map` a DEVICE array of nblocks {job index, tile index} pairs, one per
+ * (output channel, input channel) tile of each job (tiles of a job: rssf_conv_pack_job_blocks(); a block reads its tile's
+ * source rows once, with all kernel positions, and writes every tap's slab). */
 #define RSSF_MAX_TAPS 19
-#define RSSF_PACK_CHUNK 1024
 typedef struct rssf_pack_job {
   const float* w[3];              /* torch-layout fp32 sources (w[i] unused for i >= nsrc) */
   void* out;                      /* packed slabs [ntaps][rows_p][cols_p] of the batch dtype */
@@ -146,7 +146,8 @@ typedef struct rssf_pack_job {
 /* rows_p / cols_p of the packed slabs for a (rows, cols) weight matrix (rows = cout, or cin when transposed) */
 int rssf_conv_packed_rows(int rows);
 int rssf_conv_packed_cols(int cols, int dtype);
-/* (a job's packed image must stay below 2^31 elements: the kernel indexes it with 32-bit arithmetic) */
+int rssf_conv_pack_job_blocks(int rows_p, int cols_p, int transpose);
+/* (a job's packed image and its sources must stay below 2^31 elements: the kernel indexes them with 32-bit arithmetic) */
 int rssf_conv_pack_batch(const rssf_pack_job* jobs, const int* block_map, int nblocks, int dtype, void* stream);
 /* the gather convolution itself.  bias [Cout] optional; stats [RSSF_BN_SLOTS][2][Cout] optional: per-channel sum and sum of squares of
  * the OUTPUT (incl. bias) atomically accumulated for the BatchNorm that follows (fused statistics). */

@@ -27,7 +27,7 @@ class WinAttnBwdParams(ctypes.Structure):
         "dout", "dxhat", "dyhat", "domega", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv", "dwo", "dbo", "prod_ws")]
 
 
-MAX_TAPS, PACK_CHUNK = 19, 1024      # RSSF_MAX_TAPS, RSSF_PACK_CHUNK
+MAX_TAPS = 19      # RSSF_MAX_TAPS
 P2P_MAX_ITEMS, P2P_MAX_FLOATS = 8, 4096      # RSSF_P2P_MAX_ITEMS, RSSF_P2P_MAX_FLOATS
 
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "rssf_conv_packed_elems": (c_int64, [c_int, c_int, c_int, c_int]),
     "rssf_conv_packed_rows": (c_int, [c_int]),
     "rssf_conv_packed_cols": (c_int, [c_int, c_int]),
+    "rssf_conv_pack_job_blocks": (c_int, [c_int, c_int, c_int]),
     "rssf_conv_pack_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rssf_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_void_p, c_int, c_void_p]),

@@ -451,33 +451,58 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a, T* out) {
   }
 }
 
+// Batched packing, one launch for every convolution of the model.  A block owns a (co, ci) TILE of one job with ALL its taps: it reads
+// the tile's source rows once - for a fixed output channel the `ci x k x k` floats of the tile are contiguous - into LDS and writes
+// the tap slabs from there.  (The first form was indexed by OUTPUT element: consecutive threads read the source with a 36-byte
+// stride and the nine taps of a pixel sat in nine different blocks - 412 MB of line fetches for 120 MB of weights, 250 us per step.)
+// Tile: 16 co x 32 ci (forward layout, rows = co, runs of 32 ci = 64 bytes) or 32 co x 16 ci (transposed layout, rows = ci, runs of
+// 32 co).  Pad rows / columns of the packed image lie inside the tiles of the last row / column and are written as zeros.
+constexpr int PACK_TILE = 512;                           // (co, ci) pairs per block
 template <typename T>
 __global__ void __launch_bounds__(256) pack_batch_kernel(const rssf_pack_job* __restrict__ jobs, const int* __restrict__ block_map) {
   const rssf_pack_job& j = jobs[block_map[2 * blockIdx.x]];
-  // 32-bit index arithmetic (a packed image stays far below 2^31 elements - rssf_conv_pack_batch's caller sizes it - and the
-  // 64-bit divisions by run-time values were most of this kernel's 255 us per training step)
-  const unsigned total = (unsigned)j.ntaps * (unsigned)j.rows_p * (unsigned)j.cols_p;
-  const unsigned base = (unsigned)block_map[2 * blockIdx.x + 1] * (unsigned)RSSF_PACK_CHUNK;
-  const unsigned cols_p = (unsigned)j.cols_p, rows_p = (unsigned)j.rows_p;
-  T* out = reinterpret_cast<T*>(j.out);
-#pragma unroll
-  for (int u = 0; u < RSSF_PACK_CHUNK / 256; ++u) {
-    const unsigned i = base + u * 256 + threadIdx.x;
-    if (i >= total) break;
-    const unsigned rt = i / cols_p, col = i - rt * cols_p, t = rt / rows_p, row = rt - t * rows_p;
-    const unsigned co = j.transpose ? col : row, ci = j.transpose ? row : col;
-    float v = 0.f;
-    if (co < (unsigned)j.cout && ci < (unsigned)j.cin) {
-      const int s = j.src_of_tap[t], kk = j.ks[s] * j.ks[s];
-      const unsigned e0 = co * (unsigned)j.cin + ci;
-      v = j.w[s][e0 * (unsigned)kk + (unsigned)j.kpos_of_tap[t]];
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        const int s2 = j.alias_of_tap[t][e];
-        if (s2 >= 0) v += j.w[s2][e0 * (unsigned)(j.ks[s2] * j.ks[s2]) + (unsigned)j.alias_of_tap[t][e + 1]];
-      }
+  const unsigned tile = (unsigned)block_map[2 * blockIdx.x + 1];
+  const unsigned TC = j.transpose ? 32u : 16u, TI = j.transpose ? 16u : 32u;
+  const unsigned ci_p = (unsigned)(j.transpose ? j.rows_p : j.cols_p);
+  const unsigned tiles_i = (ci_p + TI - 1) / TI;
+  const unsigned co0 = (tile / tiles_i) * TC, ci0 = (tile % tiles_i) * TI;
+  const unsigned cout = (unsigned)j.cout, cin = (unsigned)j.cin;
+  __shared__ float sw[PACK_TILE * RSSF_MAX_TAPS + 3 * 32];
+  // per source: [co][ci][k] with an ODD row pitch (the transposed write phase walks co: a pitch of 144 floats would put 16 lanes on 2 banks)
+  unsigned sbase[3], pitch[3], kk[3];
+  unsigned base = 0;
+  for (int s = 0; s < 3; ++s) {
+    kk[s] = (unsigned)(j.ks[s] * j.ks[s]);
+    pitch[s] = (TI * kk[s]) | 1u;
+    sbase[s] = base;
+    if (s < j.nsrc) base += TC * pitch[s];
+  }
+  for (int s = 0; s < j.nsrc; ++s) {
+    const unsigned span = TI * kk[s];
+    const float* __restrict__ w = j.w[s];
+    for (unsigned e = threadIdx.x; e < TC * span; e += 256) {
+      const unsigned co = e / span, r = e - co * span, ci = r / kk[s];
+      const unsigned gco = co0 + co, gci = ci0 + ci;
+      sw[sbase[s] + co * pitch[s] + r] = (gco < cout && gci < cin) ? w[(gco * cin + ci0) * kk[s] + r] : 0.f;      // contiguous in r
     }
-    stf(out + i, v);
+  }
+  __syncthreads();
+  T* out = reinterpret_cast<T*>(j.out);
+  const unsigned rows_p = (unsigned)j.rows_p, cols_p = (unsigned)j.cols_p;
+  for (int t = 0; t < j.ntaps; ++t) {
+    const int s = j.src_of_tap[t];
+    const unsigned kp = (unsigned)j.kpos_of_tap[t];
+    const int s2 = j.alias_of_tap[t][0], s3 = j.alias_of_tap[t][2];
+#pragma unroll
+    for (unsigned e = threadIdx.x; e < PACK_TILE; e += 256) {
+      // consecutive threads: consecutive columns of the packed row
+      const unsigned co = j.transpose ? (e & 31u) : (e >> 5), ci = j.transpose ? (e >> 5) : (e & 31u);
+      const unsigned row = j.transpose ? ci0 + ci : co0 + co, col = j.transpose ? co0 + co : ci0 + ci;
+      float v = sw[sbase[s] + co * pitch[s] + ci * kk[s] + kp];
+      if (s2 >= 0) v += sw[sbase[s2] + co * pitch[s2] + ci * kk[s2] + (unsigned)j.alias_of_tap[t][1]];
+      if (s3 >= 0) v += sw[sbase[s3] + co * pitch[s3] + ci * kk[s3] + (unsigned)j.alias_of_tap[t][3]];
+      if (row < rows_p && col < cols_p) stf(out + ((unsigned)t * rows_p + row) * cols_p + col, v);
+    }
   }
 }
 
@@ -602,6 +627,11 @@ extern "C" int rssf_conv_packed_rows(int rows) { return (rows + pick_bn(rows) - 
 extern "C" int rssf_conv_packed_cols(int cols, int dtype) {
   const int bk = dtype == RSSF_BF16 ? MmaK<bf16_t>::BK : MmaK<float>::BK;
   return (cols + bk - 1) / bk * bk;
+}
+extern "C" int rssf_conv_pack_job_blocks(int rows_p, int cols_p, int transpose) {
+  const int co_p = transpose ? cols_p : rows_p, ci_p = transpose ? rows_p : cols_p;
+  const int tc = transpose ? 32 : 16, ti = transpose ? 16 : 32;
+  return ((co_p + tc - 1) / tc) * ((ci_p + ti - 1) / ti);
 }
 extern "C" int rssf_conv_pack_batch(const rssf_pack_job* jobs, const int* block_map, int nblocks, int dtype, void* stream) {
   RSSF_REQUIRE(jobs && block_map && nblocks > 0, "conv_pack_batch: bad arguments");

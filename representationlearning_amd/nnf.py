@@ -417,7 +417,7 @@ class PackPlan:
                     for e in range(4):
                         j.alias_of_tap[t][e] = spec.alias[t][e]
                 self.views[k] = flat[offs[i]:offs[i] + sizes[i]]
-                bmap += [(i, c) for c in range((sizes[i] + L.PACK_CHUNK - 1) // L.PACK_CHUNK)]
+                bmap += [(i, c) for c in range(lib.rssf_conv_pack_job_blocks(j.rows_p, j.cols_p, int(tr)))]
             jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             bmap_dev = torch.tensor(bmap, dtype=torch.int32).to(dev).contiguous()
             ptrs = [w.data_ptr() for k in keys for w in self.jobs[k][1]]

@@ -567,3 +567,35 @@ def test_conv_bn_act_post_relu_and_add(dtype, act):
     a, b = xg.detach(), torch.randn_like(xg)
     s = nnf.add(a, b)
     assert torch.equal(s, (a.float() + b.float()).to(dtype)) and s.stride() == a.stride()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batched_pack_equals_single_pack(dtype):
+    """rssf_conv_pack_batch (one launch for every convolution, a block per (co, ci) tile with all taps) writes exactly the images
+    rssf_conv_pack writes convolution by convolution: 3x3, 1x1, strided, the 3-channel stem and the 6-class head (pad rows / columns),
+    wide layers, and MlpDWBN's 17-tap sum with its summed centre taps - forward and transposed layouts."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(11)
+    layers = [[nn.Conv2d(32, 32, 3, 1, 1, bias=False)], [nn.Conv2d(3, 64, 3, 2, 1, bias=False)], [nn.Conv2d(480, 6, 1)], [nn.Conv2d(64, 128, 3, 2, 1, bias=False)],
+              [nn.Conv2d(256, 256, 3, 1, 1, bias=False)], [nn.Conv2d(18, 36, 3, 1, 1, bias=False)], [nn.Conv2d(32, 128, 1)], [nn.Conv2d(480, 480, 1, bias=False)],
+              [nn.Conv2d(128, 128, 1, 1), nn.Conv2d(128, 128, 3, 1, padding=6, dilation=6), nn.Conv2d(128, 128, 3, 1, padding=12, dilation=12)],
+              [nn.Conv2d(72, 72, 1, 1), nn.Conv2d(72, 72, 3, 1, padding=6, dilation=6), nn.Conv2d(72, 72, 3, 1, padding=12, dilation=12)]]
+    layers = [[c.to(DEV) for c in cs] for cs in layers]
+    plan = nnf.PackPlan()
+    plan.recording = True
+    keys = []
+    for cs in layers:
+        spec = nnf.spec_of(cs)
+        for tr in (False, True):
+            key = (id(spec), tr, dtype)
+            plan.record(key, spec, [c.weight.detach() for c in cs], tr, dtype)
+            keys.append((key, spec, cs, tr))
+    plan.recording = False
+    plan.build()
+    plan.refresh()
+    torch.cuda.synchronize()
+    for key, spec, cs, tr in keys:
+        single = nnf._pack(spec, [c.weight.detach() for c in cs], tr, dtype, torch.device(DEV), rt=nnf.Runtime())
+        got = plan.lookup(key)
+        assert got is not None and got.shape == single.shape
+        assert torch.equal(got, single), (tuple(cs[0].weight.shape), len(cs), tr)
