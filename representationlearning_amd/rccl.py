@@ -140,8 +140,23 @@ class P2PChannel:
         self.n_syncbn += 1
         nslots, items = layout if layout is not None else (1, [(0, stats.numel())])
         lib = self.ex._lib
-        for a in range(0, len(items), L.P2P_MAX_ITEMS):          # (a lock-step group of more than 8 layers: two kernels)
-            part = items[a:a + L.P2P_MAX_ITEMS]
+        # one kernel per run of items: at most P2P_MAX_ITEMS layers AND at most P2P_MAX_FLOATS values (rssf_p2p_exchange rejects
+        # more: a wider backbone or a longer lock-step group would otherwise raise in the middle of a step - ADVICE r3); a single
+        # layer above the window is named in the error
+        part, floats = [], 0
+        runs = []
+        for o, n in items:
+            if n > L.P2P_MAX_FLOATS:
+                raise RuntimeError("P2PChannel: a layer of %d statistics values exceeds the exchange window (%d floats); "
+                                   "use RSSF_SYNCBN=rccl for this model" % (n, L.P2P_MAX_FLOATS))
+            if part and (len(part) == L.P2P_MAX_ITEMS or floats + n > L.P2P_MAX_FLOATS):
+                runs.append(part)
+                part, floats = [], 0
+            part.append((o, n))
+            floats += n
+        if part:
+            runs.append(part)
+        for part in runs:
             offs = (ctypes.c_int * len(part))(*[o for o, _ in part])
             ns = (ctypes.c_int * len(part))(*[n for _, n in part])
             L.check(lib.rssf_p2p_exchange(self.ex._h, self.k, L.ptr(stats), offs, ns, len(part), nslots, L.stream()), "rssf_p2p_exchange")

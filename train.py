@@ -88,15 +88,22 @@ def build_loaders(cfg, args, rank, world, dtype):
 
 def latest_checkpoint(model_dir):
     """(step, model path, trainer-state path | None) of the newest `model-<step>.pth` in model_dir, or None."""
+    c = checkpoints(model_dir)
+    return c[0] if c else None
+
+
+def checkpoints(model_dir):
+    """Every `model-<step>.pth` of model_dir, newest first, as (step, model path, trainer-state path | None); None when there is none."""
     import glob
     import re
-    best = None
+    found = []
     for f in glob.glob(os.path.join(model_dir, "model-*.pth")):
         m = re.search(r"model-(\d+)\.pth$", f)
-        if m and (best is None or int(m.group(1)) > best[0]):
-            t = os.path.join(model_dir, "trainer-%s.pth" % m.group(1))
-            best = (int(m.group(1)), f, t if os.path.exists(t) else None)
-    return best
+        if m:
+            found.append((int(m.group(1)), f))
+    # newest first (the caller falls back to the next one when a file does not load: `resume()` below)
+    return [(step, f, os.path.join(model_dir, "trainer-%d.pth" % step) if os.path.exists(os.path.join(model_dir, "trainer-%d.pth" % step)) else None)
+            for step, f in sorted(found, reverse=True)] or None
 
 
 def save_checkpoint(model_dir, model, trainer):
@@ -106,8 +113,14 @@ def save_checkpoint(model_dir, model, trainer):
     os.makedirs(model_dir, exist_ok=True)
     flush_bn_counters(trainer)
     path = os.path.join(model_dir, "model-%d.pth" % trainer.it)
-    torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)
-    torch.save(trainer.state_dict(), os.path.join(model_dir, "trainer-%d.pth" % trainer.it))
+
+    def atomic_save(obj, dst):       # a reader (the auto-resume of the next start) sees the old file or the complete new one
+        tmp = dst + ".tmp"
+        torch.save(obj, tmp)
+        os.replace(tmp, dst)
+    # trainer state first, model last: the model file's appearance is what makes the step resumable
+    atomic_save(trainer.state_dict(), os.path.join(model_dir, "trainer-%d.pth" % trainer.it))
+    atomic_save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)
     return path
 
 
@@ -143,10 +156,19 @@ def main():
     num_iters = args.iters if args.iters is not None else tr.num_iters
     log = print if rank == 0 else (lambda *a, **k: None)
     model = registry.MODEL[cfg.model.type](cfg.model.params).cuda()
-    resume = None if args.no_resume else latest_checkpoint(args.model_dir)
-    if resume is not None:           # the model BEFORE the trainer re-seats its parameters into the flat buffer
-        sd = torch.load(resume[1], map_location="cpu")
+    resume = None
+    for cand in ([] if args.no_resume else (checkpoints(args.model_dir) or [])):
+        # newest first; a file that does not load (a run killed in the middle of a save that predates the atomic rename, a full disk)
+        # is skipped with a warning instead of stopping every later start
+        try:
+            sd = torch.load(cand[1], map_location="cpu")
+        except Exception as e:       # noqa: BLE001 - any unreadable file is skipped
+            log("skipping unreadable checkpoint %s (%s: %s)" % (cand[1], type(e).__name__, str(e)[:200]))
+            continue
+        # the model BEFORE the trainer re-seats its parameters into the flat buffer
         model.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()})
+        resume = cand
+        break
     trainer = Trainer(model, base_lr=cfg.learning_rate.params.base_lr, momentum=cfg.optimizer.params.momentum,
                       weight_decay=cfg.optimizer.params.weight_decay, max_norm=cfg.optimizer.grad_clip.max_norm,
                       power=cfg.learning_rate.params.power, max_iters=cfg.learning_rate.params.max_iters, bf16=not args.fp32,
