@@ -146,7 +146,8 @@ typedef struct rssf_pack_job {
 /* rows_p / cols_p of the packed slabs for a (rows, cols) weight matrix (rows = cout, or cin when transposed) */
 int rssf_conv_packed_rows(int rows);
 int rssf_conv_packed_cols(int cols, int dtype);
-int rssf_conv_pack_job_blocks(int rows_p, int cols_p, int transpose);
+/* kk_total = sum over the job's sources of ks * ks (the tile shrinks with the number of kernel positions it holds) */
+int rssf_conv_pack_job_blocks(int rows_p, int cols_p, int transpose, int kk_total);
 /* (a job's packed image and its sources must stay below 2^31 elements: the kernel indexes them with 32-bit arithmetic) */
 int rssf_conv_pack_batch(const rssf_pack_job* jobs, const int* block_map, int nblocks, int dtype, void* stream);
 /* the gather convolution itself.  bias [Cout] optional; stats [RSSF_BN_SLOTS][2][Cout] optional: per-channel sum and sum of squares of

@@ -87,7 +87,7 @@ SIGNATURES = {
     "rssf_conv_packed_elems": (c_int64, [c_int, c_int, c_int, c_int]),
     "rssf_conv_packed_rows": (c_int, [c_int]),
     "rssf_conv_packed_cols": (c_int, [c_int, c_int]),
-    "rssf_conv_pack_job_blocks": (c_int, [c_int, c_int, c_int]),
+    "rssf_conv_pack_job_blocks": (c_int, [c_int, c_int, c_int, c_int]),
     "rssf_conv_pack_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rssf_conv_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                c_void_p, c_int, c_void_p]),

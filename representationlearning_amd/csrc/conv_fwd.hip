@@ -455,24 +455,41 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(PackArgs a, T* out) {
 // the tile's source rows once - for a fixed output channel the `ci x k x k` floats of the tile are contiguous - into LDS and writes
 // the tap slabs from there.  (The first form was indexed by OUTPUT element: consecutive threads read the source with a 36-byte
 // stride and the nine taps of a pixel sat in nine different blocks - 412 MB of line fetches for 120 MB of weights, 250 us per step.)
-// Tile: 16 co x 32 ci (forward layout, rows = co, runs of 32 ci = 64 bytes) or 32 co x 16 ci (transposed layout, rows = ci, runs of
-// 32 co).  Pad rows / columns of the packed image lie inside the tiles of the last row / column and are written as zeros.
-constexpr int PACK_TILE = 512;                           // (co, ci) pairs per block
+// Tile: 32 channels along the packed row (ci for the forward layout, co for the transposed one: 64-byte runs) x as many of the
+// other as fit 10 KB of LDS with all kernel positions (16 for 1x1, 8 for 3x3, 4 for the 19 positions of MlpDWBN's sum): the pass
+// is latency-bound - a global round trip, a barrier, the stores - and lives on resident blocks per CU (a 39 KB tile of 512 pairs
+// for every job left four: 221 us).  Pad rows / columns of the packed image lie inside the tiles of the last row / column: zeros.
+constexpr int PACK_LDS_FLOATS = 2560;
+// (co, ci) pairs of a tile: 512 for 1x1, 256 for 3x3, 128 for the 19 positions of the MLP sum, ... down to one 32-channel row (<= 80 positions)
+__host__ __device__ inline int pack_tile_pairs(int kk_total) {
+  int p = 512;
+  while (p > 32 && p * kk_total > PACK_LDS_FLOATS) p >>= 1;
+  return p;
+}
 template <typename T>
 __global__ void __launch_bounds__(256) pack_batch_kernel(const rssf_pack_job* __restrict__ jobs, const int* __restrict__ block_map) {
   const rssf_pack_job& j = jobs[block_map[2 * blockIdx.x]];
   const unsigned tile = (unsigned)block_map[2 * blockIdx.x + 1];
-  const unsigned TC = j.transpose ? 32u : 16u, TI = j.transpose ? 16u : 32u;
+  unsigned kk[3], kk_total = 0;
+  for (int s = 0; s < 3; ++s) { kk[s] = (unsigned)(j.ks[s] * j.ks[s]); if (s < j.nsrc) kk_total += kk[s]; }
+  const unsigned pairs = (unsigned)pack_tile_pairs((int)kk_total), other = pairs >> 5;       // 32 x `other` channels
+  const unsigned TC = j.transpose ? 32u : other, TI = j.transpose ? other : 32u;
   const unsigned ci_p = (unsigned)(j.transpose ? j.rows_p : j.cols_p);
   const unsigned tiles_i = (ci_p + TI - 1) / TI;
   const unsigned co0 = (tile / tiles_i) * TC, ci0 = (tile % tiles_i) * TI;
   const unsigned cout = (unsigned)j.cout, cin = (unsigned)j.cin;
-  __shared__ float sw[PACK_TILE * RSSF_MAX_TAPS + 3 * 32];
-  // per source: [co][ci][k] with an ODD row pitch (the transposed write phase walks co: a pitch of 144 floats would put 16 lanes on 2 banks)
-  unsigned sbase[3], pitch[3], kk[3];
+  __shared__ float sw[PACK_LDS_FLOATS + 3 * 32];
+  // the job's tap tables, once per block (read through the job pointer inside the tap loop they were two dependent scalar-memory
+  // round trips per tap in front of the stores)
+  __shared__ int stap[RSSF_MAX_TAPS][6];
+  if (threadIdx.x < RSSF_MAX_TAPS * 6) {
+    const int t = threadIdx.x / 6, f = threadIdx.x % 6;
+    stap[t][f] = f == 0 ? j.src_of_tap[t] : f == 1 ? j.kpos_of_tap[t] : j.alias_of_tap[t][f - 2];
+  }
+  // per source: [co][ci][k] with an ODD row pitch (the transposed write phase walks co: an even pitch would put 32 lanes on few banks)
+  unsigned sbase[3], pitch[3];
   unsigned base = 0;
   for (int s = 0; s < 3; ++s) {
-    kk[s] = (unsigned)(j.ks[s] * j.ks[s]);
     pitch[s] = (TI * kk[s]) | 1u;
     sbase[s] = base;
     if (s < j.nsrc) base += TC * pitch[s];
@@ -480,27 +497,42 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const rssf_pack_job* __
   for (int s = 0; s < j.nsrc; ++s) {
     const unsigned span = TI * kk[s];
     const float* __restrict__ w = j.w[s];
-    for (unsigned e = threadIdx.x; e < TC * span; e += 256) {
-      const unsigned co = e / span, r = e - co * span, ci = r / kk[s];
-      const unsigned gco = co0 + co, gci = ci0 + ci;
-      sw[sbase[s] + co * pitch[s] + r] = (gco < cout && gci < cin) ? w[(gco * cin + ci0) * kk[s] + r] : 0.f;      // contiguous in r
+    // e -> (co, r = ci * kk + k): quotients of small integers through a float reciprocal (exact below 2^22: + 0.5 keeps the product
+    // off the integer boundaries); all of a thread's loads are in flight together (a loop over co serialised the round trips: 339 us)
+    const float inv_span = 1.0f / (float)span, inv_kk = 1.0f / (float)kk[s];
+    // all of a thread's loads first, then its LDS stores: as one loop (load, store, next) the round trips ran one after the other
+    constexpr int NV = (PACK_LDS_FLOATS + 255) / 256;
+    float v[NV];
+    unsigned dst[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const unsigned e = threadIdx.x + (unsigned)k * 256u;
+      const unsigned co = (unsigned)(((float)e + 0.5f) * inv_span), r = e - co * span;
+      const unsigned ci = (unsigned)(((float)r + 0.5f) * inv_kk);
+      const unsigned gco = co0 + co;
+      const bool in = e < TC * span;
+      dst[k] = in ? sbase[s] + co * pitch[s] + r : 0xffffffffu;
+      v[k] = (in && gco < cout && ci0 + ci < cin) ? w[(gco * cin + ci0) * kk[s] + r] : 0.f;      // contiguous in r
     }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (dst[k] != 0xffffffffu) sw[dst[k]] = v[k];
   }
   __syncthreads();
   T* out = reinterpret_cast<T*>(j.out);
   const unsigned rows_p = (unsigned)j.rows_p, cols_p = (unsigned)j.cols_p;
   for (int t = 0; t < j.ntaps; ++t) {
-    const int s = j.src_of_tap[t];
-    const unsigned kp = (unsigned)j.kpos_of_tap[t];
-    const int s2 = j.alias_of_tap[t][0], s3 = j.alias_of_tap[t][2];
-#pragma unroll
-    for (unsigned e = threadIdx.x; e < PACK_TILE; e += 256) {
+    const int s = stap[t][0];
+    const unsigned kp = (unsigned)stap[t][1];
+    const int s2 = stap[t][2], s3 = stap[t][4];
+    const unsigned kp2 = (unsigned)stap[t][3], kp3 = (unsigned)stap[t][5];
+    for (unsigned e = threadIdx.x; e < pairs; e += 256) {
       // consecutive threads: consecutive columns of the packed row
       const unsigned co = j.transpose ? (e & 31u) : (e >> 5), ci = j.transpose ? (e >> 5) : (e & 31u);
       const unsigned row = j.transpose ? ci0 + ci : co0 + co, col = j.transpose ? co0 + co : ci0 + ci;
       float v = sw[sbase[s] + co * pitch[s] + ci * kk[s] + kp];
-      if (s2 >= 0) v += sw[sbase[s2] + co * pitch[s2] + ci * kk[s2] + (unsigned)j.alias_of_tap[t][1]];
-      if (s3 >= 0) v += sw[sbase[s3] + co * pitch[s3] + ci * kk[s3] + (unsigned)j.alias_of_tap[t][3]];
+      if (s2 >= 0) v += sw[sbase[s2] + co * pitch[s2] + ci * kk[s2] + kp2];
+      if (s3 >= 0) v += sw[sbase[s3] + co * pitch[s3] + ci * kk[s3] + kp3];
       if (row < rows_p && col < cols_p) stf(out + ((unsigned)t * rows_p + row) * cols_p + col, v);
     }
   }
@@ -628,9 +660,11 @@ extern "C" int rssf_conv_packed_cols(int cols, int dtype) {
   const int bk = dtype == RSSF_BF16 ? MmaK<bf16_t>::BK : MmaK<float>::BK;
   return (cols + bk - 1) / bk * bk;
 }
-extern "C" int rssf_conv_pack_job_blocks(int rows_p, int cols_p, int transpose) {
+extern "C" int rssf_conv_pack_job_blocks(int rows_p, int cols_p, int transpose, int kk_total) {
+  if (kk_total < 1 || 32 * kk_total > PACK_LDS_FLOATS) return 0;      // too many kernel positions for the batched form: pack it singly
   const int co_p = transpose ? cols_p : rows_p, ci_p = transpose ? rows_p : cols_p;
-  const int tc = transpose ? 32 : 16, ti = transpose ? 16 : 32;
+  const int other = pack_tile_pairs(kk_total) / 32;
+  const int tc = transpose ? 32 : other, ti = transpose ? other : 32;
   return ((co_p + tc - 1) / tc) * ((ci_p + ti - 1) / ti);
 }
 extern "C" int rssf_conv_pack_batch(const rssf_pack_job* jobs, const int* block_map, int nblocks, int dtype, void* stream) {

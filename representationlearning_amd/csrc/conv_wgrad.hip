@@ -809,7 +809,8 @@ int pick_ksplit(int cout, int cin, int ntaps, int64_t M) {
   int64_t par = (int64_t)((cout + t - 1) / t) * ((cin + t - 1) / t);
   if (!taps_in_registers(cout, cin)) par *= ntaps;
   static const int blocks128 = getenv("RSSF_WGRAD_KS128") ? atoi(getenv("RSSF_WGRAD_KS128")) : 512;      // tuning sweeps only
-  int64_t ks = (t == 128 ? blocks128 : 1024) / par;  // measured on MI355X (tools/wgrad_bench.py sweep)
+  static const int blocks64 = getenv("RSSF_WGRAD_KS64") ? atoi(getenv("RSSF_WGRAD_KS64")) : 1024;       // tuning sweeps only
+  int64_t ks = (t == 128 ? blocks128 : blocks64) / par;  // measured on MI355X (tools/wgrad_bench.py sweep)
   const int64_t maxks = (M + 4 * KP - 1) / (4 * KP);
   if (ks > maxks) ks = maxks;
   if (ks < 1) ks = 1;

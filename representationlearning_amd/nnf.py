@@ -375,7 +375,8 @@ class PackPlan:
         self.recording = False
 
     def record(self, key, spec, weights, transpose, dtype):
-        if self.recording and key not in self.jobs and all(w.is_contiguous() and w.dtype == torch.float32 for w in weights):
+        if (self.recording and key not in self.jobs and all(w.is_contiguous() and w.dtype == torch.float32 for w in weights)
+                and 32 * sum(k * k for k in spec.ksizes[:len(weights)]) <= 2560):      # (rssf_conv_pack_job_blocks: what the batched form holds)
             self.jobs[key] = (spec, list(weights), transpose, dtype)
 
     def build(self):
@@ -417,7 +418,7 @@ class PackPlan:
                     for e in range(4):
                         j.alias_of_tap[t][e] = spec.alias[t][e]
                 self.views[k] = flat[offs[i]:offs[i] + sizes[i]]
-                bmap += [(i, c) for c in range(lib.rssf_conv_pack_job_blocks(j.rows_p, j.cols_p, int(tr)))]
+                bmap += [(i, c) for c in range(lib.rssf_conv_pack_job_blocks(j.rows_p, j.cols_p, int(tr), sum(k * k for k in spec.ksizes[:len(ws)])))]
             jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             bmap_dev = torch.tensor(bmap, dtype=torch.int32).to(dev).contiguous()
             ptrs = [w.data_ptr() for k in keys for w in self.jobs[k][1]]

@@ -198,7 +198,7 @@ def test_two_ranks_without_sync_bn_keep_local_statistics_except_mlp():
 
 
 def _p2p_worker(rank, port, out_dir, world=WORLD):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RSSF_P2P_TIMEOUT_MS="4000")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", RSSF_P2P_TIMEOUT_MS=str(4000 * max(1, world // 2)))      # the ranks share ONE GPU here: a spinning kernel waits for its peers' time slices (world 8 hit 4 s once in a full-suite run)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
