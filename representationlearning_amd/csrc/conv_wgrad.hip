@@ -397,6 +397,155 @@ __global__ void __launch_bounds__(512) conv_wgrad8_kernel(WgradArgs a) {
       }
 }
 
+// TWO taps per block (round 4).  With one tap per block every tap streams all of dout and of the input through its blocks: 17 x
+// 134 MB = 2.3 GB per launch of the MLP sum, L2 -> CU at 10 TB/s - that stream, not the transpose reads, is what the 223 us are
+// (the lattice kernel of conv_lattice.hip hit the same ceiling at 8 TB/s with its weight fragments).  Here the dout slab of a block
+// serves two taps (1.7 GB per launch), a wave keeps both taps' 64 x 32 accumulators (64 registers), and a K-step is 16 transpose
+// reads for 16 MFMAs instead of 12 for 8.  LDS: 2 x (1 + 2) slabs = 110 KB, one block of eight waves per CU; the grid is one round
+// of the chip (ksplit = CUs / tap groups).  An odd last tap runs with a second tap whose loads are out of range (zeros).
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wgrad8x2_kernel(WgradArgs a) {
+  using T = bf16_t;
+  using MK = MmaK<T>;
+  constexpr int TMN = 128, V = 8, LD = TMN + 16, CPR = TMN / V, CHUNKS = KP * CPR / 512, SLAB = KP * LD;
+  extern __shared__ __attribute__((aligned(16))) char smem_w[];
+  T* const S = reinterpret_cast<T*>(smem_w);               // [2 buffers][dout, x tap 0, x tap 1][KP * LD]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
+  const int64_t q = xcd_logical(blockIdx.x, a.xcd_per);
+  if (q >= (int64_t)a.inner * a.ksplit) return;
+  const unsigned q32 = (unsigned)q;
+  const int range = (int)(q32 / (unsigned)a.inner);
+  int bid = (int)(q32 - (unsigned)range * (unsigned)a.inner);
+  const int cit = bid % a.ctiles_n; bid /= a.ctiles_n;
+  const int cot = bid % a.ctiles_m; bid /= a.ctiles_m;
+  const int tapA = a.tap0 + 2 * bid, tapB = tapA + 1;
+  const bool hasB = tapB < a.tap0 + a.ntap;
+  const int co0 = cot * TMN, ci0 = cit * TMN;
+  const int64_t M = (int64_t)a.B * a.OH * a.OW;
+  const int64_t per = ((M + a.ksplit - 1) / a.ksplit + KP - 1) / KP * KP;
+  const int64_t kbeg = (int64_t)range * per, kend = kbeg + per < M ? kbeg + per : M;
+  const int wm = wave >> 2, wn = wave & 3;                   // 2 x 4 waves of 64 (co) x 32 (ci)
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dout), 0, (int)((int64_t)a.B * a.OH * a.OW * a.Cout * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)((int64_t)a.B * a.IH * a.IW * a.Cin * 2), 0x00020000);
+  const int dyA = a.taps.dy[tapA], dxA = a.taps.dx[tapA];
+  const int dyB = a.taps.dy[hasB ? tapB : tapA], dxB = a.taps.dx[hasB ? tapB : tapA];
+
+  f32x4 acc[2][4][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  int srow[CHUNKS], scol[CHUNKS], pix[CHUNKS], pb[CHUNKS], py[CHUNKS], px[CHUNKS];
+#pragma unroll
+  for (int c = 0; c < CHUNKS; ++c) {
+    const int id = tid + c * 512;
+    srow[c] = id / CPR; scol[c] = (id % CPR) * V;
+    pix[c] = (int)kbeg + srow[c];
+    pb[c] = pix[c] / (a.OH * a.OW);
+    const int rem = pix[c] % (a.OH * a.OW);
+    py[c] = rem / a.OW; px[c] = rem % a.OW;
+  }
+  struct Regs { u32x4 d[CHUNKS], xa[CHUNKS], xb[CHUNKS]; };
+  Regs R0, R1;
+  auto load = [&](Regs& R) {         // the slab the coordinate state points at, then advance the state by one slab
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      const bool pv = pix[c] < (int)kend;                                                  // past the range: zeros, never used
+      const int cho = co0 + scol[c], chi = ci0 + scol[c];
+      const int yy = py[c] * a.stride, xx = px[c] * a.stride;
+      const int syA = yy + dyA, sxA = xx + dxA, syB = yy + dyB, sxB = xx + dxB;
+      const bool dok = pv && cho < a.Cout;
+      const bool xokA = pv && syA >= 0 && syA < a.IH && sxA >= 0 && sxA < a.IW && chi < a.Cin;
+      const bool xokB = pv && hasB && syB >= 0 && syB < a.IH && sxB >= 0 && sxB < a.IW && chi < a.Cin;
+      const unsigned doff = (unsigned)(pix[c] * a.Cout + cho) * 2u;
+      const unsigned xoffA = (unsigned)(((pb[c] * a.IH + syA) * a.IW + sxA) * a.Cin + chi) * 2u;
+      const unsigned xoffB = (unsigned)(((pb[c] * a.IH + syB) * a.IW + sxB) * a.Cin + chi) * 2u;
+      R.d[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, dok ? doff : OOB, 0, 0));
+      R.xa[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xokA ? xoffA : OOB, 0, 0));
+      R.xb[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xokB ? xoffB : OOB, 0, 0));
+      pix[c] += KP; px[c] += KP;
+      while (px[c] >= a.OW) { px[c] -= a.OW; ++py[c]; }
+      while (py[c] >= a.OH) { py[c] -= a.OH; ++pb[c]; }
+    }
+  };
+  auto store = [&](const Regs& R, int b) {
+    T* base = S + b * 3 * SLAB;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; ++c) {
+      *reinterpret_cast<u32x4*>(base + srow[c] * LD + scol[c]) = R.d[c];
+      *reinterpret_cast<u32x4*>(base + SLAB + srow[c] * LD + scol[c]) = R.xa[c];
+      *reinterpret_cast<u32x4*>(base + 2 * SLAB + srow[c] * LD + scol[c]) = R.xb[c];
+    }
+  };
+  auto compute = [&](int b) {
+    const T* base = S + b * 3 * SLAB;
+#pragma unroll
+    for (int ks = 0; ks < KP; ks += MK::KSTEP) {
+      bf16x8 fa[4], fb[2][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = SlabFrag<T>::load(base, LD, ks, (wm * 4 + i) * 16, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[t][j] = SlabFrag<T>::load(base + (1 + t) * SLAB, LD, ks, (wn * 2 + j) * 16, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[t][i][j] = MK::mma(fa[i], fb[t][j], acc[t][i][j]);
+    }
+  };
+  const bool do_bias = a.dbias && tapA == a.tap0 && cit == 0;
+  float bsum = 0.f;
+  auto bias_rows = [&](int b) {
+    const T* base = S + b * 3 * SLAB;
+    const int col = tid & 127, r0 = (tid >> 7) * (KP / 4);
+#pragma unroll
+    for (int k = 0; k < KP / 4; ++k) bsum += ldf(base + (r0 + k) * LD + col);
+  };
+  const int nslabs = (int)((kend - kbeg + KP - 1) / KP), nrun = (nslabs + 1) & ~1;
+  load(R0); load(R1);
+  for (int s = 0; s < nrun; s += 2) {
+    store(R0, 0);
+    __syncthreads();               // buffer 0 complete; every wave is done computing out of buffer 1's previous contents
+    load(R0);
+    compute(0);
+    if (do_bias) bias_rows(0);
+    store(R1, 1);
+    __syncthreads();
+    load(R1);
+    compute(1);
+    if (do_bias) bias_rows(1);
+  }
+  if (do_bias) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(S);                  // [4][128]
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 128 && co0 + tid < a.Cout) atomicAdd(a.dbias + co0 + tid, (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]));
+  }
+  if (!a.partial) return;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t == 1 && !hasB) break;
+    const int tap = tapA + t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + (wm * 4 + i) * 16 + grp * 4 + r, ci = ci0 + (wn * 2 + j) * 16 + l15;
+          if (co < a.Cout && ci < a.Cin) a.partial[(((int64_t)range * a.ntaps_total + tap) * a.Cout + co) * a.Cin + ci] = acc[t][i][j][r];
+        }
+  }
+}
+constexpr size_t WG8X2_LDS = (size_t)2 * 3 * KP * (128 + 16) * 2;
+
 // second stage of the split-K reduction: dw[torch layout] += sum_k partial[k][tap][co][ci].  A block owns 128 consecutive
 // gradient elements (512-byte rows of the partial planes); its 8 thread groups walk interleaved k planes, fold through LDS, and
 // one thread per element does the (non-atomic) read-modify-write.
@@ -831,7 +980,21 @@ int launch_group(WgradArgs& a, int tap0, int ntap, hipStream_t st) {
     else conv_wgrad_kernel<T, TMN, (TMN == 32 ? 9 : 1), false><<<grid, 256, 0, st>>>(a);
   } else {
     static const bool wg8 = !(getenv("RSSF_WGRAD8") && getenv("RSSF_WGRAD8")[0] == '0');       // A/B switch (tools/wgrad_bench.py)
-    if (TMN == 128 && sizeof(T) == 2 && vok && a.partial && wg8) conv_wgrad8_kernel<<<grid, 512, 0, st>>>(a);
+    static const bool t2 = !(getenv("RSSF_WGRAD_T2") && getenv("RSSF_WGRAD_T2")[0] == '0');     // A/B switch: two taps per block
+    if (TMN == 128 && sizeof(T) == 2 && vok && a.partial && wg8 && t2 && ntap >= 2) {
+      // one round of the chip: tap groups x ksplit <= CUs (never more planes than the workspace was sized for)
+      static const int cus = [] { int d = 0, v = 256; (void)hipGetDevice(&d); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256; return v; }();
+      static hipError_t e2 = hipFuncSetAttribute((const void*)conv_wgrad8x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG8X2_LDS);
+      if (e2 != hipSuccess) { set_error("conv_wgrad8x2: cannot raise the LDS limit: %s", hipGetErrorString(e2)); return RSSF_ERR_LAUNCH; }
+      const int groups = (ntap + 1) / 2;
+      int ks = cus / (tiles * groups);
+      if (ks > a.ksplit) ks = a.ksplit;
+      if (ks < 1) ks = 1;
+      a.ksplit = ks;
+      a.inner = tiles * groups;
+      a.xcd_per = xcd_per((int64_t)a.inner * a.ksplit);
+      conv_wgrad8x2_kernel<<<dim3((unsigned)a.xcd_per * 8), 512, WG8X2_LDS, st>>>(a);
+    } else if (TMN == 128 && sizeof(T) == 2 && vok && a.partial && wg8) conv_wgrad8_kernel<<<grid, 512, 0, st>>>(a);
     else if (vok) conv_wgrad_kernel<T, TMN, 1, true><<<grid, 256, 0, st>>>(a);
     else conv_wgrad_kernel<T, TMN, 1, false><<<grid, 256, 0, st>>>(a);
   }
