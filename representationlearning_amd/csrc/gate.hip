@@ -41,29 +41,40 @@ __global__ void __launch_bounds__(256) gate_pool_fwd_kernel(const T* __restrict_
 // Vector form (N and C multiples of the 16-byte vector): a thread owns VEC consecutive view-pixels; for each
 // view-channel its VEC elements are one 16-byte load that lies inside ONE token row (so one {mean, rstd} pair), and the
 // (token, channel) of the next view-channel follows by adding N/C and N%C with a carry - no division in the loop.
-template <typename T>
-__global__ void __launch_bounds__(256) gate_pool_fwd_vec_kernel(const T* __restrict__ x, const T* __restrict__ y,
-                                                                const float* __restrict__ stx, const float* __restrict__ sty,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ pooled, int32_t* __restrict__ argmax,
-                                                                int B, int N, int C) {
+// PARTS waves share a run of 64 pixel groups, each walking a contiguous range of C / PARTS view-channels; the partial {sum, max,
+// argmax} are folded through LDS in channel order (strictly greater wins: the FIRST maximum, as the one-thread walk - and
+// torch.max - picks it).  With one thread per pixel group the launch was 256 blocks of 32 dependent 16-byte loads each: 23 us for
+// 33 MB at B = 16 (1.5 TB/s).
+template <typename T, int PARTS>
+__global__ void __launch_bounds__(64 * PARTS) gate_pool_fwd_vec_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                                       const float* __restrict__ stx, const float* __restrict__ sty,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                       float* __restrict__ pooled, int32_t* __restrict__ argmax,
+                                                                       int B, int N, int C) {
   constexpr int V = Vec<T>::N;
+  __shared__ float ssum[PARTS > 1 ? PARTS - 1 : 1][64][V], smax[PARTS > 1 ? PARTS - 1 : 1][64][V];
+  __shared__ int sarg[PARTS > 1 ? PARTS - 1 : 1][64][V];
   const int nv = N / V;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (int64_t)B * 2 * nv) return;
-  const int p0 = (int)(gid % nv) * V;
-  const int s = (int)((gid / nv) % 2);
-  const int b = (int)(gid / (2 * (int64_t)nv));
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int64_t gid = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = gid < (int64_t)B * 2 * nv;
+  const int64_t g = live ? gid : 0;
+  const int p0 = (int)(g % nv) * V;
+  const int s = (int)((g / nv) % 2);
+  const int b = (int)(g / (2 * (int64_t)nv));
   const T* src = (s == 0 ? x : y) + (int64_t)b * N * C;
   const float2* st = reinterpret_cast<const float2*>((s == 0 ? stx : sty) + (int64_t)b * N * 2);
   const int qn = N / C, rn = N % C;
-  int n = p0 / C, c = p0 % C;
+  const int cper = C / PARTS, cp0 = part * cper;
+  // (token, channel) of view-channel cp0 at view-pixel p0: flat index cp0 * N + p0 of the [N][C] token tensor
+  const int64_t f0 = (int64_t)cp0 * N + p0;
+  int n = (int)(f0 / C), c = (int)(f0 % C);
   float sum[V], mx[V];
   int am[V];
 #pragma unroll
-  for (int i = 0; i < V; ++i) { sum[i] = 0.f; mx[i] = -INFINITY; am[i] = 0; }
+  for (int i = 0; i < V; ++i) { sum[i] = 0.f; mx[i] = -INFINITY; am[i] = cp0; }
 #pragma unroll 8
-  for (int cp = 0; cp < C; ++cp) {
+  for (int cp = cp0; cp < cp0 + cper; ++cp) {
     Vec<T> v;
     v.load(src + (int64_t)cp * N + p0);
     const float2 ms = st[n];
@@ -76,6 +87,22 @@ __global__ void __launch_bounds__(256) gate_pool_fwd_vec_kernel(const T* __restr
     n += qn; c += rn;
     if (c >= C) { c -= C; ++n; }
   }
+  if constexpr (PARTS > 1) {
+    if (part > 0) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) { ssum[part - 1][lane][i] = sum[i]; smax[part - 1][lane][i] = mx[i]; sarg[part - 1][lane][i] = am[i]; }
+    }
+    __syncthreads();
+    if (part > 0) return;
+#pragma unroll
+    for (int k = 0; k < PARTS - 1; ++k)
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        sum[i] += ssum[k][lane][i];
+        if (smax[k][lane][i] > mx[i]) { mx[i] = smax[k][lane][i]; am[i] = sarg[k][lane][i]; }
+      }
+  }
+  if (!live) return;
   float* pb = pooled + (int64_t)b * 4 * N;
   int32_t* ab = argmax + ((int64_t)b * 2 + s) * N;
 #pragma unroll
@@ -266,12 +293,13 @@ __global__ void __launch_bounds__(256) gate_pool_bwd_kernel(const float* __restr
 
 // Vector form: a thread owns V consecutive view-pixels of one stream, keeps their {d mean, d max, argmax} in registers and
 // walks the C view-channels (one 16-byte read-modify-write each): the [B][k][N] maps are read once, not C times.
-template <typename T>
-__global__ void __launch_bounds__(256) gate_pool_bwd_vec_kernel(const float* __restrict__ dpooled, const int32_t* __restrict__ argmax,
-                                                                T* __restrict__ dxhat, T* __restrict__ dyhat, int B, int N, int C) {
+template <typename T, int PARTS>
+__global__ void __launch_bounds__(64 * PARTS) gate_pool_bwd_vec_kernel(const float* __restrict__ dpooled, const int32_t* __restrict__ argmax,
+                                                                       T* __restrict__ dxhat, T* __restrict__ dyhat, int B, int N, int C) {
   constexpr int V = Vec<T>::N;
   const int nv = N / V;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;      // PARTS waves per run of 64 pixel groups: a channel range each
+  const int64_t gid = (int64_t)blockIdx.x * 64 + lane;
   if (gid >= (int64_t)B * 2 * nv) return;
   const int p0 = (int)(gid % nv) * V;
   const int s = (int)((gid / nv) % 2);
@@ -283,8 +311,9 @@ __global__ void __launch_bounds__(256) gate_pool_bwd_vec_kernel(const float* __r
 #pragma unroll
   for (int i = 0; i < V; ++i) { gmean[i] = dm[i] / C; gmax[i] = dm[N + i]; a[i] = am[i]; }
   T* dst = (s == 0 ? dxhat : dyhat) + (int64_t)b * N * C + p0;
+  const int cper = (C + PARTS - 1) / PARTS, cp0 = part * cper, cp1 = cp0 + cper < C ? cp0 + cper : C;
 #pragma unroll 8
-  for (int cp = 0; cp < C; ++cp) {
+  for (int cp = cp0; cp < cp1; ++cp) {
     Vec<T> v;
     v.load(dst + (int64_t)cp * N);
     float o[V];
@@ -307,13 +336,15 @@ extern "C" int rssf_gate_pool_fwd(const void* x, const void* y, const float* sta
   hipStream_t st = (hipStream_t)stream;
   const int V = dtype == RSSF_BF16 ? 8 : 4;
   if ((dtype == RSSF_F32 || dtype == RSSF_BF16) && N % V == 0 && C % V == 0) {
-    dim3 gv((unsigned)((total / V + 255) / 256));
-    if (dtype == RSSF_F32)
-      gate_pool_fwd_vec_kernel<float><<<gv, 256, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta, pooled,
-                                                          argmax, B, N, C);
-    else
-      gate_pool_fwd_vec_kernel<bf16_t><<<gv, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, stats_x, stats_y, gamma, beta, pooled,
-                                                           argmax, B, N, C);
+    dim3 gv((unsigned)((total / V + 63) / 64));                // 64 pixel groups per block
+    const bool split = C % 4 == 0;                               // four waves, a quarter of the view-channels each
+    if (dtype == RSSF_F32) {
+      if (split) gate_pool_fwd_vec_kernel<float, 4><<<gv, 256, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C);
+      else gate_pool_fwd_vec_kernel<float, 1><<<gv, 64, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C);
+    } else {
+      if (split) gate_pool_fwd_vec_kernel<bf16_t, 4><<<gv, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C);
+      else gate_pool_fwd_vec_kernel<bf16_t, 1><<<gv, 64, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C);
+    }
   } else if (dtype == RSSF_F32)
     gate_pool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta,
                                                        pooled, argmax, B, N, C);
@@ -367,9 +398,9 @@ extern "C" int rssf_gate_pool_bwd(const float* dpooled, const int32_t* argmax, v
   hipStream_t st = (hipStream_t)stream;
   const int V = dtype == RSSF_BF16 ? 8 : 4;
   if ((dtype == RSSF_F32 || dtype == RSSF_BF16) && N % V == 0) {
-    dim3 gv((unsigned)(((int64_t)B * 2 * (N / V) + 255) / 256));
-    if (dtype == RSSF_F32) gate_pool_bwd_vec_kernel<float><<<gv, 256, 0, st>>>(dpooled, argmax, (float*)dxhat, (float*)dyhat, B, N, C);
-    else gate_pool_bwd_vec_kernel<bf16_t><<<gv, 256, 0, st>>>(dpooled, argmax, (bf16_t*)dxhat, (bf16_t*)dyhat, B, N, C);
+    dim3 gv((unsigned)(((int64_t)B * 2 * (N / V) + 63) / 64));   // 64 pixel groups per block, four waves with a channel range each
+    if (dtype == RSSF_F32) gate_pool_bwd_vec_kernel<float, 4><<<gv, 256, 0, st>>>(dpooled, argmax, (float*)dxhat, (float*)dyhat, B, N, C);
+    else gate_pool_bwd_vec_kernel<bf16_t, 4><<<gv, 256, 0, st>>>(dpooled, argmax, (bf16_t*)dxhat, (bf16_t*)dyhat, B, N, C);
   } else if (dtype == RSSF_F32)
     gate_pool_bwd_kernel<float><<<grid, 256, 0, st>>>(dpooled, argmax, (float*)dxhat, (float*)dyhat, B, N, C);
   else if (dtype == RSSF_BF16)
