@@ -234,6 +234,8 @@ def _p2p_worker(rank, port, out_dir, world=WORLD):
     ch0, ch1 = ex.channel(0), ex.channel(1)
     side = torch.cuda.Stream()
     firsts = []
+    torch.cuda.synchronize()
+    dist.barrier()                                      # start together: the first exchange must not wait out a peer's start-up
     for it in range(5):                                 # eager, both channels in flight on two streams
         a, b = mine.clone(), mine.clone()
         side.wait_stream(torch.cuda.current_stream())
