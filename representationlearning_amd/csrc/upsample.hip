@@ -108,6 +108,61 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const T* __restrict__
   }
 }
 
+// Large factors (x 4, x 8: the neck's 32^2 and 16^2 branches resized to 128^2, hrnet_aux.py:61-65): an input pixel gathers from up
+// to 17 x 17 output pixels, and with one thread per (pixel, 16-byte channel chunk) that was a chain of ~290 loads on 512 blocks
+// (139 us for the 134 MB of the x 8 gradient).  Here a BLOCK owns one input pixel: 256 / cols row parts of `cols` chunk lanes each;
+// a part walks every R-th output row of the window (its lanes read one contiguous C-channel pixel per load), the parts' partial sums
+// are folded through LDS.  Same sums in another order (fp32 accumulation of weighted bf16 values).
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bilinear_bwd_rows_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int IH, int IW, int OH,
+                                                                int OW, int C, int ldw, float sy, float sx) {
+  __shared__ float sred[256 * VEC];
+  const int cols = C / VEC, R = 256 / cols;                  // cols divides 256 (the launcher checks)
+  const int cv = threadIdx.x % cols, r = threadIdx.x / cols;
+  int64_t p = blockIdx.x;
+  const int ix = (int)(p % IW); p /= IW;
+  const int iy = (int)(p % IH);
+  const int b = (int)(p / IH);
+  int oy_lo = (int)floorf((iy - 1) / sy), oy_hi = (int)ceilf((iy + 1) / sy);
+  int ox_lo = (int)floorf((ix - 1) / sx), ox_hi = (int)ceilf((ix + 1) / sx);
+  oy_lo = oy_lo < 0 ? 0 : oy_lo; oy_hi = oy_hi > OH - 1 ? OH - 1 : oy_hi;
+  ox_lo = ox_lo < 0 ? 0 : ox_lo; ox_hi = ox_hi > OW - 1 ? OW - 1 : ox_hi;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int oy = oy_lo + r; oy <= oy_hi; oy += R) {
+    const float fy = src_coord(oy, sy);
+    const int y0 = (int)fy, y1 = y0 + 1 < IH ? y0 + 1 : IH - 1;
+    const float wy = fy - y0;
+    const float cy = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+    if (cy == 0.f) continue;
+    const T* row = dout + (((int64_t)b * OH + oy) * OW) * ldw + cv * VEC;
+#pragma unroll 4
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float fx = src_coord(ox, sx);
+      const int x0 = (int)fx, x1 = x0 + 1 < IW ? x0 + 1 : IW - 1;
+      const float wx = fx - x0;
+      const float w = cy * ((x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f));
+      Vec<T> v;
+      v.load(row + (int64_t)ox * ldw);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += w * v.get(e);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) sred[threadIdx.x * VEC + e] = acc[e];
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < R; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += sred[(k * cols + cv) * VEC + e];
+    Vec<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+    o.store(din + (((int64_t)b * IH + iy) * IW + ix) * C + cv * VEC);
+  }
+}
+
 // ---- few-channel tensors (the 6-class logits of the head, x 4 up-sampling of hrnet_aux.py:80): ONE thread per pixel -------------
 // The vector kernels above need C % VEC == 0; their scalar instantiation spends a full set of coordinate / index arithmetic on
 // every single element (16 x 512 x 512 x 6: 120 us forward, 94 us backward = 0.4 TB/s).  Here a thread computes the coordinates
@@ -162,6 +217,8 @@ __global__ void __launch_bounds__(256) bilinear_fwd_px_kernel(const T* __restric
   }
 }
 
+// (four lanes per input pixel, every fourth window row each, folded by lane exchange, were measured: 98 against 87 us - the pass is
+// bound by its 16-byte pieces of 67 MB, not by the chain)
 template <typename T>
 __global__ void __launch_bounds__(256) bilinear_bwd_px_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int IH, int IW, int OH, int OW,
                                                               int C, int ldw, float sy, float sx) {
@@ -309,7 +366,11 @@ int bilinear_launch(const void* in, void* out, int B, int IH, int IW, int OH, in
     if (vec) bilinear_fwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
     else bilinear_fwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
   } else {
-    if (vec) bilinear_bwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
+    const int cols = vec ? C / V : 0;
+    // factor >= 4 (a window of >= 9 x 9 output pixels per input pixel): a block per input pixel, the window's rows over its threads
+    if (vec && sy > 0.f && sx > 0.f && sy <= 0.26f && sx <= 0.26f && cols >= 4 && cols <= 256 && 256 % cols == 0 && px < ((int64_t)1 << 31))
+      bilinear_bwd_rows_kernel<T, V><<<dim3((unsigned)px), 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
+    else if (vec) bilinear_bwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
     else bilinear_bwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
   }
   return check_launch(backward ? "upsample_bilinear_bwd" : "upsample_bilinear_fwd");
