@@ -1,0 +1,175 @@
+// Point-wise (1 x 1) convolution 32 -> 128 channels on channels-last bf16 activations as a STREAM (gfx950 MFMA): MlpDWBN's fc1
+// forward and fc2's data gradient (ffn_block.py:219-225, 246-249: Conv2d(C, 4C, 1) / the transpose of Conv2d(4C, C, 1)), 16 launches
+// of a training step.
+//
+// In the generic gather kernel (conv_fwd.hip) this shape is ONE K-step per block: a 128 x 128 tile runs its tap tables, two LDS
+// stagings, barriers and the LDS-transposed epilogue around 16 MFMAs per wave - 50 us (85 us with the fused BatchNorm-backward
+// statistics) for a pass that reads 17 MB and writes 67 MB.  Here nothing is staged: a wave keeps the whole [128][32] weight matrix
+// as eight register fragments and the bias as accumulator seeds, and walks 16-pixel tiles - a tile's 16 x 64 bytes are one
+// coalesced 1 KB load that IS the MFMA operand (lane = pixel x 8-channel group), eight MFMAs form the transposed result
+// (rows = output channels, column = pixel), so a lane holds four consecutive channels of one pixel per fragment: 8-byte stores.
+// The next tile's load is in flight under the current tile's MFMAs and stores.  Epilogue per wave: the per-channel sum / sum of
+// squares for the following BatchNorm (forward) or {sum dz, sum dz * raw} of the producer's BatchNorm backward (data gradient,
+// rssf_conv_gather_bnbwd) accumulate in registers across a wave's tiles, are folded over the 16 pixel lanes by DPP, over the
+// block's waves through LDS, and leave as one atomic per channel and block.
+#include <mutex>
+#include <type_traits>
+#include "conv.hip.h"
+using namespace rssf;
+using namespace rssf::cv;
+
+namespace rssf {
+namespace cv {
+
+namespace {
+
+constexpr int PW_K = 32, PW_N = 128, PW_NT = PW_N / 16;
+
+struct PwArgs {
+  const bf16_t* in; const bf16_t* wpk; bf16_t* out; const float* bias; float* stats;
+  const bf16_t* bn_raw; const bf16_t* bn_res; const float* bn_ss; float* bn_sums; int bn_act;
+  int64_t M;            // pixels
+  int CoutP, CinP;
+};
+
+// sum over the 16 lanes of a row (the pixels of a tile), result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);       // row_half_mirror
+  v += dpp_mov<0x140>(v);       // row_mirror
+  return v;
+}
+
+template <bool BNB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) conv_pw_k32_kernel(PwArgs a) {
+  __shared__ float sred[4][2][PW_N];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.in), 0, (int)(a.M * PW_K * 2), 0x00020000);
+  // weights: fragment j = output channels 16 j .. 16 j + 15 (lane: channel 16 j + l15, input channels 8 grp .. 8 grp + 7)
+  bf16x8 fw[PW_NT];
+#pragma unroll
+  for (int j = 0; j < PW_NT; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(a.wpk + (size_t)(j * 16 + l15) * a.CinP + grp * 8);
+  // accumulator seeds: the bias of this lane's four channels of every fragment
+  f32x4 seed[PW_NT];
+#pragma unroll
+  for (int j = 0; j < PW_NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) seed[j][r] = (!BNB && a.bias) ? a.bias[j * 16 + grp * 4 + r] : 0.f;      // (a data gradient has no bias)
+  // BatchNorm-backward statistics: scale / shift of the 128 channels in LDS, read per fragment (64 registers otherwise)
+  __shared__ __attribute__((aligned(16))) float sss[BNB ? 2 * PW_N : 4];
+  if constexpr (BNB) {
+    sss[tid] = a.bn_ss[tid];                                 // 256 threads: [scale 128][shift 128]
+    __syncthreads();
+  }
+  const bool want = BNB || a.stats != nullptr;
+  float s1[PW_NT * 4], s2[PW_NT * 4];
+#pragma unroll
+  for (int e = 0; e < PW_NT * 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+
+  const int64_t ntiles = (a.M + 15) / 16;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  constexpr unsigned OOB = 0x80000000u;
+  auto tile_off = [&](int64_t tt) -> unsigned {            // byte offset of this lane's 16-byte piece; past the end: zeros
+    const int64_t pix = tt * 16 + l15;
+    return (tt < ntiles && pix < a.M) ? (unsigned)(pix * PW_K * 2 + grp * 16) : OOB;
+  };
+  u32x4 xa = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, tile_off(t), 0, 0));
+  for (; t < ntiles; t += stride) {
+    const u32x4 xc = xa;
+    xa = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, tile_off(t + stride), 0, 0));      // unconditional: exact vmcnt
+    const int64_t pix = t * 16 + l15;
+    const bool pok = pix < a.M;
+    f32x4 acc[PW_NT];
+#pragma unroll
+    for (int j = 0; j < PW_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], __builtin_bit_cast(bf16x8, xc), seed[j], 0, 0, 0);
+    bf16_t* orow = a.out + pix * PW_N + grp * 4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    u32x2 rawv[BNB ? PW_NT : 1], resv[BNB ? PW_NT : 1];
+    if constexpr (BNB) {
+      if (pok) {
+#pragma unroll
+        for (int j = 0; j < PW_NT; ++j) {
+          rawv[j] = *reinterpret_cast<const u32x2*>(a.bn_raw + pix * PW_N + grp * 4 + j * 16);
+          if (a.bn_res) resv[j] = *reinterpret_cast<const u32x2*>(a.bn_res + pix * PW_N + grp * 4 + j * 16);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PW_NT; ++j) {
+      const u32x2 o = {f2bf2(acc[j][0], acc[j][1]), f2bf2(acc[j][2], acc[j][3])};
+      if (pok) *reinterpret_cast<u32x2*>(orow + j * 16) = o;
+      if (want && pok) {
+        if constexpr (BNB) {
+          // on the bf16 values just stored: what a separate pass would read
+          const f32x4 bsc4 = *reinterpret_cast<const f32x4*>(sss + j * 16 + grp * 4), bsh4 = *reinterpret_cast<const f32x4*>(sss + PW_N + j * 16 + grp * 4);
+          auto accumulate = [&](auto ACT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const unsigned ow = o[r >> 1], rw = rawv[j][r >> 1];
+              const float g = (r & 1) ? __uint_as_float(ow & 0xffff0000u) : __uint_as_float(ow << 16);
+              const float x = (r & 1) ? __uint_as_float(rw & 0xffff0000u) : __uint_as_float(rw << 16);
+              float z = fmaf(x, bsc4[r], bsh4[r]);
+              if (a.bn_res) { const unsigned pw = resv[j][r >> 1]; z += (r & 1) ? __uint_as_float(pw & 0xffff0000u) : __uint_as_float(pw << 16); }
+              const float dz = decltype(ACT)::value == 1 ? (z > 0.f ? g : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
+              s1[j * 4 + r] += dz; s2[j * 4 + r] = fmaf(dz, x, s2[j * 4 + r]);
+            }
+          };
+          if (a.bn_act == 1) accumulate(std::integral_constant<int, 1>{});
+          else if (a.bn_act == 2) accumulate(std::integral_constant<int, 2>{});
+          else accumulate(std::integral_constant<int, 0>{});
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = acc[j][r]; s1[j * 4 + r] += v; s2[j * 4 + r] = fmaf(v, v, s2[j * 4 + r]); }
+        }
+      }
+    }
+  }
+  if (!want) return;
+  // fold: the 16 pixel lanes of a row, then the block's waves, then one atomic per channel and sum
+#pragma unroll
+  for (int e = 0; e < PW_NT * 4; ++e) { s1[e] = row16_sum(s1[e]); s2[e] = row16_sum(s2[e]); }
+  if (l15 == 0) {
+#pragma unroll
+    for (int j = 0; j < PW_NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sred[wave][0][j * 16 + grp * 4 + r] = s1[j * 4 + r]; sred[wave][1][j * 16 + grp * 4 + r] = s2[j * 4 + r]; }
+  }
+  __syncthreads();
+  if (tid < PW_N) {
+    const float u1 = (sred[0][0][tid] + sred[1][0][tid]) + (sred[2][0][tid] + sred[3][0][tid]);
+    const float u2 = (sred[0][1][tid] + sred[1][1][tid]) + (sred[2][1][tid] + sred[3][1][tid]);
+    float* slot = BNB ? a.bn_sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * PW_N : a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * PW_N;
+    atomicAdd(slot + tid, u1);
+    atomicAdd(slot + PW_N + tid, u2);
+  }
+}
+
+}  // namespace
+
+bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx) {
+  const char* sw = getenv("RSSF_PW");                        // A/B switch, read per call (tests hold the two kernels against each other)
+  const bool enabled = !(sw && sw[0] == '0');
+  return enabled && ntaps == 1 && dy[0] == 0 && dx[0] == 0 && mul == 1 && div == 1 && IH == OH && IW == OW && Cin == PW_K && Cout == PW_N &&
+         (int64_t)B * IH * IW * PW_N < ((int64_t)1 << 30);
+}
+
+int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
+              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int CinP, int CoutP, hipStream_t st) {
+  PwArgs a;
+  a.in = (const bf16_t*)in; a.wpk = (const bf16_t*)wpk; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats;
+  a.bn_raw = (const bf16_t*)bn_raw; a.bn_res = (const bf16_t*)bn_res; a.bn_ss = bn_ss; a.bn_sums = bn_sums; a.bn_act = bn_act;
+  a.M = (int64_t)B * H * W; a.CoutP = CoutP; a.CinP = CinP;
+  const int64_t ntiles = (a.M + 15) / 16;
+  int64_t blocks = (ntiles + 3) / 4;
+  static const int maxb = getenv("RSSF_PW_BLOCKS") ? atoi(getenv("RSSF_PW_BLOCKS")) : 512;      // tuning (measured at 16 x 128^2: 512 blocks 17 / 36 us, 1 024: 20 / 39, 2 048: 25 / 45)
+  if (blocks > maxb) blocks = maxb;
+  if (bn_sums) conv_pw_k32_kernel<true><<<dim3((unsigned)blocks), 256, 0, st>>>(a);
+  else conv_pw_k32_kernel<false><<<dim3((unsigned)blocks), 256, 0, st>>>(a);
+  return check_launch("conv_pw");
+}
+
+}  // namespace cv
+}  // namespace rssf

@@ -116,3 +116,67 @@ def test_lattice_dgrad_matches_gather_and_torch(B, H, W, act):
     assert rel_err(res[2].float().cpu(), (ref + addend.float()).cpu()) < 6e-3
     assert rel_err(res[2].float().cpu(), res[0].float().cpu()) < 3e-3
     assert rel_err(sums[1].cpu(), sums[0].cpu()) < 2e-3                 # statistics of bf16 values that differ in the last bit here and there
+
+
+# ---- the point-wise 32 -> 128 stream kernel (csrc/conv_pw.hip) against the gather kernel --------------------------------------------
+class _PwSwitch(_Switch):
+    def __enter__(self):
+        self.old = os.environ.get("RSSF_PW")
+        os.environ["RSSF_PW"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("RSSF_PW", None)
+        else:
+            os.environ["RSSF_PW"] = self.old
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 7, 9), (2, 32, 32), (1, 128, 128), (3, 5, 5)])
+def test_pointwise_forward_matches_gather_and_torch(B, H, W):
+    """MlpDWBN's fc1 (ffn_block.py:219-221): Conv2d(32, 128, 1) with bias and the fused BatchNorm statistics; pixel counts that are
+    and are not multiples of the 16-pixel tile."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(7)
+    conv = nn.Conv2d(32, 128, 1).to(DEV)
+    spec = nnf.spec_of([conv])
+    x = torch.randn(B, H, W, 32, device=DEV).bfloat16()
+    outs, stats = [], []
+    for on in (False, True):
+        with _PwSwitch(on):
+            st = torch.zeros(nnf.BN_SLOTS * 2 * 128, device=DEV)
+            outs.append(nnf._conv_forward(spec, x, [conv.weight.detach()], conv.bias.detach().float().contiguous(), st))
+            stats.append(st.view(nnf.BN_SLOTS, 2, 128).sum(0))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).float(), conv.weight.detach().bfloat16().float(), conv.bias.detach().float()).permute(0, 2, 3, 1)
+    assert rel_err(outs[1].float().cpu(), ref.cpu()) < 4e-3
+    # (the bias is the MFMA's accumulator input here and an fp32 add after it there: the last bf16 bit may differ)
+    assert rel_err(outs[1].float().cpu(), outs[0].float().cpu()) < 2e-3
+    assert rel_err(stats[1].cpu(), stats[0].cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 7, 9), (2, 32, 32), (1, 128, 128)])
+@pytest.mark.parametrize("act,res", [(0, False), (2, False), (1, True)])
+def test_pointwise_dgrad_matches_gather(B, H, W, act, res):
+    """fc2's data gradient (the transpose of Conv2d(128, 32, 1), ffn_block.py:246-249) with the fused BatchNorm-backward statistics
+    of the layer before it."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(8)
+    conv = nn.Conv2d(128, 32, 1).to(DEV)
+    spec = nnf.spec_of([conv])
+    dout = torch.randn(B, H, W, 32, device=DEV).bfloat16()
+    link = nnf.BnBwdLink()
+    link.raw, link.act, link.C = torch.randn(B, H, W, 128, device=DEV).bfloat16(), act, 128
+    link.rp = torch.randn(B, H, W, 128, device=DEV).bfloat16() if res else None
+    link.ss = torch.stack([torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.3]).contiguous()
+    outs, sums, plain = [], [], []
+    for on in (False, True):
+        with _PwSwitch(on):
+            sm = torch.zeros(nnf.BN_BWD_SLOTS * 2 * 128, device=DEV)
+            outs.append(nnf._conv_dgrad(spec, dout, [conv.weight.detach()], (B, H, W, 128), None, bn=(link, sm)).clone())
+            sums.append(sm.view(nnf.BN_BWD_SLOTS, 2, 128).sum(0))
+            plain.append(nnf._conv_dgrad(spec, dout, [conv.weight.detach()], (B, H, W, 128), None).clone())
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(dout.permute(0, 3, 1, 2).float(), conv.weight.detach().bfloat16().float()).permute(0, 2, 3, 1)
+    assert rel_err(outs[1].float().cpu(), ref.cpu()) < 4e-3
+    assert torch.equal(outs[1], outs[0]) and torch.equal(plain[1], plain[0])
+    assert rel_err(sums[1].cpu(), sums[0].cpu()) < 1e-4
