@@ -23,7 +23,6 @@ namespace cv {
 
 namespace {
 
-constexpr int PW_K = 32, PW_N = 128, PW_NT = PW_N / 16;
 
 struct PwArgs {
   const bf16_t* in; const bf16_t* wpk; bf16_t* out; const float* bias; float* stats;
@@ -41,16 +40,20 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <bool BNB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) conv_pw_k32_kernel(PwArgs a) {
+// KS = input channels / 32 (K-steps), NT = output channels / 16 (fragments): (1, 8) = 32 -> 128, (4, 2) = 128 -> 32
+template <int KS, int NT, bool BNB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) conv_pw_kernel(PwArgs a) {
+  constexpr int PW_K = 32 * KS, PW_N = 16 * NT, PW_NT = NT;
   __shared__ float sred[4][2][PW_N];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.in), 0, (int)(a.M * PW_K * 2), 0x00020000);
   // weights: fragment j = output channels 16 j .. 16 j + 15 (lane: channel 16 j + l15, input channels 8 grp .. 8 grp + 7)
-  bf16x8 fw[PW_NT];
+  bf16x8 fw[PW_NT][KS];
 #pragma unroll
-  for (int j = 0; j < PW_NT; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(a.wpk + (size_t)(j * 16 + l15) * a.CinP + grp * 8);
+  for (int j = 0; j < PW_NT; ++j)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) fw[j][k] = *reinterpret_cast<const bf16x8*>(a.wpk + (size_t)(j * 16 + l15) * a.CinP + k * 32 + grp * 8);
   // accumulator seeds: the bias of this lane's four channels of every fragment
   f32x4 seed[PW_NT];
 #pragma unroll
@@ -60,7 +63,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
   // BatchNorm-backward statistics: scale / shift of the 128 channels in LDS, read per fragment (64 registers otherwise)
   __shared__ __attribute__((aligned(16))) float sss[BNB ? 2 * PW_N : 4];
   if constexpr (BNB) {
-    sss[tid] = a.bn_ss[tid];                                 // 256 threads: [scale 128][shift 128]
+    if (tid < 2 * PW_N) sss[tid] = a.bn_ss[tid];             // [scale N][shift N]
     __syncthreads();
   }
   const bool want = BNB || a.stats != nullptr;
@@ -72,19 +75,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t t = (int64_t)blockIdx.x * 4 + wave;
   constexpr unsigned OOB = 0x80000000u;
-  auto tile_off = [&](int64_t tt) -> unsigned {            // byte offset of this lane's 16-byte piece; past the end: zeros
+  auto tile_off = [&](int64_t tt) -> unsigned {            // byte offset of this lane's first 16-byte piece; past the end: zeros
     const int64_t pix = tt * 16 + l15;
     return (tt < ntiles && pix < a.M) ? (unsigned)(pix * PW_K * 2 + grp * 16) : OOB;
   };
-  u32x4 xa = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, tile_off(t), 0, 0));
+  u32x4 xa[KS];
+  {
+    const unsigned o0 = tile_off(t);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) xa[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, o0, k * 64, 0));
+  }
   for (; t < ntiles; t += stride) {
-    const u32x4 xc = xa;
-    xa = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, tile_off(t + stride), 0, 0));      // unconditional: exact vmcnt
+    u32x4 xc[KS];
+    const unsigned o1 = tile_off(t + stride);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      xc[k] = xa[k];
+      xa[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, o1, k * 64, 0));      // unconditional: exact vmcnt
+    }
     const int64_t pix = t * 16 + l15;
     const bool pok = pix < a.M;
     f32x4 acc[PW_NT];
 #pragma unroll
-    for (int j = 0; j < PW_NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], __builtin_bit_cast(bf16x8, xc), seed[j], 0, 0, 0);
+    for (int j = 0; j < PW_NT; ++j) {
+      acc[j] = seed[j];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][k], __builtin_bit_cast(bf16x8, xc[k]), acc[j], 0, 0, 0);
+    }
     bf16_t* orow = a.out + pix * PW_N + grp * 4;
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     u32x2 rawv[BNB ? PW_NT : 1], resv[BNB ? PW_NT : 1];
@@ -152,12 +169,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx) {
   const char* sw = getenv("RSSF_PW");                        // A/B switch, read per call (tests hold the two kernels against each other)
   const bool enabled = !(sw && sw[0] == '0');
-  return enabled && ntaps == 1 && dy[0] == 0 && dx[0] == 0 && mul == 1 && div == 1 && IH == OH && IW == OW && Cin == PW_K && Cout == PW_N &&
-         (int64_t)B * IH * IW * PW_N < ((int64_t)1 << 30);
+  return enabled && ntaps == 1 && dy[0] == 0 && dx[0] == 0 && mul == 1 && div == 1 && IH == OH && IW == OW &&
+         ((Cin == 32 && Cout == 128) || (Cin == 128 && Cout == 32)) && (int64_t)B * IH * IW * 128 < ((int64_t)1 << 30);
 }
 
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
-              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int CinP, int CoutP, hipStream_t st) {
+              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int CinP, int CoutP, hipStream_t st) {
   PwArgs a;
   a.in = (const bf16_t*)in; a.wpk = (const bf16_t*)wpk; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats;
   a.bn_raw = (const bf16_t*)bn_raw; a.bn_res = (const bf16_t*)bn_res; a.bn_ss = bn_ss; a.bn_sums = bn_sums; a.bn_act = bn_act;
@@ -166,8 +183,14 @@ int launch_pw(const void* in, const void* wpk, void* out, const float* bias, flo
   int64_t blocks = (ntiles + 3) / 4;
   static const int maxb = getenv("RSSF_PW_BLOCKS") ? atoi(getenv("RSSF_PW_BLOCKS")) : 512;      // tuning (measured at 16 x 128^2: 512 blocks 17 / 36 us, 1 024: 20 / 39, 2 048: 25 / 45)
   if (blocks > maxb) blocks = maxb;
-  if (bn_sums) conv_pw_k32_kernel<true><<<dim3((unsigned)blocks), 256, 0, st>>>(a);
-  else conv_pw_k32_kernel<false><<<dim3((unsigned)blocks), 256, 0, st>>>(a);
+  const dim3 grid((unsigned)blocks);
+  if (Cin == 32) {
+    if (bn_sums) conv_pw_kernel<1, 8, true><<<grid, 256, 0, st>>>(a);
+    else conv_pw_kernel<1, 8, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (bn_sums) conv_pw_kernel<4, 2, true><<<grid, 256, 0, st>>>(a);
+    else conv_pw_kernel<4, 2, false><<<grid, 256, 0, st>>>(a);
+  }
   return check_launch("conv_pw");
 }
 

@@ -180,3 +180,35 @@ def test_pointwise_dgrad_matches_gather(B, H, W, act, res):
     assert rel_err(outs[1].float().cpu(), ref.cpu()) < 4e-3
     assert torch.equal(outs[1], outs[0]) and torch.equal(plain[1], plain[0])
     assert rel_err(sums[1].cpu(), sums[0].cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 7, 9), (2, 32, 32), (1, 128, 128)])
+def test_pointwise_128_to_32_forward_and_dgrad(B, H, W):
+    """The other direction of the stream kernel: fc2 forward (Conv2d(128, 32, 1) with bias and fused statistics) and fc1's data
+    gradient (the transpose of Conv2d(32, 128, 1), plain and with fused BatchNorm-backward statistics)."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(9)
+    fc2, fc1 = nn.Conv2d(128, 32, 1).to(DEV), nn.Conv2d(32, 128, 1).to(DEV)
+    s2, s1 = nnf.spec_of([fc2]), nnf.spec_of([fc1])
+    x = torch.randn(B, H, W, 128, device=DEV).bfloat16()
+    link = nnf.BnBwdLink()
+    link.raw, link.rp, link.act, link.C = torch.randn(B, H, W, 32, device=DEV).bfloat16(), None, 1, 32
+    link.ss = torch.stack([torch.rand(32, device=DEV) + 0.5, torch.randn(32, device=DEV) * 0.3]).contiguous()
+    res = []
+    for on in (False, True):
+        with _PwSwitch(on):
+            st = torch.zeros(nnf.BN_SLOTS * 2 * 32, device=DEV)
+            sm = torch.zeros(nnf.BN_BWD_SLOTS * 2 * 32, device=DEV)
+            y = nnf._conv_forward(s2, x, [fc2.weight.detach()], fc2.bias.detach().float().contiguous(), st)
+            d0 = nnf._conv_dgrad(s1, x, [fc1.weight.detach()], (B, H, W, 32), None).clone()
+            d1 = nnf._conv_dgrad(s1, x, [fc1.weight.detach()], (B, H, W, 32), None, bn=(link, sm)).clone()
+            res.append((y, st.view(nnf.BN_SLOTS, 2, 32).sum(0), d0, d1, sm.view(nnf.BN_BWD_SLOTS, 2, 32).sum(0)))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).float(), fc2.weight.detach().bfloat16().float(), fc2.bias.detach().float()).permute(0, 2, 3, 1)
+    refd = F.conv_transpose2d(x.permute(0, 3, 1, 2).float(), fc1.weight.detach().bfloat16().float()).permute(0, 2, 3, 1)
+    (y0, st0, a0, b0, sm0), (y1, st1, a1, b1, sm1) = res
+    assert rel_err(y1.float().cpu(), ref.cpu()) < 4e-3 and rel_err(y1.float().cpu(), y0.float().cpu()) < 2e-3
+    assert rel_err(st1.cpu(), st0.cpu()) < 1e-4
+    assert rel_err(a1.float().cpu(), refd.cpu()) < 4e-3 and rel_err(a1.float().cpu(), a0.float().cpu()) < 2e-3
+    assert torch.equal(a1, b1)
+    assert rel_err(sm1.cpu(), sm0.cpu()) < 2e-3

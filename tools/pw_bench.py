@@ -26,4 +26,9 @@ for on in ("0", "1"):
     tp = timed(lambda i: nnf._pack(s1, [fc1.weight.detach()], False, torch.bfloat16, dev))
     tf = timed(lambda i: nnf._conv_forward(s1, xs[i % 8], [fc1.weight.detach()], b1, st))
     td = timed(lambda i: nnf._conv_dgrad(s2, xs[i % 8], [fc2.weight.detach()], (B, H, W, 128), None, bn=(link, sm)))
-    print("RSSF_PW=%s  fc1 forward %.1f us  fc2 dgrad+bnbwd %.1f us  (each incl. a weight pack of %.1f us)" % (on, tf, td, tp), flush=True)
+    ys = [torch.randn(B, H, W, 128, device=dev).bfloat16() for _ in range(4)]
+    b2 = fc2.bias.detach().float().contiguous()
+    st2 = torch.zeros(nnf.BN_SLOTS * 64, device=dev)
+    tf2 = timed(lambda i: nnf._conv_forward(s2, ys[i % 4], [fc2.weight.detach()], b2, st2))
+    td1 = timed(lambda i: nnf._conv_dgrad(s1, ys[i % 4], [fc1.weight.detach()], (B, H, W, 32), None))
+    print("RSSF_PW=%s  fc1 forward %.1f us  fc2 dgrad+bnbwd %.1f us  fc2 forward %.1f us  fc1 dgrad %.1f us  (each incl. a weight pack of %.1f us)" % (on, tf, td, tf2, td1, tp), flush=True)
