@@ -88,7 +88,7 @@ int launch_lattice(const void* in, const void* wpk, void* out, const float* bias
 // point-wise 32 -> 128 / 128 -> 32 channel convolutions as a stream (conv_pw.hip): MlpDWBN's fc1 / fc2, forward and data gradient (bf16)
 bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
-              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int CinP, int CoutP, hipStream_t st);
+              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st);
 int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st);
 
 template <typename T> struct LdsPad;

@@ -753,7 +753,7 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
   }
   if (dtype == RSSF_BF16 && !pre && !a.stats_ws && !addend && pw_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
     return launch_pw(in, wpk, out, bias, stats, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr, bn ? bn->sums : nullptr,
-                     bn ? bn->act : 0, B, IH, IW, Cin, a.CinP, a.CoutP, st);
+                     bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st);
   if (dtype == RSSF_BF16 && !pre && !a.stats_ws && lattice_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
     return launch_lattice(in, wpk, out, bias, stats, addend, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr,
                           bn ? bn->sums : nullptr, bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, ntaps, dy, dx, st);

@@ -28,7 +28,7 @@ struct PwArgs {
   const bf16_t* in; const bf16_t* wpk; bf16_t* out; const float* bias; float* stats;
   const bf16_t* bn_raw; const bf16_t* bn_res; const float* bn_ss; float* bn_sums; int bn_act;
   int64_t M;            // pixels
-  int CoutP, CinP;
+  int CoutP, CinP, Cout;   // Cout: channels of a pixel row of `out`; a block computes the slice [16 NT blockIdx.y, + 16 NT)
 };
 
 // sum over the 16 lanes of a row (the pixels of a tile), result in every lane of the row
@@ -47,23 +47,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
   __shared__ float sred[4][2][PW_N];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = (int)blockIdx.y * PW_N, CO = a.Cout;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.in), 0, (int)(a.M * PW_K * 2), 0x00020000);
   // weights: fragment j = output channels 16 j .. 16 j + 15 (lane: channel 16 j + l15, input channels 8 grp .. 8 grp + 7)
   bf16x8 fw[PW_NT][KS];
 #pragma unroll
   for (int j = 0; j < PW_NT; ++j)
 #pragma unroll
-    for (int k = 0; k < KS; ++k) fw[j][k] = *reinterpret_cast<const bf16x8*>(a.wpk + (size_t)(j * 16 + l15) * a.CinP + k * 32 + grp * 8);
+    for (int k = 0; k < KS; ++k) fw[j][k] = *reinterpret_cast<const bf16x8*>(a.wpk + (size_t)(n0 + j * 16 + l15) * a.CinP + k * 32 + grp * 8);
   // accumulator seeds: the bias of this lane's four channels of every fragment
   f32x4 seed[PW_NT];
 #pragma unroll
   for (int j = 0; j < PW_NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) seed[j][r] = (!BNB && a.bias) ? a.bias[j * 16 + grp * 4 + r] : 0.f;      // (a data gradient has no bias)
+    for (int r = 0; r < 4; ++r) seed[j][r] = (!BNB && a.bias) ? a.bias[n0 + j * 16 + grp * 4 + r] : 0.f;      // (a data gradient has no bias)
   // BatchNorm-backward statistics: scale / shift of the 128 channels in LDS, read per fragment (64 registers otherwise)
   __shared__ __attribute__((aligned(16))) float sss[BNB ? 2 * PW_N : 4];
   if constexpr (BNB) {
-    if (tid < 2 * PW_N) sss[tid] = a.bn_ss[tid];             // [scale N][shift N]
+    if (tid < 2 * PW_N) sss[tid] = a.bn_ss[(tid / PW_N) * CO + n0 + tid % PW_N];      // [scale][shift] of this slice
     __syncthreads();
   }
   const bool want = BNB || a.stats != nullptr;
@@ -102,15 +103,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 #pragma unroll
       for (int k = 0; k < KS; ++k) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][k], __builtin_bit_cast(bf16x8, xc[k]), acc[j], 0, 0, 0);
     }
-    bf16_t* orow = a.out + pix * PW_N + grp * 4;
+    bf16_t* orow = a.out + pix * CO + n0 + grp * 4;
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     u32x2 rawv[BNB ? PW_NT : 1], resv[BNB ? PW_NT : 1];
     if constexpr (BNB) {
       if (pok) {
 #pragma unroll
         for (int j = 0; j < PW_NT; ++j) {
-          rawv[j] = *reinterpret_cast<const u32x2*>(a.bn_raw + pix * PW_N + grp * 4 + j * 16);
-          if (a.bn_res) resv[j] = *reinterpret_cast<const u32x2*>(a.bn_res + pix * PW_N + grp * 4 + j * 16);
+          rawv[j] = *reinterpret_cast<const u32x2*>(a.bn_raw + pix * CO + n0 + grp * 4 + j * 16);
+          if (a.bn_res) resv[j] = *reinterpret_cast<const u32x2*>(a.bn_res + pix * CO + n0 + grp * 4 + j * 16);
         }
       }
     }
@@ -158,9 +159,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
   if (tid < PW_N) {
     const float u1 = (sred[0][0][tid] + sred[1][0][tid]) + (sred[2][0][tid] + sred[3][0][tid]);
     const float u2 = (sred[0][1][tid] + sred[1][1][tid]) + (sred[2][1][tid] + sred[3][1][tid]);
-    float* slot = BNB ? a.bn_sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * PW_N : a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * PW_N;
-    atomicAdd(slot + tid, u1);
-    atomicAdd(slot + PW_N + tid, u2);
+    float* slot = BNB ? a.bn_sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * CO : a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * CO;
+    atomicAdd(slot + n0 + tid, u1);
+    atomicAdd(slot + CO + n0 + tid, u2);
   }
 }
 
@@ -170,19 +171,26 @@ bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int m
   const char* sw = getenv("RSSF_PW");                        // A/B switch, read per call (tests hold the two kernels against each other)
   const bool enabled = !(sw && sw[0] == '0');
   return enabled && ntaps == 1 && dy[0] == 0 && dx[0] == 0 && mul == 1 && div == 1 && IH == OH && IW == OW &&
-         ((Cin == 32 && Cout == 128) || (Cin == 128 && Cout == 32)) && (int64_t)B * IH * IW * 128 < ((int64_t)1 << 30);
+         ((Cin == 32 && Cout == 128) || (Cin == 128 && Cout == 32) || (Cin == 64 && Cout == 256)) &&
+         (int64_t)B * IH * IW * (Cin > Cout ? Cin : Cout) < ((int64_t)1 << 30);
 }
 
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
-              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int CinP, int CoutP, hipStream_t st) {
+              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st) {
   PwArgs a;
   a.in = (const bf16_t*)in; a.wpk = (const bf16_t*)wpk; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats;
   a.bn_raw = (const bf16_t*)bn_raw; a.bn_res = (const bf16_t*)bn_res; a.bn_ss = bn_ss; a.bn_sums = bn_sums; a.bn_act = bn_act;
-  a.M = (int64_t)B * H * W; a.CoutP = CoutP; a.CinP = CinP;
+  a.M = (int64_t)B * H * W; a.CoutP = CoutP; a.CinP = CinP; a.Cout = Cout;
   const int64_t ntiles = (a.M + 15) / 16;
   int64_t blocks = (ntiles + 3) / 4;
   static const int maxb = getenv("RSSF_PW_BLOCKS") ? atoi(getenv("RSSF_PW_BLOCKS")) : 512;      // tuning (measured at 16 x 128^2: 512 blocks 17 / 36 us, 1 024: 20 / 39, 2 048: 25 / 45)
   if (blocks > maxb) blocks = maxb;
+  if (Cin == 64) {                                             // 64 -> 256 (layer1's Bottleneck expansions): two slices of 128 channels
+    const dim3 grid2((unsigned)blocks, 2);
+    if (bn_sums) conv_pw_kernel<2, 8, true><<<grid2, 256, 0, st>>>(a);
+    else conv_pw_kernel<2, 8, false><<<grid2, 256, 0, st>>>(a);
+    return check_launch("conv_pw");
+  }
   const dim3 grid((unsigned)blocks);
   if (Cin == 32) {
     if (bn_sums) conv_pw_kernel<1, 8, true><<<grid, 256, 0, st>>>(a);

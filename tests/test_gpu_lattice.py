@@ -212,3 +212,33 @@ def test_pointwise_128_to_32_forward_and_dgrad(B, H, W):
     assert rel_err(a1.float().cpu(), refd.cpu()) < 4e-3 and rel_err(a1.float().cpu(), a0.float().cpu()) < 2e-3
     assert torch.equal(a1, b1)
     assert rel_err(sm1.cpu(), sm0.cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 7, 9), (2, 64, 64)])
+def test_pointwise_64_to_256_forward_and_dgrad(B, H, W):
+    """layer1's Bottleneck expansions (_hrnet_rssformer.py:249-287): Conv2d(64, 256, 1) forward with fused statistics and the data
+    gradient of Conv2d(256, 64, 1) with the fused BatchNorm-backward statistics (ReLU, residual) - two 128-channel slices per pixel tile."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(10)
+    up, down = nn.Conv2d(64, 256, 1, bias=False).to(DEV), nn.Conv2d(256, 64, 1, bias=False).to(DEV)
+    su, sd = nnf.spec_of([up]), nnf.spec_of([down])
+    x = torch.randn(B, H, W, 64, device=DEV).bfloat16()
+    link = nnf.BnBwdLink()
+    link.raw, link.rp, link.act, link.C = torch.randn(B, H, W, 256, device=DEV).bfloat16(), torch.randn(B, H, W, 256, device=DEV).bfloat16(), 1, 256
+    link.ss = torch.stack([torch.rand(256, device=DEV) + 0.5, torch.randn(256, device=DEV) * 0.3]).contiguous()
+    res = []
+    for on in (False, True):
+        with _PwSwitch(on):
+            st = torch.zeros(nnf.BN_SLOTS * 2 * 256, device=DEV)
+            sm = torch.zeros(nnf.BN_BWD_SLOTS * 2 * 256, device=DEV)
+            y = nnf._conv_forward(su, x, [up.weight.detach()], None, st)
+            d = nnf._conv_dgrad(sd, x, [down.weight.detach()], (B, H, W, 256), None, bn=(link, sm)).clone()
+            res.append((y, st.view(nnf.BN_SLOTS, 2, 256).sum(0), d, sm.view(nnf.BN_BWD_SLOTS, 2, 256).sum(0)))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).float(), up.weight.detach().bfloat16().float()).permute(0, 2, 3, 1)
+    refd = F.conv_transpose2d(x.permute(0, 3, 1, 2).float(), down.weight.detach().bfloat16().float()).permute(0, 2, 3, 1)
+    (y0, st0, d0, sm0), (y1, st1, d1, sm1) = res
+    assert rel_err(y1.float().cpu(), ref.cpu()) < 4e-3 and rel_err(y1.float().cpu(), y0.float().cpu()) < 2e-3
+    assert rel_err(st1.cpu(), st0.cpu()) < 1e-4
+    assert rel_err(d1.float().cpu(), refd.cpu()) < 4e-3 and rel_err(d1.float().cpu(), d0.float().cpu()) < 2e-3
+    assert rel_err(sm1.cpu(), sm0.cpu()) < 2e-3
