@@ -420,6 +420,10 @@ int rssf_vec_add_to3(const float* src, float* d0, float* d1, float* d2, int n, v
 /* out = a + b over n elements of `dtype` (out may alias a or b; 16-byte aligned): `fuse(x)` running sums of
  * HighResolutionModule.forward (_hrnet_rssformer.py:424-435) and gradient sums no convolution epilogue carries */
 int rssf_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+/* out = a + b + c (fp32 sum, rounded once; out may alias an operand): the gradient of a HighResolutionModule branch output x[j],
+ * which feeds its own fuse sum, the 1x1 convolution towards output 0 and the accumulating convolutions towards the other outputs
+ * (_hrnet_rssformer.py:424-435) - what autograd's own accumulation would sum with two element-wise framework launches */
+int rssf_add3(const void* a, const void* b, const void* c, void* out, int64_t n, int dtype, void* stream);
 /* fp32 image [B,C,H,W] given by its element strides (NCHW or channels-last memory) -> channels-last [B,H,W,Cp] of `dtype`, channels
  * zero-padded to the 16-byte vector (Cp = 8 bf16 / 4 fp32): the network input of HighResolutionNet.forward
  * (_hrnet_rssformer.py:605-613) in one launch. */

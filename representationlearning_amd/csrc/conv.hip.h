@@ -73,7 +73,8 @@ struct HaloArgs {
   int pre_act;
   int B, H, W, Cin, Cout, CinP, CoutP;
   int tiles_y, tiles_x, ntiles_n, xcd_per;
-  int64_t total;
+  int ntb, ntiles;       // multi-tile form (conv_halo.hip): consecutive pixel tiles per block, pixel tiles of the problem
+  int64_t total;         // blocks of the launch
   int dy[9], dx[9];
 };
 

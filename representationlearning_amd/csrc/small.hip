@@ -47,6 +47,27 @@ __global__ void __launch_bounds__(256) add_kernel(const T* __restrict__ a, const
   }
 }
 
+// out = a + b + c (one pass instead of two): the gradient of a branch output that meets an accumulated convolution gradient AND two
+// autograd consumers (nnf._Fanout with aliases) - summed in fp32, rounded once
+template <typename T>
+__global__ void __launch_bounds__(256) add3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ out,
+                                                   int64_t nvec, int64_t n) {
+  constexpr int V = Vec<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    Vec<T> x, y, z, o;
+    x.load(a + i * V); y.load(b + i * V); z.load(c + i * V);
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = x.get(e) + y.get(e) + z.get(e);
+    o.set_all(v);
+    o.store(out + i * V);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - nvec * V)) {
+    const int64_t i = nvec * V + threadIdx.x;
+    stf(out + i, ldf(a + i) + ldf(b + i) + ldf(c + i));
+  }
+}
+
 // one thread per output pixel: C strided reads (coalesced across the threads of a row for NCHW sources), one 16-byte store
 template <typename T>
 __global__ void __launch_bounds__(256) image_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t npix, int HW, int W,
@@ -96,6 +117,21 @@ extern "C" int rssf_image_to_nhwc(const float* src, void* dst, int B, int C, int
     return RSSF_ERR_UNSUPPORTED;
   }
   return check_launch("image_to_nhwc");
+}
+
+extern "C" int rssf_add3(const void* a, const void* b, const void* c, void* out, int64_t n, int dtype, void* stream) {
+  RSSF_REQUIRE(a && b && c && out && n > 0, "add3: bad arguments");
+  RSSF_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0, "add3: operands must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  const int64_t nvec = n / V;
+  int64_t blocks = (nvec + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (dtype == RSSF_BF16) add3_kernel<bf16_t><<<(unsigned)blocks, 256, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)out, nvec, n);
+  else if (dtype == RSSF_F32) add3_kernel<float><<<(unsigned)blocks, 256, 0, st>>>((const float*)a, (const float*)b, (const float*)c, (float*)out, nvec, n);
+  else { set_error("add3: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  return check_launch("add3");
 }
 
 extern "C" int rssf_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {

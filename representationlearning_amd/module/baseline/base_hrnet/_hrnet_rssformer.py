@@ -241,7 +241,7 @@ class HighResolutionModule(nn.Module):
         long.  The chain from branch 0 ends in `relu(bn(conv(.)) + low_i)`; its last convolution waits for the depth at which
         `low_i` is complete (depth max(i - 1, 1)).  Sums are formed in the reference's order (j ascending)."""
         nb, nout = self.num_branches, len(self.fuse_layers)
-        x, accs = self._fanout(x)
+        x, accs, x0 = self._fanout(x)                # x0: aliases of x[1..] for the 1x1 convolutions towards output 0
         up, cur, done = {}, {}, {}                # (i,j) -> 1x1 output / running chain value / finished chain value
         # depth at which `low_i` is complete: the 1x1 / first-stage outputs exist after depth 0, the chain from branch j >= 1 after
         # depth i - j - 1 (only output 1 of a 2-branch module needs neither: low_1 = x[1])
@@ -312,7 +312,7 @@ class HighResolutionModule(nn.Module):
         def fuse_zero():
             # output 0: its 1x1 convolutions (one group, one exchange), the upsampled sum, then the transformer block.  No gradient
             # accumulator here: these consumers of x[j] run on the main stream, the accumulating ones of outputs 1.. on the side stream
-            its = [dict(x=x[j], conv=self.fuse_layers[0][j][0], bn=self.fuse_layers[0][j][1], act=nnf.ACT_NONE) for j in range(1, nb)]
+            its = [dict(x=x0[j], conv=self.fuse_layers[0][j][0], bn=self.fuse_layers[0][j][1], act=nnf.ACT_NONE) for j in range(1, nb)]
             for j, t in zip(range(1, nb), nnf.conv_bn_act_group(its)):
                 up[(0, j)] = t
             return self._transformer_relu(low_of(0), x[0])
@@ -346,7 +346,7 @@ class HighResolutionModule(nn.Module):
                     return self._fuse_lockstep(ys)
             return self._fuse_lockstep(self._branches_lockstep(x[:nb]))
         x = nnf.parallel_map(list(self.branches), x[:self.num_branches])       # BlockChains of BasicBlocks, one stream each
-        x, accs = self._fanout(x)
+        x, accs, x0 = self._fanout(x)
 
         def fuse_output(i):
             low = None
@@ -355,7 +355,7 @@ class HighResolutionModule(nn.Module):
                     low = x[j] if low is None else nnf.add(low, x[j])
                 elif j > i:      # 1x1 conv + BN, then nearest upsample fused with the running sum
                     fl = self.fuse_layers[i][j]
-                    t = nnf.conv_bn_act(x[j], fl[0], fl[1], grad_accum=accs[j] if i > 0 else None)
+                    t = nnf.conv_bn_act(x[j] if i > 0 else x0[j], fl[0], fl[1], grad_accum=accs[j] if i > 0 else None)
                     low = nnf.upsample_nearest_add(low, t, int(fl[2].scale_factor))
                 else:
                     t = nnf.run_sequential(self.fuse_layers[i][j], x[j], grad_accum=accs[j])
@@ -373,13 +373,21 @@ class HighResolutionModule(nn.Module):
 
     def _fanout(self, x):
         """Branch output j feeds one convolution per fuse path (i != j): their data gradients accumulate in one buffer
-        (nnf.GradAccum) instead of being summed by autograd with an elementwise kernel per consumer."""
-        xs, accs = [], []
+        (nnf.GradAccum) instead of being summed by autograd with an elementwise kernel per consumer.  Branch outputs 1.. have two
+        more consumers - their own fuse sum (`low_j`, an identity) and the 1x1 convolution towards output 0 (main stream, no
+        accumulator): each gets its own alias (second list), and the three gradients meet in the fan-out node's ONE launch."""
+        xs, accs, xs0 = [], [], []
         for j in range(self.num_branches):
-            t, acc = nnf.fanout(x[j], sum(1 for i in range(1, len(self.fuse_layers)) if i != j))      # (path 0 runs on another stream)
+            n_acc = sum(1 for i in range(1, len(self.fuse_layers)) if i != j)      # (path 0 runs on another stream)
+            t, acc = nnf.fanout(x[j], n_acc, n_alias=2 if j >= 1 else 1)
+            if j >= 1:
+                t, t0 = t
+            else:
+                t0 = t
             xs.append(t)
+            xs0.append(t0)
             accs.append(acc)
-        return xs, accs
+        return xs, accs, xs0
 
 
 class HighResolutionNet(nn.Module):

@@ -790,36 +790,66 @@ def add(a, b):
     return a + b
 
 
+def _sum_into(t, gs):
+    """t += sum(gs) in place (t: a buffer this node owns); two addends meet in ONE launch (rssf_add3)."""
+    gs = [g for g in gs if g is not None]
+    ok = lambda g: (g.dtype == t.dtype and g.shape == t.shape and g.stride() == t.stride() and g.data_ptr() % 16 == 0)
+    if (len(gs) == 2 and t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and _dense(t) and t.data_ptr() % 16 == 0 and ok(gs[0]) and ok(gs[1])):
+        L.check(L.load().rssf_add3(L.ptr(t), L.ptr(gs[0]), L.ptr(gs[1]), L.ptr(t), t.numel(), L.dtype_code(t), L.stream()), "rssf_add3")
+        return t
+    for g in gs:
+        t = _add_into(t, g)
+    return t
+
+
 class _Fanout(torch.autograd.Function):
+    """x -> n aliases of x (n >= 1).  Backward: the accumulated convolution gradients (GradAccum) plus the gradients of the aliases,
+    summed by the library's own launches - handing ONE tensor to several autograd consumers instead leaves the sum to the
+    engine's accumulation (an element-wise framework launch per extra consumer)."""
+
     @staticmethod
-    def forward(ctx, x, acc):
+    def forward(ctx, x, acc, n):
         ctx.acc = acc
         ctx.set_materialize_grads(False)
-        return x.view_as(x)
+        if n == 1:
+            return x.view_as(x)
+        return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
-    def backward(ctx, g):
-        buf, ctx.acc.buf = ctx.acc.buf, None
+    def backward(ctx, *gs):
+        acc = ctx.acc
+        buf = None
+        if acc is not None:
+            buf, acc.buf = acc.buf, None
+        gs = [g for g in gs if g is not None]
         if buf is None:
-            return g, None
-        if ctx.acc.stream is not None:      # the consumers ran on a side stream (fork_side): order this node after them
+            if len(gs) <= 1:
+                return (gs[0] if gs else None), None, None
+            first = gs[0]
+            if len(gs) == 2 and first.dtype == gs[1].dtype and first.shape == gs[1].shape and first.stride() == gs[1].stride():
+                return add(first, gs[1]), None, None
+            t = first.clone()
+            return _sum_into(t, gs[1:]), None, None
+        if acc.stream is not None:      # the consumers ran on a side stream (fork_side): order this node after them
             cur = torch.cuda.current_stream(buf.device)
-            if ctx.acc.stream != cur:
-                cur.wait_stream(ctx.acc.stream)
+            if acc.stream != cur:
+                cur.wait_stream(acc.stream)
                 buf.record_stream(cur)
         t = _nchw(buf)
-        return (t if g is None else _add_into(t, g)), None
+        return (t if not gs else _sum_into(t, gs)), None, None
 
 
-def fanout(x, n_conv_consumers):
+def fanout(x, n_conv_consumers, n_alias=1):
     """(x', GradAccum) for a tensor with convolution consumers that take `grad_accum=`; (x, None) when there are none.  Also with a
     SINGLE such consumer: when that consumer runs on a side stream (fork_side), its gradient must not meet the other consumers'
     in autograd's own cross-stream accumulation - under hipGraph capture that ended in a crash of the capture (ROCm 7.0) - but in
-    the fan-out node, which orders itself after the side stream explicitly."""
-    if n_conv_consumers < 1 or not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
-        return x, None
-    acc = GradAccum()
-    return _Fanout.apply(x, acc), acc
+    the fan-out node, which orders itself after the side stream explicitly.
+    n_alias > 1: x' is a tuple of n_alias aliases, one per further autograd consumer - their gradients meet the accumulated ones
+    inside the node (rssf_add3 / rssf_add) instead of in the engine's accumulation."""
+    if not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda) or (n_conv_consumers < 1 and n_alias < 2):
+        return (x if n_alias == 1 else tuple([x] * n_alias)), None
+    acc = GradAccum() if n_conv_consumers >= 1 else None
+    return _Fanout.apply(x, acc, n_alias), acc
 
 
 def _accumulate_dgrad(accum, spec, dout, weights, in_shape, rt):
@@ -1737,6 +1767,35 @@ def conv_nhwc(xh, conv, addend=None):
     bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
     return _conv_forward(spec, xh if xh.is_contiguous() else xh.contiguous(), [w], bias, None, current(), addend=addend,
                          cache_pack=not torch.is_grad_enabled())
+
+
+def _specs_of_module(m):
+    sp = list(m.__dict__.get("_rssf_specs", {}).values())
+    if m.__dict__.get("_rssf_spec") is not None:
+        sp.append(m.__dict__["_rssf_spec"])
+    out = []
+    for s_ in sp:
+        out.append(s_)
+        out += list(s_.parts or [])
+    return out
+
+
+def invalidate_packed(model):
+    """Drop the packed-weight copies the inference path keeps on a model's convolutions (`_pack(cache=True)`).  The cache is keyed
+    on (address, version counter) of the weights: writers that bypass the counter - the trainer's fused SGD kernel, `.data`
+    assignments, raw pointers - must call this before the model is used through conv_nhwc again.  Returns the number
+    of entries dropped."""
+    n = 0
+    for m in model.modules():
+        for sp in _specs_of_module(m):
+            n += len(sp.__dict__.get("_packed", {}))
+            sp.__dict__.pop("_packed", None)
+    return n
+
+
+def packed_weights(model):
+    """The packed-weight tensors currently cached on a model's convolutions (a captured graph that reads them keeps this list alive)."""
+    return [hit[1] for m in model.modules() for sp in _specs_of_module(m) for hit in sp.__dict__.get("_packed", {}).values()]
 
 
 def flush_bn_counters(model, extra=0):

@@ -52,7 +52,8 @@ def multi_scale_cam_with_ref_mat(model, inputs, scales):
 class GraphedMultiScaleCam:
     """multi_scale_cam for a FIXED input shape as one replayed hipGraph: at the reference's batch of two the six forwards are a few
     hundred short launches and the call is bound by issuing them.  The packed weights are formed during the warm-up calls (outside
-    the capture) and stay cached until a parameter changes - re-create the object after loading new weights.
+    the capture) and stay cached until a parameter changes; the object holds the packed buffers its graph reads and refuses to replay once a
+    parameter's address or version counter differs from the capture's - re-create it after loading new weights.
 
         cam_fn = GraphedMultiScaleCam(model, inputs, scales);  cams = cam_fn(inputs)        # cams: a buffer the next call overwrites
     """
@@ -70,6 +71,15 @@ class GraphedMultiScaleCam:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = self._run(model)
+        # the graph reads the packed weights the warm-up calls cached on the convolutions: hold them (a later re-pack replaces the
+        # cache entry and would free the buffer under the graph), and remember which parameter values they were packed from
+        from ... import nnf
+        self._held = nnf.packed_weights(model)
+        self._params = list(model.parameters())
+        self._tags = self._param_tags()
+
+    def _param_tags(self):
+        return [(p.data_ptr(), p._version) for p in self._params]
 
     def _run(self, model):
         with torch.autocast("cuda", dtype=self.dtype or torch.bfloat16, enabled=self.dtype is not None):
@@ -78,6 +88,9 @@ class GraphedMultiScaleCam:
     def __call__(self, inputs):
         if inputs.shape != self.static_in.shape:
             raise ValueError(f"GraphedMultiScaleCam was captured for {tuple(self.static_in.shape)}, got {tuple(inputs.shape)}")
+        if self._param_tags() != self._tags:
+            raise RuntimeError("GraphedMultiScaleCam: the model's parameters changed after the capture (load_state_dict / an optimizer "
+                               "step) - the graph holds the weights packed at capture time; create a new GraphedMultiScaleCam")
         self.static_in.copy_(inputs)
         self.graph.replay()
         return self.static_out

@@ -25,8 +25,14 @@ class FlatParams:
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
         self.offsets = [0]
-        for s in sizes:
-            self.offsets.append(self.offsets[-1] + (s + 3) // 4 * 4)     # 16-byte aligned slices
+        for i, s in enumerate(sizes):
+            # 16-byte aligned slices - except that a convolution kernel whose size is no multiple of four floats is followed
+            # WITHOUT a gap by a same-shaped one: the two 7x7 SpatialAttention kernels of a transformer block (98 floats each,
+            # multihead_isa_pool_attention.py:30-31) are then ONE [2, 2, 7, 7] operand of the gate kernels (autograd._gate_kernels:
+            # a view, not a stack copy per block and step); the pair ends on a 16-byte boundary again
+            tight = (s % 4 != 0 and (2 * s) % 4 == 0 and self.offsets[-1] % 4 == 0 and i + 1 < len(sizes) and self.params[i].dim() == 4
+                     and self.params[i + 1].shape == self.params[i].shape)
+            self.offsets.append(self.offsets[-1] + s if tight else (self.offsets[-1] + s + 3) // 4 * 4)
         n = self.offsets[-1]
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -76,7 +82,8 @@ class GradBuckets:
         end, cur = n, []
         for i in range(len(flat.params) - 1, -1, -1):
             cur.append(i)
-            if end - flat.offsets[i] >= target or i == 0:
+            # (a bucket never starts at the second kernel of a tightly packed pair: bucket slices stay 16-byte aligned)
+            if (end - flat.offsets[i] >= target and flat.offsets[i] % 4 == 0) or i == 0:
                 self.bounds.append((flat.offsets[i], end))
                 self.members.append(cur)
                 end, cur = flat.offsets[i], []
@@ -495,6 +502,18 @@ class Trainer:
             if m is not None:
                 self.flat.mom[o:o + p.numel()].view_as(p).copy_(m)
         self.it = int(sd["it"])
+
+    def check_exchange(self):
+        """Raise if a peer-to-peer SyncBN exchange ever ran into its bounded spin (RSSF_P2P_TIMEOUT_MS: a debugging bound - in
+        production the variable stays UNSET and the spin is unbounded).  A rank that waited out the bound added a stale word to
+        its BatchNorm totals: the replicas have diverged and the run must stop, loudly.  Call where the host
+        synchronises anyway (train.py: the log interval's float(loss)); the status word is one 4-byte device read."""
+        if self.p2p is None:
+            return
+        late = self.p2p.timed_out()
+        if late:
+            raise RuntimeError("peer-to-peer SyncBN exchange: rank %d waited out RSSF_P2P_TIMEOUT_MS for rank %d - its BatchNorm "
+                               "statistics are stale and the replicas have diverged; stopping" % (dist.get_rank() if dist.is_initialized() else 0, late - 1))
 
     def close(self):
         """Destroy the RCCL communicators (before torch.distributed's process group goes away) and release the captured step NOW,

@@ -202,6 +202,7 @@ def main():
             it = trainer.it                       # iterations finished
             if it % tr.log_interval_step == 0 or it == num_iters or it == 1:
                 lv = float(loss)                  # the only host sync of the loop
+                trainer.check_exchange()          # a peer-to-peer SyncBN exchange that hit its (debug) spin bound stops the run here
                 t2 = time.perf_counter()
                 t_load, t_step, n_timed = t_load + (t1 - t0), t_step + (t2 - t1), n_timed + 1
                 log("iter %d  epoch %d  fc_loss %.5f  lr %.6f" % (it, epoch, lv, float(trainer.lr_dev)), flush=True)
