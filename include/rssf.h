@@ -326,6 +326,17 @@ typedef struct rssf_bn_reduce_item {
   int C, act;
 } rssf_bn_reduce_item;
 int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n, int dtype, void* stream);
+/* rssf_bn_bwd_apply per item: the BatchNorm-backward apply of the layers whose weight gradient cannot carry it (the 1x1 and strided
+ * fuse convolutions of one depth of HighResolutionModule._make_fuse_layers, _hrnet_rssformer.py:361-405) as one grid */
+typedef struct rssf_bn_bwd_apply_item {
+  const void* dy; const void* raw; const float* scale_shift; const float* mean_invstd; const float* sums; const void* res_pre;
+  void* draw; void* dres; float* dgamma; float* dbeta;
+  int64_t rows;
+  double n;
+  int C, act, training;
+  float param_grad_scale;
+} rssf_bn_bwd_apply_item;
+int rssf_bn_bwd_apply_group(const rssf_bn_bwd_apply_item* items, int n, int dtype, void* stream);
 
 /* rssf_bn_bwd_reduce / rssf_bn_bwd_apply of a layer run forward with res_post (and possibly RSSF_ACT_POST_RELU in `act`): the
  * gradient that enters the activation is g = dy where y > 0 (all of dy without the flag); dpost (optional) = g is the gradient of

@@ -69,6 +69,11 @@ class BnReduceItem(ctypes.Structure):       # rssf_bn_reduce_item
     _fields_ = [(n, c_void_p) for n in ("dy", "raw", "scale_shift", "res_pre", "sums")] + [("rows", c_int64), ("C", c_int), ("act", c_int)]
 
 
+class BnBwdApplyItem(ctypes.Structure):     # rssf_bn_bwd_apply_item
+    _fields_ = ([(n, c_void_p) for n in ("dy", "raw", "scale_shift", "mean_invstd", "sums", "res_pre", "draw", "dres", "dgamma", "dbeta")]
+                + [("rows", c_int64), ("n", ctypes.c_double), ("C", c_int), ("act", c_int), ("training", c_int), ("param_grad_scale", c_float)])
+
+
 # name -> (restype, argtypes); every symbol include/rssf.h declares must appear here (tests check it)
 SIGNATURES = {
     "rssf_version": (ctypes.c_char_p, []),
@@ -107,6 +112,7 @@ SIGNATURES = {
     "rssf_conv3x3_wgrad_group": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rssf_bn_finalize_apply_group": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_reduce_group": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "rssf_bn_bwd_apply_group": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),
     "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),

@@ -370,21 +370,21 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_group_kernel(ReduceGroup g)
 // draw = scale*(dz - k1 - xhat*k2) (training) or scale*dz (eval);  dres (optional) = dz.   Same thread layout as
 // bn_apply_kernel: per-channel constants (scale, shift, mean, invstd, k1, k2) are computed once per thread.
 template <typename T, int VEC>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
+__device__ __forceinline__ void bn_bwd_apply_block(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
                                                            const float* __restrict__ mi, const float* __restrict__ sums,
                                                            const T* __restrict__ res_pre, T* __restrict__ draw, T* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
                                                            int act, float n, int training, float pscale, const T* __restrict__ res_post,
-                                                           T* __restrict__ dpost) {
+                                                           T* __restrict__ dpost, const unsigned bx, const unsigned by, const unsigned gx, float* tot) {
   const int allcols = C / VEC;
-  const int colbase = blockIdx.y * 256;
+  const int colbase = by * 256;
   const int cols = allcols - colbase < 256 ? allcols - colbase : 256;
   const int rpb = 256 / cols;
   const int col = threadIdx.x % cols, rlocal = threadIdx.x / cols;
   const bool active = rlocal < rpb;
   const int c0 = (colbase + col) * VEC;
-  const int64_t stride = (int64_t)gridDim.x * rpb;
-  int64_t r = (int64_t)blockIdx.x * rpb + rlocal;
+  const int64_t stride = (int64_t)gx * rpb;
+  int64_t r = (int64_t)bx * rpb + rlocal;
   // the first row's operands and the per-channel constants are requested before the slot totals are folded, so that
   // the fold's load -> LDS -> barrier chain overlaps with them (each thread only sees a handful of rows)
   Vec<T> vd, vr, vp, vq;
@@ -402,7 +402,6 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; mean[e] = mi[c0 + e]; istd[e] = mi[C + c0 + e]; }
   }
-  extern __shared__ float tot[];                           // [2][cols*VEC] slot totals of this block's channels
   for (int i = threadIdx.x; i < 2 * cols * VEC; i += blockDim.x) {
     const int half = i / (cols * VEC), c = colbase * VEC + i % (cols * VEC);
     float t = 0.f;
@@ -422,7 +421,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     k2[e] = dot / n;
     // one writer per channel.  pscale = 1/world under SyncBN: `sums` are then the GLOBAL totals, while DDP averages the LOCAL
     // parameter gradients (torch SyncBatchNorm takes grad_weight/grad_bias from the local sums) - global/world == that mean
-    if (dgamma && blockIdx.x == 0 && rlocal == 0) { dgamma[c] += dot * pscale; dbeta[c] += s1 * pscale; }
+    if (dgamma && bx == 0 && rlocal == 0) { dgamma[c] += dot * pscale; dbeta[c] += s1 * pscale; }
     // draw = sc*(dz - k1 - (x - mean)*istd*k2) = sc*dz + cb*x + cc : two FMAs per element instead of six operations (the pass
     // runs 8 waves per SIMD at 22 % VALU-active each: instruction issue, not the fabric, was its limit)
   }
@@ -470,6 +469,39 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
       if (dpost) stf(dpost + off, g);
     }
   }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ raw, const float* __restrict__ ss,
+                                                           const float* __restrict__ mi, const float* __restrict__ sums,
+                                                           const T* __restrict__ res_pre, T* __restrict__ draw, T* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
+                                                           int act, float n, int training, float pscale, const T* __restrict__ res_post,
+                                                           T* __restrict__ dpost) {
+  extern __shared__ float tot[];                           // [2][cols*VEC] slot totals of this block's channels
+  bn_bwd_apply_block<T, VEC>(dy, raw, ss, mi, sums, res_pre, draw, dres, dgamma, dbeta, rows, C, act, n, training, pscale, res_post, dpost,
+                             blockIdx.x, blockIdx.y, gridDim.x, tot);
+}
+// the layers of a lock-step group in one grid (see bn_finapply_group_kernel): the 1x1 / strided fuse convolutions of one depth
+struct BwdApplyItem {
+  const void* dy; const void* raw; const float* ss; const float* mi; const float* sums; const void* rp; void* draw; void* dres;
+  float* dgamma; float* dbeta;
+  int64_t rows;
+  int C, act, training, gx;
+  float n, pscale;
+};
+struct BwdApplyGroup { BwdApplyItem it[RSSF_GROUP_MAX]; int start[RSSF_GROUP_MAX + 1]; int n; };
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) bn_bwd_apply_group_kernel(BwdApplyGroup g) {
+  extern __shared__ float tot[];
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
+    if (k < g.n && blockIdx.x >= (unsigned)g.start[k]) i = k;
+  const BwdApplyItem& a = g.it[i];
+  const unsigned r = blockIdx.x - (unsigned)g.start[i], gx = (unsigned)a.gx;
+  bn_bwd_apply_block<T, VEC>((const T*)a.dy, (const T*)a.raw, a.ss, a.mi, a.sums, (const T*)a.rp, (T*)a.draw, (T*)a.dres, a.dgamma, a.dbeta, a.rows,
+                             a.C, a.act, a.n, a.training, a.pscale, nullptr, nullptr, r % gx, r / gx, gx, tot);
 }
 
 // (row blocks, column blocks of <= 256 vector columns) for the fixed-column thread layout
@@ -692,6 +724,26 @@ int reduce_group_launch(const rssf_bn_reduce_item* items, int n, hipStream_t st)
   bn_bwd_reduce_group_kernel<T, V><<<(unsigned)blocks, 256, 2 * maxc * sizeof(float), st>>>(g);
   return check_launch("bn_bwd_reduce_group");
 }
+template <typename T>
+int bwd_apply_group_launch(const rssf_bn_bwd_apply_item* items, int n, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  BwdApplyGroup g;
+  g.n = n;
+  int blocks = 0, maxc = 0;
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_bwd_apply_item& it = items[i];
+    const dim3 grid = grid2d(it.rows, it.C, V);
+    g.it[i] = {it.dy, it.raw, it.scale_shift, it.mean_invstd, it.sums, it.res_pre, it.draw, it.dres, it.dgamma, it.dbeta, it.rows, it.C, it.act,
+               it.training, (int)grid.x, (float)it.n, it.param_grad_scale};
+    g.start[i] = blocks;
+    blocks += (int)(grid.x * grid.y);
+    const int nch = it.C < 256 * V ? it.C : 256 * V;
+    if (nch > maxc) maxc = nch;
+  }
+  for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = blocks;
+  bn_bwd_apply_group_kernel<T, V><<<(unsigned)blocks, 256, 2 * maxc * sizeof(float), st>>>(g);
+  return check_launch("bn_bwd_apply_group");
+}
 const bool g_group_enabled = !(getenv("RSSF_GROUP_KERNELS") && getenv("RSSF_GROUP_KERNELS")[0] == '0');      // A/B switch (tools/group_bench.py)
 }  // namespace
 
@@ -732,6 +784,28 @@ extern "C" int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n,
   for (int i = 0; i < n; ++i) {
     const rssf_bn_reduce_item& it = items[i];
     const int rc = rssf_bn_bwd_reduce(it.dy, it.raw, it.scale_shift, it.res_pre, it.sums, it.rows, it.C, it.act, nullptr, dtype, stream);
+    if (rc) return rc;
+  }
+  return RSSF_OK;
+}
+
+extern "C" int rssf_bn_bwd_apply_group(const rssf_bn_bwd_apply_item* items, int n, int dtype, void* stream) {
+  RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_bwd_apply_group: bad arguments");
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_bwd_apply_item& it = items[i];
+    RSSF_REQUIRE(it.dy && it.raw && it.scale_shift && it.mean_invstd && it.sums && it.draw && it.rows > 0 && it.C > 0 && it.act >= 0 && it.act <= 2,
+                 "bn_bwd_apply_group: bad item %d", i);
+    RSSF_REQUIRE((it.dgamma == nullptr) == (it.dbeta == nullptr), "bn_bwd_apply_group: dgamma and dbeta go together (item %d)", i);
+    grouped = grouped && (it.C % V) == 0;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (grouped) return dtype == RSSF_BF16 ? bwd_apply_group_launch<bf16_t>(items, n, st) : bwd_apply_group_launch<float>(items, n, st);
+  for (int i = 0; i < n; ++i) {
+    const rssf_bn_bwd_apply_item& it = items[i];
+    const int rc = rssf_bn_bwd_apply(it.dy, it.raw, it.scale_shift, it.mean_invstd, it.sums, it.res_pre, it.draw, it.dres, it.dgamma, it.dbeta, it.rows,
+                                     it.C, it.act, it.n, it.training, it.param_grad_scale, dtype, stream);
     if (rc) return rc;
   }
   return RSSF_OK;

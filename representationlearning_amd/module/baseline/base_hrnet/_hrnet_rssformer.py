@@ -91,7 +91,12 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x, producer=None, want_link=False):
-        res = x if self.downsample is None else nnf.run_sequential(self.downsample, x)
+        if self.downsample is None:
+            res = x
+        else:
+            # x feeds the projection AND conv1: one alias each, their gradients meet in the fan-out node's launch (not in autograd's)
+            (xd, x), _ = nnf.fanout(x, 0, n_alias=2)
+            res = nnf.run_sequential(self.downsample, xd)
         link = nnf.residual_link(x, res)
         l1, l2 = nnf.bwd_stats_link(), nnf.bwd_stats_link()
         out = nnf.conv_bn_act(x, self.conv1, self.bn1, nnf.ACT_RELU, grad_sink=link, stats_out=l1,
@@ -327,7 +332,7 @@ class HighResolutionModule(nn.Module):
             return [self.branches[0](x[0])]
         if self._lockstep_ok():
             nb = self.num_branches
-            split = os.environ.get("RSSF_LOCKSTEP_SPLIT", "0,1")
+            split = os.environ.get("RSSF_LOCKSTEP_SPLIT", "0")
             if ";" in split:                       # per branch count: "<2 branches>;<3 branches>;<4 branches>"
                 split = (split.split(";") + ["all"] * 3)[nb - 2]
             # (one stream only - eager launches, a single SyncBN communicator: all branches in ONE group, the fewest launches / exchanges)
@@ -481,7 +486,12 @@ class HighResolutionNet(nn.Module):
             nb = getattr(self, "stage{}_cfg".format(s))["num_branches"]
             xs = []
             # (transition1: layer1's 256-channel output feeds both new branches - its two data gradients share one buffer)
-            last, acc = nnf.fanout(ys[-1], sum(1 for i in range(nb) if trans[i] is not None))
+            # the last branch feeds the new branches' convolutions (accumulating) and, where it lives on, the stage itself: an alias
+            keeps = len(ys) - 1 < nb and trans[len(ys) - 1] is None
+            last, acc = nnf.fanout(ys[-1], sum(1 for i in range(nb) if trans[i] is not None), n_alias=2 if keeps else 1)
+            if keeps:
+                last, ident = last
+                ys = list(ys[:-1]) + [ident]
             for i in range(nb):
                 if trans[i] is None:
                     xs.append(ys[i])

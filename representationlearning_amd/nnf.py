@@ -206,7 +206,10 @@ def can_fork_side(t):
 
 def fork_side(fn_side, fn_main, tensors):
     """(fn_side(), fn_main()): fn_side on a side stream when branch streams are enabled, concurrently with fn_main on the current
-    stream; joined before returning.  `tensors`: what fn_side reads (they were produced on the current stream)."""
+    stream; joined before returning.  `tensors`: what fn_side reads (they were produced on the current stream).
+    (Measured and dropped, round 4: a data-driven form - no fork-time wait for inputs the side stream produced itself, the join of
+    the fuse fork deferred to the first reader on another stream - leaves the step where it is, 29.84 against 29.80-29.87 ms:
+    the streams share one GPU's CUs and fabric, the extra freedom buys nothing.)"""
     rt = current()
     ts = [t for t in tensors if t is not None]
     if not (rt.branch_streams and _FORK_FUSE and ts and ts[0].is_cuda) or (rt.exchanging() and not rt.stream_comms) or rt.in_side:
@@ -846,6 +849,9 @@ def fanout(x, n_conv_consumers, n_alias=1):
     the fan-out node, which orders itself after the side stream explicitly.
     n_alias > 1: x' is a tuple of n_alias aliases, one per further autograd consumer - their gradients meet the accumulated ones
     inside the node (rssf_add3 / rssf_add) instead of in the engine's accumulation."""
+    if n_alias > 1 and os.environ.get("RSSF_FANOUT_ALIAS", "1") == "0":       # A/B switch: the consumers share x, autograd sums their gradients
+        t, acc = fanout(x, n_conv_consumers)
+        return tuple([t] * n_alias), acc
     if not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda) or (n_conv_consumers < 1 and n_alias < 2):
         return (x if n_alias == 1 else tuple([x] * n_alias)), None
     acc = GradAccum() if n_conv_consumers >= 1 else None
@@ -1338,9 +1344,33 @@ class _ConvBNActGroup(torch.autograd.Function):
                     if not _group_wgrad3x3([st[i] for i in ch], [dyhs[i] for i in ch], [sums[i] for i in ch], [ctx.ns[i] for i in ch], pscale, rt):
                         continue
                     grouped_w.update(ch)
+        # the layers whose weight-gradient kernel cannot carry the BatchNorm-backward apply (1x1 and strided convolutions: the fuse
+        # paths of one depth) get it as ONE grouped launch; their weight gradients then read the finished draw
+        applied = set()
+        sel = [i for i in range(n_items) if i not in grouped_w and st[i]["xpre"] is None and not _is_plain3x3(st[i]["spec"])
+               and _GROUP_LAUNCH and not rt.deterministic]
+        if len(sel) >= 2 and all(st[i]["raw"].dtype == st[sel[0]]["raw"].dtype for i in sel):
+            for ch in _chunks(sel):
+                if len(ch) < 2:
+                    continue
+                arr = (L.BnBwdApplyItem * len(ch))()
+                for k, i in enumerate(ch):
+                    d, q = st[i], arr[k]
+                    q.dy, q.raw, q.scale_shift, q.mean_invstd, q.sums = dyhs[i].data_ptr(), d["raw"].data_ptr(), d["ss"].data_ptr(), d["mi"].data_ptr(), sums[i].data_ptr()
+                    q.res_pre = 0 if d["rph"] is None else d["rph"].data_ptr()
+                    q.draw, q.dres = d["draw"].data_ptr(), (0 if d["dres"] is None else d["dres"].data_ptr())
+                    q.dgamma, q.dbeta = d["dgamma"].data_ptr(), d["dbeta"].data_ptr()
+                    q.rows, q.n, q.C, q.act, q.training = d["rows"], ctx.ns[i], d["C"], d["act"], int(d["tr"])
+                    q.param_grad_scale = pscale if d["tr"] else 1.0
+                L.check(lib.rssf_bn_bwd_apply_group(ctypes.cast(arr, ctypes.c_void_p), len(ch), L.dtype_code(st[ch[0]]["raw"]), L.stream()),
+                        "rssf_bn_bwd_apply_group")
+                applied.update(ch)
         for i in range(n_items):
             d = st[i]
             if i in grouped_w:
+                continue
+            if i in applied:
+                d["fuse_apply"] = False                # draw is final: the plain weight gradient below reads it
                 continue
             if d["fuse_apply"]:
                 _conv_wgrad(d["spec"], d["draw"], d["xh"], [d["tw"]], None, rt,
