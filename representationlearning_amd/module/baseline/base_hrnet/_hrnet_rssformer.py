@@ -6,6 +6,7 @@ channels-last memory (NHWC physically) end to end — the layout the HIP kernels
 Every Conv2d -> BatchNorm2d (-> ReLU / + residual) group runs as one fused autograd node on the hand-written
 implicit-GEMM / BN kernels (representationlearning_amd.nnf), nearest upsampling is fused with the branch sum;
 the remaining branch adds / ReLU are ATen elementwise kernels.  nn.Conv2d / nn.BatchNorm2d modules only hold the parameters."""
+import contextlib
 import os
 
 import torch
@@ -42,6 +43,9 @@ model_extra = {
 
 def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+_FANOUT_SIDE = os.environ.get("RSSF_FANOUT_SIDE", "1") != "0"      # A/B switch
 
 
 class BasicBlock(nn.Module):
@@ -384,7 +388,12 @@ class HighResolutionModule(nn.Module):
         xs, accs, xs0 = [], [], []
         for j in range(self.num_branches):
             n_acc = sum(1 for i in range(1, len(self.fuse_layers)) if i != j)      # (path 0 runs on another stream)
-            t, acc = nnf.fanout(x[j], n_acc, n_alias=2 if j >= 1 else 1)
+            # The node of a branch output 1.. is created under the SIDE stream (a view: no launch), so its backward - the sum of the
+            # accumulated gradients, the fuse sum's and path 0's - runs there: two of its three inputs and its consumer (the
+            # branch's backward) live on that stream, only path 0's gradient changes streams (RSSF_FANOUT_SIDE=0: on this stream)
+            s = nnf.side_stream(x[j]) if (j >= 1 and _FANOUT_SIDE) else None
+            with (torch.cuda.stream(s) if s is not None else contextlib.nullcontext()):
+                t, acc = nnf.fanout(x[j], n_acc, n_alias=2 if j >= 1 else 1)
             if j >= 1:
                 t, t0 = t
             else:

@@ -204,6 +204,16 @@ def can_fork_side(t):
     return bool(rt.branch_streams and _FORK_FUSE and t is not None and t.is_cuda and not rt.in_side and not (rt.exchanging() and not rt.stream_comms))
 
 
+def side_stream(t):
+    """The stream fork_side() would run its side function on, or None when it would not fork (see can_fork_side)."""
+    if not can_fork_side(t):
+        return None
+    pool = current().side_streams.setdefault(t.device, [])
+    if not pool:
+        pool.append(torch.cuda.Stream(t.device))
+    return pool[0]
+
+
 def fork_side(fn_side, fn_main, tensors):
     """(fn_side(), fn_main()): fn_side on a side stream when branch streams are enabled, concurrently with fn_main on the current
     stream; joined before returning.  `tensors`: what fn_side reads (they were produced on the current stream).
