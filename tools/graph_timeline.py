@@ -33,3 +33,21 @@ for q, ks in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])
     print("queue %s: %4d kernels, busy %.2f ms, span %.2f ms, gaps < 20 us: %d, sum %.2f ms (median %.2f us); gaps >= 20 us: %d, sum %.2f ms; overlapping starts %d"
           % (q, len(ks), dur / 1e6, (ks[-1][1] - ks[0][0]) / 1e6, len(small), sum(small) / 1e6, (sorted(small)[len(small) // 2] / 1e3 if small else 0),
              sum(1 for g in gaps if g >= 20000), sum(g for g in gaps if g >= 20000) / 1e6, sum(1 for g in gaps if g < 0)))
+
+# ---- where each queue waits: its gaps >= 30 us, the kernels around them and what the other queues ran meanwhile
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("rssf::", "").replace("cv::", "")
+    return n.split('(')[0][:44]
+allk = sorted((s, e, n, q) for q, ks in byq.items() for s, e, n in ks)
+for q, ks in sorted(byq.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1]))[:3]:
+    ks.sort()
+    big = [(ks[i + 1][0] - ks[i][1], i) for i in range(len(ks) - 1) if ks[i + 1][0] - ks[i][1] >= 30000]
+    print("\nqueue %s: %d gaps >= 30 us, %.2f ms" % (q, len(big), sum(g for g, _ in big) / 1e6))
+    for g, i in sorted(big, reverse=True)[:int(sys.argv[2]) if len(sys.argv) > 2 else 14]:
+        gs, ge = ks[i][1], ks[i + 1][0]
+        others = collections.Counter()
+        for s, e, n, oq in allk:
+            if oq != q and e > gs and s < ge:
+                others[short(n)] += min(e, ge) - max(s, gs)
+        top = ", ".join("%s %.0f" % (n, d / 1e3) for n, d in others.most_common(3))
+        print("  %7.1f us at +%.2f ms  after %-40s before %-40s | meanwhile (us): %s" % (g / 1e3, (gs - t0) / 1e6, short(ks[i][2])[-40:], short(ks[i + 1][2])[-40:], top))

@@ -1,0 +1,5 @@
+#!/bin/bash
+o=gpurun_out/$1; mkdir -p $o
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+for v in "RSSF_WGRAD_SIDE=0" "RSSF_WGRAD_SIDE=1" "RSSF_WGRAD_SIDE=1 RSSF_WGRAD_SIDE_MIN=4096" "RSSF_WGRAD_SIDE=1 RSSF_WGRAD_SIDE_MIN=1000000" "RSSF_WGRAD_SIDE=0" "RSSF_WGRAD_SIDE=1"; do echo "== $v" >> $o/bench.txt; env $v timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>$o/err.txt | cut -c1-200 >> $o/bench.txt; tail -2 $o/err.txt | cut -c1-200; done
+cat $o/bench.txt
