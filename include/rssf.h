@@ -435,6 +435,12 @@ int rssf_add(const void* a, const void* b, void* out, int64_t n, int dtype, void
  * which feeds its own fuse sum, the 1x1 convolution towards output 0 and the accumulating convolutions towards the other outputs
  * (_hrnet_rssformer.py:424-435) - what autograd's own accumulation would sum with two element-wise framework launches */
 int rssf_add3(const void* a, const void* b, const void* c, void* out, int64_t n, int dtype, void* stream);
+/* Channel padding of the operands whose channel count is no multiple of the 16-byte vector (the 6-class head gradient of
+ * SimpleFusion8 / hrnet_aux.py:51-68, the 3-channel stem input): dst[r][0..Cp) = src[r][0..C), zeros behind; and the way back for
+ * the parameter gradients of such a layer: dst[r][c] += src[r][c], c < cols, with row pitches (fp32) - what F.pad and a sliced
+ * add_ did with two framework launches each. */
+int rssf_pad_channels(const void* src, void* dst, int64_t rows, int C, int Cp, int dtype, void* stream);
+int rssf_add_rows(float* dst, const float* src, int rows, int cols, int ld_dst, int ld_src, void* stream);
 /* fp32 image [B,C,H,W] given by its element strides (NCHW or channels-last memory) -> channels-last [B,H,W,Cp] of `dtype`, channels
  * zero-padded to the 16-byte vector (Cp = 8 bf16 / 4 fp32): the network input of HighResolutionNet.forward
  * (_hrnet_rssformer.py:605-613) in one launch. */

@@ -144,6 +144,8 @@ SIGNATURES = {
     "rssf_vec_add_to3": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "rssf_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rssf_add3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rssf_pad_channels": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "rssf_add_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_image_to_nhwc": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_int64] * 4 + [c_int, c_void_p]),
     "rssf_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "rssf_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_float, c_void_p, c_float, c_float,

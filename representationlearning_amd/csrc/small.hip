@@ -68,6 +68,23 @@ __global__ void __launch_bounds__(256) add3_kernel(const T* __restrict__ a, cons
   }
 }
 
+// dst[r][0..Cp) = src[r][0..C) followed by zeros (Cp a multiple of the 16-byte vector): one thread per output row
+template <typename T>
+__global__ void __launch_bounds__(256) pad_channels_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t rows, int C, int Cp) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  for (int c = 0; c < Cp; ++c) stf(dst + r * Cp + c, c < C ? ldf(src + r * C + c) : 0.f);
+}
+
+// dst[r][c] += src[r][c] for c < cols, row pitches ld_dst / ld_src (fp32): a gradient computed for a channel-padded problem added
+// into the unpadded parameter gradient
+__global__ void __launch_bounds__(256) add_rows_kernel(float* __restrict__ dst, const float* __restrict__ src, int rows, int cols, int ld_dst, int ld_src) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  dst[(int64_t)r * ld_dst + c] += src[(int64_t)r * ld_src + c];
+}
+
 // one thread per output pixel: C strided reads (coalesced across the threads of a row for NCHW sources), one 16-byte store
 template <typename T>
 __global__ void __launch_bounds__(256) image_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t npix, int HW, int W,
@@ -117,6 +134,23 @@ extern "C" int rssf_image_to_nhwc(const float* src, void* dst, int B, int C, int
     return RSSF_ERR_UNSUPPORTED;
   }
   return check_launch("image_to_nhwc");
+}
+
+extern "C" int rssf_pad_channels(const void* src, void* dst, int64_t rows, int C, int Cp, int dtype, void* stream) {
+  RSSF_REQUIRE(src && dst && rows > 0 && C > 0 && Cp >= C, "pad_channels: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((rows + 255) / 256);
+  if (dtype == RSSF_BF16) pad_channels_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)src, (bf16_t*)dst, rows, C, Cp);
+  else if (dtype == RSSF_F32) pad_channels_kernel<float><<<blocks, 256, 0, st>>>((const float*)src, (float*)dst, rows, C, Cp);
+  else { set_error("pad_channels: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
+  return check_launch("pad_channels");
+}
+
+extern "C" int rssf_add_rows(float* dst, const float* src, int rows, int cols, int ld_dst, int ld_src, void* stream) {
+  RSSF_REQUIRE(dst && src && rows > 0 && cols > 0 && ld_dst >= cols && ld_src >= cols, "add_rows: bad arguments");
+  const int64_t n = (int64_t)rows * cols;
+  add_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(dst, src, rows, cols, ld_dst, ld_src);
+  return check_launch("add_rows");
 }
 
 extern "C" int rssf_add3(const void* a, const void* b, const void* c, void* out, int64_t n, int dtype, void* stream) {

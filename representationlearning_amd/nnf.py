@@ -623,7 +623,14 @@ def _pad_channels(t):
     the kernels then take their vector paths; the packed weight slabs are zero there anyway."""
     v = 8 if t.dtype == torch.bfloat16 else 4
     c = t.shape[-1]
-    return t if c % v == 0 else torch.nn.functional.pad(t, (0, v - c % v))
+    if c % v == 0:
+        return t
+    if t.is_cuda and t.dtype in (torch.bfloat16, torch.float32) and t.is_contiguous():
+        cp = (c + v - 1) // v * v
+        out = torch.empty(*t.shape[:-1], cp, device=t.device, dtype=t.dtype)
+        L.check(L.load().rssf_pad_channels(L.ptr(t), L.ptr(out), t.numel() // c, c, cp, L.dtype_code(t), L.stream()), "rssf_pad_channels")
+        return out
+    return torch.nn.functional.pad(t, (0, v - c % v))
 
 
 def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None, preact=None, cache_pack=False):
@@ -915,9 +922,10 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None):
     _, OH, OW, CO = dout.shape
     padded = C != spec.cin or CO != spec.cout
     tgt, tdb = list(dws), db
-    if padded:            # gradients of the padded problem, sliced back afterwards
-        tgt = [torch.zeros(CO, C, k, k, device=xh.device, dtype=torch.float32) for k in spec.ksizes]
-        tdb = torch.zeros(CO, device=xh.device, dtype=torch.float32) if db is not None else None
+    if padded:            # gradients of the padded problem (slices of the step's pre-zeroed pool), added back row by row afterwards
+        rt0 = rt or current()
+        tgt = [_zeros(CO * C * k * k, xh.device, rt0).view(CO, C, k, k) for k in spec.ksizes]
+        tdb = _zeros(CO, xh.device, rt0) if db is not None else None
     d = tgt + [None, None]
     lib = L.load()
     nws = lib.rssf_conv_wgrad_workspace_elems(B, OH, OW, C, CO, spec.ntaps)
@@ -953,10 +961,17 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None):
         if ref is not None and bytes(job) != bytes(ref):
             raise RuntimeError("WgradPlan: a deferred weight-gradient reduction changed between steps")
     if padded:
-        for g, t in zip(dws, tgt):
-            g += t[:spec.cout, :spec.cin]
+        for g, t, k in zip(dws, tgt, spec.ksizes):
+            if g.is_contiguous() and g.dtype == torch.float32:
+                # rows = output channels; [C, k, k] is channel-major, so the unpadded input channels are the first cin * k * k values of a row
+                L.check(lib.rssf_add_rows(L.ptr(g), L.ptr(t), spec.cout, spec.cin * k * k, spec.cin * k * k, C * k * k, L.stream()), "rssf_add_rows")
+            else:
+                g += t[:spec.cout, :spec.cin]
         if db is not None:
-            db += tdb[:spec.cout]
+            if db.is_contiguous() and db.dtype == torch.float32:
+                L.check(lib.rssf_add_rows(L.ptr(db), L.ptr(tdb), 1, spec.cout, spec.cout, CO, L.stream()), "rssf_add_rows")
+            else:
+                db += tdb[:spec.cout]
 
 
 class _ConvBNAct(torch.autograd.Function):
@@ -1541,6 +1556,7 @@ class _ConvBias(torch.autograd.Function):
         dyh = _nhwc(dy)
         if dyh.dtype != xh.dtype:
             dyh = dyh.to(xh.dtype)
+        dyh = _pad_channels(dyh)                 # once for both gradient launches (the 6-class head: 6 -> 8 channels)
         rt = ctx.rt
         dx = _nchw(_conv_dgrad(spec, dyh, [weight], xh.shape, None, rt)) if x_req else None
         p_w, p_b = ctx.params

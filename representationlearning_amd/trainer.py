@@ -326,6 +326,7 @@ class Trainer:
         self.graph = None
         self._static = None
         self._side = None
+        self._seed = None                # d loss / d loss = 1, allocated once
 
     def _flush_wgrad(self):
         wp = self.rt.wgrad_plan
@@ -358,13 +359,16 @@ class Trainer:
             try:
                 with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
                     out = self.model(img, target)
-                loss = sum(v for k, v in out.items() if k.endswith("loss"))
+                terms = [v for k, v in out.items() if k.endswith("loss")]
+                loss = terms[0] if len(terms) == 1 else sum(terms[1:], terms[0])      # (Python's sum() starts at 0: 0 + loss was a launch)
                 if self.sgd_ranges is None:
                     live = reachable_parameters(loss)
                     self.sgd_ranges = self.flat.ranges_of([i for i, p in enumerate(self.flat.params) if id(p) in live])
                     if self.buckets is not None:
                         self.buckets.set_live(live)
-                loss.backward()
+                if self._seed is None or self._seed.dtype != loss.dtype or self._seed.device != loss.device:
+                    self._seed = torch.ones((), device=loss.device, dtype=loss.dtype)
+                loss.backward(self._seed)                 # the seed gradient is a constant of the trainer, not a fill per step
             finally:
                 nnf.step_end()
         if self.buckets is not None:

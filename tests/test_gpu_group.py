@@ -397,3 +397,19 @@ def test_lockstep_module_equals_branchwise_module(monkeypatch, nb, widths, size,
         assert float((a - b).norm()) <= 2 * tol * float(b.norm()) + 1e-6, k
     for k, b in res["branch"][3].items():      # running statistics (bf16: of activations that differ in the last bit here and there)
         assert torch.allclose(res["lockstep"][3][k], b, rtol=1e-4 if dtype != BF else 5e-3, atol=1e-5 if dtype != BF else 2e-4), k
+
+
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+def test_pad_channels_and_add_rows(dtype):
+    """rssf_pad_channels = F.pad of the channel dimension; rssf_add_rows = the sliced add of a padded gradient (both bit-exact)"""
+    L, lib = _lib()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(5, 9, 7, 6, generator=g).to(DEV, dtype)
+    out = torch.full((5, 9, 7, 8), 7.0, device=DEV, dtype=dtype)
+    L.check(lib.rssf_pad_channels(L.ptr(x), L.ptr(out), 5 * 9 * 7, 6, 8, L.dtype_code(x), _stream()), "pad")
+    assert torch.equal(out, torch.nn.functional.pad(x, (0, 2)))
+    w = torch.randn(6, 3, 3, 3, generator=g).to(DEV)
+    t = torch.randn(8, 8, 3, 3, generator=g).to(DEV)
+    want = w + t[:6, :3]
+    L.check(lib.rssf_add_rows(L.ptr(w), L.ptr(t), 6, 27, 27, 72, _stream()), "add_rows")
+    assert torch.equal(w, want)
