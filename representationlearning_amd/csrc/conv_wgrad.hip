@@ -1088,7 +1088,9 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
   a.ksplit = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RSSF_BF16 && workspace && !dbias && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx)) {
-    const WgradHaloArgs h = make_wgrad_halo(dout, in, workspace, B, IH, IW, Cin, Cout, bn, xpre, a.ksplit);
+    static const int stpb = getenv("RSSF_WGRAD_HALO_TPB") ? atoi(getenv("RSSF_WGRAD_HALO_TPB")) : 8;          // tuning sweeps only
+    static const int smin = getenv("RSSF_WGRAD_HALO_MINBLK") ? atoi(getenv("RSSF_WGRAD_HALO_MINBLK")) : 256;
+    const WgradHaloArgs h = make_wgrad_halo(dout, in, workspace, B, IH, IW, Cin, Cout, bn, xpre, a.ksplit, stpb, smin);
     const dim3 hgrid((unsigned)h.xcd_per * 8);
     if (xpre) {
       if (!bn) conv3x3_wgrad_halo_kernel<false, false, true><<<hgrid, HWG_THREADS, 0, st>>>(h);
