@@ -388,6 +388,13 @@ int rssf_head_upsample_softmax(const void* logits, float* probs, int32_t* pred, 
  * backward = 1: `in` is the output gradient, `out` [B,IH,IW,C] = its s x s block sums (acc ignored). */
 int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B, int IH, int IW, int scale, int C, int backward,
                               int dtype, void* stream);
+/* The whole fuse sum of one HighResolutionModule output in one pass (_hrnet_rssformer.py:424-435: `y = y + fuse[i][j](x[j])` over
+ * j): backward = 0: io [B,OH,OW,C] = sum_k up(terms[k] [B,OH/s_k,OW/s_k,C], s_k), scales[k] = 1 for the terms at the output's
+ * resolution; fp32 accumulation in the order given, rounded once.  backward = 1: io is the output gradient, terms[k] receives its
+ * s_k x s_k block sums for every s_k > 1 (all of them in one grid); terms[k] may be null for s_k = 1 (that gradient is io itself).
+ * nterms <= 4; C a multiple of the 16-byte vector.  terms / scales are HOST arrays. */
+int rssf_upsample_nearest_sum(const void* const* terms, const int* scales, int nterms, void* io, int B, int OH, int OW, int C,
+                              int backward, int dtype, void* stream);
 
 /* ---- image-level auxiliary head: `self.headaux(self.avg_pool(f0).flatten(1))` (module/baseline/hrnet_aux.py:86-87, 99-100):
  *      global average pool of the channels-last branch-0 feature [B, HW, C] (C <= 64) -> Linear(C, K) (K <= 16), forward only (the

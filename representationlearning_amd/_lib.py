@@ -126,6 +126,7 @@ SIGNATURES = {
     "rssf_upsample_bilinear_slice": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     "rssf_head_upsample_softmax": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "rssf_upsample_nearest_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    "rssf_upsample_nearest_sum": (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rssf_aux_head_workspace_elems": (c_int64, [c_int, c_int]),
     "rssf_aux_head_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "rssf_maxpool3x3s2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -466,6 +466,126 @@ extern "C" int rssf_upsample_bilinear(const void* in, void* out, int B, int IH, 
   return rssf_upsample_bilinear_slice(in, out, B, IH, IW, OH, OW, C, C, backward, dtype, stream);
 }
 
+// ---- the fuse sum of a HighResolutionModule output in ONE pass (_hrnet_rssformer.py:424-435): out = sum_k up(term_k, s_k), s_k = 1
+// for the terms that live at the output's resolution (the branch itself, the down-sampling chains), 2 / 4 / 8 for the 1x1 paths
+// from the lower-resolution branches.  The chain of nearest_add launches read and wrote the running sum once per term; here every
+// term is read once and the sum is written once (fp32 accumulation in the reference's order of j, rounded once).  Backward: the
+// s x s block sums of the output gradient for every term with s > 1, all terms in one grid (the identity terms take the gradient
+// itself).
+namespace {
+constexpr int NS_MAX = 4;
+struct NearestSumArgs {
+  const void* term[NS_MAX];      // forward: [B, OH / s, OW / s, C]; backward: the gradients to write (null for s == 1)
+  int scale[NS_MAX];
+  int start[NS_MAX + 1];         // backward: first block of each term
+  int n, B, OH, OW, C;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) nearest_sum_fwd_kernel(NearestSumArgs a, T* __restrict__ out) {
+  constexpr int VEC = Vec<T>::N;
+  const int cols = a.C / VEC;
+  const int64_t total = (int64_t)a.B * a.OH * a.OW * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % cols);
+    int64_t p = i / cols;
+    const int ox = (int)(p % a.OW); p /= a.OW;
+    const int oy = (int)(p % a.OH);
+    const int b = (int)(p / a.OH);
+    Vec<T> v[NS_MAX];
+#pragma unroll
+    for (int k = 0; k < NS_MAX; ++k)
+      if (k < a.n) {
+        const int s = a.scale[k], ih = a.OH / s, iw = a.OW / s;
+        v[k].load((const T*)a.term[k] + (((int64_t)b * ih + oy / s) * iw + ox / s) * a.C + cv * VEC);
+      }
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS_MAX; ++k)
+      if (k < a.n) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += v[k].get(e);
+      }
+    Vec<T> r;
+    r.set_all(acc);
+    r.store(out + i * VEC);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) nearest_sum_bwd_kernel(NearestSumArgs a, const T* __restrict__ dout) {
+  constexpr int VEC = Vec<T>::N;
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < NS_MAX; ++j)
+    if (j < a.n && blockIdx.x >= (unsigned)a.start[j]) k = j;
+  const int s = a.scale[k], IH = a.OH / s, IW = a.OW / s, cols = a.C / VEC;
+  const int64_t total = (int64_t)a.B * IH * IW * cols;
+  const int64_t nblk = a.start[k + 1] - a.start[k];
+  T* din = (T*)const_cast<void*>(a.term[k]);
+  for (int64_t i = (int64_t)(blockIdx.x - a.start[k]) * 256 + threadIdx.x; i < total; i += nblk * 256) {
+    const int cv = (int)(i % cols);
+    int64_t p = i / cols;
+    const int ix = (int)(p % IW); p /= IW;
+    const int iy = (int)(p % IH);
+    const int b = (int)(p / IH);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int dy = 0; dy < s; ++dy)
+      for (int dx = 0; dx < s; ++dx) {
+        Vec<T> v;
+        v.load(dout + (((int64_t)b * a.OH + iy * s + dy) * a.OW + ix * s + dx) * a.C + cv * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += v.get(e);
+      }
+    Vec<T> o;
+    o.set_all(acc);
+    o.store(din + i * VEC);
+  }
+}
+template <typename T>
+int nearest_sum_launch(const void* const* terms, const int* scales, int n, void* io, int B, int OH, int OW, int C, int backward, hipStream_t st) {
+  constexpr int V = Vec<T>::N;
+  NearestSumArgs a = {};
+  a.B = B; a.OH = OH; a.OW = OW; a.C = C;
+  if (!backward) {
+    a.n = n;
+    for (int k = 0; k < n; ++k) { a.term[k] = terms[k]; a.scale[k] = scales[k]; }
+    nearest_sum_fwd_kernel<T><<<grid_for((int64_t)B * OH * OW * (C / V)), 256, 0, st>>>(a, (T*)io);
+    return check_launch("upsample_nearest_sum");
+  }
+  int m = 0, blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    if (scales[k] == 1) continue;                              // identity terms take the gradient itself: nothing to write
+    a.term[m] = terms[k]; a.scale[m] = scales[k];
+    a.start[m] = blocks;
+    blocks += grid_for((int64_t)B * (OH / scales[k]) * (OW / scales[k]) * (C / V));
+    ++m;
+  }
+  if (m == 0) return RSSF_OK;
+  a.n = m;
+  for (int k = m; k <= NS_MAX; ++k) a.start[k] = blocks;
+  nearest_sum_bwd_kernel<T><<<blocks, 256, 0, st>>>(a, (const T*)io);
+  return check_launch("upsample_nearest_sum(bwd)");
+}
+}  // namespace
+
+extern "C" int rssf_upsample_nearest_sum(const void* const* terms, const int* scales, int nterms, void* io, int B, int OH, int OW, int C,
+                                         int backward, int dtype, void* stream) {
+  RSSF_REQUIRE(terms && scales && io && nterms >= 1 && nterms <= NS_MAX && B > 0 && OH > 0 && OW > 0 && C > 0, "upsample_nearest_sum: bad arguments");
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  RSSF_REQUIRE(C % V == 0, "upsample_nearest_sum: %d channels are no multiple of the %d-element vector", C, V);
+  for (int k = 0; k < nterms; ++k)
+    RSSF_REQUIRE((terms[k] || (backward && scales[k] == 1)) && scales[k] >= 1 && OH % scales[k] == 0 && OW % scales[k] == 0,
+                 "upsample_nearest_sum: bad term %d (scale %d)", k, scales[k]);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RSSF_F32) return nearest_sum_launch<float>(terms, scales, nterms, io, B, OH, OW, C, backward, st);
+  if (dtype == RSSF_BF16) return nearest_sum_launch<bf16_t>(terms, scales, nterms, io, B, OH, OW, C, backward, st);
+  set_error("upsample_nearest_sum: unsupported dtype %d", dtype);
+  return RSSF_ERR_UNSUPPORTED;
+}
+
 extern "C" int rssf_upsample_nearest_add(const void* acc, const void* in, void* out, int B, int IH, int IW, int scale, int C, int backward,
                                          int dtype, void* stream) {
   RSSF_REQUIRE(in && out && B > 0 && IH > 0 && IW > 0 && scale >= 1 && C > 0, "upsample_nearest_add: bad arguments");

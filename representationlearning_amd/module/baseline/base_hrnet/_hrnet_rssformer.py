@@ -258,15 +258,11 @@ class HighResolutionModule(nn.Module):
         lows, outs = {}, [None] * nout
 
         def low_of(i):
-            low = None
+            terms, scales = [], []
             for j in range(1, nb):
-                if j == i:
-                    low = x[j] if low is None else nnf.add(low, x[j])
-                elif j > i:
-                    low = nnf.upsample_nearest_add(low, up[(i, j)], int(self.fuse_layers[i][j][2].scale_factor))
-                else:
-                    low = done[(i, j)] if low is None else nnf.add(low, done[(i, j)])
-            return low
+                terms.append(x[j] if j == i else up[(i, j)] if j > i else done[(i, j)])
+                scales.append(int(self.fuse_layers[i][j][2].scale_factor) if j > i else 1)
+            return nnf.fuse_sum(terms, scales)
 
         def fuse_rest():
             depth = 0
@@ -358,17 +354,17 @@ class HighResolutionModule(nn.Module):
         x, accs, x0 = self._fanout(x)
 
         def fuse_output(i):
-            low = None
+            terms, scales = [], []
             for j in range(1, self.num_branches):
                 if j == i:
-                    low = x[j] if low is None else nnf.add(low, x[j])
-                elif j > i:      # 1x1 conv + BN, then nearest upsample fused with the running sum
+                    terms.append(x[j]); scales.append(1)
+                elif j > i:      # 1x1 conv + BN; its nearest upsample rides in the fuse sum
                     fl = self.fuse_layers[i][j]
-                    t = nnf.conv_bn_act(x[j] if i > 0 else x0[j], fl[0], fl[1], grad_accum=accs[j] if i > 0 else None)
-                    low = nnf.upsample_nearest_add(low, t, int(fl[2].scale_factor))
+                    terms.append(nnf.conv_bn_act(x[j] if i > 0 else x0[j], fl[0], fl[1], grad_accum=accs[j] if i > 0 else None))
+                    scales.append(int(fl[2].scale_factor))
                 else:
-                    t = nnf.run_sequential(self.fuse_layers[i][j], x[j], grad_accum=accs[j])
-                    low = t if low is None else nnf.add(low, t)
+                    terms.append(nnf.run_sequential(self.fuse_layers[i][j], x[j], grad_accum=accs[j])); scales.append(1)
+            low = nnf.fuse_sum(terms, scales)
             if i == 0:
                 return self._transformer_relu(low, x[0])     # residual comes from `low`; x[0] only feeds K/V (:430-431)
             # relu(fuse[i][0](x[0]) + low) (:432-435): sum and ReLU ride in the last down-sampling conv's BatchNorm pass

@@ -1703,6 +1703,66 @@ def max_pool_3x3_s2(x):
     return _nchw(out)
 
 
+class _NearestSum(torch.autograd.Function):
+    """sum_k nn.Upsample(scale_factor=s_k, mode='nearest')(t_k) (s_k = 1: t_k itself) in one launch; backward: the block sums of the
+    output gradient for the up-sampled terms in one launch, the gradient itself for the others."""
+
+    @staticmethod
+    def forward(ctx, scales, *terms):
+        L.require_gpu(*terms)
+        ths = [_nhwc(t) for t in terms]
+        k0 = scales.index(1) if 1 in scales else None
+        if k0 is not None:
+            B, OH, OW, C = ths[k0].shape
+        else:
+            B, ih, iw, C = ths[0].shape
+            OH, OW = ih * scales[0], iw * scales[0]
+        for t, sc in zip(ths, scales):
+            if t.dtype != ths[0].dtype or tuple(t.shape) != (B, OH // sc, OW // sc, C) or OH % sc or OW % sc:
+                raise RuntimeError("upsample_nearest_sum: term of shape %s / scale %d does not fit [%d, %d, %d, %d]" % (tuple(t.shape), sc, B, OH, OW, C))
+        out = torch.empty(B, OH, OW, C, device=ths[0].device, dtype=ths[0].dtype)
+        ptrs = (ctypes.c_void_p * len(ths))(*[t.data_ptr() for t in ths])
+        L.check(L.load().rssf_upsample_nearest_sum(ptrs, _ia(list(scales)), len(ths), L.ptr(out), B, OH, OW, C, 0, L.dtype_code(out), L.stream()),
+                "rssf_upsample_nearest_sum")
+        ctx.meta = (tuple(scales), B, OH, OW, C)
+        return _nchw(out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        scales, B, OH, OW, C = ctx.meta
+        dyh = _nhwc(dy)
+        outs = [None if sc == 1 else torch.empty(B, OH // sc, OW // sc, C, device=dy.device, dtype=dy.dtype) for sc in scales]
+        if any(o is not None for o in outs):
+            ptrs = (ctypes.c_void_p * len(outs))(*[None if o is None else o.data_ptr() for o in outs])
+            L.check(L.load().rssf_upsample_nearest_sum(ptrs, _ia(list(scales)), len(outs), L.ptr(dyh), B, OH, OW, C, 1, L.dtype_code(dyh), L.stream()),
+                    "rssf_upsample_nearest_sum(bwd)")
+        return (None, *[dy if o is None else _nchw(o) for o in outs])
+
+
+_NEAREST_SUM = os.environ.get("RSSF_NEAREST_SUM", "1") != "0"      # A/B switch: the fuse sum of an output in one launch
+
+
+def fuse_sum(terms, scales):
+    """sum_k up(terms[k], scales[k]) (nearest, scale 1 = the term itself), in the order given - the `y = y + fuse[i][j](x[j])` loop of
+    HighResolutionModule.forward (_hrnet_rssformer.py:424-435).  One launch where the kernel takes the operands (<= 4 dense terms of
+    one dtype, channels a multiple of the vector), else the chain of pairwise launches."""
+    terms, scales = list(terms), [int(sc) for sc in scales]
+    if len(terms) == 1 and scales[0] == 1:
+        return terms[0]
+    t0 = terms[0]
+    v = 8 if t0.dtype == torch.bfloat16 else 4
+    if (_NEAREST_SUM and 2 <= len(terms) <= 4 and t0.is_cuda and t0.dtype in (torch.bfloat16, torch.float32) and t0.shape[1] % v == 0
+            and all(t.dtype == t0.dtype and t.is_cuda for t in terms)):
+        return _NearestSum.apply(tuple(scales), *terms)
+    low = None
+    for t, sc in zip(terms, scales):
+        if sc == 1:
+            low = t if low is None else add(low, t)
+        else:
+            low = upsample_nearest_add(low, t, sc)
+    return low
+
+
 def upsample_nearest_add(acc, x, scale):
     """(acc or 0) + nn.Upsample(scale_factor=scale, mode='nearest')(x)."""
     return _NearestAdd.apply(acc, x, int(scale))

@@ -413,3 +413,23 @@ def test_pad_channels_and_add_rows(dtype):
     want = w + t[:6, :3]
     L.check(lib.rssf_add_rows(L.ptr(w), L.ptr(t), 6, 27, 27, 72, _stream()), "add_rows")
     assert torch.equal(w, want)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (BF, 2e-2)])
+@pytest.mark.parametrize("scales", [(2, 4, 8), (1, 2, 4), (1, 1, 2), (1, 1, 1), (2, 1), (4, 2)])
+def test_fuse_sum_equals_torch(dtype, tol, scales):
+    """nnf.fuse_sum (rssf_upsample_nearest_sum, one launch forward and one backward) against nn.Upsample(nearest) + adds in fp32"""
+    from representationlearning_amd import nnf
+    B, OH, OW, C = 2, 16, 24, 16
+    g = torch.Generator(device="cpu").manual_seed(sum(scales))
+    ts = [torch.randn(B, C, OH // s, OW // s, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True) for s in scales]
+    out = nnf.fuse_sum(ts, list(scales))
+    dy = torch.randn(B, C, OH, OW, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+    out.backward(dy)
+    ref_in = [t.detach().float().requires_grad_(True) for t in ts]
+    ref = sum(r if s == 1 else torch.nn.functional.interpolate(r, scale_factor=s, mode="nearest") for r, s in zip(ref_in, scales))
+    ref.backward(dy.float())
+    assert out.shape == ref.shape
+    assert torch.allclose(out.float(), ref, rtol=tol, atol=tol)
+    for t, r, s in zip(ts, ref_in, scales):
+        assert torch.allclose(t.grad.float(), r.grad, rtol=tol, atol=tol * s * s)
