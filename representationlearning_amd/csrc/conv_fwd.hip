@@ -590,7 +590,8 @@ int launch_conv(ConvArgs a, hipStream_t st) {
   pick_tile(M, a.Cout, bm, bnt);
   // many-tap 128-channel layers (the MLP's 17-tap sum): a 256-pixel tile halves the weight-slab traffic per MFMA and
   // makes the wave tile 128 x 64 (LDS fragment reads per MFMA 0.375 instead of 0.5)
-  if (sizeof(T) == 2 && bm == 128 && bnt == 128 && a.taps.n * a.CinP >= RSSF_BM256_MINK && a.div == 1 && (a.Cin % Vec<T>::N) == 0 &&
+  static const int bm256_mink = getenv("RSSF_BM256_MINK") ? atoi(getenv("RSSF_BM256_MINK")) : RSSF_BM256_MINK;      // tuning sweeps
+  if (sizeof(T) == 2 && bm == 128 && bnt == 128 && a.taps.n * a.CinP >= bm256_mink && a.div == 1 && (a.Cin % Vec<T>::N) == 0 &&
       (M + 255) / 256 * ((a.Cout + 127) / 128) >= 512)
     bm = 256;
   a.ntiles_n = (a.Cout + bnt - 1) / bnt;
