@@ -27,6 +27,7 @@ template <int C_, int HEADS_> struct Dims {
 
 struct Geom {           // runtime geometry (image / window grid)
   int B, H, W, win, L, QH, QW, padT, padL, nWin, N;
+  int xcd_major;      // forward launcher: workgroups numbered XCD-major (win_attn_fwd.hip)
 };
 
 inline Geom make_geom(int B, int H, int W, int win) {
@@ -37,6 +38,7 @@ inline Geom make_geom(int B, int H, int W, int win) {
   g.padT = ph / 2; g.padL = pw / 2;          // center pad: floor(P/2) before (multihead_isa_attention.py:375-381)
   g.nWin = B * g.QH * g.QW;
   g.N = H * W;
+  g.xcd_major = 0;
   return g;
 }
 

@@ -244,7 +244,9 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   const int nslots = gridDim.x * LY::PAIRS;
   const int iters = (g.nWin + nslots - 1) / nslots;
   for (int iter = 0; iter < iters; ++iter) {
-    const int wi_raw = iter * nslots + blockIdx.x * LY::PAIRS + pair;
+    // (workgroups numbered XCD-major: the windows of one round that share 128-byte lines meet in one L2 - see win_attn_fwd.hip)
+    const int lb = g.xcd_major ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int wi_raw = iter * nslots + lb * LY::PAIRS + pair;
     const bool active = wi_raw < g.nWin;
     const int wi = active ? wi_raw : 0;
     const int b = wi / wpi, qh = (wi % wpi) / g.QW, qw = wi % g.QW;
@@ -819,7 +821,10 @@ int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) 
   });
   if (e != hipSuccess) { set_error("winattn_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   if (blocks > cus[dev]) blocks = cus[dev];   // one resident workgroup per CU (157 KB LDS): persistent, one gradient flush each
-  kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, g);
+  static const bool xcd_on = !(getenv("RSSF_ATTN_XCD") && getenv("RSSF_ATTN_XCD")[0] == '0');      // A/B switch
+  Geom gx = g;
+  gx.xcd_major = (xcd_on && blocks % 8 == 0 && blocks >= 8) ? 1 : 0;
+  kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, gx);
   int rc = check_launch("winattn_bwd");
   if (rc || !p->prod_ws) return rc;
   const int64_t n = (int64_t)g.B * 2 * g.N;

@@ -285,7 +285,11 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
   T* OUT = reinterpret_cast<T*>(p.out);
   const int wpi = g.QH * g.QW;
   const int stride = gridDim.x * LY::WAVES;
-  int wi = blockIdx.x * LY::WAVES + wave;
+  // Workgroups go round-robin over the 8 XCDs (conv.hip.h): numbered XCD-major, the workgroups of ONE XCD take a contiguous run of
+  // windows per round - row neighbours, whose 448-byte token rows share 128-byte lines, then meet in one L2 (g.xcd_major, set by
+  // the launcher when the grid is a multiple of 8; the window -> result map does not depend on who computes a window)
+  const int lb = g.xcd_major ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  int wi = lb * LY::WAVES + wave;
   // softmax in base 2 with the scale folded into the q projection: Wq and bq are staged multiplied by log2(e)/sqrt(d), so q needs no
   // epilogue arithmetic at all (v_exp_f32 is a base-2 exponential).  M = q^T k is linear in q: alpha reads mean(M) + max(M) back
   // through 1/log2(e).
@@ -597,7 +601,10 @@ int launch_fwd(const rssf_winattn_fwd_params* p, const Geom& g, hipStream_t st) 
   });
   if (e != hipSuccess) { set_error("winattn_fwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   if (blocks > resident[dev]) blocks = resident[dev];
-  kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, g);
+  static const bool xcd_on = !(getenv("RSSF_ATTN_XCD") && getenv("RSSF_ATTN_XCD")[0] == '0');      // A/B switch
+  Geom gx = g;
+  gx.xcd_major = (xcd_on && blocks % 8 == 0 && blocks >= 8) ? 1 : 0;
+  kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, gx);
   return check_launch("winattn_fwd");
 }
 
