@@ -280,8 +280,6 @@ int rssf_bn_bwd_apply(const void* dy, const void* raw, const float* scale_shift,
  *      single-problem entry point named with each struct (same kernels' block bodies).  n > RSSF_GROUP_MAX, mixed kinds or
  *      shapes without a grouped kernel run problem by problem through those entry points - always valid, never faster. */
 #define RSSF_GROUP_MAX 4
-/* the BatchNorm passes take more problems per launch (small items: the twelve fuse paths of one depth of a 4-branch module) */
-#define RSSF_BN_GROUP_MAX 12
 /* rssf_conv_gather_add / _bnbwd / _preact of a 3x3, stride-1, "same" convolution (taps in forward order; mirrored = 1:
  * data-gradient order, i.e. dy/dx negated, wpk the transposed pack).  Unused optional parts are NULL. */
 typedef struct rssf_conv3x3_item {

@@ -43,7 +43,6 @@ class WgradReduceJob(ctypes.Structure):       # rssf_wgrad_reduce_job
 
 
 GROUP_MAX = 4      # RSSF_GROUP_MAX
-BN_GROUP_MAX = 12  # RSSF_BN_GROUP_MAX (rssf_bn_finalize_apply_group / rssf_bn_bwd_reduce_group / rssf_bn_bwd_apply_group)
 c_double = ctypes.c_double
 
 

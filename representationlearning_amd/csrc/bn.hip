@@ -223,13 +223,13 @@ struct FinApplyItem {
   int C, act, training, gx;
   float n, momentum, eps;
 };
-struct FinApplyGroup { FinApplyItem it[RSSF_BN_GROUP_MAX]; int start[RSSF_BN_GROUP_MAX + 1]; int n; };
+struct FinApplyGroup { FinApplyItem it[RSSF_GROUP_MAX]; int start[RSSF_GROUP_MAX + 1]; int n; };
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bn_finapply_group_kernel(FinApplyGroup g) {
   extern __shared__ float lds[];
   int i = 0;
 #pragma unroll
-  for (int k = 1; k < RSSF_BN_GROUP_MAX; ++k)
+  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
     if (k < g.n && blockIdx.x >= (unsigned)g.start[k]) i = k;
   const FinApplyItem& a = g.it[i];
   const unsigned r = blockIdx.x - (unsigned)g.start[i], gx = (unsigned)a.gx;
@@ -354,13 +354,13 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
   bn_bwd_reduce_block<T, VEC, DET>(dy, raw, ss, res_pre, sums, rows, C, act, det_ws, blockIdx.x, blockIdx.y, gridDim.x, sacc, res_post);
 }
 struct ReduceItem { const void* dy; const void* raw; const float* ss; const void* rp; float* sums; int64_t rows; int C, act, gx; };
-struct ReduceGroup { ReduceItem it[RSSF_BN_GROUP_MAX]; int start[RSSF_BN_GROUP_MAX + 1]; int n; };
+struct ReduceGroup { ReduceItem it[RSSF_GROUP_MAX]; int start[RSSF_GROUP_MAX + 1]; int n; };
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_group_kernel(ReduceGroup g) {
   extern __shared__ float sacc[];
   int i = 0;
 #pragma unroll
-  for (int k = 1; k < RSSF_BN_GROUP_MAX; ++k)
+  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
     if (k < g.n && blockIdx.x >= (unsigned)g.start[k]) i = k;
   const ReduceItem& a = g.it[i];
   const unsigned r = blockIdx.x - (unsigned)g.start[i], gx = (unsigned)a.gx;
@@ -490,13 +490,13 @@ struct BwdApplyItem {
   int C, act, training, gx;
   float n, pscale;
 };
-struct BwdApplyGroup { BwdApplyItem it[RSSF_BN_GROUP_MAX]; int start[RSSF_BN_GROUP_MAX + 1]; int n; };
+struct BwdApplyGroup { BwdApplyItem it[RSSF_GROUP_MAX]; int start[RSSF_GROUP_MAX + 1]; int n; };
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bn_bwd_apply_group_kernel(BwdApplyGroup g) {
   extern __shared__ float tot[];
   int i = 0;
 #pragma unroll
-  for (int k = 1; k < RSSF_BN_GROUP_MAX; ++k)
+  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
     if (k < g.n && blockIdx.x >= (unsigned)g.start[k]) i = k;
   const BwdApplyItem& a = g.it[i];
   const unsigned r = blockIdx.x - (unsigned)g.start[i], gx = (unsigned)a.gx;
@@ -700,7 +700,7 @@ int finapply_group_launch(const rssf_bn_apply_item* items, int n, hipStream_t st
     const int nch = (it.C / V < 256 ? it.C / V : 256) * V;
     if (nch > maxc) maxc = nch;
   }
-  for (int k = n; k <= RSSF_BN_GROUP_MAX; ++k) g.start[k] = blocks;
+  for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = blocks;
   bn_finapply_group_kernel<T, V><<<(unsigned)blocks, 256, 2 * maxc * sizeof(float), st>>>(g);
   return check_launch("bn_finalize_apply_group");
 }
@@ -720,7 +720,7 @@ int reduce_group_launch(const rssf_bn_reduce_item* items, int n, hipStream_t st)
     blocks += (int)gx * cblocks;
     if (it.C > maxc) maxc = it.C;
   }
-  for (int k = n; k <= RSSF_BN_GROUP_MAX; ++k) g.start[k] = blocks;
+  for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = blocks;
   bn_bwd_reduce_group_kernel<T, V><<<(unsigned)blocks, 256, 2 * maxc * sizeof(float), st>>>(g);
   return check_launch("bn_bwd_reduce_group");
 }
@@ -740,7 +740,7 @@ int bwd_apply_group_launch(const rssf_bn_bwd_apply_item* items, int n, hipStream
     const int nch = it.C < 256 * V ? it.C : 256 * V;
     if (nch > maxc) maxc = nch;
   }
-  for (int k = n; k <= RSSF_BN_GROUP_MAX; ++k) g.start[k] = blocks;
+  for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = blocks;
   bn_bwd_apply_group_kernel<T, V><<<(unsigned)blocks, 256, 2 * maxc * sizeof(float), st>>>(g);
   return check_launch("bn_bwd_apply_group");
 }
@@ -750,7 +750,7 @@ const bool g_group_enabled = !(getenv("RSSF_GROUP_KERNELS") && getenv("RSSF_GROU
 extern "C" int rssf_bn_finalize_apply_group(const rssf_bn_apply_item* items, int n, int dtype, void* stream) {
   RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_finalize_apply_group: bad arguments");
   const int V = dtype == RSSF_BF16 ? 8 : 4;
-  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_BN_GROUP_MAX;
+  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
   for (int i = 0; i < n; ++i) {
     const rssf_bn_apply_item& it = items[i];
     RSSF_REQUIRE(it.raw && it.gamma && it.beta && it.mean_invstd && it.scale_shift && it.y && it.rows > 0 && it.C > 0 && act_ok(it.act),
@@ -773,7 +773,7 @@ extern "C" int rssf_bn_finalize_apply_group(const rssf_bn_apply_item* items, int
 extern "C" int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n, int dtype, void* stream) {
   RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_bwd_reduce_group: bad arguments");
   const int V = dtype == RSSF_BF16 ? 8 : 4;
-  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_BN_GROUP_MAX;
+  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
   for (int i = 0; i < n; ++i) {
     const rssf_bn_reduce_item& it = items[i];
     RSSF_REQUIRE(it.dy && it.raw && it.scale_shift && it.sums && it.rows > 0 && it.C > 0 && it.act >= 0 && it.act <= 2, "bn_bwd_reduce_group: bad item %d", i);
@@ -792,7 +792,7 @@ extern "C" int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n,
 extern "C" int rssf_bn_bwd_apply_group(const rssf_bn_bwd_apply_item* items, int n, int dtype, void* stream) {
   RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_bwd_apply_group: bad arguments");
   const int V = dtype == RSSF_BF16 ? 8 : 4;
-  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_BN_GROUP_MAX;
+  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
   for (int i = 0; i < n; ++i) {
     const rssf_bn_bwd_apply_item& it = items[i];
     RSSF_REQUIRE(it.dy && it.raw && it.scale_shift && it.mean_invstd && it.sums && it.draw && it.rows > 0 && it.C > 0 && it.act >= 0 && it.act <= 2,

@@ -1163,15 +1163,6 @@ def _chunks(idx):
     return [idx[k:k + L.GROUP_MAX] for k in range(0, len(idx), L.GROUP_MAX)]
 
 
-def _bn_chunks(idx):
-    """Runs of at most RSSF_BN_GROUP_MAX item indices: the BatchNorm passes take up to twelve small problems per launch."""
-    n = _BN_GROUP_MAX
-    return [idx[k:k + n] for k in range(0, len(idx), n)]
-
-
-_BN_GROUP_MAX = min(L.BN_GROUP_MAX, max(2, int(os.environ.get("RSSF_BN_GROUP", str(L.BN_GROUP_MAX)))))      # A/B: 4 = round 4's first form
-
-
 def _group_conv3x3(entries, mirrored, code):
     """entries: dicts of rssf_conv3x3_item fields (tensors or None, scalars) -> grouped launches of <= RSSF_GROUP_MAX problems."""
     lib = L.load()
@@ -1271,7 +1262,7 @@ class _ConvBNActGroup(torch.autograd.Function):
             defers.append(defer)
         code = L.dtype_code(raws[0])
         same = all(r.dtype == raws[0].dtype for r in raws)
-        for ch in (_bn_chunks(list(range(len(todo)))) if (same and _GROUP_LAUNCH) else [[k] for k in range(len(todo))]):
+        for ch in (_chunks(list(range(len(todo)))) if (same and _GROUP_LAUNCH) else [[k] for k in range(len(todo))]):
             arr = (L.BnApplyItem * len(ch))()
             for k, j in enumerate(ch):
                 for name, v in todo[j].items():
@@ -1331,7 +1322,7 @@ class _ConvBNActGroup(torch.autograd.Function):
                     L.check(lib.rssf_bn_bwd_reduce(L.ptr(dyhs[i]), L.ptr(raw), L.ptr(ss), L.ptr(rph), L.ptr(sums[i]), rows, C, m[1], L.ptr(dws),
                                                    L.dtype_code(raw), L.stream()), "rssf_bn_bwd_reduce")
             else:
-                for ch in _bn_chunks(list(range(n_items))):
+                for ch in _chunks(list(range(n_items))):
                     arr = (L.BnReduceItem * len(ch))()
                     for k, i in enumerate(ch):
                         xh, raw, ss, mi, rph, w = sv[i * 6:(i + 1) * 6]
@@ -1384,7 +1375,7 @@ class _ConvBNActGroup(torch.autograd.Function):
         sel = [i for i in range(n_items) if i not in grouped_w and st[i]["xpre"] is None and not _is_plain3x3(st[i]["spec"])
                and _GROUP_LAUNCH and not rt.deterministic]
         if len(sel) >= 2 and all(st[i]["raw"].dtype == st[sel[0]]["raw"].dtype for i in sel):
-            for ch in _bn_chunks(sel):
+            for ch in _chunks(sel):
                 if len(ch) < 2:
                     continue
                 arr = (L.BnBwdApplyItem * len(ch))()

@@ -272,7 +272,7 @@ def test_wgrad3x3_group_equals_single_launches(shapes, res, xpre):
 def test_bn_group_passes_equal_single_launches(dtype):
     """finalize + apply and the backward statistics of four layers in one grid each"""
     L, lib = _lib()
-    shapes = [(2 * 32 * 32, 32), (2 * 16 * 16, 64), (333, 128), (57, 256), (700, 32), (64, 64), (129, 32), (48, 128), (1000, 64)]      # 9 problems: one launch (RSSF_BN_GROUP_MAX = 12)
+    shapes = [(2 * 32 * 32, 32), (2 * 16 * 16, 64), (333, 128), (57, 256)]
     n = len(shapes)
     code = L.RSSF_BF16 if dtype == BF else L.RSSF_F32
     res = {}
@@ -320,7 +320,7 @@ def test_bn_bwd_apply_group_equals_single_launches(dtype):
     """the BatchNorm-backward apply of four layers (the 1x1 / strided fuse convolutions of one depth) in one grid: draw, dres and
     the parameter gradients bit-identical to rssf_bn_bwd_apply per layer"""
     L, lib = _lib()
-    shapes = [(2 * 32 * 32, 32), (2 * 16 * 16, 64), (333, 128), (57, 256), (700, 32), (64, 64), (129, 32), (48, 128), (1000, 64)]      # 9 problems: one launch (RSSF_BN_GROUP_MAX = 12)
+    shapes = [(2 * 32 * 32, 32), (2 * 16 * 16, 64), (333, 128), (57, 256)]
     n = len(shapes)
     code = L.RSSF_BF16 if dtype == BF else L.RSSF_F32
     res = {}
