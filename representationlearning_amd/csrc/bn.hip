@@ -744,13 +744,12 @@ int bwd_apply_group_launch(const rssf_bn_bwd_apply_item* items, int n, hipStream
   bn_bwd_apply_group_kernel<T, V><<<(unsigned)blocks, 256, 2 * maxc * sizeof(float), st>>>(g);
   return check_launch("bn_bwd_apply_group");
 }
-const bool g_group_enabled = !(getenv("RSSF_GROUP_KERNELS") && getenv("RSSF_GROUP_KERNELS")[0] == '0');      // A/B switch (tools/group_bench.py)
 }  // namespace
 
 extern "C" int rssf_bn_finalize_apply_group(const rssf_bn_apply_item* items, int n, int dtype, void* stream) {
   RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_finalize_apply_group: bad arguments");
   const int V = dtype == RSSF_BF16 ? 8 : 4;
-  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
+  bool grouped = n >= 2 && n <= RSSF_GROUP_MAX;
   for (int i = 0; i < n; ++i) {
     const rssf_bn_apply_item& it = items[i];
     RSSF_REQUIRE(it.raw && it.gamma && it.beta && it.mean_invstd && it.scale_shift && it.y && it.rows > 0 && it.C > 0 && act_ok(it.act),
@@ -773,7 +772,7 @@ extern "C" int rssf_bn_finalize_apply_group(const rssf_bn_apply_item* items, int
 extern "C" int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n, int dtype, void* stream) {
   RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_bwd_reduce_group: bad arguments");
   const int V = dtype == RSSF_BF16 ? 8 : 4;
-  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
+  bool grouped = n >= 2 && n <= RSSF_GROUP_MAX;
   for (int i = 0; i < n; ++i) {
     const rssf_bn_reduce_item& it = items[i];
     RSSF_REQUIRE(it.dy && it.raw && it.scale_shift && it.sums && it.rows > 0 && it.C > 0 && it.act >= 0 && it.act <= 2, "bn_bwd_reduce_group: bad item %d", i);
@@ -792,7 +791,7 @@ extern "C" int rssf_bn_bwd_reduce_group(const rssf_bn_reduce_item* items, int n,
 extern "C" int rssf_bn_bwd_apply_group(const rssf_bn_bwd_apply_item* items, int n, int dtype, void* stream) {
   RSSF_REQUIRE(items && n >= 1 && (dtype == RSSF_F32 || dtype == RSSF_BF16), "bn_bwd_apply_group: bad arguments");
   const int V = dtype == RSSF_BF16 ? 8 : 4;
-  bool grouped = g_group_enabled && n >= 2 && n <= RSSF_GROUP_MAX;
+  bool grouped = n >= 2 && n <= RSSF_GROUP_MAX;
   for (int i = 0; i < n; ++i) {
     const rssf_bn_bwd_apply_item& it = items[i];
     RSSF_REQUIRE(it.dy && it.raw && it.scale_shift && it.mean_invstd && it.sums && it.draw && it.rows > 0 && it.C > 0 && it.act >= 0 && it.act <= 2,

@@ -73,7 +73,7 @@ struct HaloArgs {
   int pre_act;
   int B, H, W, Cin, Cout, CinP, CoutP;
   int tiles_y, tiles_x, ntiles_n, xcd_per;
-  int ntb, ntiles;       // multi-tile form (conv_halo.hip): consecutive pixel tiles per block, pixel tiles of the problem
+  int ntiles;            // pixel tiles of the problem
   int64_t total;         // blocks of the launch
   int dy[9], dx[9];
 };
@@ -81,11 +81,12 @@ struct HaloArgs {
 bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_halo(HaloArgs a, hipStream_t st);
 int launch_halo_group(HaloArgs* items, int n, hipStream_t st);      // n <= RSSF_GROUP_MAX problems as one grid
-// dilated two-ring tap sets on their pixel lattice (conv_lattice.hip): MlpDWBN's fused 17-tap sum, forward and data gradient (bf16)
-bool lattice_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
-int launch_lattice(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, const void* bn_raw,
-                   const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP,
-                   int CoutP, int ntaps, const int* dy, const int* dx, hipStream_t st);
+// many-tap 128 -> 128 channel convolutions with the pixel operand in registers (conv_taps128.hip): MlpDWBN's fused 17-tap sum, forward
+// and data gradient (bf16)
+bool taps128_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps);
+int launch_taps128(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, const void* bn_raw,
+                   const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int ntaps, const int* dy,
+                   const int* dx, hipStream_t st);
 // point-wise 32 -> 128 / 128 -> 32 channel convolutions as a stream (conv_pw.hip): MlpDWBN's fc1 / fc2, forward and data gradient (bf16)
 bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,

@@ -590,7 +590,7 @@ int launch_conv(ConvArgs a, hipStream_t st) {
   pick_tile(M, a.Cout, bm, bnt);
   // many-tap 128-channel layers (the MLP's 17-tap sum): a 256-pixel tile halves the weight-slab traffic per MFMA and
   // makes the wave tile 128 x 64 (LDS fragment reads per MFMA 0.375 instead of 0.5)
-  static const int bm256_mink = getenv("RSSF_BM256_MINK") ? atoi(getenv("RSSF_BM256_MINK")) : RSSF_BM256_MINK;      // tuning sweeps
+  constexpr int bm256_mink = RSSF_BM256_MINK;
   if (sizeof(T) == 2 && bm == 128 && bnt == 128 && a.taps.n * a.CinP >= bm256_mink && a.div == 1 && (a.Cin % Vec<T>::N) == 0 &&
       (M + 255) / 256 * ((a.Cout + 127) / 128) >= 512)
     bm = 256;
@@ -703,8 +703,7 @@ struct BnBwdStats {            // see HaloArgs::bn_* (conv.hip.h)
   const void* raw; const void* res; const float* ss; float* sums; int act;
 };
 bool halo_path(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx, int dtype) {
-  static const int maxc = getenv("RSSF_HALO_MAXC") ? atoi(getenv("RSSF_HALO_MAXC")) : (1 << 30);      // tuning sweeps only (tools/conv3x3_bench.py)
-  return dtype == RSSF_BF16 && Cin <= maxc && (int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx);
+  return dtype == RSSF_BF16 && (int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && halo_eligible(IH, IW, Cin, OH, OW, mul, div, ntaps, dy, dx);
 }
 struct PreAct {              // see HaloArgs::pre_* (conv.hip.h)
   const float* stats; const float* gamma; const float* beta; float* rmean; float* rvar; float* mi; float* ss;
@@ -728,7 +727,11 @@ HaloArgs make_halo(const void* in, const void* wpk, void* out, const float* bias
 }
 int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, float* stats_ws,
                      const BnBwdStats* bn, const PreAct* pre, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
-                     const int* dy, const int* dx, int dtype, void* stream) {
+                     const int* dy, const int* dx, int dtype_flags, void* stream) {
+  // RSSF_CONV_GENERIC OR-ed into the dtype argument: the generic gather / halo kernels only (what the shape-specialised kernels are
+  // held against in the parity tests); an explicit argument of the call, not process state
+  const bool generic = (dtype_flags & RSSF_CONV_GENERIC) != 0;
+  const int dtype = dtype_flags & ~RSSF_CONV_GENERIC;
   RSSF_REQUIRE(in && wpk && out && dy && dx && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 &&
                    ntaps >= 1 && ntaps <= MAX_TAPS && mul >= 1 && div >= 1,
                "conv_gather: bad arguments");
@@ -752,12 +755,12 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
     if (rc || !bn || fused) return rc;
     return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
   }
-  if (dtype == RSSF_BF16 && !pre && !a.stats_ws && !addend && pw_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
+  if (!generic && dtype == RSSF_BF16 && !pre && !a.stats_ws && !addend && pw_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
     return launch_pw(in, wpk, out, bias, stats, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr, bn ? bn->sums : nullptr,
                      bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st);
-  if (dtype == RSSF_BF16 && !pre && !a.stats_ws && lattice_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
-    return launch_lattice(in, wpk, out, bias, stats, addend, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr,
-                          bn ? bn->sums : nullptr, bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, ntaps, dy, dx, st);
+  if (!generic && dtype == RSSF_BF16 && !pre && !a.stats_ws && taps128_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps))
+    return launch_taps128(in, wpk, out, bias, stats, addend, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr,
+                          bn ? bn->sums : nullptr, bn ? bn->act : 0, B, IH, IW, ntaps, dy, dx, st);
   if (pre) { set_error("conv_gather_preact: no kernel with a pre-activation input for this shape (ask rssf_conv_gather_preact_supported)"); return RSSF_ERR_UNSUPPORTED; }
   const bool gfused = bn && dtype == RSSF_BF16 && (Cout % 8) == 0;          // the gather kernels' 16-byte-row epilogue carries them too
   a.bn_raw = gfused ? bn->raw : nullptr; a.bn_res = gfused ? bn->res : nullptr; a.bn_ss = gfused ? bn->ss : nullptr;
@@ -814,8 +817,7 @@ extern "C" int rssf_conv3x3_group(const rssf_conv3x3_item* items, int n, int mir
   RSSF_REQUIRE(items && n >= 1 && (mirrored == 0 || mirrored == 1), "conv3x3_group: bad arguments");
   int dy[9], dx[9];
   for (int t = 0; t < 9; ++t) { dy[t] = (mirrored ? -1 : 1) * (t / 3 - 1); dx[t] = (mirrored ? -1 : 1) * (t % 3 - 1); }
-  static const bool enabled = !(getenv("RSSF_GROUP_KERNELS") && getenv("RSSF_GROUP_KERNELS")[0] == '0');      // A/B switch (tools/group_bench.py)
-  bool grouped = enabled && n >= 2 && n <= RSSF_GROUP_MAX && dtype == RSSF_BF16;
+  bool grouped = n >= 2 && n <= RSSF_GROUP_MAX && dtype == RSSF_BF16;
   for (int i = 0; i < n; ++i) {
     const rssf_conv3x3_item& it = items[i];
     RSSF_REQUIRE(it.in && it.wpk && it.out && it.B > 0 && it.H > 0 && it.W > 0 && it.Cin > 0 && it.Cout > 0, "conv3x3_group: bad item %d", i);

@@ -20,12 +20,6 @@ namespace cv {
 
 namespace {
 
-#ifndef RSSF_HALO_NTB_DEFAULT
-#define RSSF_HALO_NTB_DEFAULT 0
-#endif
-#ifndef RSSF_HALO_MT_WAVES
-#define RSSF_HALO_MT_WAVES 3      // waves per SIMD the 32-column multi-tile kernels are compiled for (<= 168 VGPRs: no spills; at 4 the mirrored form spills 52)
-#endif
 #ifndef RSSF_HALO_LDK_PAD
 #define RSSF_HALO_LDK_PAD 8
 #endif
@@ -346,374 +340,11 @@ __device__ __forceinline__ void halo_block(const HaloArgs& a, const unsigned q) 
   }
 }
 
-// MULTI-TILE form (round 4, late): a block walks `a.ntb` CONSECUTIVE pixel tiles of one output-channel column instead of one.
-// What a one-tile block pays per tile and this form pays once per block: the weight slabs of a single-chunk problem (Cin <= 32:
-// 18 KB through the L2 and 4.5 load + LDS-store pairs per thread - more bytes than the tile's own halo), the producer's BatchNorm
-// finalize (PRE), the buffer descriptors / weight offsets, and the statistics' LDS fold + atomics (they accumulate in registers
-// across the tiles).  And the latency chain load -> LDS -> MFMA -> epilogue of a tile (lesson 32) now has the NEXT tile's global
-// loads in flight under the current tile's MFMAs and epilogue, as the chunks of one tile always had.  LDS: the transposed output
-// tile aliases the halo region only, the weight region stays live.  STATS: forward launches carry the BatchNorm statistics,
-// mirrored (data-gradient) launches the fused BatchNorm-backward statistics - compile-time here (the launcher checks).
-template <int TH, int BN, bool MIRROR, bool PRE>
-__device__ __forceinline__ void halo_block_mt(const HaloArgs& a, const unsigned u) {
-  constexpr int MI = TH / 4, NI = BN / 16, HP = (TH + 2) * (TW + 2), BMP = TH * TW;
-  constexpr int LDC = BN + 8, C_ELEMS = BMP * LDC;
-  constexpr int A_ELEMS = (HP * LDK) > C_ELEMS ? (HP * LDK) : C_ELEMS, B_ELEMS = 9 * BN * LDK;
-  constexpr int A_LOADS = (HP * 4 + 255) / 256, B_LOADS = (9 * BN * 4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) bf16_t lds[A_ELEMS + B_ELEMS];
-  __shared__ float sstat[4 * 2 * BN];
-  __shared__ __attribute__((aligned(16))) float sbn[2 * BN];             // scale / shift of the fused BatchNorm-backward statistics
-  bf16_t* As = lds;
-  bf16_t* Bs = lds + A_ELEMS;
-  bf16_t* Cs = lds;
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
-  const unsigned ntn = (unsigned)a.ntiles_n, ntx = (unsigned)a.tiles_x, nty = (unsigned)a.tiles_y;
-  const unsigned tg = u / ntn;
-  const int n0 = (int)(u - tg * ntn) * BN;
-  const unsigned t_begin = tg * (unsigned)a.ntb;
-  const unsigned t_end = t_begin + (unsigned)a.ntb < (unsigned)a.ntiles ? t_begin + (unsigned)a.ntb : (unsigned)a.ntiles;
-
-  constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.in), 0,
-                                                                         (int)((int64_t)a.B * a.H * a.W * a.Cin * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wpk), 0, 9 * a.CoutP * a.CinP * 2, 0x00020000);
-  unsigned aoff[A_LOADS], boff[B_LOADS];
-  // a thread's halo slots: pixel (py, px) of the haloed tile and its 8-channel group are the same for every tile
-  int apy[A_LOADS], apx[A_LOADS];
-  const int asub = (tid & 3) * 8;
-#pragma unroll
-  for (int i = 0; i < A_LOADS; ++i) {
-    const int idx = tid + i * 256, p = idx >> 2;
-    apy[i] = p / (TW + 2);
-    apx[i] = p - apy[i] * (TW + 2);
-    if (idx >= HP * 4) apy[i] = -0x10000;                                    // a slot past the halo: never inside an image
-  }
-  auto set_tile = [&](unsigned t, int& b, int& y0, int& x0) {
-    const unsigned t1 = t / ntx;
-    x0 = (int)(t - t1 * ntx) * TW;
-    b = (int)(t1 / nty);
-    y0 = (int)(t1 - (unsigned)b * nty) * TH;
-  };
-  auto set_aoff = [&](int b, int y0, int x0) {
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int gy = y0 - 1 + apy[i], gx = x0 - 1 + apx[i];
-      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      aoff[i] = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.Cin + asub) * 2) : OOB;
-    }
-  };
-  {
-    static_assert(64 % BN == 0, "a thread's weight chunks must keep their column");
-    const int row0 = tid >> 2;
-    const unsigned b0 = (unsigned)((((row0 / BN) * a.CoutP + (row0 % BN)) * a.CinP + (tid & 3) * 8) * 2);
-    const unsigned bstep = (unsigned)((64 / BN) * a.CoutP * a.CinP * 2);
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) boff[i] = ((9 * BN * 4) % 256 == 0 || tid + i * 256 < 9 * BN * 4) ? b0 + i * bstep : OOB;
-  }
-  Vec<bf16_t> ra[A_LOADS], rb[B_LOADS];
-  constexpr int PRE_MAXC = 256;
-  __shared__ __attribute__((aligned(16))) float spre[PRE ? 2 * PRE_MAXC : 4];
-  auto finalize_producer = [&]() {
-    for (int c = tid; c < a.Cin; c += 256) {
-      float mean, var;
-      if (a.pre_training) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < RSSF_BN_SLOTS; ++k) { s1 += a.pre_stats[(size_t)k * 2 * a.Cin + c]; s2 += a.pre_stats[(size_t)k * 2 * a.Cin + a.Cin + c]; }
-        mean = s1 / a.pre_n;
-        var = fmaxf(s2 / a.pre_n - mean * mean, 0.f);
-      } else {
-        mean = a.pre_rmean[c];
-        var = a.pre_rvar[c];
-      }
-      const float invstd = rsqrtf(var + a.pre_eps);
-      const float sc = a.pre_gamma[c] * invstd, sh = a.pre_beta[c] - mean * sc;
-      spre[c] = sc; spre[PRE_MAXC + c] = sh;
-      if (u == 0) {
-        a.pre_mi[c] = mean; a.pre_mi[a.Cin + c] = invstd;
-        a.pre_ss[c] = sc; a.pre_ss[a.Cin + c] = sh;
-        if (a.pre_training && a.pre_rmean) {
-          a.pre_rmean[c] = (1.f - a.pre_momentum) * a.pre_rmean[c] + a.pre_momentum * mean;
-          a.pre_rvar[c] = (1.f - a.pre_momentum) * a.pre_rvar[c] + a.pre_momentum * var * (a.pre_n > 1.f ? a.pre_n / (a.pre_n - 1.f) : 1.f);
-        }
-      }
-    }
-  };
-  const int nchunks = a.CinP / KC;
-  const bool reloadB = nchunks > 1;                                          // one chunk: the nine slabs are staged once per block
-  auto load_chunk = [&](int kc, bool withB) {
-    const int crem = a.Cin - kc * KC;
-    const int soff = kc * KC * 2, swoff = (n0 * a.CinP + kc * KC) * 2;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i)
-      ra[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, asub < crem ? aoff[i] : OOB, soff, 0));
-    if (withB) {
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i)
-        rb[i].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, boff[i], swoff, 0));
-    }
-  };
-  // `valid` bits of the tile whose chunk sits in ra (PRE: the padding of the ACTIVATION is zero, not act(shift))
-  unsigned avalid = 0;
-  auto store_chunk = [&](int kc, bool withB) {
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int idx = tid + i * 256;
-      if constexpr (PRE) {
-        const bool valid = ((avalid >> i) & 1u) && asub < a.Cin - kc * KC;
-        const int c0 = valid ? kc * KC + asub : 0;
-        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(spre + c0), sc1 = *reinterpret_cast<const f32x4*>(spre + c0 + 4);
-        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(spre + PRE_MAXC + c0), sh1 = *reinterpret_cast<const f32x4*>(spre + PRE_MAXC + c0 + 4);
-        auto apply = [&](auto ACT) {
-          float o[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float z = fmaf(ra[i].get(e), e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
-            o[e] = decltype(ACT)::value == 1 ? fmaxf(z, 0.f) : decltype(ACT)::value == 2 ? gelu_erf(z) : z;
-          }
-          ra[i].set_all(o);
-        };
-        if (a.pre_act == 1) apply(std::integral_constant<int, 1>{});
-        else if (a.pre_act == 2) apply(std::integral_constant<int, 2>{});
-        else apply(std::integral_constant<int, 0>{});
-        if (!valid) ra[i].clear();
-      }
-      if ((HP * 4) % 256 == 0 || idx < HP * 4) ra[i].store(As + (idx >> 2) * LDK + (idx & 3) * 8);
-    }
-    if (withB) {
-#pragma unroll
-      for (int i = 0; i < B_LOADS; ++i) {
-        const int idx = tid + i * 256;
-        if ((9 * BN * 4) % 256 == 0 || idx < 9 * BN * 4) rb[i].store(Bs + (idx >> 2) * LDK + (idx & 3) * 8);
-      }
-    }
-  };
-  auto valid_bits = [&]() {
-    unsigned v = 0;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) v |= (aoff[i] != OOB ? 1u : 0u) << i;
-    return v;
-  };
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
-
-  // statistics accumulated over the block's tiles (registers), folded once behind the loop
-  constexpr int OCPR = BN / 8;
-  const bool fwd_stats = !MIRROR && a.stats != nullptr;
-  const bool bnb = MIRROR && a.bn_sums != nullptr;
-  const bool vec_out = (a.Cout % 8) == 0;
-  const int ccl = (tid % OCPR) * 8;
-  float s1a[NI], s2a[NI], t1[8], t2[8];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) { s1a[ni] = 0.f; s2a[ni] = 0.f; }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
-  if (bnb) {
-    for (int i = tid; i < 2 * BN; i += 256) {
-      const int c = n0 + (i % BN);
-      sbn[i] = c < a.Cout ? a.bn_ss[(i / BN) * a.Cout + c] : 0.f;
-    }
-  }
-  const int out_bytes = (int)((int64_t)a.B * a.H * a.W * a.Cout * 2);
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.addend ? a.addend : a.out), 0, out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rraw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(bnb ? a.bn_raw : a.out), 0, out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(bnb && a.bn_res ? a.bn_res : a.out), 0, out_bytes, 0x00020000);
-
-  unsigned t = t_begin;
-  int kc = 0, b, y0, x0, nb_ = 0, ny_ = 0, nx_ = 0;
-  set_tile(t, b, y0, x0);
-  set_aoff(b, y0, x0);
-  load_chunk(0, true);
-  unsigned nvalid = valid_bits();
-  if constexpr (PRE) finalize_producer();
-  if (PRE || bnb) __syncthreads();
-  while (true) {
-    avalid = nvalid;
-    store_chunk(kc, reloadB || t == t_begin);
-    __syncthreads();
-    const bool last_chunk = kc + 1 == nchunks;
-    const unsigned tn = last_chunk ? t + 1 : t;
-    const int kn = last_chunk ? 0 : kc + 1;
-    const bool more = tn < t_end;
-    if (more) {
-      if (last_chunk) {
-        set_tile(tn, nb_, ny_, nx_);
-        set_aoff(nb_, ny_, nx_);
-        nvalid = valid_bits();
-      }
-      load_chunk(kn, reloadB);
-    }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = MIRROR ? 1 - tap / 3 : tap / 3 - 1, dx = MIRROR ? 1 - tap % 3 : tap % 3 - 1;
-      bf16x8 fa[MI], fb[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        fa[mi] = *reinterpret_cast<const bf16x8*>(As + ((wave * MI + mi + 1 + dy) * (TW + 2) + l15 + 1 + dx) * LDK + grp * 8);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        fb[ni] = *reinterpret_cast<const bf16x8*>(Bs + (tap * BN + ni * 16 + l15) * LDK + grp * 8);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();
-    if (last_chunk) {
-      // ---- epilogue of tile t: bias, statistics partials, transposed store (Cs aliases the halo region: dead until the next store)
-      const bool full = y0 + TH <= a.H && x0 + TW <= a.W;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int lcol = ni * 16 + l15, col = n0 + lcol;
-        const float bv = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int py = wave * MI + mi;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            acc[mi][ni][r] += bv;
-            stf(Cs + (py * TW + grp * 4 + r) * LDC + lcol, acc[mi][ni][r]);
-          }
-        }
-        if (fwd_stats) {
-          if (full) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { const float v = acc[mi][ni][r]; s1a[ni] += v; s2a[ni] = fmaf(v, v, s2a[ni]); }
-          } else {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-              const bool yok = y0 + wave * MI + mi < a.H;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float v = acc[mi][ni][r];
-                if (yok && x0 + grp * 4 + r < a.W) { s1a[ni] += v; s2a[ni] = fmaf(v, v, s2a[ni]); }
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = {0.f, 0.f, 0.f, 0.f};
-      }
-      __syncthreads();
-      if (vec_out) {
-        static_assert((BMP * OCPR) % 256 == 0 && 256 % OCPR == 0, "whole passes of the 256 threads over the output chunks, fixed channel chunk");
-#pragma unroll
-        for (int it = 0; it < BMP * OCPR / 256; ++it) {
-          const int c = tid + it * 256;
-          const int pix = c / OCPR, cc = (c % OCPR) * 8;
-          const int gy = y0 + pix / TW, gx = x0 + pix % TW, col = n0 + cc;
-          const bool ok = gy < a.H && gx < a.W && col < a.Cout;
-          const unsigned off = ok ? (unsigned)((((b * a.H + gy) * a.W + gx) * a.Cout + col) * 2) : OOB;
-          Vec<bf16_t> v, xr, xp;
-          if (bnb) {
-            xr.raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rraw, off, 0, 0));
-            if (a.bn_res) xp.raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, 0));
-          }
-          v.load(Cs + pix * LDC + cc);
-          if (a.addend) {
-            Vec<bf16_t> w;
-            w.raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, off, 0, 0));
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = v.get(e) + w.get(e);
-            v.set_all(o);
-          }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, v.raw), rout, off, 0, 0);
-          if (bnb) {
-            if (!ok) v.clear();
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(sbn + ccl), c1 = *reinterpret_cast<const f32x4*>(sbn + ccl + 4);
-            const f32x4 h0 = *reinterpret_cast<const f32x4*>(sbn + BN + ccl), h1 = *reinterpret_cast<const f32x4*>(sbn + BN + ccl + 4);
-            auto accumulate = [&](auto ACT) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float x = xr.get(e);
-                float z = fmaf(x, e < 4 ? c0[e & 3] : c1[e & 3], e < 4 ? h0[e & 3] : h1[e & 3]);
-                if (a.bn_res) z += xp.get(e);
-                const float g = v.get(e);
-                const float dz = decltype(ACT)::value == 1 ? (z > 0.f ? g : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
-                t1[e] += dz; t2[e] = fmaf(dz, x, t2[e]);
-              }
-            };
-            if (a.bn_act == 1) accumulate(std::integral_constant<int, 1>{});
-            else if (a.bn_act == 2) accumulate(std::integral_constant<int, 2>{});
-            else accumulate(std::integral_constant<int, 0>{});
-          }
-        }
-      } else {
-        for (int c = tid; c < BMP * OCPR; c += 256) {
-          const int pix = c / OCPR, cc = (c % OCPR) * 8;
-          const int gy = y0 + pix / TW, gx = x0 + pix % TW, col = n0 + cc;
-          if (gy >= a.H || gx >= a.W || col >= a.Cout) continue;
-          bf16_t* dst = a.out + (((int64_t)b * a.H + gy) * a.W + gx) * a.Cout + col;
-          const bf16_t* add = a.addend ? a.addend + (dst - a.out) : nullptr;
-          for (int e = 0; e < 8 && col + e < a.Cout; ++e) stf(dst + e, ldf(Cs + pix * LDC + cc + e) + (add ? ldf(add + e) : 0.f));
-        }
-      }
-      if (more) __syncthreads();                               // the next store overwrites the region Cs lives in
-    }
-    if (!more) break;
-    if (last_chunk) { b = nb_; y0 = ny_; x0 = nx_; }
-    t = tn; kc = kn;
-  }
-
-  // ---- the block's statistics: one LDS row of partials per wave, summed in a fixed order, one atomic per channel and sum
-  if (fwd_stats) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const float s1 = rows_reduce<OpSum>(s1a[ni]), s2 = rows_reduce<OpSum>(s2a[ni]);
-      if (grp == 0) { sstat[wave * 2 * BN + ni * 16 + l15] = s1; sstat[(wave * 2 + 1) * BN + ni * 16 + l15] = s2; }
-    }
-    __syncthreads();
-    float* slot = a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * a.Cout;
-    for (int i = tid; i < BN; i += 256) {
-      float u1 = 0.f, u2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { u1 += sstat[w * 2 * BN + i]; u2 += sstat[(w * 2 + 1) * BN + i]; }
-      if (n0 + i < a.Cout) { atomicAdd(slot + n0 + i, u1); atomicAdd(slot + a.Cout + n0 + i, u2); }
-    }
-  }
-  if (bnb && vec_out) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (OCPR == 4) { t1[e] += dpp_mov<0x124>(t1[e]); t2[e] += dpp_mov<0x124>(t2[e]); }      // row_ror:4
-      t1[e] += dpp_mov<0x128>(t1[e]); t2[e] += dpp_mov<0x128>(t2[e]);                          // row_ror:8
-      t1[e] = rows_reduce<OpSum>(t1[e]); t2[e] = rows_reduce<OpSum>(t2[e]);
-    }
-    if (lane < OCPR) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { sstat[wave * 2 * BN + ccl + e] = t1[e]; sstat[(wave * 2 + 1) * BN + ccl + e] = t2[e]; }
-    }
-    __syncthreads();
-    float* slot = a.bn_sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * a.Cout;
-    for (int i = tid; i < BN; i += 256) {
-      float u1 = 0.f, u2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { u1 += sstat[w * 2 * BN + i]; u2 += sstat[(w * 2 + 1) * BN + i]; }
-      if (n0 + i < a.Cout) { atomicAdd(slot + n0 + i, u1); atomicAdd(slot + a.Cout + n0 + i, u2); }
-    }
-  }
-}
-
 template <int TH, int BN, bool MIRROR, bool PRE = false>
 __global__ void __launch_bounds__(256) conv3x3_halo_kernel(HaloArgs a) {
   const int64_t q64 = xcd_logical(blockIdx.x, a.xcd_per);
   if (q64 >= a.total) return;
   halo_block<TH, BN, MIRROR, PRE>(a, (unsigned)q64);
-}
-
-template <int TH, int BN, bool MIRROR, bool PRE = false>
-__global__ void __launch_bounds__(256, BN == 64 ? 2 : RSSF_HALO_MT_WAVES) conv3x3_halo_mt_kernel(HaloArgs a) {
-  const int64_t q64 = xcd_logical(blockIdx.x, a.xcd_per);
-  if (q64 >= a.total) return;
-  halo_block_mt<TH, BN, MIRROR, PRE>(a, (unsigned)q64);
 }
 
 // GROUPED launch: up to RSSF_GROUP_MAX independent problems (the parallel branches of a HighResolutionModule run the same
@@ -743,28 +374,6 @@ __global__ void __launch_bounds__(256) conv3x3_halo_group_kernel(HaloGroupArgs g
   halo_block<TH, 32, MIRROR, PRE>(a, (unsigned)q);
 }
 
-template <bool MIRROR, bool PRE>
-__global__ void __launch_bounds__(256, RSSF_HALO_MT_WAVES) conv3x3_halo_group_mt_kernel(HaloGroupArgs g) {
-  const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-  int i = 0;
-#pragma unroll
-  for (int k = 1; k < RSSF_GROUP_MAX; ++k)
-    if (k < g.n && idx >= (unsigned)g.start[k]) i = k;
-  const HaloArgs& a = g.it[i];
-  const int64_t q = (int64_t)xcd * a.xcd_per + (idx - (unsigned)g.start[i]);
-  if (q >= a.total) return;
-  halo_block_mt<8, 32, MIRROR, PRE>(a, (unsigned)q);
-}
-
-// tiles per block of the multi-tile form; 0: the one-tile kernels (RSSF_HALO_NTB, A/B switch and tuning sweeps)
-static int halo_ntb() {
-  const char* e = getenv("RSSF_HALO_NTB");             // read per call: the parity tests flip it inside one process
-  const int v = e ? atoi(e) : RSSF_HALO_NTB_DEFAULT;
-  return v < 0 ? 0 : v > 64 ? 64 : v;
-}
-// the multi-tile form carries the forward statistics in forward order and the BatchNorm-backward statistics in mirrored order
-static bool mt_serves(const HaloArgs& a, bool mirror) { return !a.stats_ws && (mirror ? a.stats == nullptr : a.bn_sums == nullptr); }
-
 }  // namespace
 
 // true when the halo kernel covers this call (bf16 only; the caller checked the dtype)
@@ -784,15 +393,14 @@ bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, in
   return tap_order(dy, dx) != 0;
 }
 
-static int tile_problem(HaloArgs& a, int th, int bn, int ntb = 1) {
+static int tile_problem(HaloArgs& a, int th, int bn) {
   a.tiles_x = (a.W + TW - 1) / TW;
   a.tiles_y = (a.H + th - 1) / th;
   a.ntiles_n = (a.Cout + bn - 1) / bn;
   const int64_t ntiles = (int64_t)a.B * a.tiles_y * a.tiles_x;
   if (ntiles >= ((int64_t)1 << 31)) { set_error("conv3x3_halo: %lld tiles exceed the 32-bit tile arithmetic", (long long)ntiles); return RSSF_ERR_UNSUPPORTED; }
-  a.ntb = ntb < 1 ? 1 : ntb;
   a.ntiles = (int)ntiles;
-  a.total = ((ntiles + a.ntb - 1) / a.ntb) * a.ntiles_n;       // blocks: runs of ntb consecutive tiles x output-channel columns
+  a.total = ntiles * a.ntiles_n;                               // blocks: pixel tiles x output-channel columns
   if (a.total >= ((int64_t)1 << 31)) { set_error("conv3x3_halo: %lld blocks exceed the 32-bit tile arithmetic", (long long)a.total); return RSSF_ERR_UNSUPPORTED; }
   a.xcd_per = xcd_per(a.total);
   return RSSF_OK;
@@ -810,9 +418,7 @@ int launch_halo_group(HaloArgs* items, int n, hipStream_t st) {
   HaloGroupArgs g;
   g.n = n;
   int idx = 0;
-  static const int gth = getenv("RSSF_GROUP_TH") ? atoi(getenv("RSSF_GROUP_TH")) : 8;      // tuning sweeps only (tools/group_bench.py)
-  int ntb = gth == 8 ? halo_ntb() : 0;
-  for (int k = 0; k < n; ++k) ntb = mt_serves(items[k], mirror) ? ntb : 0;
+  constexpr int gth = 8;           // tile height of the grouped form (16-row tiles measured equal: round 4)
   for (int k = 0; k < n; ++k) {
     HaloArgs& a = items[order[k]];
     if ((tap_order(a.dy, a.dx) < 0) != mirror || (a.pre_ss != nullptr) != pre || a.stats_ws) {
@@ -820,24 +426,13 @@ int launch_halo_group(HaloArgs* items, int n, hipStream_t st) {
       return RSSF_ERR_BAD_ARG;
     }
     if (pre && (mirror || a.Cin > 256)) { set_error("conv3x3_halo_group: a pre-activation input is a forward-launch feature (<= 256 channels)"); return RSSF_ERR_UNSUPPORTED; }
-    if (const int rc = tile_problem(a, gth, 32, ntb)) return rc;
+    if (const int rc = tile_problem(a, gth, 32)) return rc;
     g.it[k] = a;
     g.start[k] = idx;
     idx += a.xcd_per;
   }
   for (int k = n; k <= RSSF_GROUP_MAX; ++k) g.start[k] = idx;
   const dim3 grid((unsigned)idx * 8);
-  if (ntb >= 1) {
-    if (mirror) conv3x3_halo_group_mt_kernel<true, false><<<grid, 256, 0, st>>>(g);
-    else if (pre) conv3x3_halo_group_mt_kernel<false, true><<<grid, 256, 0, st>>>(g);
-    else conv3x3_halo_group_mt_kernel<false, false><<<grid, 256, 0, st>>>(g);
-    return check_launch("conv3x3_halo_group");
-  }
-  if (gth == 16) {
-    if (mirror) conv3x3_halo_group_kernel<true, false, 16><<<grid, 256, 0, st>>>(g);
-    else if (pre) conv3x3_halo_group_kernel<false, true, 16><<<grid, 256, 0, st>>>(g);
-    else conv3x3_halo_group_kernel<false, false, 16><<<grid, 256, 0, st>>>(g);
-  } else
   if (mirror) conv3x3_halo_group_kernel<true, false><<<grid, 256, 0, st>>>(g);
   else if (pre) conv3x3_halo_group_kernel<false, true><<<grid, 256, 0, st>>>(g);
   else conv3x3_halo_group_kernel<false, false><<<grid, 256, 0, st>>>(g);
@@ -851,18 +446,12 @@ int launch_halo(HaloArgs a, hipStream_t st) {
   if (a.Cout >= 64 && tiles8 * ((a.Cout + 63) / 64) >= 512) bn = 64;
   else if (tiles8 * ((a.Cout + 31) / 32) < 512) th = 4;
   const bool mirror = tap_order(a.dy, a.dx) < 0;
-  const int ntb = mt_serves(a, mirror) ? halo_ntb() : 0;
-  if (const int rc = tile_problem(a, th, bn, ntb)) return rc;
+  if (const int rc = tile_problem(a, th, bn)) return rc;
   dim3 grid((unsigned)a.xcd_per * 8);
   if (a.pre_ss && (mirror || a.Cin > 256)) { set_error("conv3x3_halo: a pre-activation input is a forward-launch feature (<= 256 channels)"); return RSSF_ERR_UNSUPPORTED; }
 #define RSSF_HALO(THv, BNv)                                                      \
   do {                                                                           \
-    if (ntb >= 1) {                                                              \
-      if (mirror) conv3x3_halo_mt_kernel<THv, BNv, true><<<grid, 256, 0, st>>>(a);    \
-      else if (a.pre_ss) conv3x3_halo_mt_kernel<THv, BNv, false, true><<<grid, 256, 0, st>>>(a);  \
-      else conv3x3_halo_mt_kernel<THv, BNv, false><<<grid, 256, 0, st>>>(a);     \
-    }                                                                            \
-    else if (mirror) conv3x3_halo_kernel<THv, BNv, true><<<grid, 256, 0, st>>>(a);    \
+    if (mirror) conv3x3_halo_kernel<THv, BNv, true><<<grid, 256, 0, st>>>(a);    \
     else if (a.pre_ss) conv3x3_halo_kernel<THv, BNv, false, true><<<grid, 256, 0, st>>>(a);  \
     else conv3x3_halo_kernel<THv, BNv, false><<<grid, 256, 0, st>>>(a);          \
   } while (0)

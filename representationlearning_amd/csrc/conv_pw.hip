@@ -168,9 +168,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 }  // namespace
 
 bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx) {
-  const char* sw = getenv("RSSF_PW");                        // A/B switch, read per call (tests hold the two kernels against each other)
-  const bool enabled = !(sw && sw[0] == '0');
-  return enabled && ntaps == 1 && dy[0] == 0 && dx[0] == 0 && mul == 1 && div == 1 && IH == OH && IW == OW &&
+  return ntaps == 1 && dy[0] == 0 && dx[0] == 0 && mul == 1 && div == 1 && IH == OH && IW == OW &&
          ((Cin == 32 && Cout == 128) || (Cin == 128 && Cout == 32) || (Cin == 64 && Cout == 256)) &&
          (int64_t)B * IH * IW * (Cin > Cout ? Cin : Cout) < ((int64_t)1 << 30);
 }
@@ -183,7 +181,7 @@ int launch_pw(const void* in, const void* wpk, void* out, const float* bias, flo
   a.M = (int64_t)B * H * W; a.CoutP = CoutP; a.CinP = CinP; a.Cout = Cout;
   const int64_t ntiles = (a.M + 15) / 16;
   int64_t blocks = (ntiles + 3) / 4;
-  static const int maxb = getenv("RSSF_PW_BLOCKS") ? atoi(getenv("RSSF_PW_BLOCKS")) : 512;      // tuning (measured at 16 x 128^2: 512 blocks 17 / 36 us, 1 024: 20 / 39, 2 048: 25 / 45)
+  constexpr int maxb = 512;                                    // (measured at 16 x 128^2: 512 blocks 17 / 36 us, 1 024: 20 / 39, 2 048: 25 / 45)
   if (blocks > maxb) blocks = maxb;
   if (Cin == 64) {                                             // 64 -> 256 (layer1's Bottleneck expansions): two slices of 128 channels
     const dim3 grid2((unsigned)blocks, 2);

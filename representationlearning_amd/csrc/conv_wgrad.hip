@@ -957,8 +957,7 @@ int pick_ksplit(int cout, int cin, int ntaps, int64_t M) {
   const int t = tile_of(cout, cin);
   int64_t par = (int64_t)((cout + t - 1) / t) * ((cin + t - 1) / t);
   if (!taps_in_registers(cout, cin)) par *= ntaps;
-  static const int blocks128 = getenv("RSSF_WGRAD_KS128") ? atoi(getenv("RSSF_WGRAD_KS128")) : 512;      // tuning sweeps only
-  static const int blocks64 = getenv("RSSF_WGRAD_KS64") ? atoi(getenv("RSSF_WGRAD_KS64")) : 1024;       // tuning sweeps only
+  constexpr int blocks128 = 512, blocks64 = 1024;           // swept in the step, round 4: 1 024 blocks 31.70 ms, 768: 31.66, 512: 31.84, 256: 32.83
   int64_t ks = (t == 128 ? blocks128 : blocks64) / par;  // measured on MI355X (tools/wgrad_bench.py sweep)
   const int64_t maxks = (M + 4 * KP - 1) / (4 * KP);
   if (ks > maxks) ks = maxks;
@@ -979,9 +978,7 @@ int launch_group(WgradArgs& a, int tap0, int ntap, hipStream_t st) {
     if (vok) conv_wgrad_kernel<T, TMN, (TMN == 32 ? 9 : 1), true><<<grid, 256, 0, st>>>(a);
     else conv_wgrad_kernel<T, TMN, (TMN == 32 ? 9 : 1), false><<<grid, 256, 0, st>>>(a);
   } else {
-    static const bool wg8 = !(getenv("RSSF_WGRAD8") && getenv("RSSF_WGRAD8")[0] == '0');       // A/B switch (tools/wgrad_bench.py)
-    static const bool t2 = !(getenv("RSSF_WGRAD_T2") && getenv("RSSF_WGRAD_T2")[0] == '0');     // A/B switch: two taps per block
-    if (TMN == 128 && sizeof(T) == 2 && vok && a.partial && wg8 && t2 && ntap >= 2) {
+    if (TMN == 128 && sizeof(T) == 2 && vok && a.partial && ntap >= 2) {
       // one round of the chip: tap groups x ksplit <= CUs (never more planes than the workspace was sized for)
       static const int cus = [] { int d = 0, v = 256; (void)hipGetDevice(&d); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256; return v; }();
       static hipError_t e2 = hipFuncSetAttribute((const void*)conv_wgrad8x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG8X2_LDS);
@@ -994,7 +991,7 @@ int launch_group(WgradArgs& a, int tap0, int ntap, hipStream_t st) {
       a.inner = tiles * groups;
       a.xcd_per = xcd_per((int64_t)a.inner * a.ksplit);
       conv_wgrad8x2_kernel<<<dim3((unsigned)a.xcd_per * 8), 512, WG8X2_LDS, st>>>(a);
-    } else if (TMN == 128 && sizeof(T) == 2 && vok && a.partial && wg8) conv_wgrad8_kernel<<<grid, 512, 0, st>>>(a);
+    } else if (TMN == 128 && sizeof(T) == 2 && vok && a.partial) conv_wgrad8_kernel<<<grid, 512, 0, st>>>(a);
     else if (vok) conv_wgrad_kernel<T, TMN, 1, true><<<grid, 256, 0, st>>>(a);
     else conv_wgrad_kernel<T, TMN, 1, false><<<grid, 256, 0, st>>>(a);
   }
@@ -1088,8 +1085,7 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
   a.ksplit = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RSSF_BF16 && workspace && !dbias && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx)) {
-    static const int stpb = getenv("RSSF_WGRAD_HALO_TPB") ? atoi(getenv("RSSF_WGRAD_HALO_TPB")) : 8;          // tuning sweeps only
-    static const int smin = getenv("RSSF_WGRAD_HALO_MINBLK") ? atoi(getenv("RSSF_WGRAD_HALO_MINBLK")) : 256;
+    constexpr int stpb = 8, smin = 256;          // tiles per block / fewest blocks (swept in round 4: tools/wgrad_bench.py)
     const WgradHaloArgs h = make_wgrad_halo(dout, in, workspace, B, IH, IW, Cin, Cout, bn, xpre, a.ksplit, stpb, smin);
     const dim3 hgrid((unsigned)h.xcd_per * 8);
     if (xpre) {
@@ -1166,8 +1162,7 @@ extern "C" int rssf_conv3x3_wgrad_group(const rssf_wgrad3x3_item* items, int n, 
   int dy[9], dx[9];
   for (int t = 0; t < 9; ++t) { dy[t] = t / 3 - 1; dx[t] = t % 3 - 1; }
   static const int ks9[1] = {3}, src9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, kpos9[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
-  static const bool enabled = !(getenv("RSSF_GROUP_KERNELS") && getenv("RSSF_GROUP_KERNELS")[0] == '0');      // A/B switch (tools/group_bench.py)
-  bool grouped = enabled && n >= 2 && n <= RSSF_GROUP_MAX && dtype == RSSF_BF16;
+  bool grouped = n >= 2 && n <= RSSF_GROUP_MAX && dtype == RSSF_BF16;
   for (int i = 0; i < n; ++i) {
     const rssf_wgrad3x3_item& it = items[i];
     RSSF_REQUIRE(it.in && it.dw && it.B > 0 && it.H > 0 && it.W > 0 && it.Cin > 0 && it.Cout > 0 && (it.bn_dy ? it.draw != nullptr : it.dout != nullptr),
@@ -1194,8 +1189,7 @@ extern "C" int rssf_conv3x3_wgrad_group(const rssf_wgrad3x3_item* items, int n, 
       int ksplit = 1;
       // the problems of a group fill the chip TOGETHER: each may run longer tile runs per block (fewer split-K partial planes for
       // the second stage to fold: 3.5 GB per step with runs of 8) as long as it keeps >= gmin blocks
-      static const int gtpb = getenv("RSSF_GROUP_WGRAD_TPB") ? atoi(getenv("RSSF_GROUP_WGRAD_TPB")) : 16;
-      static const int gmin = getenv("RSSF_GROUP_WGRAD_MINBLK") ? atoi(getenv("RSSF_GROUP_WGRAD_MINBLK")) : 128;
+      constexpr int gtpb = 16, gmin = 128;
       g.it[i] = make_wgrad_halo(it.bn_dy ? it.draw : it.dout, it.in, it.workspace, it.B, it.H, it.W, it.Cin, it.Cout, it.bn_dy ? &bn : nullptr,
                                 it.in_ss ? &xp : nullptr, ksplit, n >= 2 ? gtpb : 8, n >= 2 ? gmin : 256);
       g.start[i] = idx;

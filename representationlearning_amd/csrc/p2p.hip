@@ -119,8 +119,7 @@ extern "C" int rssf_p2p_create(rssf_p2p** out, int rank, int world, int channels
   }
   memcpy(ipc_handle64, &ih, 64);
   h->peer[rank] = h->window;
-  const char* ms = getenv("RSSF_P2P_TIMEOUT_MS");
-  h->timeout_ticks = (long long)(ms ? atoll(ms) : 10000) * 100000LL;       // wall_clock64: 100 MHz
+  h->timeout_ticks = 10000LL * 100000LL;       // 10 s at wall_clock64's 100 MHz until rssf_p2p_set_timeout_ms says otherwise
   *out = h;
   return RSSF_OK;
 }

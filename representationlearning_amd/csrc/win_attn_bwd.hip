@@ -821,9 +821,8 @@ int launch_bwd(const rssf_winattn_bwd_params* p, const Geom& g, hipStream_t st) 
   });
   if (e != hipSuccess) { set_error("winattn_bwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   if (blocks > cus[dev]) blocks = cus[dev];   // one resident workgroup per CU (157 KB LDS): persistent, one gradient flush each
-  static const bool xcd_on = !(getenv("RSSF_ATTN_XCD") && getenv("RSSF_ATTN_XCD")[0] == '0');      // A/B switch
   Geom gx = g;
-  gx.xcd_major = (xcd_on && blocks % 8 == 0 && blocks >= 8) ? 1 : 0;
+  gx.xcd_major = (blocks % 8 == 0 && blocks >= 8) ? 1 : 0;
   kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, gx);
   int rc = check_launch("winattn_bwd");
   if (rc || !p->prod_ws) return rc;

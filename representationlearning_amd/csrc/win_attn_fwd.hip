@@ -601,9 +601,8 @@ int launch_fwd(const rssf_winattn_fwd_params* p, const Geom& g, hipStream_t st) 
   });
   if (e != hipSuccess) { set_error("winattn_fwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   if (blocks > resident[dev]) blocks = resident[dev];
-  static const bool xcd_on = !(getenv("RSSF_ATTN_XCD") && getenv("RSSF_ATTN_XCD")[0] == '0');      // A/B switch
   Geom gx = g;
-  gx.xcd_major = (xcd_on && blocks % 8 == 0 && blocks >= 8) ? 1 : 0;
+  gx.xcd_major = (blocks % 8 == 0 && blocks >= 8) ? 1 : 0;
   kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, gx);
   return check_launch("winattn_fwd");
 }

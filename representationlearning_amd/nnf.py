@@ -633,13 +633,15 @@ def _pad_channels(t):
     return torch.nn.functional.pad(t, (0, v - c % v))
 
 
-def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None, preact=None, cache_pack=False):
+def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None, preact=None, cache_pack=False, generic=False):
+    """generic: run the generic gather / halo kernels only (rssf.h RSSF_CONV_GENERIC) - what the parity tests hold the
+    shape-specialised kernels (conv_pw.hip, conv_taps128.hip) against."""
     if spec.parts is not None:                      # > 19 taps: partial sums chained through the epilogue's addend (inference)
         if stats is not None:
             raise NotImplementedError("librssf conv: fused statistics are not available for tap-split convolutions")
         out = None
         for k, part in enumerate(spec.parts):
-            out = _conv_forward(part, xh, weights, bias if k == 0 else None, None, rt, addend=out, cache_pack=cache_pack)
+            out = _conv_forward(part, xh, weights, bias if k == 0 else None, None, rt, addend=out, cache_pack=cache_pack, generic=generic)
         return out
     xh = _pad_channels(xh)
     B, H, W, C = xh.shape
@@ -660,8 +662,8 @@ def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None, preact=N
                 "rssf_conv_gather_preact")
         return out
     L.check(lib.rssf_conv_gather_add(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), L.ptr(addend), L.ptr(ws), B, H, W, C, OH, OW,
-                                     spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
-            "rssf_conv_gather")
+                                     spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh) | (L.CONV_GENERIC if generic else 0),
+                                     L.stream()), "rssf_conv_gather")
     return out
 
 
@@ -886,7 +888,7 @@ def _accumulate_dgrad(accum, spec, dout, weights, in_shape, rt):
         _conv_dgrad(spec, dout, weights, in_shape, accum.buf, rt, out=accum.buf)
 
 
-def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, bn=None):
+def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, bn=None, generic=False):
     """bn: (BnBwdLink, zeroed sums buffer) - the launch also accumulates the BatchNorm-backward statistics of the layer that
     produced the convolution's input (see BnBwdLink)."""
     B, H, W, C = in_shape
@@ -904,10 +906,10 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, b
                                % (tuple(link.raw.shape), link.raw.dtype, tuple(dx.shape), dx.dtype))
         L.check(L.load().rssf_conv_gather_bnbwd(L.ptr(dout), L.ptr(wpk), L.ptr(dx), L.ptr(addend), L.ptr(link.raw), L.ptr(link.rp), L.ptr(link.ss),
                                                 link.act, L.ptr(sums), B, OH, OW, cout_p, H, W, C, 1, spec.stride, spec.ntaps, spec.c_ndy,
-                                                spec.c_ndx, L.dtype_code(dout), L.stream()), "rssf_conv_gather_bnbwd")
+                                                spec.c_ndx, L.dtype_code(dout) | (L.CONV_GENERIC if generic else 0), L.stream()), "rssf_conv_gather_bnbwd")
         return dx
     L.check(L.load().rssf_conv_gather_add(L.ptr(dout), L.ptr(wpk), L.ptr(dx), None, None, L.ptr(addend), None, B, OH, OW, cout_p, H, W, C, 1, spec.stride,
-                                      spec.ntaps, spec.c_ndy, spec.c_ndx, L.dtype_code(dout),
+                                      spec.ntaps, spec.c_ndy, spec.c_ndx, L.dtype_code(dout) | (L.CONV_GENERIC if generic else 0),
                                       L.stream()), "rssf_conv_gather(dgrad)")
     return dx
 

@@ -105,79 +105,6 @@ def test_conv3x3_group_equals_single_launches(shapes, mirrored):
             assert torch.allclose(a, b, rtol=2e-5, atol=2e-4 * float(b.abs().max()) + 1e-6)      # slotted atomics: order differs
 
 
-@pytest.mark.parametrize("ntb", [1, 3])
-@pytest.mark.parametrize("kind", ["forward", "mirrored", "preact"])
-def test_conv3x3_multi_tile_form_equals_one_tile_form(ntb, kind):
-    """RSSF_HALO_NTB (opt-in): a block walks `ntb` consecutive pixel tiles - weights of a one-chunk problem staged once, the next
-    tile's loads in flight under the current tile's MFMAs and epilogue, statistics carried in registers across the tiles - and
-    returns the bits of the one-tile kernels (statistics up to summation order); grouped and single launches, ragged tile counts."""
-    L, lib = _lib()
-    shapes = [(3, 40, 72, 32), (2, 24, 24, 64), (1, 16, 16, 256), (5, 8, 16, 128)]
-    n = len(shapes)
-    mirrored = int(kind == "mirrored")
-    probs = [_problem(s, 41 + i) for i, s in enumerate(shapes)]
-    wpk = [_pack(w, bool(mirrored)) for _, w in probs]
-    res = {}
-    old = os.environ.get("RSSF_HALO_NTB")
-    try:
-        for mode in (0, ntb):
-            os.environ["RSSF_HALO_NTB"] = str(mode)
-            for launch in ("group", "single"):
-                outs, accs, keep = [], [], []
-                arr = (L.Conv3x3Item * n)()
-                for i, ((x, w), s) in enumerate(zip(probs, shapes)):
-                    B, H, W, C = s
-                    g = torch.Generator(device="cpu").manual_seed(91 + i)
-                    out = torch.zeros(B, H, W, C, device=DEV, dtype=BF)
-                    kw = dict(in_=x, wpk=wpk[i], out=out, B=B, H=H, W=W, Cin=C, Cout=C)
-                    if kind == "mirrored":
-                        add = torch.randn(B, H, W, C, generator=g).to(DEV, BF)
-                        raw = torch.randn(B, H, W, C, generator=g).to(DEV, BF)
-                        rp = torch.randn(B, H, W, C, generator=g).to(DEV, BF) if i % 2 == 0 else None
-                        ss = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1]).to(DEV).contiguous()
-                        sm = torch.zeros(8 * 2 * C, device=DEV)
-                        kw.update(addend=add if i != 1 else None, bn_raw=raw, bn_res=rp, bn_ss=ss, bn_sums=sm, bn_act=1 if i % 3 else 2)
-                        accs.append((sm, 8))
-                        keep += [add, raw, rp, ss]
-                    else:
-                        st = torch.zeros(16 * 2 * C, device=DEV)
-                        kw.update(stats=st)
-                        accs.append((st, 16))
-                        if kind == "preact":
-                            pst = torch.zeros(16, 2, C)
-                            pst[:, 0] = torch.randn(16, C, generator=g) * 3
-                            pst[:, 1] = torch.rand(16, C, generator=g) * 40 + 20
-                            pst = pst.to(DEV).contiguous()
-                            gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
-                            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-                            mi, ss = torch.zeros(2, C, device=DEV), torch.zeros(2, C, device=DEV)
-                            kw.update(pre_stats=pst, pre_gamma=gamma, pre_beta=beta, pre_running_mean=rm, pre_running_var=rv, pre_mean_invstd=mi,
-                                      pre_ss=ss, pre_n=float(B * H * W), pre_momentum=0.1, pre_eps=1e-5, pre_training=1, pre_act=1 + (i % 2))
-                            outs += [mi, ss, rm, rv]
-                            keep += [pst, gamma, beta]
-                    _fill(arr[i], **kw)
-                    outs.append(out)
-                if launch == "group":
-                    L.check(lib.rssf_conv3x3_group(ctypes.cast(arr, ctypes.c_void_p), n, mirrored, L.RSSF_BF16, _stream()), "group")
-                else:
-                    for i in range(n):
-                        one = (L.Conv3x3Item * 1)(arr[i])
-                        L.check(lib.rssf_conv3x3_group(ctypes.cast(one, ctypes.c_void_p), 1, mirrored, L.RSSF_BF16, _stream()), "single")
-                torch.cuda.synchronize()
-                res[(mode, launch)] = (outs, [t.view(k, -1).sum(0) for t, k in accs])
-    finally:
-        if old is None:
-            os.environ.pop("RSSF_HALO_NTB", None)
-        else:
-            os.environ["RSSF_HALO_NTB"] = old
-    for launch in ("group", "single"):
-        want, got = res[(0, launch)], res[(ntb, launch)]
-        for a, b in zip(got[0], want[0]):
-            assert torch.equal(a, b)
-        for a, b in zip(got[1], want[1]):
-            assert torch.allclose(a, b, rtol=2e-5, atol=2e-4 * float(b.abs().max()) + 1e-6)
-
-
 @pytest.mark.parametrize("shapes", GROUPS[:3])
 def test_conv3x3_group_preact_equals_single(shapes):
     """pre-activation inputs: the producer's BatchNorm finalize + apply on load (rssf_conv_gather_preact per problem)"""
