@@ -501,10 +501,13 @@ int rssf_comm_destroy(rssf_comm* comm);
 typedef struct rssf_p2p rssf_p2p;
 int rssf_p2p_create(rssf_p2p** p2p, int rank, int world, int channels, void* ipc_handle64);
 int rssf_p2p_connect(rssf_p2p* p2p, int peer, const void* ipc_handle64);
+/* the same for a peer that lives in THIS process (one rank per stream or per device of one process; a hipIpc handle cannot be opened
+ * by the process that exported it): rank `peer` is `other`, which must outlive every exchange of `p2p` */
+int rssf_p2p_connect_local(rssf_p2p* p2p, int peer, rssf_p2p* other);
 int rssf_p2p_exchange(rssf_p2p* p2p, int channel, float* stats, const int* item_off, const int* item_n, int nitems, int nslots,
                       void* stream);
 /* bound of the wait for a peer in the exchanges launched from now on; 0 = unbounded (what a collective does).  A new object starts
- * with RSSF_P2P_TIMEOUT_MS from the environment (default 10 000). */
+ * with 10 000 ms. */
 int rssf_p2p_set_timeout_ms(rssf_p2p* p2p, int ms);
 int rssf_p2p_status(rssf_p2p* p2p, int* timed_out);
 int rssf_p2p_destroy(rssf_p2p* p2p);

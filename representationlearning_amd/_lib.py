@@ -163,6 +163,7 @@ SIGNATURES = {
     "rssf_p2p_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "rssf_p2p_connect": (c_int, [c_void_p, c_int, c_void_p]),
     "rssf_p2p_exchange": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rssf_p2p_connect_local": (c_int, [c_void_p, c_int, c_void_p]),
     "rssf_p2p_set_timeout_ms": (c_int, [c_void_p, c_int]),
     "rssf_p2p_status": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "rssf_p2p_destroy": (c_int, [c_void_p]),

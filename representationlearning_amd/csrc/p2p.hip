@@ -141,6 +141,16 @@ extern "C" int rssf_p2p_connect(rssf_p2p* h, int peer, const void* ipc_handle64)
   return RSSF_OK;
 }
 
+// Ranks that live in ONE process (one rank per stream or per device of the process: hipIpc handles cannot be opened by the process
+// that exported them): rank `peer` is the object `other`, its window is addressed directly.
+extern "C" int rssf_p2p_connect_local(rssf_p2p* h, int peer, rssf_p2p* other) {
+  RSSF_REQUIRE(h && other && peer >= 0 && peer < h->world && other->rank == peer && other->world == h->world && other->channels == h->channels,
+               "p2p_connect_local: bad arguments");
+  if (peer == h->rank || h->peer[peer]) return RSSF_OK;
+  h->peer[peer] = other->window;          // not `opened`: the owner frees it
+  return RSSF_OK;
+}
+
 extern "C" int rssf_p2p_exchange(rssf_p2p* h, int channel, float* stats, const int* item_off, const int* item_n, int nitems, int nslots,
                                  void* stream) {
   RSSF_REQUIRE(h && stats && item_off && item_n && channel >= 0 && channel < h->channels && nitems >= 1 && nitems <= RSSF_P2P_MAX_ITEMS &&

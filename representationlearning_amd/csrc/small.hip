@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(256) vec_add_to3_kernel(const float* __restric
 // running sums of a HighResolutionModule's fuse outputs (_hrnet_rssformer.py:424-435) and the gradient of a tensor that has both
 // convolution and non-convolution consumers (nnf._Fanout) - as the library's own launch: the training step holds no framework kernel
 template <typename T>
-__global__ void __launch_bounds__(256) add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t nvec, int64_t n) {
+// (no __restrict__: out may alias a or b - every thread reads its elements before it writes them)
+__global__ void __launch_bounds__(256) add_kernel(const T* a, const T* b, T* out, int64_t nvec, int64_t n) {
   constexpr int V = Vec<T>::N;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
     Vec<T> x, y, o;
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(256) add_kernel(const T* __restrict__ a, const
 // out = a + b + c (one pass instead of two): the gradient of a branch output that meets an accumulated convolution gradient AND two
 // autograd consumers (nnf._Fanout with aliases) - summed in fp32, rounded once
 template <typename T>
-__global__ void __launch_bounds__(256) add3_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ out,
+__global__ void __launch_bounds__(256) add3_kernel(const T* a, const T* b, const T* c, T* out,      // may alias, as in add_kernel
                                                    int64_t nvec, int64_t n) {
   constexpr int V = Vec<T>::N;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {

@@ -170,6 +170,12 @@ def parallel_map(fns, args):
     rt = current()
     dp = rt.exchanging()
     if not (rt.branch_streams and n > 1 and args[0].is_cuda) or rt.in_side or (dp and (rt.stream_comms is None or len(rt.stream_comms) < n - 1)):
+        if dp and rt.branch_streams and n > 1 and not rt.in_side and not getattr(rt, "_warned_serial_branches", False):
+            # a module whose branches cannot walk in lock-step, under data parallelism, with fewer side communicators than branches:
+            # correct, but the step's layout is not the single-GPU one any more - say so once
+            rt._warned_serial_branches = True
+            print("[rssf] %d parallel branches run one after the other: %d side communicator(s) for SyncBN exchanges (RSSF_LOCKSTEP=0 "
+                  "gives every branch stream its own)" % (n, 0 if rt.stream_comms is None else len(rt.stream_comms)), flush=True)
         return [f(a) for f, a in zip(fns, args)]
     dev = args[0].device
     cur = torch.cuda.current_stream(dev)

@@ -88,14 +88,20 @@ class P2PExchange:
     """The peer-to-peer SyncBN exchange of librssf (`rssf_p2p_*`, csrc/p2p.hip): one window per rank, mapped by every peer through
     hipIpc; `channel(k)` hands out the communicator-like object of exchange sequence k (one per stream)."""
 
-    def __init__(self, channels):
+    def __init__(self, channels, rank=None, world=None):
+        """rank / world: given explicitly, the object is one of `world` ranks of THIS process (see `local_group`) and no rendezvous
+        takes place; otherwise rank and world are torch.distributed's and the window handles travel over its rendezvous."""
         lib = L.load()
-        self.rank, self.world, self.channels = dist.get_rank(), dist.get_world_size(), channels
+        local = rank is not None
+        self.rank, self.world, self.channels = (rank, world, channels) if local else (dist.get_rank(), dist.get_world_size(), channels)
         self._lib, self._h = lib, ctypes.c_void_p()
         mine = ctypes.create_string_buffer(64)
         err = None
         if lib.rssf_p2p_create(ctypes.byref(self._h), self.rank, self.world, channels, mine) != 0:
             err = lib.rssf_last_error().decode()
+        if local:
+            self.error = err
+            return
         handles = [None] * self.world
         dist.all_gather_object(handles, None if err else mine.raw)              # every rank joins this, failed or not
         if err is None and any(h is None for h in handles):
@@ -106,6 +112,19 @@ class P2PExchange:
                     err = lib.rssf_last_error().decode()
                     break
         self.error = err
+
+    @classmethod
+    def local_group(cls, world, channels):
+        """`world` ranks in this process, connected window to window (rssf_p2p_connect_local): one rank per stream - the form the
+        exchange kernel is tested in at the node's world size without another process competing for the GPU's hardware queues."""
+        group = [cls(channels, rank=r, world=world) for r in range(world)]
+        for a in group:
+            if a.error:
+                raise RuntimeError("P2PExchange.local_group: %s" % a.error)
+            for b in group:
+                if a is not b:
+                    L.check(a._lib.rssf_p2p_connect_local(a._h, b.rank, b._h), "rssf_p2p_connect_local")
+        return group
 
     def channel(self, k):
         return P2PChannel(self, k)

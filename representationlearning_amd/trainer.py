@@ -21,17 +21,24 @@ class FlatParams:
     """Re-seats every parameter (and its .grad) of `model` as a view into flat fp32 buffers."""
 
     def __init__(self, model):
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
+        names = [n for n, _ in named]
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
         self.offsets = [0]
+        # 16-byte aligned slices - with ONE exception, by name: the two 7x7 SpatialAttention kernels of a transformer block
+        # (`...atrous_block1.conv1.weight` followed by `...atrous_block2.conv1.weight`, 98 floats each,
+        # multihead_isa_pool_attention.py:30-31) sit WITHOUT a gap: they are then ONE [2, 2, 7, 7] operand of the gate kernels
+        # (autograd._gate_kernels: a view, not a stack copy per block and step) and the pair ends on a 16-byte boundary again.
+        # `self.pairs` holds the index of each pair's first parameter: ranges_of() never starts a range on the second one alone.
+        self.pairs = set()
         for i, s in enumerate(sizes):
-            # 16-byte aligned slices - except that a convolution kernel whose size is no multiple of four floats is followed
-            # WITHOUT a gap by a same-shaped one: the two 7x7 SpatialAttention kernels of a transformer block (98 floats each,
-            # multihead_isa_pool_attention.py:30-31) are then ONE [2, 2, 7, 7] operand of the gate kernels (autograd._gate_kernels:
-            # a view, not a stack copy per block and step); the pair ends on a 16-byte boundary again
-            tight = (s % 4 != 0 and (2 * s) % 4 == 0 and self.offsets[-1] % 4 == 0 and i + 1 < len(sizes) and self.params[i].dim() == 4
-                     and self.params[i + 1].shape == self.params[i].shape)
+            tight = (names[i].endswith("atrous_block1.conv1.weight") and i + 1 < len(sizes)
+                     and names[i + 1] == names[i].replace("atrous_block1", "atrous_block2") and self.params[i + 1].shape == self.params[i].shape
+                     and s % 4 != 0 and (2 * s) % 4 == 0 and self.offsets[-1] % 4 == 0)
+            if tight:
+                self.pairs.add(i)
             self.offsets.append(self.offsets[-1] + s if tight else (self.offsets[-1] + s + 3) // 4 * 4)
         n = self.offsets[-1]
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -52,6 +59,10 @@ class FlatParams:
 
     def ranges_of(self, keep):
         """Merged [start, end) ranges of the flat buffer covered by the parameters whose index is in `keep`."""
+        keep = set(keep)
+        for i in self.pairs:                 # a tightly packed pair goes in or out as a whole: every range starts 16-byte aligned
+            if (i in keep) != (i + 1 in keep):
+                keep |= {i, i + 1}
         out = []
         for i in sorted(keep):
             s, e = self.offsets[i], self.offsets[i + 1]

@@ -198,10 +198,10 @@ def test_two_ranks_without_sync_bn_keep_local_statistics_except_mlp():
 
 
 def _p2p_worker(rank, port, out_dir, world=WORLD):
-    # The ranks share ONE GPU here: 8 processes x 2 streams of spinning kernels oversubscribe the hardware queues, and a peer's kernel
-    # may wait for the scheduler's rotation longer than any bound worth testing (world 8 hit 4 s and 16 s bounds in about half of the
-    # full-suite runs, whatever the bound).  The spin stays bounded (an unbounded one would turn a starved queue into a hung test);
-    # the world-8 case does not hold the error word against the run (see the test), worlds 2 and 4 do.
+    # The ranks share ONE GPU here.  Worlds 2 and 4 run two channels on two streams per rank; at world 8 that is 16 spinning kernels
+    # of 8 processes on one GPU's hardware queues, and a peer's kernel may wait for the scheduler's rotation longer than any bound
+    # worth testing - so world 8 runs ONE channel per rank here (8 queues), and the two-channel form at world 8 is what
+    # test_p2p_exchange_eight_ranks_in_one_process checks with no other process in the way.  The spin stays bounded.
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                       RSSF_P2P_TIMEOUT_MS="16000" if world >= 8 else "8000")
     import torch.distributed as dist
@@ -233,6 +233,7 @@ def _p2p_worker(rank, port, out_dir, world=WORLD):
     mine = base[rank].cuda()
     ch0, ch1 = ex.channel(0), ex.channel(1)
     side = torch.cuda.Stream()
+    two = world < 8                                     # both channels in flight on two streams
     firsts = []
     torch.cuda.synchronize()
     dist.barrier()                                      # start together: the first exchange must not wait out a peer's start-up
@@ -240,9 +241,12 @@ def _p2p_worker(rank, port, out_dir, world=WORLD):
         a, b = mine.clone(), mine.clone()
         side.wait_stream(torch.cuda.current_stream())
         ch0.syncbn_exchange_(a, layout)
-        with torch.cuda.stream(side):
+        if two:
+            with torch.cuda.stream(side):
+                ch1.syncbn_exchange_(b, layout)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
             ch1.syncbn_exchange_(b, layout)
-        torch.cuda.current_stream().wait_stream(side)
         firsts.append(check(a, "eager ch0 #%d" % it))
         check(b, "eager ch1 #%d" % it)
     # the same inside a captured graph, replayed: the epoch lives in device memory and advances per replay
@@ -257,9 +261,12 @@ def _p2p_worker(rank, port, out_dir, world=WORLD):
             side.wait_stream(torch.cuda.current_stream())
             ch0.syncbn_exchange_(sa, layout)
             ch0.syncbn_exchange_(sa, (1, [(0, n1)]))       # a second, unslotted exchange of the totals of layer 1: x world
-            with torch.cuda.stream(side):
+            if two:
+                with torch.cuda.stream(side):
+                    ch1.syncbn_exchange_(sb, layout)
+                torch.cuda.current_stream().wait_stream(side)
+            else:
                 ch1.syncbn_exchange_(sb, layout)
-            torch.cuda.current_stream().wait_stream(side)
         for it in range(4):
             gr.replay()
             torch.cuda.synchronize()
@@ -275,12 +282,7 @@ def _p2p_worker(rank, port, out_dir, world=WORLD):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_p2p_syncbn_exchange_two_processes(world):
-    """The peer-to-peer SyncBN exchange (csrc/p2p.hip: hipIpc-mapped windows, value+epoch words, rank-ordered sums) between 2, 4
-    and 8 processes - as on a node, except that all live on the one GPU of the box: eager on two channels / two streams at once,
-    and inside a replayed hipGraph.  Totals equal the slot-folded sum over ranks, the other slots are cleared, all ranks hold
-    bit-identical results, nobody timed out.  (World 8 is the node the driver's scaling run uses.)"""
+def _run_p2p_world(world):
     ctx = mp.get_context("spawn")
     port = _free_port()
     with tempfile.TemporaryDirectory() as d:
@@ -290,21 +292,100 @@ def test_p2p_syncbn_exchange_two_processes(world):
         for p in procs:
             p.join(600)
             assert p.exitcode == 0, "rank process failed (exit code %s)" % p.exitcode
-        res = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=False) for r in range(world)]
-    late = [r["timed_out"] for r in res if r["timed_out"]]
-    if world >= 8 and late:
-        # a rank that waited out the bound added a STALE word to its totals (that is what the bound means; the trainer stops a run
-        # on it: Trainer.check_exchange) and the ranks' epochs drift apart from there on: the sums of such a run say nothing about
-        # the kernel.  Eight spinning processes on ONE GPU's hardware queues do that now and then; on a node every rank has its own.
-        pytest.skip("world %d on one GPU: a rank waited out the bounded spin for rank %d (hardware-queue oversubscription of this "
-                    "stand-in for a node)" % (world, late[0] - 1))
+        return [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=False) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_p2p_syncbn_exchange_two_processes(world):
+    """The peer-to-peer SyncBN exchange (csrc/p2p.hip: hipIpc-mapped windows, value+epoch words, rank-ordered sums) between 2, 4
+    and 8 processes - as on a node, except that all live on the one GPU of the box: eager on two channels (two streams at once up to
+    world 4) and inside a replayed hipGraph.  Totals equal the slot-folded sum over ranks, the other slots are cleared, all ranks
+    hold bit-identical results, nobody timed out.  World 8 - the node of the scaling run - is eight processes on ONE GPU's hardware
+    queues: a rank that waits out the bounded spin there says something about this stand-in, so that world gets ONE second attempt;
+    a second late rank fails the test (it never skips)."""
+    res = _run_p2p_world(world)
+    if world >= 8 and any(r["timed_out"] for r in res):
+        print("world %d: rank(s) %s waited out the bounded spin on the first attempt; running once more"
+              % (world, [i for i, r in enumerate(res) if r["timed_out"]]))
+        res = _run_p2p_world(world)
     for r in res:
+        assert r["timed_out"] == 0, "a rank waited out the bounded spin for rank %d" % (r["timed_out"] - 1)
         assert r["ok"], r["msgs"][:5]
-        # eight processes on one GPU oversubscribe its hardware queues: a rank may find a peer late by more than the bound (see
-        # _p2p_worker) - a property of this stand-in for a node, reported, not failed; on 2 and 4 ranks nobody may time out
-        if world < 8:
-            assert r["timed_out"] == 0, r["timed_out"]
-        elif r["timed_out"]:
-            print("world %d: a rank waited out the bounded spin for rank %d (queue oversubscription on one GPU)" % (world, r["timed_out"] - 1))
     for r in res[1:]:
         assert torch.equal(res[0]["first"], r["first"])
+
+
+def _local8_worker():
+    # eight streams whose kernels wait for each other need eight hardware queues (the runtime's default is four: two rank streams
+    # on one queue would put a kernel behind the one that waits for it); read when the runtime starts, hence a process of its own
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+    from representationlearning_amd import rccl
+    world, nslots, c1, c2 = 8, 16, 32, 128
+    n1, n2 = 2 * c1, 2 * c2
+    layout = (nslots, [(0, n1), (nslots * n1, n2)])
+    group = rccl.P2PExchange.local_group(world, 2)
+    try:
+        for ex in group:
+            ex.set_timeout_ms(20000)
+        g = torch.Generator().manual_seed(6)
+        base = [torch.randn(nslots * (n1 + n2), generator=g).cuda() for _ in range(world)]
+        want = None
+        for r in range(world):                          # rank-ordered, like the kernel
+            loc = torch.cat([base[r][:nslots * n1].view(nslots, n1).sum(0), base[r][nslots * n1:].view(nslots, n2).sum(0)])
+            want = loc if want is None else want + loc
+        streams = [torch.cuda.Stream() for _ in range(world)]
+        main = torch.cuda.current_stream()
+
+        def totals(buf):
+            return torch.cat([buf[:n1], buf[nslots * n1:nslots * n1 + n2]]), torch.cat([buf[n1:nslots * n1], buf[nslots * n1 + n2:]])
+
+        def fan(fn):                                    # every rank's work on its own stream, joined afterwards
+            for r in range(world):
+                streams[r].wait_stream(main)
+                with torch.cuda.stream(streams[r]):
+                    fn(r)
+            for r in range(world):
+                main.wait_stream(streams[r])
+
+        for it in range(12):                            # both window parities many times over, both channels
+            bufs = [[base[r].clone() for r in range(world)] for _ in range(2)]
+            fan(lambda r: [group[r].channel(k).syncbn_exchange_(bufs[k][r], layout) for k in range(2)])
+            torch.cuda.synchronize()
+            for k in range(2):
+                tot0, _ = totals(bufs[k][0])
+                assert torch.allclose(tot0, want, rtol=1e-5, atol=1e-5), (it, k, float((tot0 - want).abs().max()))
+                for r in range(world):
+                    tot, rest = totals(bufs[k][r])
+                    assert torch.equal(tot, tot0) and float(rest.abs().sum()) == 0.0, (it, k, r)
+        # chunked: 24 layers of 2 * 256 values = 12 288 floats, three window runs per exchange
+        nl, nv = 24, 512
+        big = [torch.randn(4 * nl * nv, generator=g).cuda() for _ in range(world)]
+        blayout = (4, [(i * 4 * nv, nv) for i in range(nl)])
+        acc = None
+        for r in range(world):
+            loc = big[r].view(nl, 4, nv).sum(1)
+            acc = loc if acc is None else acc + loc
+        bb = [b.clone() for b in big]
+        fan(lambda r: group[r].channel(0).syncbn_exchange_(bb[r], blayout))
+        torch.cuda.synchronize()
+        got0 = bb[0].view(nl, 4, nv)
+        assert torch.allclose(got0[:, 0], acc, rtol=1e-5, atol=1e-5) and float(got0[:, 1:].abs().sum()) == 0.0
+        for r in range(1, world):
+            assert torch.equal(bb[r], bb[0]), r
+        for ex in group:
+            assert ex.timed_out() == 0
+    finally:
+        for ex in group:
+            ex.destroy()
+
+
+def test_p2p_exchange_eight_ranks_in_one_process():
+    """World 8 without another process in the way: eight rank objects of ONE process (rssf_p2p_connect_local), one stream each,
+    two channels each - the exchange kernel's rank-ordered sums, the parity double-buffering of its windows across 12 back-to-back
+    epochs, a chunked exchange (more values than one window run).  Every rank must hold the same bits, equal to the slot-folded
+    sums; no rank may time out.  This test cannot skip.  (The replayed-graph form runs between processes above.)"""
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_local8_worker)
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, "the eight-rank process failed (exit code %s)" % p.exitcode

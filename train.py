@@ -156,26 +156,42 @@ def main():
     num_iters = args.iters if args.iters is not None else tr.num_iters
     log = print if rank == 0 else (lambda *a, **k: None)
     model = registry.MODEL[cfg.model.type](cfg.model.params).cuda()
-    resume = None
-    for cand in ([] if args.no_resume else (checkpoints(args.model_dir) or [])):
-        # newest first; a file that does not load (a run killed in the middle of a save that predates the atomic rename, a full disk)
-        # is skipped with a warning instead of stopping every later start
-        try:
-            sd = torch.load(cand[1], map_location="cpu")
-        except Exception as e:       # noqa: BLE001 - any unreadable file is skipped
-            log("skipping unreadable checkpoint %s (%s: %s)" % (cand[1], type(e).__name__, str(e)[:200]))
-            continue
-        # the model BEFORE the trainer re-seats its parameters into the flat buffer
-        model.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()})
-        resume = cand
-        break
+    # The resume point is RANK 0's choice, broadcast before anybody loads: ranks that skipped different files would start with
+    # different iteration counters - different learning rates, loop lengths that do not match, collectives that hang.
+    # Rank 0 takes the newest checkpoint whose model AND trainer state load (a run killed in the middle of a save that predates the
+    # atomic rename, a full disk: skipped with a warning); a rank that then cannot load the agreed files stops the run.
+    resume, resume_sd, resume_tr = None, None, None
+    if rank == 0:
+        for cand in ([] if args.no_resume else (checkpoints(args.model_dir) or [])):
+            try:
+                sd = torch.load(cand[1], map_location="cpu")
+                sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+                missing = set(model.state_dict().keys()) ^ set(sd.keys())
+                if missing:
+                    raise KeyError("state_dict keys differ (%d), e.g. %s" % (len(missing), sorted(missing)[:2]))
+                tsd = torch.load(cand[2], map_location="cpu") if cand[2] is not None else None
+            except Exception as e:       # noqa: BLE001 - any unreadable / unusable file is skipped
+                log("skipping unusable checkpoint %s (%s: %s)" % (cand[1], type(e).__name__, str(e)[:200]))
+                continue
+            resume, resume_sd, resume_tr = cand, sd, tsd
+            break
+    if world > 1:
+        import torch.distributed as dist
+        box = [resume]
+        dist.broadcast_object_list(box, src=0)
+        resume = box[0]
+        if resume is not None and rank != 0:
+            resume_sd = {(k[7:] if k.startswith("module.") else k): v for k, v in torch.load(resume[1], map_location="cpu").items()}
+            resume_tr = torch.load(resume[2], map_location="cpu") if resume[2] is not None else None
+    if resume is not None:
+        model.load_state_dict(resume_sd)      # the model BEFORE the trainer re-seats its parameters into the flat buffer
     trainer = Trainer(model, base_lr=cfg.learning_rate.params.base_lr, momentum=cfg.optimizer.params.momentum,
                       weight_decay=cfg.optimizer.params.weight_decay, max_norm=cfg.optimizer.grad_clip.max_norm,
                       power=cfg.learning_rate.params.power, max_iters=cfg.learning_rate.params.max_iters, bf16=not args.fp32,
                       sync_bn=tr.sync_bn)
     if resume is not None:
-        if resume[2] is not None:
-            trainer.load_state_dict(torch.load(resume[2], map_location="cpu"))
+        if resume_tr is not None:
+            trainer.load_state_dict(resume_tr)
         else:
             trainer.it = resume[0]
         log("resumed from %s (iteration %d)" % (resume[1], trainer.it))
@@ -216,11 +232,14 @@ def main():
         if tr.get("eval_per_epoch", True) and tr.eval_interval_epoch and ep_done % tr.eval_interval_epoch == 0:
             evaluate()
         if rank == 0 and tr.save_ckpt_interval_epoch and ep_done % tr.save_ckpt_interval_epoch == 0:
-            log("saved", save_checkpoint(args.model_dir, model, trainer))
+            trainer.check_exchange()          # never a checkpoint of replicas that may have diverged
+            trainer.check_exchange()
+        log("saved", save_checkpoint(args.model_dir, model, trainer))
     if n_timed:
         log("host time per logged iteration: loader (draw + decode-if-new + one rssf_input_pipeline launch) %.2f ms, step enqueue+sync %.2f ms; "
             "resident tiles %.0f %%" % (1e3 * t_load / n_timed, 1e3 * t_step / n_timed, 100 * loader.resident_fraction()))
     if rank == 0:
+        trainer.check_exchange()
         log("saved", save_checkpoint(args.model_dir, model, trainer))
     if tr.get("eval_after_train", True):
         evaluate()
