@@ -42,20 +42,22 @@ def _source_sha16(*rel):
 
 ATTN_SOURCES = ("representationlearning_amd/csrc/win_attn_fwd.hip", "representationlearning_amd/csrc/win_attn.hip.h",
                 "representationlearning_amd/csrc/common.hip.h")
+MLP_SOURCES = ("representationlearning_amd/csrc/conv_taps128.hip", "representationlearning_amd/csrc/conv.hip.h",
+               "representationlearning_amd/csrc/common.hip.h")
 
 
-def _profiled_traffic(kernel):
+def _profiled_traffic(kernel, sources=ATTN_SOURCES, stamp="source_sha16"):
     """HBM-side bytes per launch of `kernel` from the committed counter pass (the newest profiles/rNN_hbm_traffic.json whose source stamp matches, written by
     tools/hbm_traffic.sh + tools/hbm_traffic_json.py: rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum in a
     run of its own, reads doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read inside this process.
     The file is stamped with the hash of the kernel's sources: a number measured on OTHER code is reported as null, not stale."""
     import glob
-    sha = _source_sha16(*ATTN_SOURCES)
+    sha = _source_sha16(*sources)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):      # newest round first
         try:
             with open(path) as f:
                 d = json.load(f)
-            if d.get("source_sha16") == sha:
+            if d.get(stamp) == sha:
                 e = d[kernel]
                 return int(e["read_bytes"] + e["write_bytes"])
         except (OSError, KeyError, ValueError):
@@ -191,9 +193,10 @@ def measure_mlp_conv(B, S, iters=20, C=128):
     ms = _time_us(launch, iters) / 1e3
     flops = 2.0 * B * H * W * C * C * 19             # the reference's three convolutions: 1 + 9 + 9 kernel positions
     tf = flops / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="conv_gather_kernel<bf16,256,128> (MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12}, %d->%d ch)" % (C, C),
+    return dict(bound="mfma", kernel="conv_taps128_kernel (MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12}, %d->%d ch)" % (C, C),
                 achieved=round(tf, 1), peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s", frac=round(tf * 1e12 / MFMA_BF16_PEAK, 4),
-                traffic=None, us_per_launch=round(ms * 1e3, 2), algorithmic_flops=flops,
+                traffic=_profiled_traffic("conv_taps128_kernel", MLP_SOURCES, "mlp_source_sha16") if (B, S, C) == (16, 512, 128) else None,
+                us_per_launch=round(ms * 1e3, 2), algorithmic_flops=flops,
                 executed_flops=2.0 * B * H * W * C * C * spec.ntaps)       # the three centre taps share one pixel: 17 taps run
 
 

@@ -154,6 +154,10 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
   T* XS = base;                 T* YS = XS + LY::REGX;     T* GS = YS + LY::REGX;
   T* QS = GS + LY::REGX;        T* KS = QS + LY::REGV;     T* VS = KS + LY::REGV;      // later dq, dk, dv (head by head)
   T* dMs = VS + LY::REGV + hw * LY::SCRATCH;
+#if defined(RSSF_BWD_ZERO_LDS)      // debug builds (tools/ab_lib.sh): does anything read LDS it never wrote?
+  for (int i = threadIdx.x; i < (int)(LY::BYTES / 4); i += blockDim.x) reinterpret_cast<unsigned*>(smem_raw)[i] = 0u;
+  __syncthreads();
+#endif
 
   if constexpr (CV == C && C % 4 == 0) {
     // head width = its padded width (C = 32): the staged images are the row-major matrices themselves - one 16-byte load per
@@ -345,7 +349,10 @@ winattn_bwd_kernel(rssf_winattn_bwd_params bp, Geom g) {
       // second pass: built with the folded form, the fp32 C = 48 kernel returned v_proj gradients 60x too large at -O3 / -O2 and
       // correct ones at -O1 (same source; tools/attn_c48_dbg.py) - a code-generation problem at that register pressure, not
       // worth chasing for the parity-mode kernel.
-      constexpr bool FOLD = TPH == 1;
+#ifndef RSSF_BWD_FOLD_ALL
+#define RSSF_BWD_FOLD_ALL 0        // 1: the folded form for C = 48 too (A/B builds: tools/ab_lib.sh; see the note above)
+#endif
+      constexpr bool FOLD = TPH == 1 || RSSF_BWD_FOLD_ALL;
       if constexpr (FOLD)
 #pragma unroll
       for (int mi = 0; mi < TPH; ++mi)

@@ -9,9 +9,9 @@ src, dst = sys.argv[1], sys.argv[2]
 out = {"_source": "%s (tools/hbm_traffic.sh: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum in a "
                   "pass of its own; reads = RDREQ x 64 B x 2 per MI355X_MICROARCH.md (HBM, gfx950), writes = 32 B / 64 B requests; "
                   "B=16, 128x128 tokens, C=32, bf16)" % os.path.basename(src),
-       "source_sha16": bench._source_sha16(*bench.ATTN_SOURCES)}
+       "source_sha16": bench._source_sha16(*bench.ATTN_SOURCES), "mlp_source_sha16": bench._source_sha16(*bench.MLP_SOURCES)}
 for line in open(src):
-    for name in ("winattn_fwd_kernel", "winattn_bwd_kernel", "domega_reduce_kernel"):
+    for name in ("winattn_fwd_kernel", "winattn_bwd_kernel", "domega_reduce_kernel", "conv_taps128_kernel"):
         if name in line and name not in out:
             f = line.split()
             out[name] = {"read_bytes": int(float(f[-2]) * 1e6), "write_bytes": int(float(f[-1]) * 1e6), "launches": int(f[-5])}
