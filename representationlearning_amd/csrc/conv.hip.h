@@ -85,8 +85,8 @@ int launch_halo_group(HaloArgs* items, int n, hipStream_t st);      // n <= RSSF
 // and data gradient (bf16)
 bool taps128_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps);
 int launch_taps128(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, const void* bn_raw,
-                   const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int ntaps, const int* dy,
-                   const int* dx, hipStream_t st);
+                   const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP,
+                   int CoutP, int ntaps, const int* dy, const int* dx, hipStream_t st);
 // point-wise 32 -> 128 / 128 -> 32 channel convolutions as a stream (conv_pw.hip): MlpDWBN's fc1 / fc2, forward and data gradient (bf16)
 bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,

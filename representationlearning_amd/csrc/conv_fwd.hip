@@ -760,7 +760,7 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
                      bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st);
   if (!generic && dtype == RSSF_BF16 && !pre && !a.stats_ws && taps128_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps))
     return launch_taps128(in, wpk, out, bias, stats, addend, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr,
-                          bn ? bn->sums : nullptr, bn ? bn->act : 0, B, IH, IW, ntaps, dy, dx, st);
+                          bn ? bn->sums : nullptr, bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, ntaps, dy, dx, st);
   if (pre) { set_error("conv_gather_preact: no kernel with a pre-activation input for this shape (ask rssf_conv_gather_preact_supported)"); return RSSF_ERR_UNSUPPORTED; }
   const bool gfused = bn && dtype == RSSF_BF16 && (Cout % 8) == 0;          // the gather kernels' 16-byte-row epilogue carries them too
   a.bn_raw = gfused ? bn->raw : nullptr; a.bn_res = gfused ? bn->res : nullptr; a.bn_ss = gfused ? bn->ss : nullptr;

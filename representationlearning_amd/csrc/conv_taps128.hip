@@ -48,11 +48,14 @@ constexpr int T_WELEMS = 128 * T_PITCH;
 #define RSSF_T128_PAIRS 1                     // 1: "pair" loads (two lanes per pixel and load, one exchange stage); 0: quad loads, two stages
 #endif
 
+constexpr int T_MAXS = 40;                    // K-steps of a launch: (tap, 128-channel chunk of the input) pairs
 struct T128Args {
   const bf16_t* in; const bf16_t* wpk; bf16_t* out; const float* bias; float* stats; const bf16_t* addend;
   const bf16_t* bn_raw; const bf16_t* bn_res; const float* bn_ss; float* bn_sums; int bn_act;
-  int B, H, W, ntaps, per;
-  int dy[MAX_TAPS], dx[MAX_TAPS];
+  int B, H, W, nsteps, per;
+  int Cin, Cout, CinP, CoutP, ntn;            // general form: channels of a pixel row in / out, packed slab sizes, 128-channel output tiles
+  int dy[T_MAXS], dx[T_MAXS];                 // per K-step: the tap's displacement,
+  int cin0[T_MAXS], woff[T_MAXS];             // first input channel of the chunk, BYTE offset of slab element (row 0, that channel)
 };
 
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
@@ -70,25 +73,33 @@ template <int CTRL> __device__ __forceinline__ void lane_exchange(u32x4& a, u32x
 
 // LP: pair loads - lane = [k5 k4 | p2 p1 p0 | k2], load J = [p3 k3]: one exchange stage (lane bit 0 <-> p3) at twice the cache lines per
 // load instruction.  BNB: the BatchNorm-backward statistics epilogue (data-gradient launches).
-template <int LP, bool BNB>
+// GEN: the general form - any number of input / output channels (multiples of 32 / 8): a K-step is a (tap, 128-channel chunk of the
+// input) pair, a workgroup computes one 128-channel tile of the output (the tiles of a pixel range are neighbours on one XCD); past
+// the last input channel the slab columns are staged as zeros and the pixel operand reads the next pixel's (finite) values or - at
+// the end of the image row - the range check's zeros.  !GEN: 128 -> 128 channels with compile-time strides (MlpDWBN).
+template <int LP, bool BNB, bool GEN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_taps128_kernel(T128Args a) {
   constexpr int C = T_C, NW = T_NW;
+  const int CI = GEN ? a.Cin : C, CO = GEN ? a.Cout : C, CIP = GEN ? a.CinP : C, COP = GEN ? a.CoutP : C;
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * T_WELEMS];
   __shared__ float sred[NW][2][C];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned q = (blockIdx.x & 7u) * (unsigned)a.per + (blockIdx.x >> 3);      // XCD-major: neighbouring pixel tiles share an L2
   const int M = a.B * a.H * a.W;
-  const int m0 = (int)q * (NW * 64);
+  const unsigned qm = GEN ? q / (unsigned)a.ntn : q;
+  const int n0 = GEN ? (int)(q - qm * (unsigned)a.ntn) * C : 0;   // first output channel of this workgroup
+  const int m0 = (int)qm * (NW * 64);
   if (m0 >= M) return;
   const int mw = m0 + wave * 64;                                  // wave-uniform: 64 consecutive pixels of one image row (W % 64 == 0)
   const int x0 = mw % a.W, yrow = (mw / a.W) % a.H, img = mw / (a.W * a.H);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wpk), 0, a.ntaps * C * C * 2, 0x00020000);
-  const unsigned lane_base = LP ? (unsigned)((x0 + ((lane >> 1) & 7)) * (C * 2) + grp * 64 + (lane & 1) * 16)
-                                : (unsigned)((x0 + ((lane >> 2) & 3)) * (C * 2) + grp * 64 + (lane & 3) * 16);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.wpk), 0, 0x7fffffff, 0x00020000);
+  const unsigned lane_base = LP ? (unsigned)((x0 + ((lane >> 1) & 7)) * (CI * 2) + grp * 64 + (lane & 1) * 16)
+                                : (unsigned)((x0 + ((lane >> 2) & 3)) * (CI * 2) + grp * 64 + (lane & 3) * 16);
   // weight staging: thread -> row tid / 16 (+ 32 i), LDS chunk position qp = tid % 16 = 4 kappa + G, i.e. global chunk 4 G + kappa
   const int qp = tid & 15;
-  const unsigned bsrc = (unsigned)((tid >> 4) * (C * 2) + ((((qp & 3) << 2) | (qp >> 2)) << 4));
+  const int gq8 = (((qp & 3) << 2) | (qp >> 2)) << 3;            // first channel (within the 128-channel chunk) of this thread's slab chunk
+  const unsigned bsrc = (unsigned)((n0 + (tid >> 4)) * (CIP * 2) + gq8 * 2);
   const int bdst = (tid >> 4) * T_PITCH + qp * 8;
   const int foff = l15 * T_PITCH + grp * 8;                       // + ct * 16 * T_PITCH + kappa * 32 elements
 
@@ -99,23 +110,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int ct = 0; ct < 8; ++ct) acc[mi][ct] = {0.f, 0.f, 0.f, 0.f};
   u32x4 RA[4][4];                  // [tile mi][load J]; after the exchanges [mi][register of a K-step]
   u32x4 RB[4];
-  auto row_rsrc = [&](int t) {     // descriptor of the image row tap t reads for this wave (scalar arithmetic)
-    const int r = yrow + a.dy[t < a.ntaps ? t : 0];
-    const bool ok = t < a.ntaps && r >= 0 && r < a.H;
-    const bf16_t* p = a.in + (size_t)((img * a.H + (ok ? r : 0)) * a.W) * C;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p), 0, ok ? a.W * C * 2 : 0, 0x00020000);
+  // descriptor of the image row K-step t reads for this wave, from the chunk's first channel on (scalar arithmetic): a pixel past the
+  // end of the row - or, GEN, a channel past the end of its last pixel - is out of range
+  auto row_rsrc = [&](int t) {
+    const int ts = t < a.nsteps ? t : 0;
+    const int r = yrow + a.dy[ts], c0 = GEN ? a.cin0[ts] : 0;
+    const bool ok = t < a.nsteps && r >= 0 && r < a.H;
+    const bf16_t* p = a.in + (size_t)((img * a.H + (ok ? r : 0)) * a.W) * CI + c0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p), 0, ok ? (a.W * CI - c0) * 2 : 0, 0x00020000);
   };
   auto load_A = [&](int mi, const __amdgpu_buffer_rsrc_t& rs, int dxb) {
-    const unsigned v = lane_base + (unsigned)(mi * 16 * C * 2 + dxb);             // may wrap below zero: out of range -> zeros
+    const unsigned v = lane_base + (unsigned)(mi * 16 * CI * 2 + dxb);            // may wrap below zero: out of range -> zeros
 #pragma unroll
     for (int J = 0; J < 4; ++J)
-      RA[mi][J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, v + (unsigned)(LP ? (J >> 1) * 8 * C * 2 + (J & 1) * 32 : J * 4 * C * 2), 0, 0));
+      RA[mi][J] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, v + (unsigned)(LP ? (J >> 1) * 8 * CI * 2 + (J & 1) * 32 : J * 4 * CI * 2), 0, 0));
   };
-  auto load_B = [&](int t) {       // taps past the end: zeros, never used
-    const int woff = t < a.ntaps ? t * (C * C * 2) : 0;
+  auto load_B = [&](int t) {       // K-steps past the end, slab columns past the last input channel: zeros
+    const int ts = t < a.nsteps ? t : 0;
+    const int woff = GEN ? a.woff[ts] : ts * (C * C * 2);
+    const bool ok = t < a.nsteps && (!GEN || a.cin0[ts] + gq8 < CIP);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      RB[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, t < a.ntaps ? bsrc : 0x80000000u, woff + i * 32 * C * 2, 0));
+      RB[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? bsrc : 0x80000000u, woff + i * 32 * CIP * 2, 0));
   };
   auto store_B = [&](bf16_t* Bs) {
 #pragma unroll
@@ -130,20 +146,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   __builtin_amdgcn_sched_barrier(0);
   {
     const __amdgpu_buffer_rsrc_t rs = row_rsrc(0);
-    const int dxb = a.dx[0] * (C * 2);
+    const int dxb = a.dx[0] * (CI * 2);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) load_A(mi, rs, dxb);
   }
   __builtin_amdgcn_sched_barrier(0);
 
   const bool hi1 = lane & 2, hi0 = lane & 1;
-  for (int t = 0; t < a.ntaps; ++t) {
+  for (int t = 0; t < a.nsteps; ++t) {
     const bf16_t* Bs = lds + (t & 1) * T_WELEMS;
     __syncthreads();
     store_B(lds + ((t + 1) & 1) * T_WELEMS);
     load_B(t + 2);
     const __amdgpu_buffer_rsrc_t rs = row_rsrc(t + 1);
-    const int dxb = (t + 1 < a.ntaps ? a.dx[t + 1] : 0) * (C * 2);
+    const int dxb = (t + 1 < a.nsteps ? a.dx[t + 1] : 0) * (CI * 2);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
@@ -190,23 +206,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     s1[e] = 0.f; s2[e] = 0.f;
-    bsc[e] = BNB ? a.bn_ss[cc * 8 + e] : 0.f;
-    bsh[e] = BNB ? a.bn_ss[C + cc * 8 + e] : 0.f;
+    const bool cok = BNB && n0 + cc * 8 + e < CO;
+    bsc[e] = cok ? a.bn_ss[n0 + cc * 8 + e] : 0.f;
+    bsh[e] = cok ? a.bn_ss[CO + n0 + cc * 8 + e] : 0.f;
   }
+  const bool cok8 = n0 + cc * 8 < CO;         // this lane's channel chunk exists (Cout is a multiple of 8)
   f32x4 bv[8];
 #pragma unroll
-  for (int ct = 0; ct < 8; ++ct) bv[ct] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ct * 16 + grp * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ct = 0; ct < 8; ++ct)
+    bv[ct] = (a.bias && n0 + ct * 16 + grp * 4 < CO) ? *reinterpret_cast<const f32x4*>(a.bias + n0 + ct * 16 + grp * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     // the rows this lane stores: pixels (lane >> 4) + 4 j of the tile; their addend / raw / residual rows are requested first
     Vec<bf16_t> va[4], xr[4], xp[4];
-    const size_t mrow = (size_t)(mw + mi * 16 + (lane >> 4)) * C + cc * 8;
+    const size_t mrow = (size_t)(mw + mi * 16 + (lane >> 4)) * CO + (cok8 ? n0 + cc * 8 : 0);       // (a chunk past Cout: loaded from channel 0, never stored)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (a.addend) va[j].load(a.addend + mrow + (size_t)j * 4 * C);
+      if (a.addend) va[j].load(a.addend + mrow + (size_t)j * 4 * CO);
       if (BNB) {
-        xr[j].load(a.bn_raw + mrow + (size_t)j * 4 * C);
-        if (a.bn_res) xp[j].load(a.bn_res + mrow + (size_t)j * 4 * C);
+        xr[j].load(a.bn_raw + mrow + (size_t)j * 4 * CO);
+        if (a.bn_res) xp[j].load(a.bn_res + mrow + (size_t)j * 4 * CO);
       }
     }
 #pragma unroll
@@ -228,7 +247,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int e = 0; e < 8; ++e) o[e] = v.get(e) + va[j].get(e);
         v.set_all(o);
       }
-      v.store(a.out + mrow + (size_t)j * 4 * C);
+      if (!GEN || cok8) v.store(a.out + mrow + (size_t)j * 4 * CO);
       if (BNB) {                             // on the values just stored: what rssf_bn_bwd_reduce would read
         auto accumulate = [&](auto ACT) {    // block-uniform activation: one specialised loop runs
 #pragma unroll
@@ -260,12 +279,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       for (int e = 0; e < 8; ++e) { sred[wave][0][cc * 8 + e] = s1[e]; sred[wave][1][cc * 8 + e] = s2[e]; }
     }
     __syncthreads();
-    if (tid < 2 * C) {
+    if (tid < 2 * C && n0 + tid % C < CO) {
       float tsum = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) tsum += sred[w][tid / C][tid % C];
-      float* dst = BNB ? a.bn_sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * C : a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * C;
-      atomicAdd(dst + tid, tsum);
+      float* dst = BNB ? a.bn_sums + (size_t)(blockIdx.x % RSSF_BN_BWD_SLOTS) * 2 * CO : a.stats + (size_t)(blockIdx.x % RSSF_BN_SLOTS) * 2 * CO;
+      atomicAdd(dst + (tid / C) * CO + n0 + tid % C, tsum);
     }
   }
 }
@@ -276,24 +295,45 @@ bool taps128_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, 
 #ifdef RSSF_T128_DISABLE       // A/B builds only (tools/ab_lib.sh): the step without this kernel
   return false;
 #endif
-  // at least 8 taps: below that the [128][128] weight tile per barrier does not pay (the 3x3 layers take the halo kernel anyway)
-  return mul == 1 && div == 1 && IH == OH && IW == OW && Cin == T_C && Cout == T_C && ntaps >= 8 && (IW % 64) == 0 &&
-         ((int64_t)B * IH * IW) % (T_NW * 64) == 0 && (int64_t)B * IH * IW * T_C < ((int64_t)1 << 30);
+  if (mul != 1 || div != 1 || IH != OH || IW != OW || (IW % 64) != 0 || ((int64_t)B * IH * IW) % (T_NW * 64) != 0) return false;
+  if ((int64_t)B * IH * IW * (Cin > Cout ? Cin : Cout) >= ((int64_t)1 << 30)) return false;
+  // 128 -> 128 channels (MlpDWBN's sum): at least 8 taps - below that the [128][128] weight tile per barrier does not pay (the 3x3
+  // layers take the halo kernel anyway)
+  if (Cin == T_C && Cout == T_C) return ntaps >= 8;
+  // general form: wide layers only - every output tile re-reads the pixels, and a tile narrower than 96 channels wastes the 64 x 128
+  // wave tile (the neck's 480 -> 480 point-wise convolution, hrnet_aux.py:45-49, is the case on the training path)
+  const int steps = ntaps * ((Cin + T_C - 1) / T_C);
+  return Cin >= T_C && (Cin % 32) == 0 && (Cout % 8) == 0 && Cout >= 96 && (Cout % T_C == 0 || Cout % T_C >= 96) && steps >= 4 && steps <= T_MAXS;
 }
 
 int launch_taps128(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, const void* bn_raw,
-                   const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int ntaps, const int* dy,
-                   const int* dx, hipStream_t st) {
+                   const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP,
+                   int CoutP, int ntaps, const int* dy, const int* dx, hipStream_t st) {
   T128Args a;
   a.in = (const bf16_t*)in; a.wpk = (const bf16_t*)wpk; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats; a.addend = (const bf16_t*)addend;
   a.bn_raw = (const bf16_t*)bn_raw; a.bn_res = (const bf16_t*)bn_res; a.bn_ss = bn_ss; a.bn_sums = bn_sums; a.bn_act = bn_act;
-  a.B = B; a.H = H; a.W = W; a.ntaps = ntaps;
-  for (int t = 0; t < MAX_TAPS; ++t) { a.dy[t] = t < ntaps ? dy[t] : 0; a.dx[t] = t < ntaps ? dx[t] : 0; }
-  const int64_t total = (int64_t)B * H * W / (T_NW * 64);
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.CinP = CinP; a.CoutP = CoutP;
+  const int kcn = (Cin + T_C - 1) / T_C;
+  a.nsteps = ntaps * kcn;
+  a.ntn = (Cout + T_C - 1) / T_C;
+  if (a.nsteps > T_MAXS || (int64_t)ntaps * CoutP * CinP * 2 >= ((int64_t)1 << 31)) { set_error("conv_taps128: %d K-steps / slab size out of range", a.nsteps); return RSSF_ERR_UNSUPPORTED; }
+  for (int s = 0; s < T_MAXS; ++s) {
+    const int t = s < a.nsteps ? s / kcn : 0, kc = s < a.nsteps ? s % kcn : 0;
+    a.dy[s] = s < a.nsteps ? dy[t] : 0; a.dx[s] = s < a.nsteps ? dx[t] : 0;
+    a.cin0[s] = kc * T_C;
+    a.woff[s] = (int)(((int64_t)t * CoutP * CinP + kc * T_C) * 2);
+  }
+  const bool gen = !(Cin == T_C && Cout == T_C && CinP == T_C && CoutP == T_C);
+  const int64_t total = (int64_t)B * H * W / (T_NW * 64) * a.ntn;
   a.per = xcd_per(total);
   const dim3 grid((unsigned)a.per * 8u);
-  if (bn_sums) conv_taps128_kernel<RSSF_T128_PAIRS, true><<<grid, 512, 0, st>>>(a);
-  else conv_taps128_kernel<RSSF_T128_PAIRS, false><<<grid, 512, 0, st>>>(a);
+  if (gen) {
+    if (bn_sums) conv_taps128_kernel<RSSF_T128_PAIRS, true, true><<<grid, 512, 0, st>>>(a);
+    else conv_taps128_kernel<RSSF_T128_PAIRS, false, true><<<grid, 512, 0, st>>>(a);
+  } else {
+    if (bn_sums) conv_taps128_kernel<RSSF_T128_PAIRS, true, false><<<grid, 512, 0, st>>>(a);
+    else conv_taps128_kernel<RSSF_T128_PAIRS, false, false><<<grid, 512, 0, st>>>(a);
+  }
   return check_launch("conv_taps128");
 }
 

@@ -224,3 +224,54 @@ def test_pointwise_64_to_256_forward_and_dgrad(B, H, W):
     assert rel_err(st1.cpu(), st0.cpu()) < 1e-4
     assert rel_err(d1.float().cpu(), refd.cpu()) < 4e-3 and rel_err(d1.float().cpu(), d0.float().cpu()) < 2e-3
     assert rel_err(sm1.cpu(), sm0.cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,taps", [
+    (2, 16, 64, 480, 480, [(0, 0)]),                                   # the neck's point-wise convolution (hrnet_aux.py:45-49), small map
+    (1, 8, 64, 160, 224, [(0, 0), (-1, 2), (3, -5)]),                 # a ragged last input chunk (32 of 128) and output tile (96 of 128)
+    (1, 8, 128, 128, 256, [(dy, dx) for dy in (-1, 0, 1) for dx in (-2, 0, 2)][:5]),
+])
+@pytest.mark.parametrize("mode", ["forward", "dgrad_bn"])
+def test_taps128_general_channels_match_gather_and_torch(B, H, W, Cin, Cout, taps, mode):
+    """The general form of csrc/conv_taps128.hip (K-steps = (tap, 128-channel chunk) pairs, one 128-channel output tile per workgroup):
+    bias + statistics epilogue / addend + BatchNorm-backward statistics epilogue, against the generic kernel (RSSF_CONV_GENERIC) and
+    an fp32 torch contraction of the same packed slabs."""
+    import ctypes
+    from representationlearning_amd import _lib as L, nnf
+    lib = L.load()
+    torch.manual_seed(21)
+    nt = len(taps)
+    rows_p, cols_p = lib.rssf_conv_packed_rows(Cout), lib.rssf_conv_packed_cols(Cin, L.RSSF_BF16)
+    wpk = torch.zeros(nt, rows_p, cols_p, device=DEV)
+    wpk[:, :Cout, :Cin] = torch.randn(nt, Cout, Cin, device=DEV) * (0.5 / (Cin * nt) ** 0.5)
+    wpk = wpk.bfloat16()
+    x = torch.randn(B, H, W, Cin, device=DEV).bfloat16()
+    dy = (ctypes.c_int * nt)(*[t[0] for t in taps]); dx = (ctypes.c_int * nt)(*[t[1] for t in taps])
+    bias = torch.randn(Cout, device=DEV)
+    addend = torch.randn(B, H, W, Cout, device=DEV).bfloat16()
+    raw = torch.randn(B, H, W, Cout, device=DEV).bfloat16()
+    ss = torch.stack([torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV) * 0.3]).contiguous()
+    outs, sts = [], []
+    for flag in (L.CONV_GENERIC, 0):
+        out = torch.empty(B, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+        if mode == "forward":
+            st = torch.zeros(nnf.BN_SLOTS * 2 * Cout, device=DEV)
+            L.check(lib.rssf_conv_gather_add(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(st), None, None, B, H, W, Cin, H, W, Cout, 1, 1,
+                                             nt, dy, dx, L.RSSF_BF16 | flag, L.stream()), "rssf_conv_gather_add")
+            sts.append(st.view(nnf.BN_SLOTS, 2, Cout).sum(0))
+        else:
+            st = torch.zeros(nnf.BN_BWD_SLOTS * 2 * Cout, device=DEV)
+            L.check(lib.rssf_conv_gather_bnbwd(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(addend), L.ptr(raw), None, L.ptr(ss), 2, L.ptr(st), B, H, W,
+                                               Cin, H, W, Cout, 1, 1, nt, dy, dx, L.RSSF_BF16 | flag, L.stream()), "rssf_conv_gather_bnbwd")
+            sts.append(st.view(nnf.BN_BWD_SLOTS, 2, Cout).sum(0))
+        outs.append(out)
+    torch.cuda.synchronize()
+    py, px = max(abs(t[0]) for t in taps), max(abs(t[1]) for t in taps)
+    xf = F.pad(x.float(), (0, 0, px, px, py, py))
+    ref = torch.zeros(B, H, W, Cout, device=DEV)
+    for t, (ddy, ddx) in enumerate(taps):
+        ref += xf[:, py + ddy:py + ddy + H, px + ddx:px + ddx + W, :] @ wpk[t, :Cout, :Cin].float().t()
+    ref = ref + bias if mode == "forward" else ref + addend.float()
+    assert rel_err(outs[1].float().cpu(), ref.cpu()) < 8e-3
+    assert rel_err(outs[1].float().cpu(), outs[0].float().cpu()) < 4e-3
+    assert rel_err(sts[1].cpu(), sts[0].cpu()) < (3e-4 if mode == "forward" else 3e-3)
