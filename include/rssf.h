@@ -220,6 +220,17 @@ int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, float* dw1, fl
                     const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias, float* workspace,
                     int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy,
                     const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream);
+/* First stage of the same weight gradient from a TRANSPOSED copy of the input (rssf_bn_finalize_apply_planes): 128 -> 128 channels,
+ * stride 1, "same" size, >= 8 taps with even dx, |dy|, |dx| <= pad, W a multiple of 128 (MlpDWBN's fused sum, ffn_block.py:226-228).
+ * The input operand goes coalesced into registers, only dout passes through LDS, shared by the taps of one dy (csrc/
+ * conv_wgrad_planes.hip).  Same workspace (rssf_conv_wgrad_workspace_elems covers both), same partial layout, same second stage,
+ * same results up to the summation order as rssf_conv_wgrad(dout, in, ...). */
+int rssf_conv_wgrad_planes_supported(int B, int H, int W, int Cin, int Cout, int stride, int ntaps, const int* dy, const int* dx, int pad,
+                                     int dtype);
+int rssf_conv_wgrad_planes(const void* dout, const void* in_planes, int pad, float* dw0, float* dw1, float* dw2, const int* ksizes, int nsrc,
+                           const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias, float* workspace, int B,
+                           int H, int W, int C, int ntaps, const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype,
+                           void* stream);
 /* WEIGHT-GRADIENT launch that also performs the BatchNorm-backward apply of its own layer (torch autograd:
  * native_batch_norm_backward's input gradient + the activation mask, then convolution_backward's weight gradient): the
  * output-gradient operand of the weight gradient is draw = rssf_bn_bwd_apply(bn_dy, bn_raw, ...), so the halo-tiled 3x3 kernel
@@ -262,6 +273,14 @@ int rssf_bn_finalize_apply(const void* raw, const float* stats, const float* gam
                            float* running_var, float* mean_invstd, float* scale_shift, const void* res_pre, const void* res_post,
                            void* y, int64_t rows, int C, int act, double n, float momentum, float eps, int training, int dtype,
                            void* stream);
+/* the same (no residuals) that ALSO writes the activation TRANSPOSED and zero-padded, y_planes[C][B][H + 2 pad][W + 2 pad] (pixels
+ * contiguous; only the interior is written: zero the buffer once) - the input operand of rssf_conv_wgrad_planes, formed in the pass
+ * that holds every value anyway (reference: the BatchNorm + GELU between MlpDWBN's fc1 and its depth-wise sum, ffn_block.py:219-228).
+ * y and the BatchNorm results are those of rssf_bn_finalize_apply. */
+int rssf_bn_finalize_apply_planes_supported(int B, int H, int W, int C, int pad, int dtype);
+int rssf_bn_finalize_apply_planes(const void* raw, const float* stats, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float* mean_invstd, float* scale_shift, void* y, void* y_planes, int B, int H, int W,
+                                  int C, int pad, int act, double n, float momentum, float eps, int training, int dtype, void* stream);
 /* sums [RSSF_BN_BWD_SLOTS][2][C] fp32, zeroed by the caller: slot (block mod slots) += { sum dz, sum dz*raw },
  * dz = dy * act'(raw*scale + shift + res_pre).  rssf_bn_bwd_apply sums the slots (all-reduce the whole buffer for SyncBN) */
 /* det_ws (optional): deterministic mode - per-block partials [blocks][2][C] (rssf_bn_bwd_reduce_workspace_elems() floats),

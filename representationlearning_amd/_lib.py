@@ -102,6 +102,9 @@ SIGNATURES = {
     "rssf_conv_gather_add": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_gather_bnbwd": (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] + [c_int] * 10 + [c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_workspace_elems": (c_int64, [c_int] * 6),
+    "rssf_conv_wgrad_planes_supported": (c_int, [c_int] * 7 + [c_void_p, c_void_p, c_int, c_int]),
+    "rssf_conv_wgrad_planes": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_bnapply": (c_int, [c_void_p] * 10 + [c_int, ctypes.c_double, c_int, c_float] + [c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_preact_supported": (c_int, [c_int] * 10 + [c_void_p, c_void_p, c_int, c_int]),
@@ -116,6 +119,8 @@ SIGNATURES = {
     "rssf_bn_bwd_apply_group": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "rssf_bn_finalize": (c_int, [c_void_p] * 7 + [c_int, ctypes.c_double, c_float, c_float, c_int, c_void_p]),
     "rssf_bn_apply": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_void_p]),
+    "rssf_bn_finalize_apply_planes_supported": (c_int, [c_int] * 6),
+    "rssf_bn_finalize_apply_planes": (c_int, [c_void_p] * 10 + [c_int] * 6 + [ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),
     "rssf_bn_finalize_apply": (c_int, [c_void_p] * 11 + [c_int64, c_int, c_int, ctypes.c_double, c_float, c_float, c_int, c_int, c_void_p]),
     "rssf_bn_bwd_reduce_workspace_elems": (c_int64, [c_int64, c_int]),
     "rssf_bn_bwd_reduce": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -627,6 +627,114 @@ extern "C" int rssf_bn_finalize_apply(const void* raw, const float* stats, const
   return RSSF_ERR_UNSUPPORTED;
 }
 
+// ---- finalize + apply that ALSO writes the activation TRANSPOSED: y_planes[c][b][H + 2 pad][W + 2 pad] (pixels contiguous, the
+// border is never written: the caller zeroed the buffer once) - the input operand of rssf_conv_wgrad_planes (conv_wgrad_planes.hip),
+// produced in the pass that has every value in registers anyway instead of a transposing pass of its own (read 67 MB, write 94 MB
+// per MlpDWBN block).  bf16, C = 128 (the hidden width of MlpDWBN at Base), W a multiple of 64: a workgroup walks tiles of 64
+// pixels of one image row x 128 channels; rows go to y as they come (16-byte stores), the tile turns around through LDS and leaves
+// as 64-byte runs of one channel.
+namespace {
+constexpr int PL_C = 128, PL_PX = 64, PL_PITCH = PL_C + 8;
+__global__ void __launch_bounds__(256) bn_finapply_planes_kernel(const bf16_t* __restrict__ raw, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                 float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                                 bf16_t* __restrict__ y, bf16_t* __restrict__ planes, int B, int H, int W, int pad,
+                                                                 int act, float n, float momentum, float eps, int training) {
+  constexpr int C = PL_C;
+  __shared__ float scsh[2 * C];
+  __shared__ __attribute__((aligned(16))) bf16_t tile[PL_PX * PL_PITCH];
+  const int tid = threadIdx.x;
+  if (tid < C) {                       // the arithmetic of bn_finapply_block
+    const int c = tid;
+    float mean, var;
+    if (training) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < RSSF_BN_SLOTS; ++k) { s1 += stats[(size_t)k * 2 * C + c]; s2 += stats[(size_t)k * 2 * C + C + c]; }
+      mean = s1 / n;
+      var = fmaxf(s2 / n - mean * mean, 0.f);
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
+    }
+    const float invstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
+    scsh[c] = sc; scsh[C + c] = sh;
+    if (blockIdx.x == 0) {
+      mean_invstd[c] = mean; mean_invstd[C + c] = invstd;
+      scale_shift[c] = sc; scale_shift[C + c] = sh;
+      if (training && running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
+      }
+    }
+  }
+  __syncthreads();
+  const int chunk = tid & 15, prow = tid >> 4;          // apply phase: 16-byte channel chunk, pixel row within a pass of 16
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scsh[chunk * 8 + e]; sh[e] = scsh[C + chunk * 8 + e]; }
+  const int tpr = W / PL_PX, ntiles = B * H * tpr;
+  const int HP = H + 2 * pad, WP = W + 2 * pad;
+  const int tch = tid & 127, thalf = tid >> 7;          // transposed phase: channel, half of the tile's pixels
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int row = t / tpr, x0 = (t - row * tpr) * PL_PX;
+    const int b = row / H, yy = row - b * H;
+    const size_t pix0 = (size_t)row * W + x0;
+    Vec<bf16_t> v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v[p].load(raw + (pix0 + p * 16 + prow) * C + chunk * 8);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = act_fwd(fmaf(v[p].get(e), sc[e], sh[e]), act);
+      Vec<bf16_t> w;
+      w.set_all(o);
+      w.store(y + (pix0 + p * 16 + prow) * C + chunk * 8);
+      w.store(tile + (p * 16 + prow) * PL_PITCH + chunk * 8);
+    }
+    __syncthreads();
+    // channel tch, pixels 32 thalf .. + 31 of the tile: 64 contiguous bytes of its plane row
+    uint32_t pk[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t lo = tile[(thalf * 32 + 2 * k) * PL_PITCH + tch].v, hi = tile[(thalf * 32 + 2 * k + 1) * PL_PITCH + tch].v;
+      pk[k] = lo | (hi << 16);
+    }
+    bf16_t* dst = planes + ((size_t)tch * B + b) * HP * WP + (size_t)(yy + pad) * WP + pad + x0 + thalf * 32;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {              // 8-byte stores: the run starts 2 * pad bytes into the (16-byte aligned) plane row
+      typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+      *reinterpret_cast<u32x2_t*>(dst + 4 * k) = u32x2_t{pk[2 * k], pk[2 * k + 1]};
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int rssf_bn_finalize_apply_planes_supported(int B, int H, int W, int C, int pad, int dtype) {
+  return dtype == RSSF_BF16 && C == PL_C && B > 0 && H > 0 && W > 0 && (W % PL_PX) == 0 && pad >= 0 && (pad % 2) == 0 && ((W + 2 * pad) % 4) == 0 &&
+                 (int64_t)PL_C * B * (H + 2 * pad) * (W + 2 * pad) < ((int64_t)1 << 30)
+             ? 1 : 0;
+}
+
+extern "C" int rssf_bn_finalize_apply_planes(const void* raw, const float* stats, const float* gamma, const float* beta, float* running_mean,
+                                             float* running_var, float* mean_invstd, float* scale_shift, void* y, void* y_planes, int B,
+                                             int H, int W, int C, int pad, int act, double n, float momentum, float eps, int training,
+                                             int dtype, void* stream) {
+  RSSF_REQUIRE(raw && gamma && beta && mean_invstd && scale_shift && y && y_planes && act >= 0 && act <= 2, "bn_finalize_apply_planes: bad arguments");
+  RSSF_REQUIRE(training ? (stats != nullptr && n >= 1) : (running_mean && running_var), "bn_finalize_apply_planes: missing statistics");
+  RSSF_REQUIRE(rssf_bn_finalize_apply_planes_supported(B, H, W, C, pad, dtype), "bn_finalize_apply_planes: unsupported shape (ask _supported)");
+  const int ntiles = B * H * (W / PL_PX);
+  const int blocks = ntiles < 2048 ? ntiles : 2048;
+  bn_finapply_planes_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)raw, stats, gamma, beta, running_mean, running_var, mean_invstd,
+                                                                     scale_shift, (bf16_t*)y, (bf16_t*)y_planes, B, H, W, pad, act, (float)n,
+                                                                     momentum, eps, training);
+  return check_launch("bn_finalize_apply_planes");
+}
+
 extern "C" int64_t rssf_bn_bwd_reduce_workspace_elems(int64_t rows, int C) { return (int64_t)REDUCE_MAX_BLOCKS * 2 * C; }
 
 extern "C" int rssf_bn_bwd_reduce(const void* dy, const void* raw, const float* scale_shift, const void* res_pre, float* sums,

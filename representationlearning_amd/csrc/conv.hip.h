@@ -92,6 +92,8 @@ bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int m
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
               const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st);
 int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st);
+int launch_wgrad_reduce(const rssf_wgrad_reduce_job& j, hipStream_t st);      // second stage of a split-K weight gradient (conv_wgrad.hip)
+int64_t wgrad_planes_workspace_elems(int B, int H, int W, int Cin, int Cout, int ntaps);     // 0: conv_wgrad_planes.hip does not serve the shape
 
 template <typename T> struct LdsPad;
 template <> struct LdsPad<bf16_t> { static constexpr int X = 8; };   // +16 B per row: conflict-free ds_read_b128

@@ -622,6 +622,16 @@ int finish_reduce(const WgradArgs& a, rssf_wgrad_reduce_job* defer, hipStream_t 
   return check_launch("conv_wgrad_reduce");
 }
 
+}  // namespace
+namespace rssf { namespace cv {
+// the second stage for a first stage that lives in another translation unit (conv_wgrad_planes.hip)
+int launch_wgrad_reduce(const rssf_wgrad_reduce_job& j, hipStream_t st) {
+  const int64_t per = (int64_t)j.ntaps * j.cout * j.cin;
+  wgrad_reduce_kernel<<<(unsigned)((per + RI - 1) / RI), 256, 0, st>>>(j);
+  return check_launch("conv_wgrad_reduce");
+}
+} }
+namespace {
 // ---- halo-tiled weight gradient of the 3x3 / stride-1 / "same" bf16 convolutions (HRNet BasicBlock / Bottleneck) -------
 // A block owns one 32 x 32 (co, ci) tile and a run of 8 x 16-pixel spatial tiles.  Per spatial tile it stages the dout tile
 // [128 px][32 co] and the input HALO [10 x 18 px][32 ci] once (pixel-major, plain 16-byte copies, next tile's global loads
@@ -1026,7 +1036,8 @@ int launch_all(WgradArgs& a, int ntaps, rssf_wgrad_reduce_job* defer, hipStream_
 extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Cin, int Cout, int ntaps) {
   int ks = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
   if (ntaps == 9) { const int hk = halo_ksplit(B, OH, OW, Cout, Cin); if (hk > ks) ks = hk; }   // either kernel may run
-  return (int64_t)ks * ntaps * Cout * Cin;
+  const int64_t generic = (int64_t)ks * ntaps * Cout * Cin, planes = wgrad_planes_workspace_elems(B, OH, OW, Cin, Cout, ntaps);
+  return generic > planes ? generic : planes;       // either first stage may run (rssf_conv_wgrad_planes takes the same workspace)
 }
 
 namespace {
