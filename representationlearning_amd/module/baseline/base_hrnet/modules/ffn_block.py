@@ -35,6 +35,9 @@ class MlpDWBN(nn.Module):
                 raise NotImplementedError("MlpDWBN (HIP): GELU activations only (the RSSFormer configuration)")
         # each hidden activation has ONE consumer: its BatchNorm-backward statistics ride on that consumer's data-gradient launch
         l1, l2 = nnf.bwd_stats_link(), nnf.bwd_stats_link()
+        if l1 is not None:
+            # the tap sum's weight gradient reads its input TRANSPOSED (csrc/conv_wgrad_planes.hip): norm1's apply writes that copy too
+            l1.want_planes = True
         t = nnf.conv_bn_act(t, self.fc1, self.norm1, nnf.ACT_GELU, stats_out=l1)
         t = nnf.conv_bn_act(t, [self.dw, self.dw6, self.dw12], self.norm2, nnf.ACT_GELU, stats_out=l2, stats_in=l1)
         return nnf.conv_bn_act(t, self.fc2, self.norm3, nnf.ACT_GELU, res_post=residual, stats_in=l2, post_relu=post_relu)

@@ -91,6 +91,23 @@ class Runtime:
         self.wgrad_plan = None
         # fixed-order reductions for the BatchNorm statistics (bit-identical runs): RSSF_DETERMINISTIC=1 or set by the caller
         self.deterministic = os.environ.get("RSSF_DETERMINISTIC", "0") == "1"
+        # transposed zero-bordered activation copies ([C][B][H + 2 pad][W + 2 pad]) for rssf_conv_wgrad_planes: one per producing
+        # layer, allocated and zeroed ONCE (the kernels write the interior only, the border stays zero), so a captured step
+        # replays against fixed addresses.  planes_gen counts the writes: a backward pass that finds a newer copy than the one
+        # its forward pass wrote (the layer ran twice before its backward) takes the ordinary weight-gradient path
+        self.planes = {}
+        self.planes_gen = {}
+
+    def planes_buffer(self, key, shape, dtype, device):
+        k = (key, tuple(shape), dtype, str(device))
+        buf = self.planes.get(k)
+        if buf is None:
+            buf = self.planes[k] = torch.zeros(shape, device=device, dtype=dtype)
+        self.planes_gen[k] = gen = self.planes_gen.get(k, 0) + 1
+        return buf, k, gen
+
+    def planes_current(self, k, gen):
+        return self.planes_gen.get(k) == gen
 
     @property
     def world(self):
@@ -718,10 +735,13 @@ class BnBwdLink:
     conv_bn_act(y, .., stats_in=link) - y being that layer's output, consumed by nothing else but a residual skip whose gradient
     rides on the same launch (GradLink) - produces them.  The caller vouches for the single consumer."""
 
-    __slots__ = ("raw", "ss", "rp", "act", "C", "sums", "deferred", "pre")
+    __slots__ = ("raw", "ss", "rp", "act", "C", "sums", "deferred", "pre", "want_planes", "planes")
 
     def __init__(self):
         self.raw = self.ss = self.rp = self.sums = None
+        # want_planes: the consumer's weight gradient takes its input TRANSPOSED (rssf_conv_wgrad_planes) - the producer's BatchNorm
+        # apply then writes that copy beside its output (rssf_bn_finalize_apply_planes) and leaves (buffer, pad) in `planes`
+        self.want_planes, self.planes = False, None
         self.act, self.C = ACT_NONE, 0
         self.deferred = False      # the producer returned its RAW convolution output: the consumer applies BatchNorm + activation on load
         self.pre = None            # (stats, gamma, beta, running mean / var, mi, ss, n, momentum, eps, training) of a deferred producer
@@ -754,6 +774,8 @@ _GROUP_LAUNCH = os.environ.get("RSSF_GROUP_LAUNCH", "1") != "0"      # A/B switc
 _PLAN_BIAS = os.environ.get("RSSF_WGRAD_PLAN_BIAS", "1") != "0"      # A/B switch: deferred split-K reduction also for convolutions with a bias
 _FORK_FUSE = os.environ.get("RSSF_FORK_FUSE", "1") != "0"      # A/B switch: fuse outputs 1.. beside the transformer block (fork_side)
 _DEFER_BN_APPLY = os.environ.get("RSSF_DEFER_BN_APPLY", "1") != "0"      # A/B switch: forward BatchNorm apply inside the consumer's staging
+_WGRAD_PLANES = os.environ.get("RSSF_WGRAD_PLANES", "1") != "0"          # A/B switch: transposed-input weight gradient of the MLP's tap sum
+PLANES_PAD = 12                      # zero border of the transposed copy: the largest tap offset of the MLP's dilated convolutions
 _FUSED_BN_APPLY = os.environ.get("RSSF_FUSED_BN_APPLY", "1") != "0"      # A/B switch: BatchNorm-backward apply inside the weight-gradient launch
 _FUSED_BN_STATS = os.environ.get("RSSF_FUSED_BN_STATS", "1") != "0"      # A/B switch (tools)
 
@@ -920,7 +942,7 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, b
     return dx
 
 
-def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None):
+def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=None):
     """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional).  Under a WgradPlan the split-K
     reduction is deferred to the plan's one batched launch (the gradients are complete after WgradPlan.flush()).
     bn: (dy, raw, ss, mi, sums, res_pre, dres, dgamma, dbeta, act, n, training, pscale) - `dout` is then an OUTPUT: the launch
@@ -953,7 +975,21 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None):
     tail = (L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws), spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb),
             L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps, spec.c_dy, spec.c_dx, None if job is None else ctypes.byref(job),
             L.dtype_code(xh), L.stream())
-    if bn is not None:
+    use_planes = (planes is not None and (rt or current()).planes_current(planes[2], planes[3]) and not padded and xpre is None and
+                  spec.stride == 1 and OH == H and OW == W and tuple(planes[0].shape) == (C, B, H + 2 * planes[1], W + 2 * planes[1]) and
+                  lib.rssf_conv_wgrad_planes_supported(B, H, W, C, CO, 1, spec.ntaps, spec.c_dy, spec.c_dx, planes[1], L.dtype_code(xh)) == 1)
+    if use_planes:
+        # the input operand comes TRANSPOSED (written by the producer's BatchNorm apply): csrc/conv_wgrad_planes.hip.  A fused
+        # BatchNorm-backward apply is what the library itself falls back to for this shape: the apply pass, then the weight gradient
+        if bn is not None:
+            bdy, braw, bss, bmi, bsums, brp, bdres, bdg, bdb, bact, bn_n, btr, bps = bn
+            L.check(lib.rssf_bn_bwd_apply(L.ptr(bdy), L.ptr(braw), L.ptr(bss), L.ptr(bmi), L.ptr(bsums), L.ptr(brp), L.ptr(dout), L.ptr(bdres),
+                                          L.ptr(bdg), L.ptr(bdb), braw.numel() // CO, CO, bact, bn_n, int(btr), bps, L.dtype_code(braw), L.stream()),
+                    "rssf_bn_bwd_apply")
+        L.check(lib.rssf_conv_wgrad_planes(L.ptr(dout), L.ptr(planes[0]), planes[1], L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws),
+                                           spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb), L.ptr(ws), B, H, W, C, spec.ntaps, spec.c_dy, spec.c_dx,
+                                           None if job is None else ctypes.byref(job), L.dtype_code(xh), L.stream()), "rssf_conv_wgrad_planes")
+    elif bn is not None:
         if padded:
             raise RuntimeError("conv_wgrad: the fused BatchNorm-backward apply needs channel counts the kernels take unpadded")
         bdy, braw, bss, bmi, bsums, brp, bdres, bdg, bdb, bact, bn_n, btr, bps = bn
@@ -1025,9 +1061,21 @@ class _ConvBNAct(torch.autograd.Function):
             y = raw
         else:
             y = torch.empty_like(raw)
-            L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi), L.ptr(ss),
-                                               L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, n, momentum, eps, int(training), L.dtype_code(raw),
-                                               L.stream()), "rssf_bn_finalize_apply")
+            so_ = links[3] if len(links) > 3 else None
+            planes = None
+            if so_ is not None and so_.want_planes and rp is None and rq is None and not (act & ACT_POST_RELU) and _WGRAD_PLANES:
+                Bp, Hp, Wp, _ = raw.shape
+                if lib.rssf_bn_finalize_apply_planes_supported(Bp, Hp, Wp, C, PLANES_PAD, L.dtype_code(raw)) == 1:
+                    planes = rt.planes_buffer(gamma.data_ptr(), (C, Bp, Hp + 2 * PLANES_PAD, Wp + 2 * PLANES_PAD), raw.dtype, dev)
+                    L.check(lib.rssf_bn_finalize_apply_planes(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi),
+                                                              L.ptr(ss), L.ptr(y), L.ptr(planes[0]), Bp, Hp, Wp, C, PLANES_PAD, act, n, momentum, eps,
+                                                              int(training), L.dtype_code(raw), L.stream()), "rssf_bn_finalize_apply_planes")
+            if so_ is not None:
+                so_.planes = None if planes is None else (planes[0], PLANES_PAD, planes[1], planes[2])
+            if planes is None:
+                L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(rmean), L.ptr(rvar), L.ptr(mi), L.ptr(ss),
+                                                   L.ptr(rp), L.ptr(rq), L.ptr(y), rows, C, act, n, momentum, eps, int(training), L.dtype_code(raw),
+                                                   L.stream()), "rssf_bn_finalize_apply")
         if act & ACT_POST_RELU and (defer or (len(links) > 3 and links[3] is not None)):
             raise RuntimeError("conv_bn_act: a ReLU behind res_post belongs to a layer without a BatchNorm-statistics link")
         ctx.rq = rq if (act & ACT_POST_RELU) else None          # (held by the node: the residual stream is alive until the block's backward anyway)
@@ -1044,6 +1092,7 @@ class _ConvBNAct(torch.autograd.Function):
             so.deferred = bool(defer)
             so.pre = (stats, gamma, beta, rmean, rvar, mi, ss, n, momentum, eps, training) if defer else None
         ctx.xpre = (si_.ss, si_.act) if preact is not None else None
+        ctx.xplanes = si_.planes if (si_ is not None and preact is None) else None      # (buffer, pad): xh transposed, for the weight gradient
         return _nchw(y)
 
     @staticmethod
@@ -1099,11 +1148,11 @@ class _ConvBNAct(torch.autograd.Function):
             gbs = []
             if nbias == 1:          # the weight-gradient kernel accumulates straight into the bias gradient: no staging buffer, no add
                 tb, direct = grad_target(p_biases[0], rt)
-                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn, xpre=xpre)
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn, xpre=xpre, planes=ctx.xplanes)
                 gbs.append(grad_result(p_biases[0], tb, direct, rt))
             else:
                 db = _zeros(C, raw.device, rt) if nbias else None
-                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt, bn=bn, xpre=xpre)
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt, bn=bn, xpre=xpre, planes=ctx.xplanes)
                 tbs = [grad_target(b, rt) for b in p_biases]      # every summed conv's bias sees the same gradient: one launch
                 if tbs:
                     d = [t[0] for t in tbs] + [None, None]

@@ -275,3 +275,148 @@ def test_taps128_general_channels_match_gather_and_torch(B, H, W, Cin, Cout, tap
     assert rel_err(outs[1].float().cpu(), ref.cpu()) < 8e-3
     assert rel_err(outs[1].float().cpu(), outs[0].float().cpu()) < 4e-3
     assert rel_err(sts[1].cpu(), sts[0].cpu()) < (3e-4 if mode == "forward" else 3e-3)
+
+
+# ---- csrc/conv_wgrad_planes.hip: the tap sum's weight gradient from a transposed, zero-bordered copy of its input ----
+def _planes_of(x, rt, key):
+    from representationlearning_amd import nnf
+    B, H, W, C = x.shape
+    P = nnf.PLANES_PAD
+    buf, k, gen = rt.planes_buffer(key, (C, B, H + 2 * P, W + 2 * P), x.dtype, x.device)
+    buf.zero_()
+    buf[:, :, P:P + H, P:P + W] = x.permute(3, 0, 1, 2)
+    return (buf, P, k, gen)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 128), (2, 128, 128), (1, 16, 256), (3, 4, 128), (1, 30, 128)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_wgrad_planes_matches_generic_and_torch(B, H, W, with_bias):
+    from representationlearning_amd import nnf, _lib as L
+    C = 128
+    convs = _convs(C, 11)
+    spec = nnf.spec_of(convs)
+    x = torch.randn(B, H, W, C, device=DEV).bfloat16()
+    dout = (torch.randn(B, H, W, C, device=DEV) * 0.5).bfloat16()
+    rt = nnf.current()
+    planes = _planes_of(x, rt, ("test", B, H, W))
+    assert L.load().rssf_conv_wgrad_planes_supported(B, H, W, C, C, 1, spec.ntaps, spec.c_dy, spec.c_dx, planes[1], L.dtype_code(x)) == 1
+    got = []
+    for pl in (None, planes):
+        dws = [torch.zeros_like(c.weight, dtype=torch.float32) + 0.25 for c in convs]        # the kernels ACCUMULATE
+        db = torch.full((C,), 0.5, device=DEV) if with_bias else None
+        nnf._conv_wgrad(spec, dout, x, dws, db, rt, planes=pl)
+        got.append((dws, db))
+    torch.cuda.synchronize()
+    xr = x.permute(0, 3, 1, 2).float()
+    ws = [c.weight.detach().clone().float().requires_grad_(True) for c in convs]
+    y = sum(F.conv2d(xr, w, None, 1, c.padding, c.dilation) for w, c in zip(ws, convs))
+    y.backward(dout.permute(0, 3, 1, 2).float())
+    for i in range(3):
+        ref = ws[i].grad + 0.25
+        assert rel_err(got[1][0][i].cpu(), ref.cpu()) < 2e-5, i           # bf16 operands are exact in fp32: only the summation order differs
+        assert rel_err(got[1][0][i].cpu(), got[0][0][i].cpu()) < 2e-5, i
+    if with_bias:
+        ref = dout.float().sum((0, 1, 2)) + 0.5
+        assert rel_err(got[1][1].cpu(), ref.cpu()) < 2e-5
+        assert rel_err(got[1][1].cpu(), got[0][1].cpu()) < 2e-5
+
+
+def test_wgrad_planes_stale_copy_takes_the_ordinary_path():
+    """A transposed copy that was overwritten since the forward pass that made it (the layer ran twice) must not be used."""
+    from representationlearning_amd import nnf
+    C, B, H, W = 128, 1, 8, 128
+    convs = _convs(C, 12)
+    spec = nnf.spec_of(convs)
+    x = torch.randn(B, H, W, C, device=DEV).bfloat16()
+    dout = torch.randn(B, H, W, C, device=DEV).bfloat16()
+    rt = nnf.current()
+    old = _planes_of(x, rt, ("stale",))
+    new = _planes_of(torch.zeros_like(x), rt, ("stale",))          # the same buffer, rewritten (zeros): `old` is stale now
+    assert old[0].data_ptr() == new[0].data_ptr() and not rt.planes_current(old[2], old[3]) and rt.planes_current(new[2], new[3])
+    a = [torch.zeros_like(c.weight, dtype=torch.float32) for c in convs]
+    b = [torch.zeros_like(c.weight, dtype=torch.float32) for c in convs]
+    nnf._conv_wgrad(spec, dout, x, a, None, rt, planes=old)
+    nnf._conv_wgrad(spec, dout, x, b, None, rt, planes=None)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert float(v.abs().max()) > 0 and torch.equal(u, v)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 128), (2, 128, 128), (1, 2, 256)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_finalize_apply_planes_matches_apply(B, H, W, act, training):
+    """rssf_bn_finalize_apply_planes: y, the BatchNorm results and the running statistics of rssf_bn_finalize_apply, plus the transposed
+    copy (interior = y, border untouched)."""
+    from representationlearning_amd import nnf, _lib as L
+    C, P = 128, nnf.PLANES_PAD
+    lib = L.load()
+    raw = (torch.randn(B, H, W, C, device=DEV) * 1.5 + 0.3).bfloat16()
+    r = raw.float().reshape(-1, C)
+    stats = torch.zeros(nnf.BN_SLOTS, 2, C, device=DEV)
+    stats[0, 0], stats[0, 1] = r.sum(0), (r * r).sum(0)
+    stats[3] = 0.0
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+    n = float(B * H * W)
+    res = []
+    for planes_on in (False, True):
+        rm, rv = torch.full((C,), 0.1, device=DEV), torch.full((C,), 0.9, device=DEV)
+        mi, ss = torch.empty(2, C, device=DEV), torch.empty(2, C, device=DEV)
+        y = torch.empty_like(raw)
+        st = stats.clone().view(-1)
+        if planes_on:
+            assert lib.rssf_bn_finalize_apply_planes_supported(B, H, W, C, P, L.dtype_code(raw)) == 1
+            pl = torch.full((C, B, H + 2 * P, W + 2 * P), 7.0, device=DEV, dtype=raw.dtype)
+            L.check(lib.rssf_bn_finalize_apply_planes(L.ptr(raw), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(mi), L.ptr(ss),
+                                                      L.ptr(y), L.ptr(pl), B, H, W, C, P, act, n, 0.1, 1e-5, int(training), L.dtype_code(raw),
+                                                      L.stream()), "planes")
+        else:
+            pl = None
+            L.check(lib.rssf_bn_finalize_apply(L.ptr(raw), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(mi), L.ptr(ss), None, None,
+                                               L.ptr(y), B * H * W, C, act, n, 0.1, 1e-5, int(training), L.dtype_code(raw), L.stream()), "apply")
+        res.append((y, mi, ss, rm, rv, pl))
+    torch.cuda.synchronize()
+    a, b = res
+    for u, v in zip(a[1:5], b[1:5]):                    # the same fp32 expressions; the compiler contracts them into FMAs kernel by kernel
+        assert rel_err(v.cpu(), u.cpu()) < 1e-6
+    assert rel_err(b[0].float().cpu(), a[0].float().cpu()) < 1e-4           # (a last-bit scale difference moves a few bf16 roundings)
+    pl = b[5]
+    assert torch.equal(pl[:, :, P:P + H, P:P + W], b[0].permute(3, 0, 1, 2))
+    border = pl.clone()
+    border[:, :, P:P + H, P:P + W] = 7.0
+    assert bool((border == 7.0).all())                 # only the interior is written
+
+
+def test_mlp_block_gradients_with_and_without_planes():
+    """MlpDWBN forward + backward with the transposed-copy weight gradient on and off: the same outputs, the same gradients up to the
+    summation order of the tap sum's weight gradient (and the bf16 rounding noise named below)."""
+    from representationlearning_amd import nnf
+    from representationlearning_amd.module.baseline.base_hrnet.modules.ffn_block import MlpDWBN
+    torch.manual_seed(5)
+    m = MlpDWBN(128, 128, 128).to(DEV).train()
+    x = torch.randn(2, 128, 128, 128, device=DEV).bfloat16()            # [B, H, W, C]
+    dy = torch.randn(2, 128, 128, 128, device=DEV).bfloat16()
+    runs = []
+    keep = nnf._WGRAD_PLANES
+    try:
+        for on in (False, False, True):
+            nnf._WGRAD_PLANES = on
+            for p in m.parameters():
+                p.grad = None
+            xi = x.clone().permute(0, 3, 1, 2).requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m.forward_nhwc(xi)
+            y.backward(dy.permute(0, 3, 1, 2))
+            torch.cuda.synchronize()
+            runs.append((y.detach().float(), xi.grad.float(), {k: p.grad.float().clone() for k, p in m.named_parameters()}))
+    finally:
+        nnf._WGRAD_PLANES = keep
+    assert any(k[0] == m.norm1.weight.data_ptr() for k in nnf.current().planes)       # the path under test ran
+    # two runs of ONE configuration already differ (the BatchNorm statistics are sums of atomics; bf16 roundings move with their last
+    # bit): the run with the transposed copy must sit within a small multiple of that floor
+    def floor(a, b):
+        return max(3.0 * rel_err(a.cpu(), b.cpu()), 5e-4)
+    assert rel_err(runs[2][0].cpu(), runs[0][0].cpu()) < floor(runs[1][0], runs[0][0])
+    assert rel_err(runs[2][1].cpu(), runs[0][1].cpu()) < floor(runs[1][1], runs[0][1])
+    for k in runs[0][2]:
+        assert rel_err(runs[2][2][k].cpu(), runs[0][2][k].cpu()) < floor(runs[1][2][k], runs[0][2][k]), k
