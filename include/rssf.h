@@ -26,8 +26,9 @@ extern "C" {
 typedef enum { RSSF_F32 = 0, RSSF_BF16 = 1 } rssf_dtype;
 /* Kernel selection is a function of the call's arguments only (shape, dtype, which optional operands are present): no environment
  * variable or other process state steers it.  The one explicit knob: OR RSSF_CONV_GENERIC into the `dtype` argument of the
- * rssf_conv_gather* entry points to run the generic gather / halo kernels instead of a shape-specialised one (the point-wise stream
- * kernel, the 128-channel many-tap kernel) - same results up to the summation order; the parity tests hold the two against each other. */
+ * rssf_conv_gather* / rssf_conv_wgrad* entry points to run the generic gather / halo / tiled kernels instead of a shape-specialised one
+ * (the point-wise stream kernels of the forward pass and of the weight gradient, the 128-channel many-tap kernel) - same results up to
+ * the summation order; the parity tests hold the two against each other. */
 #define RSSF_CONV_GENERIC 0x100
 /* per-channel BatchNorm statistics are accumulated into this many interleaved copies (slot = block index mod slots) to
  * spread same-address atomics; every statistics buffer below is [RSSF_BN_SLOTS][2][C] fp32 and consumers sum the slots */

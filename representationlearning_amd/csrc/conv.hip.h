@@ -94,6 +94,16 @@ int launch_pw(const void* in, const void* wpk, void* out, const float* bias, flo
 int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st);
 int launch_wgrad_reduce(const rssf_wgrad_reduce_job& j, hipStream_t st);      // second stage of a split-K weight gradient (conv_wgrad.hip)
 int64_t wgrad_planes_workspace_elems(int B, int H, int W, int Cin, int Cout, int ntaps);     // 0: conv_wgrad_planes.hip does not serve the shape
+// arguments of rssf_bn_bwd_apply for a weight-gradient launch that performs the apply on the way (rssf_conv_wgrad_bnapply)
+struct WgradBn {
+  const void* dy; const void* raw; const float* ss; const float* mi; const float* sums; const void* res; void* draw; void* dres;
+  float* dgamma; float* dbeta; double n; int act, training; float pscale;
+};
+// narrow point-wise weight gradients, one block per pixel range (conv_wgrad_pw.hip); wgrad_pw_ksplit() partial planes [Cout][Cin]
+bool wgrad_pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx);
+int wgrad_pw_ksplit(int B, int OH, int OW, int Cin, int Cout);
+int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbias, int B, int OH, int OW, int Cin, int Cout, int ksplit,
+                    const WgradBn* bn, hipStream_t st);
 
 template <typename T> struct LdsPad;
 template <> struct LdsPad<bf16_t> { static constexpr int X = 8; };   // +16 B per row: conflict-free ds_read_b128

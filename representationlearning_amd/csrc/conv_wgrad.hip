@@ -1036,15 +1036,17 @@ int launch_all(WgradArgs& a, int ntaps, rssf_wgrad_reduce_job* defer, hipStream_
 extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Cin, int Cout, int ntaps) {
   int ks = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
   if (ntaps == 9) { const int hk = halo_ksplit(B, OH, OW, Cout, Cin); if (hk > ks) ks = hk; }   // either kernel may run
+  static const int dy0[1] = {0}, dx0[1] = {0};
+  if (ntaps == 1 && wgrad_pw_eligible(B, OH, OW, Cin, OH, OW, Cout, 1, 1, dy0, dx0)) {       // (a stride-1 point-wise layer or not: the bound holds)
+    const int pk = wgrad_pw_ksplit(B, OH, OW, Cin, Cout);
+    if (pk > ks) ks = pk;
+  }
   const int64_t generic = (int64_t)ks * ntaps * Cout * Cin, planes = wgrad_planes_workspace_elems(B, OH, OW, Cin, Cout, ntaps);
   return generic > planes ? generic : planes;       // either first stage may run (rssf_conv_wgrad_planes takes the same workspace)
 }
 
 namespace {
-struct BnApply {               // arguments of rssf_bn_bwd_apply (see WgradHaloArgs::bn_*)
-  const void* dy; const void* raw; const float* ss; const float* mi; const float* sums; const void* res; void* draw; void* dres;
-  float* dgamma; float* dbeta; double n; int act, training; float pscale;
-};
+using BnApply = rssf::cv::WgradBn;               // arguments of rssf_bn_bwd_apply (see WgradHaloArgs::bn_*)
 struct XPreAct { const float* ss; int act; };
 // arguments of the halo-tiled kernel for one problem; ksplit_out = partial planes the second stage has to fold
 WgradHaloArgs make_wgrad_halo(const void* dout, const void* in, float* workspace, int B, int H, int W, int Cin, int Cout, const BnApply* bn,
@@ -1072,8 +1074,10 @@ WgradHaloArgs make_wgrad_halo(const void* dout, const void* in, float* workspace
 int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, float* dw2, const int* ksizes,
                     int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
                     float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
-                    const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, const BnApply* bn, const XPreAct* xpre, int dtype,
+                    const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, const BnApply* bn, const XPreAct* xpre, int dtype_flags,
                     void* stream) {
+  const int dtype = dtype_flags & 0xff;
+  const bool generic = (dtype_flags & RSSF_CONV_GENERIC) != 0;       // the narrow point-wise kernel off (rssf.h): parity tests, A/B runs
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
                    ntaps <= MAX_TAPS && B > 0 && IH > 0 && IW > 0 && Cin > 0 && OH > 0 && OW > 0 && Cout > 0 && stride >= 1,
                "conv_wgrad: bad arguments");
@@ -1112,6 +1116,14 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
     return finish_reduce(a, defer_reduce, st);
   }
   if (xpre) { set_error("conv_wgrad: no kernel with a pre-activation input operand for this shape (ask rssf_conv_wgrad_preact_supported)"); return RSSF_ERR_UNSUPPORTED; }
+#ifndef RSSF_WGRAD_PW_DISABLE       // (A/B builds: tools/ab_lib_flags.sh)
+  if (dtype == RSSF_BF16 && workspace && !generic && wgrad_pw_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx)) {
+    // narrow point-wise layers: one block per pixel range streams both operands once (conv_wgrad_pw.hip), the apply rides along
+    a.ksplit = wgrad_pw_ksplit(B, OH, OW, Cin, Cout);
+    if (int rc = launch_wgrad_pw(dout, in, workspace, dbias, B, OH, OW, Cin, Cout, a.ksplit, bn, st)) return rc;
+    return finish_reduce(a, defer_reduce, st);
+  }
+#endif
   if (bn) {                    // no kernel with a fused apply for this shape: the separate pass, then the plain weight gradient
     const int rc = rssf_bn_bwd_apply(bn->dy, bn->raw, bn->ss, bn->mi, bn->sums, bn->res, bn->draw, bn->dres, bn->dgamma, bn->dbeta,
                                      (int64_t)B * OH * OW, Cout, bn->act, bn->n, bn->training, bn->pscale, dtype, stream);

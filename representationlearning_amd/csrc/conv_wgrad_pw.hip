@@ -1,0 +1,310 @@
+// Weight gradient of the NARROW point-wise convolutions (1x1, stride 1, bf16): MlpDWBN's fc1 / fc2 (reference ffn_block.py:218, 236: 32 <-> 128
+// channels at 1/4 resolution), layer1's Bottleneck reductions / expansions (_hrnet_rssformer.py:146-156: 64 <-> 256) and the 1x1 fuse
+// convolutions of the HighResolutionModules.
+//
+//   dW[co][ci] = sum_p dout[p][co] * in[p][ci],   K = B*H*W pixels (262 144 at the benchmark geometry), Cout * Cin <= 16 384
+//
+// A GEMM that is ALL operand traffic (84 MB of activations for 2 GFLOP): the job is to stream both operands once at the fabric's rate.
+// The generic kernel (conv_wgrad.hip) tiles the channels 64 x 64 - for 32 channels half of every staged slab is padding, for 256 the
+// narrow operand is re-read four times - keeps one 64-pixel slab per block in flight and ran these layers at 2.4 TB/s (36 launches
+// of 35 us per step).  Here a block owns EVERY (co, ci) pair of a pixel range: the two operand chunks of 32 / 64 pixels are plain
+// contiguous spans of memory (16-byte loads, thread t takes bytes 16 t, 16 (t + 256), ...), staged pixel-major in LDS, and the MFMA
+// fragments come out of gfx950's transposing LDS reads (SlabFrag, see conv_wgrad.hip); the next chunk's loads are in flight
+// under the current chunk's MFMAs, several blocks per CU.  Split-K partials + the common second stage as everywhere else.
+//
+// FUSE: the BatchNorm-backward APPLY of the layer rides in the launch (rssf_conv_wgrad_bnapply): the block owns all channels of its
+// pixels, so it computes draw = sc * dz + cb * raw + cc for its chunk exactly once - from dy and raw instead of loading draw -
+// writes it out for the data-gradient launch (and dz for a residual branch) and contracts it from LDS.  One tensor pass
+// (read dy + raw, write draw) and one launch less per layer: bn_bwd_apply_kernel's arithmetic, bit for bit (common.hip.h).
+#include <cstring>
+#include <type_traits>
+#include "conv.hip.h"
+using namespace rssf;
+using namespace rssf::cv;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short v4s;
+
+struct PwWgradArgs {
+  const bf16_t* dout;     // [M][CO]  (FUSE: not read)
+  const bf16_t* in;       // [M][CI]
+  float* partial;         // [ksplit][CO][CI]
+  float* dbias;           // [CO] or null
+  int64_t M;
+  int per;                // pixels per block (a multiple of the chunk)
+  // fused BatchNorm-backward apply (see WgradHaloArgs in conv_wgrad.hip)
+  const bf16_t* bn_dy; const bf16_t* bn_raw; const bf16_t* bn_res;
+  const float* bn_ss; const float* bn_mi; const float* bn_sums;
+  bf16_t* draw_out; bf16_t* dres_out;
+  float* dgamma; float* dbeta;
+  float bn_n, bn_pscale;
+  int bn_act, bn_training;
+};
+
+// MFMA fragment of a K-step (32 pixel rows from k0) for 16 channels from column c0 of a pixel-major tile: conv_wgrad.hip's SlabFrag
+__device__ __forceinline__ bf16x8 frag(const bf16_t* tile, int ld, int k0, int c0, int lane) {
+  const int grp = lane >> 4, i = lane & 15;
+  const bf16_t* p = tile + (k0 + grp * 4 + (i >> 2)) * ld + c0 + (i & 3) * 4;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p + 16 * ld));
+  union { struct { v4s a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+// GM x GN waves (GN = 4 / GM), each WM x WN tiles of 16 x 16: CO = 16 GM WM output channels, CI = 16 GN WN input channels; KPX pixels per chunk
+template <int GM, int WM, int WN, int KPX, bool FUSE, bool RES>
+__global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
+  constexpr int GN = 4 / GM, CO = 16 * GM * WM, CI = 16 * GN * WN;
+  constexpr int LDD = CO + 16, LDX = CI + 16;                       // +32 B per row: conflict-free transposing reads (conv_wgrad.hip)
+  constexpr int DV = KPX * CO / 8 / 256, XV = KPX * CI / 8 / 256;   // 16-byte vectors per thread and chunk
+  static_assert(DV * 256 * 8 == KPX * CO && XV * 256 * 8 == KPX * CI && DV >= 1 && XV >= 1, "the chunk divides over the block exactly");
+  static_assert(KPX % 32 == 0 && 256 % (CO / 8) == 0 && 256 % (CI / 8) == 0, "a thread's channel group is the same in every vector");
+  __shared__ __attribute__((aligned(16))) bf16_t DS[KPX * LDD];
+  __shared__ __attribute__((aligned(16))) bf16_t XS[KPX * LDX];
+  __shared__ __attribute__((aligned(16))) float sbn[4][FUSE ? CO : 4];      // scale, shift, cb, cc
+  __shared__ float sbias[CO];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
+  const int wm = wave / GN, wn = wave % GN;
+  const int range = blockIdx.x;
+  const int64_t kbeg = (int64_t)range * a.per;
+  const int64_t kend = kbeg + a.per < a.M ? kbeg + a.per : a.M;
+  const bool do_bias = a.dbias != nullptr;
+  if (tid < CO) sbias[tid] = 0.f;
+
+  if constexpr (FUSE) {
+    if (tid < CO) {
+      const int c = tid;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < RSSF_BN_BWD_SLOTS; ++k) { s1 += a.bn_sums[(size_t)k * 2 * CO + c]; s2 += a.bn_sums[(size_t)k * 2 * CO + CO + c]; }
+      const float mean = a.bn_mi[c], istd = a.bn_mi[CO + c];
+      const float sc = a.bn_ss[c], sh = a.bn_ss[CO + c];
+      float dot, cb, cc;
+      bn_bwd_constants(sc, mean, istd, s1, s2, a.bn_n, dot, cb, cc);
+      if (a.dgamma && range == 0) { a.dgamma[c] += dot * a.bn_pscale; a.dbeta[c] += s1 * a.bn_pscale; }       // one writer per channel
+      sbn[0][c] = sc; sbn[1][c] = sh; sbn[2][c] = cb; sbn[3][c] = cc;
+    }
+  }
+  __syncthreads();
+
+  // hardware-bounds-checked buffer accesses, 32-bit byte offsets (the entry point keeps the tensors below 2^31 bytes)
+  const int dbytes = (int)(a.M * CO * 2), xbytes = (int)(a.M * CI * 2);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.in), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(FUSE ? a.bn_dy : a.dout), 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rraw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(FUSE ? a.bn_raw : a.dout), 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(FUSE && RES ? a.bn_res : a.dout), 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdraw = __builtin_amdgcn_make_buffer_rsrc(FUSE ? a.draw_out : const_cast<bf16_t*>(a.dout), 0, dbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdres = __builtin_amdgcn_make_buffer_rsrc(FUSE && a.dres_out ? a.dres_out : (FUSE ? a.draw_out : const_cast<bf16_t*>(a.dout)), 0, dbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+  float bs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+
+  Vec<bf16_t> rd[DV], rx[XV], rr[FUSE ? DV : 1], rq[FUSE && RES ? DV : 1], vdz[FUSE ? DV : 1];
+  unsigned soff[DV];
+  auto load_chunk = [&](int64_t k0) {
+    const unsigned db = (unsigned)(k0 * CO * 2) + (unsigned)tid * 16u, xb = (unsigned)(k0 * CI * 2) + (unsigned)tid * 16u;
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+      rd[c].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdo, db + c * 4096u, 0, 0));
+      if constexpr (FUSE) {
+        rr[c].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rraw, db + c * 4096u, 0, 0));
+        if constexpr (RES) rq[c].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, db + c * 4096u, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < XV; ++c) rx[c].raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, xb + c * 4096u, 0, 0));
+  };
+  const int cg8 = (tid % (CO / 8)) * 8;           // this thread's 8 output channels (the same in every vector of every chunk)
+  // draw / dz of the staged chunk: block-uniform activation, one specialised loop runs
+  auto apply_chunk = [&](auto ACT) {
+    float bsc[8], bsh[8], bcb[8], bcc[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&sbn[0][cg8 + 4 * h]), v1 = *reinterpret_cast<const f32x4*>(&sbn[1][cg8 + 4 * h]);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(&sbn[2][cg8 + 4 * h]), v3 = *reinterpret_cast<const f32x4*>(&sbn[3][cg8 + 4 * h]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bsc[4 * h + e] = v0[e]; bsh[4 * h + e] = v1[e]; bcb[4 * h + e] = v2[e]; bcc[4 * h + e] = v3[e]; }
+    }
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+      float o1[8], o2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = rr[c].get(e);
+        float z = fmaf(x, bsc[e], bsh[e]);
+        if constexpr (RES) z += rq[c].get(e);
+        const float g = rd[c].get(e);
+        const float dz = decltype(ACT)::value == 1 ? g * (z > 0.f ? 1.f : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
+        o2[e] = dz;
+        o1[e] = a.bn_training ? fmaf(bsc[e], dz, fmaf(bcb[e], x, bcc[e])) : bsc[e] * dz;
+      }
+      rd[c].set_all(o1); vdz[c].set_all(o2);
+    }
+  };
+  auto stage = [&](int64_t k0) {                   // registers -> LDS (+ the apply)
+    if constexpr (FUSE) {
+      if (a.bn_act == 1) apply_chunk(std::integral_constant<int, 1>{});
+      else if (a.bn_act == 2) apply_chunk(std::integral_constant<int, 2>{});
+      else apply_chunk(std::integral_constant<int, 0>{});
+    }
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+      const int id = tid + c * 256, row = id / (CO / 8), col = (id % (CO / 8)) * 8;
+      rd[c].store(DS + row * LDD + col);
+      soff[c] = (unsigned)(k0 * CO * 2) + (unsigned)id * 16u;
+      if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] += rd[c].get(e);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < XV; ++c) {
+      const int id = tid + c * 256, row = id / (CI / 8), col = (id % (CI / 8)) * 8;
+      rx[c].store(XS + row * LDX + col);
+    }
+  };
+  // the chunk's draw / dz go out AFTER the next chunk's loads were issued (vmcnt counts in order: stores in front of those loads
+  // would have to complete before the loads can be waited for)
+  Vec<bf16_t> kd[FUSE ? DV : 1], kz[FUSE ? DV : 1];
+  auto flush_stores = [&]() {
+#pragma unroll
+    for (int c = 0; c < DV; ++c) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, kd[c].raw), rdraw, soff[c], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, kz[c].raw), rdres,
+                                             a.dres_out ? soff[c] : OOB, 0, 0);
+    }
+  };
+
+  if (kbeg < kend) load_chunk(kbeg);
+  for (int64_t k0 = kbeg; k0 < kend; k0 += KPX) {
+    stage(k0);
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int c = 0; c < DV; ++c) { kd[c] = rd[c]; kz[c] = vdz[c]; }
+    }
+    __syncthreads();
+    if (k0 + KPX < kend) load_chunk(k0 + KPX);
+    if constexpr (FUSE) flush_stores();
+#pragma unroll
+    for (int ks = 0; ks < KPX; ks += 32) {
+      bf16x8 fa[WM], fb[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) fa[i] = frag(DS, LDD, ks, (wm * WM + i) * 16, lane);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) fb[j] = frag(XS, LDX, ks, (wn * WN + j) * 16, lane);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // partial plane of this pixel range: rows = co (4 grp + r), columns = ci (l15)
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = (wm * WM + i) * 16 + grp * 4 + r, ci = (wn * WN + j) * 16 + l15;
+        a.partial[((int64_t)range * CO + co) * CI + ci] = acc[i][j][r];
+      }
+  if (do_bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&sbias[cg8 + e], bs[e]);
+    __syncthreads();
+    if (tid < CO) atomicAdd(a.dbias + tid, sbias[tid]);
+  }
+}
+
+struct Shape { int co, ci, kpx, kpx_fuse; };
+// the instantiated channel pairs (Cout, Cin) -> pixels per chunk, without / with the fused apply (the chunk that keeps the three staged
+// tensors + the apply's temporaries under ~160 registers).  (Measured: a plain chunk of 128 pixels - twice the loads in flight per block -
+// left the 32 <- 128 layers at 25 us and cost the low-resolution layers blocks; what helps is MORE BLOCKS per CU, see wgrad_pw_ksplit.)
+constexpr Shape SHAPES[] = {{128, 32, 64, 64}, {32, 128, 64, 64}, {256, 64, 32, 32}, {64, 256, 32, 32}, {32, 64, 64, 64}, {64, 32, 64, 64},
+                            {64, 128, 64, 64}, {128, 64, 64, 64}, {64, 64, 64, 64}};
+const Shape* shape_of(int cout, int cin) {
+  for (const Shape& s : SHAPES)
+    if (s.co == cout && s.ci == cin) return &s;
+  return nullptr;
+}
+
+template <int GM, int WM, int WN, int KPX, int KPF>
+int launch_shape(const PwWgradArgs& a, int ksplit, bool fuse, bool res, hipStream_t st) {
+  const dim3 grid((unsigned)ksplit);
+  if (!fuse) conv_wgrad_pw_kernel<GM, WM, WN, KPX, false, false><<<grid, 256, 0, st>>>(a);
+  else if (res) conv_wgrad_pw_kernel<GM, WM, WN, KPF, true, true><<<grid, 256, 0, st>>>(a);
+  else conv_wgrad_pw_kernel<GM, WM, WN, KPF, true, false><<<grid, 256, 0, st>>>(a);
+  return check_launch("conv_wgrad_pw");
+}
+
+}  // namespace
+
+namespace rssf { namespace cv {
+
+bool wgrad_pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx) {
+  if (ntaps != 1 || stride != 1 || IH != OH || IW != OW || dy[0] != 0 || dx[0] != 0) return false;
+  const Shape* s = shape_of(Cout, Cin);
+  const int64_t M = (int64_t)B * OH * OW;
+  return s != nullptr && M % s->kpx == 0 && M >= 16 * s->kpx;            // (kpx_fuse divides kpx)
+}
+
+// split-K factor: every block a whole number of chunks, >= 2 of them.  Swept in the step (tools/ab_lib_flags.sh): see DESIGN.md
+#ifndef RSSF_PW_KS_SMALL
+#define RSSF_PW_KS_SMALL 512
+#endif
+#ifndef RSSF_PW_KS_BIG
+#define RSSF_PW_KS_BIG 256
+#endif
+int wgrad_pw_ksplit(int B, int OH, int OW, int Cin, int Cout) {
+  const Shape* s = shape_of(Cout, Cin);
+  const int64_t chunks = (int64_t)B * OH * OW / s->kpx;
+  int64_t ks = (int64_t)Cout * Cin > 8192 ? RSSF_PW_KS_BIG : RSSF_PW_KS_SMALL;
+  if (ks > chunks / 2) ks = chunks / 2;
+  if (ks < 1) ks = 1;
+  const int64_t cpb = (chunks + ks - 1) / ks;           // chunks per block
+  return (int)((chunks + cpb - 1) / cpb);
+}
+
+int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbias, int B, int OH, int OW, int Cin, int Cout, int ksplit,
+                    const WgradBn* bn, hipStream_t st) {
+  const Shape* s = shape_of(Cout, Cin);
+  if (!s) { set_error("conv_wgrad_pw: no kernel for %d -> %d channels", Cin, Cout); return RSSF_ERR_UNSUPPORTED; }
+  PwWgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dout = (const bf16_t*)dout; a.in = (const bf16_t*)in; a.partial = partial; a.dbias = dbias;
+  a.M = (int64_t)B * OH * OW;
+  const int64_t chunks = a.M / s->kpx;
+  a.per = (int)((chunks + ksplit - 1) / ksplit) * s->kpx;
+  bool res = false;
+  if (bn) {
+    a.bn_dy = (const bf16_t*)bn->dy; a.bn_raw = (const bf16_t*)bn->raw; a.bn_res = (const bf16_t*)bn->res;
+    a.bn_ss = bn->ss; a.bn_mi = bn->mi; a.bn_sums = bn->sums;
+    a.draw_out = (bf16_t*)bn->draw; a.dres_out = (bf16_t*)bn->dres; a.dgamma = bn->dgamma; a.dbeta = bn->dbeta;
+    a.bn_n = (float)bn->n; a.bn_pscale = bn->pscale; a.bn_act = bn->act; a.bn_training = bn->training;
+    res = bn->res != nullptr;
+  }
+  const bool fuse = bn != nullptr;
+  const int co = Cout, ci = Cin;
+  if (co == 128 && ci == 32) return launch_shape<4, 2, 2, 64, 64>(a, ksplit, fuse, res, st);
+  if (co == 32 && ci == 128) return launch_shape<1, 2, 2, 64, 64>(a, ksplit, fuse, res, st);
+  if (co == 256 && ci == 64) return launch_shape<4, 4, 4, 32, 32>(a, ksplit, fuse, res, st);
+  if (co == 64 && ci == 256) return launch_shape<1, 4, 4, 32, 32>(a, ksplit, fuse, res, st);
+  if (co == 32 && ci == 64) return launch_shape<1, 2, 1, 64, 64>(a, ksplit, fuse, res, st);
+  if (co == 64 && ci == 32) return launch_shape<4, 1, 2, 64, 64>(a, ksplit, fuse, res, st);
+  if (co == 64 && ci == 128) return launch_shape<2, 2, 4, 64, 64>(a, ksplit, fuse, res, st);
+  if (co == 128 && ci == 64) return launch_shape<2, 4, 2, 64, 64>(a, ksplit, fuse, res, st);
+  return launch_shape<2, 2, 2, 64, 64>(a, ksplit, fuse, res, st);       // 64 x 64
+}
+
+} }

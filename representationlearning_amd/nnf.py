@@ -942,7 +942,7 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, b
     return dx
 
 
-def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=None):
+def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=None, generic=False):
     """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional).  Under a WgradPlan the split-K
     reduction is deferred to the plan's one batched launch (the gradients are complete after WgradPlan.flush()).
     bn: (dy, raw, ss, mi, sums, res_pre, dres, dgamma, dbeta, act, n, training, pscale) - `dout` is then an OUTPUT: the launch
@@ -974,7 +974,7 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=Non
         ws = torch.empty(nws, device=xh.device, dtype=torch.float32)
     tail = (L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws), spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb),
             L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps, spec.c_dy, spec.c_dx, None if job is None else ctypes.byref(job),
-            L.dtype_code(xh), L.stream())
+            L.dtype_code(xh) | (L.CONV_GENERIC if generic else 0), L.stream())
     use_planes = (planes is not None and (rt or current()).planes_current(planes[2], planes[3]) and not padded and xpre is None and
                   spec.stride == 1 and OH == H and OW == W and tuple(planes[0].shape) == (C, B, H + 2 * planes[1], W + 2 * planes[1]) and
                   lib.rssf_conv_wgrad_planes_supported(B, H, W, C, CO, 1, spec.ntaps, spec.c_dy, spec.c_dx, planes[1], L.dtype_code(xh)) == 1)

@@ -420,3 +420,68 @@ def test_mlp_block_gradients_with_and_without_planes():
     assert rel_err(runs[2][1].cpu(), runs[0][1].cpu()) < floor(runs[1][1], runs[0][1])
     for k in runs[0][2]:
         assert rel_err(runs[2][2][k].cpu(), runs[0][2][k].cpu()) < floor(runs[1][2][k], runs[0][2][k]), k
+
+
+# ---- csrc/conv_wgrad_pw.hip: the narrow point-wise weight gradients, one block per pixel range ----
+PW_WGRAD_SHAPES = [(128, 32), (32, 128), (256, 64), (64, 256), (32, 64), (64, 32), (64, 128), (128, 64), (64, 64)]       # (Cout, Cin)
+
+
+@pytest.mark.parametrize("cout,cin", PW_WGRAD_SHAPES)
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 128, 128), (3, 24, 32)])
+def test_pointwise_wgrad_matches_generic_and_torch(cout, cin, B, H, W):
+    from representationlearning_amd import nnf
+    torch.manual_seed(21)
+    conv = nn.Conv2d(cin, cout, 1).to(DEV)
+    spec = nnf.spec_of([conv])
+    x = torch.randn(B, H, W, cin, device=DEV).bfloat16()
+    dout = (torch.randn(B, H, W, cout, device=DEV) * 0.5).bfloat16()
+    got = []
+    for generic in (True, False):
+        dw = torch.full_like(conv.weight, 0.25, dtype=torch.float32)           # the kernels ACCUMULATE
+        db = torch.full((cout,), 0.5, device=DEV)
+        nnf._conv_wgrad(spec, dout, x, [dw], db, generic=generic)
+        got.append((dw, db))
+    torch.cuda.synchronize()
+    ref = torch.einsum("bhwo,bhwi->oi", dout.float(), x.float()).view(cout, cin, 1, 1) + 0.25
+    assert rel_err(got[1][0].cpu(), ref.cpu()) < 2e-5               # exact products, fp32 sums in another order
+    assert rel_err(got[1][0].cpu(), got[0][0].cpu()) < 2e-5
+    refb = dout.float().sum((0, 1, 2)) + 0.5
+    assert rel_err(got[1][1].cpu(), refb.cpu()) < 2e-5 and rel_err(got[1][1].cpu(), got[0][1].cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("cout,cin", [(128, 32), (256, 64), (32, 128), (64, 64)])
+@pytest.mark.parametrize("act,res,training", [(2, False, True), (1, True, True), (0, False, True), (1, False, False)])
+def test_pointwise_wgrad_with_fused_bn_apply_matches_two_launches(cout, cin, act, res, training):
+    """rssf_conv_wgrad_bnapply on the narrow point-wise kernel: draw / dz / dgamma / dbeta of rssf_bn_bwd_apply (bit-identical: one shared
+    definition of the arithmetic) and the weight gradient of the separate launches."""
+    from representationlearning_amd import nnf, _lib as L
+    lib = L.load()
+    torch.manual_seed(22)
+    B, H, W = 2, 64, 64
+    conv = nn.Conv2d(cin, cout, 1, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    x = torch.randn(B, H, W, cin, device=DEV).bfloat16()
+    dy = torch.randn(B, H, W, cout, device=DEV).bfloat16()
+    raw = (torch.randn(B, H, W, cout, device=DEV) * 1.3 + 0.2).bfloat16()
+    rp = torch.randn(B, H, W, cout, device=DEV).bfloat16() if res else None
+    mean, var = raw.float().mean((0, 1, 2)), raw.float().var((0, 1, 2), unbiased=False)
+    istd = torch.rsqrt(var + 1e-5)
+    gamma, beta = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.2
+    ss = torch.stack([gamma * istd, beta - mean * gamma * istd]).contiguous()
+    mi = torch.stack([mean, istd]).contiguous()
+    rows, n = B * H * W, float(B * H * W)
+    sums = torch.zeros(nnf.BN_BWD_SLOTS * 2 * cout, device=DEV)
+    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dy), L.ptr(raw), L.ptr(ss), L.ptr(rp), L.ptr(sums), rows, cout, act, None, L.dtype_code(raw), L.stream()), "reduce")
+    outs = []
+    for generic in (True, False):
+        draw, dres = torch.empty_like(raw), (torch.empty_like(raw) if res else None)
+        dg, dbt = torch.full((cout,), 0.125, device=DEV), torch.full((cout,), 0.25, device=DEV)
+        dw = torch.zeros_like(conv.weight, dtype=torch.float32)
+        bn = (dy, raw, ss, mi, sums, rp, dres, dg, dbt, act, n, training, 0.5)
+        nnf._conv_wgrad(spec, draw, x, [dw], None, bn=bn, generic=generic)
+        outs.append((draw, dres, dg, dbt, dw))
+    torch.cuda.synchronize()
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and (not res or torch.equal(a[1], b[1]))
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert float(b[4].abs().max()) > 0 and rel_err(b[4].cpu(), a[4].cpu()) < 2e-5
