@@ -129,6 +129,22 @@ def measure_dominant_kernels(B, S, iters=30, C=32):
     dw = torch.zeros_like(conv.weight)
     us = _time_us(lambda: nnf._conv_wgrad(spec, dy, x, [dw], None), iters)
     entry("conv3x3_wgrad_halo_kernel + wgrad_reduce_kernel", us, 2 * tensor_bytes, "3x3 weight gradient %dx%d: read dout, in" % (C, C), flops)
+    # MlpDWBN's fc1 backward at the same map: 4C <- C point-wise weight gradient with the BatchNorm-backward apply fused in
+    # (conv_wgrad_pw.hip): reads dy, raw [4C] and the input [C], writes draw [4C]
+    C4 = 4 * C
+    fc1 = torch.nn.Conv2d(C, C4, 1, bias=False).to(dev)
+    spec1 = nnf.spec_of([fc1])
+    x1 = torch.randn(B, H, W, C, device=dev).bfloat16()
+    dy4, raw4, draw4 = (torch.randn(B, H, W, C4, device=dev).bfloat16() for _ in range(3))
+    ss4 = torch.stack([torch.ones(C4, device=dev), torch.zeros(C4, device=dev)]).contiguous()
+    mi4 = torch.stack([torch.zeros(C4, device=dev), torch.ones(C4, device=dev)]).contiguous()
+    sums4 = torch.zeros(nnf.BN_BWD_SLOTS * 2 * C4, device=dev)
+    dg4, db4 = torch.zeros(C4, device=dev), torch.zeros(C4, device=dev)
+    dw1 = torch.zeros_like(fc1.weight, dtype=torch.float32)
+    bn4 = (dy4, raw4, ss4, mi4, sums4, None, None, dg4, db4, 2, float(rows), True, 1.0)
+    us = _time_us(lambda: nnf._conv_wgrad(spec1, draw4, x1, [dw1], None, bn=bn4), iters)
+    entry("conv_wgrad_pw_kernel<fused apply> + wgrad_reduce_kernel", us, 3 * rows * C4 * 2 + tensor_bytes,
+          "point-wise weight gradient %d<-%d + BatchNorm backward apply (GELU): read dy, raw, in; write draw" % (C4, C), 2.0 * rows * C * C4)
     # attention backward (the kernel furthest below its roofline in round 1)
     N = H * W
     xa = torch.randn(B, N, C, device=dev).bfloat16(); ya = torch.randn(B, N, C, device=dev).bfloat16(); da = torch.randn(B, N, C, device=dev).bfloat16()
@@ -193,11 +209,44 @@ def measure_mlp_conv(B, S, iters=20, C=128):
     ms = _time_us(launch, iters) / 1e3
     flops = 2.0 * B * H * W * C * C * 19             # the reference's three convolutions: 1 + 9 + 9 kernel positions
     tf = flops / (ms * 1e-3) / 1e12
+
+    # the other two GEMMs of the same layer (one number per direction): the data gradient - the same kernel on the mirrored
+    # taps and the transposed pack - and the weight gradient's first stage from the transposed input copy (conv_wgrad_planes.hip; the
+    # split-K second stage is the step's ONE batched reduction, not part of this launch)
+    import ctypes
+    dout = torch.randn(B, H, W, C, device=dev).bfloat16()
+    wpk_t = nnf._pack(spec, [c.weight for c in convs], True, x.dtype, x.device)
+    dx = torch.empty_like(x)
+
+    def launch_dgrad():
+        L.check(lib.rssf_conv_gather_add(L.ptr(dout), L.ptr(wpk_t), L.ptr(dx), None, None, None, None, B, H, W, C, H, W, C, 1, 1, spec.ntaps,
+                                         spec.c_ndy, spec.c_ndx, L.dtype_code(x), L.stream()), "rssf_conv_gather_add")
+
+    us_d = _time_us(launch_dgrad, iters)
+    family = [dict(direction="data gradient", kernel="conv_taps128_kernel", us_per_launch=round(us_d, 2),
+                   frac=round(flops / (us_d * 1e-6) / MFMA_BF16_PEAK, 4))]
+    P = nnf.PLANES_PAD
+    if lib.rssf_conv_wgrad_planes_supported(B, H, W, C, C, 1, spec.ntaps, spec.c_dy, spec.c_dx, P, L.dtype_code(x)) == 1:
+        planes = torch.zeros(C, B, H + 2 * P, W + 2 * P, device=dev, dtype=x.dtype)
+        planes[:, :, P:P + H, P:P + W] = x.permute(3, 0, 1, 2)
+        dws = [torch.zeros_like(c.weight, dtype=torch.float32) for c in convs]
+        ws = torch.empty(lib.rssf_conv_wgrad_workspace_elems(B, H, W, C, C, spec.ntaps), device=dev, dtype=torch.float32)
+        job = L.WgradReduceJob()
+
+        def launch_wgrad():
+            L.check(lib.rssf_conv_wgrad_planes(L.ptr(dout), L.ptr(planes), P, L.ptr(dws[0]), L.ptr(dws[1]), L.ptr(dws[2]), spec.c_ksizes, 3, spec.c_src,
+                                               spec.c_kpos, spec.c_alias, None, L.ptr(ws), B, H, W, C, spec.ntaps, spec.c_dy, spec.c_dx,
+                                               ctypes.byref(job), L.dtype_code(x), L.stream()), "rssf_conv_wgrad_planes")
+
+        us_w = _time_us(launch_wgrad, iters)
+        family.append(dict(direction="weight gradient (first stage)", kernel="conv_wgrad_planes_kernel", us_per_launch=round(us_w, 2),
+                           frac=round(flops / (us_w * 1e-6) / MFMA_BF16_PEAK, 4), partial_planes=int(job.ksplit)))
     return dict(bound="mfma", kernel="conv_taps128_kernel (MlpDWBN fused {1x1 + 3x3 dil 6 + 3x3 dil 12}, %d->%d ch)" % (C, C),
                 achieved=round(tf, 1), peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s", frac=round(tf * 1e12 / MFMA_BF16_PEAK, 4),
                 traffic=_profiled_traffic("conv_taps128_kernel", MLP_SOURCES, "mlp_source_sha16") if (B, S, C) == (16, 512, 128) else None,
                 us_per_launch=round(ms * 1e3, 2), algorithmic_flops=flops,
-                executed_flops=2.0 * B * H * W * C * C * spec.ntaps)       # the three centre taps share one pixel: 17 taps run
+                executed_flops=2.0 * B * H * W * C * C * spec.ntaps,       # the three centre taps share one pixel: 17 taps run
+                same_layer=family)
 
 
 def _cpu_baseline_child(threads, batch, max_steps):

@@ -546,44 +546,55 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 constexpr size_t WG8X2_LDS = (size_t)2 * 3 * KP * (128 + 16) * 2;
 
-// second stage of the split-K reduction: dw[torch layout] += sum_k partial[k][tap][co][ci].  A block owns 128 consecutive
-// gradient elements (512-byte rows of the partial planes); its 8 thread groups walk interleaved k planes, fold through LDS, and
+// second stage of the split-K reduction: dw[torch layout] += sum_k partial[k][tap][co][ci].  A block owns RI consecutive
+// gradient elements (rows of the partial planes); its 8 thread groups walk interleaved k planes, fold through LDS, and
 // one thread per element does the (non-atomic) read-modify-write.
-constexpr int RI = 128, RG = 8, RT = RI / 4;      // columns per block, plane groups, threads per plane group (4 columns each)
+#ifndef RSSF_REDUCE_COLS
+#define RSSF_REDUCE_COLS 256
+#endif
+constexpr int RI = RSSF_REDUCE_COLS, RG = 8, RT = 256 / RG, RV = RI / (4 * RT);      // columns per block, plane groups, threads per group, 16-byte vectors per thread
+static_assert(RV >= 1 && RV * 4 * RT == RI && RI % 256 == 0 || RI == 128, "column tiling");
 // second stage of the split-K weight gradient: dw += sum over the ksplit planes of `partial`, for one job (= one convolution).
-// `blk` = block index within the job (RI columns of the [ntaps*Cout*Cin] plane each).  A thread owns 4 consecutive columns and
-// every RG-th plane, four 16-byte loads in flight (the pass reads 3.2 GB per training step: with 4-byte loads it ran at 2.9 TB/s).
+// `blk` = block index within the job (RI columns of the [ntaps*Cout*Cin] plane each).  A thread owns RV x 4 columns and
+// every RG-th plane, 4 RV 16-byte loads in flight (the pass reads 2.5 GB per training step: with 4-byte loads it ran at 2.9 TB/s,
+// with 128 columns per block - 248 000 blocks of ~10 KB each - at 4.1 TB/s).
 __device__ __forceinline__ void wgrad_reduce_body(const rssf_wgrad_reduce_job& a, int blk) {
   __shared__ float red[RG][RI];
   const int64_t per = (int64_t)a.ntaps * a.cout * a.cin;
   const int it = threadIdx.x % RT, kg = threadIdx.x / RT;
-  const int64_t i = (int64_t)blk * RI + it * 4;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  if ((per & 3) == 0) {                                      // 16-byte aligned rows (every layer of the path)
-    if (i < per) {
-      const float* p = a.partial + i;
-      auto ld = [&](int k) { return *reinterpret_cast<const f32x4*>(p + (int64_t)k * per); };
-      int k = kg;
-      for (; k + 3 * RG < a.ksplit; k += 4 * RG) {
-        const f32x4 v0 = ld(k), v1 = ld(k + RG), v2 = ld(k + 2 * RG), v3 = ld(k + 3 * RG);
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-      }
-      for (; k < a.ksplit; k += RG) s0 += ld(k);
-    }
-  } else {
+  f32x4 tot[RV];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (i + e < per)
-        for (int k = kg; k < a.ksplit; k += RG) s0[e] += a.partial[(int64_t)k * per + i + e];
+  for (int v = 0; v < RV; ++v) {
+    const int64_t i = (int64_t)blk * RI + (v * RT + it) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if ((per & 3) == 0) {                                      // 16-byte aligned rows (every layer of the path)
+      if (i < per) {
+        const float* p = a.partial + i;
+        auto ld = [&](int k) { return *reinterpret_cast<const f32x4*>(p + (int64_t)k * per); };
+        int k = kg;
+        for (; k + 3 * RG < a.ksplit; k += 4 * RG) {
+          const f32x4 v0 = ld(k), v1 = ld(k + RG), v2 = ld(k + 2 * RG), v3 = ld(k + 3 * RG);
+          s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; k < a.ksplit; k += RG) s0 += ld(k);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i + e < per)
+          for (int k = kg; k < a.ksplit; k += RG) s0[e] += a.partial[(int64_t)k * per + i + e];
+    }
+    tot[v] = (s0 + s1) + (s2 + s3);
   }
-  const f32x4 st = (s0 + s1) + (s2 + s3);
-  *reinterpret_cast<f32x4*>(&red[kg][it * 4]) = st;
+#pragma unroll
+  for (int v = 0; v < RV; ++v) *reinterpret_cast<f32x4*>(&red[kg][(v * RT + it) * 4]) = tot[v];
   __syncthreads();
-  const int64_t j = (int64_t)blk * RI + threadIdx.x;         // one thread per column does the (non-atomic) read-modify-write
-  if (threadIdx.x < RI && j < per) {
+  for (int c = threadIdx.x; c < RI; c += 256) {               // one thread per column does the (non-atomic) read-modify-write
+    const int64_t j = (int64_t)blk * RI + c;
+    if (j >= per) break;
     float s = 0.f;
 #pragma unroll
-    for (int g = 0; g < RG; ++g) s += red[g][threadIdx.x];
+    for (int g = 0; g < RG; ++g) s += red[g][c];
     const int ci = (int)(j % a.cin), co = (int)((j / a.cin) % a.cout), tap = (int)(j / ((int64_t)a.cin * a.cout));
     const int sc = a.src_of_tap[tap], kk = a.ks[sc] * a.ks[sc];
     a.dw[sc][((int64_t)co * a.cin + ci) * kk + a.kpos_of_tap[tap]] += s;

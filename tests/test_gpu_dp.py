@@ -202,14 +202,18 @@ def _p2p_worker(rank, port, out_dir, world=WORLD):
     # of 8 processes on one GPU's hardware queues, and a peer's kernel may wait for the scheduler's rotation longer than any bound
     # worth testing - so world 8 runs ONE channel per rank here (8 queues), and the two-channel form at world 8 is what
     # test_p2p_exchange_eight_ranks_in_one_process checks with no other process in the way.  The spin stays bounded.
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      RSSF_P2P_TIMEOUT_MS="16000" if world >= 8 else "8000")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world >= 8:
+        # two hardware queues per process (read when the HIP runtime starts): 16 queues for the eight processes - what one process
+        # is known to get co-resident (_local8_worker) - instead of 32, which the scheduler serves by rotating whole processes
+        os.environ["GPU_MAX_HW_QUEUES"] = "2"
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from representationlearning_amd import rccl
     ex = rccl.P2PExchange(2)
     assert ex.error is None, ex.error
+    ex.set_timeout_ms(30000 if world >= 8 else 10000)       # the bound on the spin (an argument of the exchange, not the environment)
     nslots, c1, c2 = 16, 32, 128                       # two layers: [16][2*32] and [16][2*128] statistics blocks
     n1, n2 = 2 * c1, 2 * c2
     layout = (nslots, [(0, n1), (nslots * n1, n2)])
