@@ -190,7 +190,8 @@ int rssf_conv_gather_bnbwd(const void* in, const void* wpk, void* out, const voi
  * launch FINALIZES that BatchNorm too: the pre_* arguments are rssf_bn_finalize's (statistics from the producer's epilogue,
  * all-reduced under SyncBN; running statistics updated in place; mean / invstd and scale / shift written for the backward pass
  * and for rssf_conv_wgrad_bnapply(in_scale_shift)).  Results are those of rssf_bn_finalize_apply + rssf_conv_gather.  Only shapes
- * for which rssf_conv_gather_preact_supported() returns 1 (bf16, 3x3 / stride 1 / "same", channels multiples of 8, Cin <= 256). */
+ * for which rssf_conv_gather_preact_supported() returns 1 (bf16; 3x3 / stride 1 / "same", channels multiples of 8, Cin <= 256; or the
+ * 128 -> 32 point-wise stream kernel: MlpDWBN's fc2 applying norm2 + GELU, ffn_block.py:229-236). */
 int rssf_conv_gather_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
                                       const int* dy, const int* dx, int dtype);
 int rssf_conv_gather_preact(const void* in_raw, const float* pre_stats, const float* pre_gamma, const float* pre_beta,
@@ -242,9 +243,17 @@ int rssf_conv_wgrad_planes(const void* dout, const void* in_planes, int pad, flo
  * the rest rssf_conv_wgrad's (its `dout` is `draw`).
  * in_scale_shift (optional, [2][Cin]) / in_act: `in` is then the RAW output of the producing convolution and the operand
  * contracted is act(in * scale + shift) - the layer was run forward by rssf_conv_gather_preact; only where
- * rssf_conv_wgrad_preact_supported() says so. */
+ * rssf_conv_wgrad_preact_supported() says so: 1 = a kernel that takes the pre-activation operand AND the fused apply (3x3 / stride 1,
+ * bias-free), 2 = the pre-activation operand only (MlpDWBN's fc2, 32 <- 128 point-wise, ffn_block.py:236: with BatchNorm arguments the
+ * apply runs as its separate pass first), 0 = none.
+ * rssf_conv_wgrad_preact: rssf_conv_wgrad with such an input operand and no BatchNorm of its own in the call (a layer whose backward
+ * apply is a different pass, e.g. rssf_bn_bwd_apply_post). */
 int rssf_conv_wgrad_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, int nsrc,
                                      const int* dy, const int* dx, int has_bias, int dtype);
+int rssf_conv_wgrad_preact(const void* dout, const void* in_raw, const float* in_scale_shift, int in_act, float* dw0, float* dw1, float* dw2,
+                           const int* ksizes, int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
+                           float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy,
+                           const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream);
 int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, const float* bn_scale_shift, const float* bn_mean_invstd,
                             const float* bn_sums, const void* bn_res_pre, void* draw, void* dres, float* dgamma, float* dbeta,
                             int bn_act, double bn_n, int bn_training, float param_grad_scale, const void* in,

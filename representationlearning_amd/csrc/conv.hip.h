@@ -89,8 +89,15 @@ int launch_taps128(const void* in, const void* wpk, void* out, const float* bias
                    int CoutP, int ntaps, const int* dy, const int* dx, hipStream_t st);
 // point-wise 32 -> 128 / 128 -> 32 channel convolutions as a stream (conv_pw.hip): MlpDWBN's fc1 / fc2, forward and data gradient (bf16)
 bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
+// the producer's BatchNorm for a launch that applies it on load (rssf_conv_gather_preact): the arguments of rssf_bn_finalize
+struct PwPre {
+  const float* stats; const float* gamma; const float* beta; float* rmean; float* rvar; float* mi; float* ss;
+  float n, momentum, eps; int training, act;
+};
+bool pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
-              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st);
+              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st,
+              const PwPre* pre = nullptr);
 int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st);
 int launch_wgrad_reduce(const rssf_wgrad_reduce_job& j, hipStream_t st);      // second stage of a split-K weight gradient (conv_wgrad.hip)
 int64_t wgrad_planes_workspace_elems(int B, int H, int W, int Cin, int Cout, int ntaps);     // 0: conv_wgrad_planes.hip does not serve the shape
@@ -102,8 +109,9 @@ struct WgradBn {
 // narrow point-wise weight gradients, one block per pixel range (conv_wgrad_pw.hip); wgrad_pw_ksplit() partial planes [Cout][Cin]
 bool wgrad_pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx);
 int wgrad_pw_ksplit(int B, int OH, int OW, int Cin, int Cout);
+bool wgrad_pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx);
 int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbias, int B, int OH, int OW, int Cin, int Cout, int ksplit,
-                    const WgradBn* bn, hipStream_t st);
+                    const WgradBn* bn, hipStream_t st, const float* x_ss = nullptr, int x_act = 0);
 
 template <typename T> struct LdsPad;
 template <> struct LdsPad<bf16_t> { static constexpr int X = 8; };   // +16 B per row: conflict-free ds_read_b128

@@ -755,6 +755,11 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
     if (rc || !bn || fused) return rc;
     return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
   }
+  if (dtype == RSSF_BF16 && pre && !bn && !a.stats_ws && !addend && pw_preact_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx)) {
+    // (the stream kernel is the only one with a pre-activation operand for this shape: RSSF_CONV_GENERIC does not apply)
+    const PwPre pp = {pre->stats, pre->gamma, pre->beta, pre->rmean, pre->rvar, pre->mi, pre->ss, pre->n, pre->momentum, pre->eps, pre->training, pre->act};
+    return launch_pw(in, wpk, out, bias, stats, nullptr, nullptr, nullptr, nullptr, 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st, &pp);
+  }
   if (!generic && dtype == RSSF_BF16 && !pre && !a.stats_ws && !addend && pw_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
     return launch_pw(in, wpk, out, bias, stats, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr, bn ? bn->sums : nullptr,
                      bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st);
@@ -794,7 +799,9 @@ extern "C" int rssf_conv_gather_bnbwd(const void* in, const void* wpk, void* out
 
 extern "C" int rssf_conv_gather_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps,
                                                  const int* dy, const int* dx, int dtype) {
-  return dy && dx && Cin <= 256 && halo_path(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype) ? 1 : 0;
+  if (!dy || !dx) return 0;
+  if (Cin <= 256 && halo_path(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype)) return 1;
+  return dtype == RSSF_BF16 && pw_preact_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx) ? 1 : 0;      // MlpDWBN's fc2
 }
 
 extern "C" int rssf_conv_gather_preact(const void* in_raw, const float* pre_stats, const float* pre_gamma, const float* pre_beta,

@@ -12,6 +12,7 @@
 // squares for the following BatchNorm (forward) or {sum dz, sum dz * raw} of the producer's BatchNorm backward (data gradient,
 // rssf_conv_gather_bnbwd) accumulate in registers across a wave's tiles, are folded over the 16 pixel lanes by DPP, over the
 // block's waves through LDS, and leave as one atomic per channel and block.
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 #include "conv.hip.h"
@@ -29,6 +30,10 @@ struct PwArgs {
   const bf16_t* bn_raw; const bf16_t* bn_res; const float* bn_ss; float* bn_sums; int bn_act;
   int64_t M;            // pixels
   int CoutP, CinP, Cout;   // Cout: channels of a pixel row of `out`; a block computes the slice [16 NT blockIdx.y, + 16 NT)
+  // PRE (rssf_conv_gather_preact): `in` is the RAW output of the producing convolution; its BatchNorm is finalized here (the arguments
+  // of rssf_bn_finalize, see HaloArgs::pre_* in conv.hip.h) and act(in * scale + shift) is formed on the operand registers
+  const float* pre_stats; const float* pre_gamma; const float* pre_beta; float* pre_rmean; float* pre_rvar; float* pre_mi; float* pre_ss;
+  float pre_n, pre_momentum, pre_eps; int pre_training, pre_act;
 };
 
 // sum over the 16 lanes of a row (the pixels of a tile), result in every lane of the row
@@ -41,7 +46,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // KS = input channels / 32 (K-steps), NT = output channels / 16 (fragments): (1, 8) = 32 -> 128, (4, 2) = 128 -> 32
-template <int KS, int NT, bool BNB>
+template <int KS, int NT, bool BNB, bool PRE = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) conv_pw_kernel(PwArgs a) {
   constexpr int PW_K = 32 * KS, PW_N = 16 * NT, PW_NT = NT;
   __shared__ float sred[4][2][PW_N];
@@ -65,6 +70,37 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
   __shared__ __attribute__((aligned(16))) float sss[BNB ? 2 * PW_N : 4];
   if constexpr (BNB) {
     if (tid < 2 * PW_N) sss[tid] = a.bn_ss[(tid / PW_N) * CO + n0 + tid % PW_N];      // [scale][shift] of this slice
+    __syncthreads();
+  }
+  // PRE: scale / shift of the PW_K input channels (the arithmetic of bn_finalize_kernel / conv_halo.hip's finalize_producer), read back
+  // per tile: a lane's channels are 32 k + 8 grp .. + 7 of every K-step k
+  __shared__ __attribute__((aligned(16))) float spre[PRE ? 2 * PW_K : 4];
+  if constexpr (PRE) {
+    if (tid < PW_K) {
+      const int c = tid;
+      float mean, var;
+      if (a.pre_training) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RSSF_BN_SLOTS; ++k) { t1 += a.pre_stats[(size_t)k * 2 * PW_K + c]; t2 += a.pre_stats[(size_t)k * 2 * PW_K + PW_K + c]; }
+        mean = t1 / a.pre_n;
+        var = fmaxf(t2 / a.pre_n - mean * mean, 0.f);
+      } else {
+        mean = a.pre_rmean[c];
+        var = a.pre_rvar[c];
+      }
+      const float invstd = rsqrtf(var + a.pre_eps);
+      const float sc = a.pre_gamma[c] * invstd, sh = a.pre_beta[c] - mean * sc;
+      spre[c] = sc; spre[PW_K + c] = sh;
+      if (blockIdx.x == 0 && blockIdx.y == 0) {                              // one block publishes for the backward pass
+        a.pre_mi[c] = mean; a.pre_mi[PW_K + c] = invstd;
+        a.pre_ss[c] = sc; a.pre_ss[PW_K + c] = sh;
+        if (a.pre_training && a.pre_rmean) {
+          a.pre_rmean[c] = (1.f - a.pre_momentum) * a.pre_rmean[c] + a.pre_momentum * mean;
+          a.pre_rvar[c] = (1.f - a.pre_momentum) * a.pre_rvar[c] + a.pre_momentum * var * (a.pre_n > 1.f ? a.pre_n / (a.pre_n - 1.f) : 1.f);
+        }
+      }
+    }
     __syncthreads();
   }
   const bool want = BNB || a.stats != nullptr;
@@ -96,6 +132,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
     }
     const int64_t pix = t * 16 + l15;
     const bool pok = pix < a.M;
+    if constexpr (PRE) {
+      // act(raw * scale + shift) on the operand registers (a pixel past the end loaded zeros and is never stored)
+      auto apply = [&](auto ACT) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const f32x4 sc0 = *reinterpret_cast<const f32x4*>(spre + k * 32 + grp * 8), sc1 = *reinterpret_cast<const f32x4*>(spre + k * 32 + grp * 8 + 4);
+          const f32x4 sh0 = *reinterpret_cast<const f32x4*>(spre + PW_K + k * 32 + grp * 8), sh1 = *reinterpret_cast<const f32x4*>(spre + PW_K + k * 32 + grp * 8 + 4);
+          Vec<bf16_t> v;
+          v.raw = xc[k];
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float z = fmaf(v.get(e), e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+            o[e] = decltype(ACT)::value == 1 ? fmaxf(z, 0.f) : decltype(ACT)::value == 2 ? gelu_erf(z) : z;
+          }
+          v.set_all(o);
+          xc[k] = v.raw;
+        }
+      };
+      if (a.pre_act == 1) apply(std::integral_constant<int, 1>{});
+      else if (a.pre_act == 2) apply(std::integral_constant<int, 2>{});
+      else apply(std::integral_constant<int, 0>{});
+    }
     f32x4 acc[PW_NT];
 #pragma unroll
     for (int j = 0; j < PW_NT; ++j) {
@@ -173,9 +232,21 @@ bool pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int m
          (int64_t)B * IH * IW * (Cin > Cout ? Cin : Cout) < ((int64_t)1 << 30);
 }
 
+bool pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx) {
+  return Cin == 128 && Cout == 32 && pw_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx);
+}
+
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
-              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st) {
+              const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st,
+              const PwPre* pre) {
   PwArgs a;
+  memset(&a, 0, sizeof(a));
+  if (pre) {
+    if (bn_sums || !(Cin == 128 && Cout == 32)) { set_error("conv_pw: a pre-activation input is a forward feature of the 128 -> 32 kernel"); return RSSF_ERR_UNSUPPORTED; }
+    a.pre_stats = pre->stats; a.pre_gamma = pre->gamma; a.pre_beta = pre->beta; a.pre_rmean = pre->rmean; a.pre_rvar = pre->rvar;
+    a.pre_mi = pre->mi; a.pre_ss = pre->ss; a.pre_n = pre->n; a.pre_momentum = pre->momentum; a.pre_eps = pre->eps;
+    a.pre_training = pre->training; a.pre_act = pre->act;
+  }
   a.in = (const bf16_t*)in; a.wpk = (const bf16_t*)wpk; a.out = (bf16_t*)out; a.bias = bias; a.stats = stats;
   a.bn_raw = (const bf16_t*)bn_raw; a.bn_res = (const bf16_t*)bn_res; a.bn_ss = bn_ss; a.bn_sums = bn_sums; a.bn_act = bn_act;
   a.M = (int64_t)B * H * W; a.CoutP = CoutP; a.CinP = CinP; a.Cout = Cout;
@@ -195,6 +266,7 @@ int launch_pw(const void* in, const void* wpk, void* out, const float* bias, flo
     else conv_pw_kernel<1, 8, false><<<grid, 256, 0, st>>>(a);
   } else {
     if (bn_sums) conv_pw_kernel<4, 2, true><<<grid, 256, 0, st>>>(a);
+    else if (pre) conv_pw_kernel<4, 2, false, true><<<grid, 256, 0, st>>>(a);
     else conv_pw_kernel<4, 2, false><<<grid, 256, 0, st>>>(a);
   }
   return check_launch("conv_pw");

@@ -1126,6 +1126,16 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
     if (int rc = check_launch("conv3x3_wgrad_halo")) return rc;
     return finish_reduce(a, defer_reduce, st);
   }
+  if (xpre && dtype == RSSF_BF16 && workspace && wgrad_pw_preact_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx)) {
+    if (bn) {                  // (this kernel has no form with both: the layer's own apply as the separate pass, `dout` is its `draw`)
+      const int rc = rssf_bn_bwd_apply(bn->dy, bn->raw, bn->ss, bn->mi, bn->sums, bn->res, bn->draw, bn->dres, bn->dgamma, bn->dbeta,
+                                       (int64_t)B * OH * OW, Cout, bn->act, bn->n, bn->training, bn->pscale, dtype, stream);
+      if (rc) return rc;
+    }
+    a.ksplit = wgrad_pw_ksplit(B, OH, OW, Cin, Cout);
+    if (int rc = launch_wgrad_pw(dout, in, workspace, dbias, B, OH, OW, Cin, Cout, a.ksplit, nullptr, st, xpre->ss, xpre->act)) return rc;
+    return finish_reduce(a, defer_reduce, st);
+  }
   if (xpre) { set_error("conv_wgrad: no kernel with a pre-activation input operand for this shape (ask rssf_conv_wgrad_preact_supported)"); return RSSF_ERR_UNSUPPORTED; }
 #ifndef RSSF_WGRAD_PW_DISABLE       // (A/B builds: tools/ab_lib_flags.sh)
   if (dtype == RSSF_BF16 && workspace && !generic && wgrad_pw_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx)) {
@@ -1153,6 +1163,17 @@ extern "C" int rssf_conv_wgrad(const void* dout, const void* in, float* dw0, flo
                                const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream) {
   return conv_wgrad_impl(dout, in, dw0, dw1, dw2, ksizes, nsrc, src_of_tap, kpos_of_tap, alias_of_tap, dbias, workspace, B, IH, IW, Cin, OH,
                          OW, Cout, stride, ntaps, dy, dx, defer_reduce, nullptr, nullptr, dtype, stream);
+}
+
+extern "C" int rssf_conv_wgrad_preact(const void* dout, const void* in_raw, const float* in_scale_shift, int in_act, float* dw0, float* dw1,
+                                      float* dw2, const int* ksizes, int nsrc, const int* src_of_tap, const int* kpos_of_tap,
+                                      const int* alias_of_tap, float* dbias, float* workspace, int B, int IH, int IW, int Cin, int OH, int OW,
+                                      int Cout, int stride, int ntaps, const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce,
+                                      int dtype, void* stream) {
+  RSSF_REQUIRE(in_scale_shift && in_act >= 0 && in_act <= 2, "conv_wgrad_preact: bad pre-activation arguments");
+  const XPreAct xp = {in_scale_shift, in_act};
+  return conv_wgrad_impl(dout, in_raw, dw0, dw1, dw2, ksizes, nsrc, src_of_tap, kpos_of_tap, alias_of_tap, dbias, workspace, B, IH, IW, Cin, OH,
+                         OW, Cout, stride, ntaps, dy, dx, defer_reduce, nullptr, &xp, dtype, stream);
 }
 
 extern "C" int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, const float* bn_scale_shift, const float* bn_mean_invstd,
@@ -1187,7 +1208,10 @@ extern "C" int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, c
 
 extern "C" int rssf_conv_wgrad_preact_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, int nsrc,
                                                 const int* dy, const int* dx, int has_bias, int dtype) {
-  return dtype == RSSF_BF16 && !has_bias && dy && dx && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx) ? 1 : 0;
+  if (dtype != RSSF_BF16 || !dy || !dx) return 0;
+  if (!has_bias && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx)) return 1;
+  // MlpDWBN's fc2 (plain weight gradient only - its own BatchNorm is not applied in the same launch: rssf_conv_wgrad_preact)
+  return nsrc == 1 && wgrad_pw_preact_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx) ? 2 : 0;
 }
 
 // ---- grouped 3x3 weight gradients (rssf.h "Grouped launches") ----------------------------------------------------------------

@@ -40,6 +40,8 @@ struct PwWgradArgs {
   float* dgamma; float* dbeta;
   float bn_n, bn_pscale;
   int bn_act, bn_training;
+  // XPRE: `in` is the RAW output of the producing convolution, the operand contracted is act(in * scale + shift) (x_ss: [2][CI])
+  const float* x_ss; int x_act;
 };
 
 // MFMA fragment of a K-step (32 pixel rows from k0) for 16 channels from column c0 of a pixel-major tile: conv_wgrad.hip's SlabFrag
@@ -54,7 +56,7 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* tile, int ld, int k0, int c
 }
 
 // GM x GN waves (GN = 4 / GM), each WM x WN tiles of 16 x 16: CO = 16 GM WM output channels, CI = 16 GN WN input channels; KPX pixels per chunk
-template <int GM, int WM, int WN, int KPX, bool FUSE, bool RES>
+template <int GM, int WM, int WN, int KPX, bool FUSE, bool RES, bool XPRE = false>
 __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   constexpr int GN = 4 / GM, CO = 16 * GM * WM, CI = 16 * GN * WN;
   constexpr int LDD = CO + 16, LDX = CI + 16;                       // +32 B per row: conflict-free transposing reads (conv_wgrad.hip)
@@ -65,6 +67,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t XS[KPX * LDX];
   __shared__ __attribute__((aligned(16))) float sbn[4][FUSE ? CO : 4];      // scale, shift, cb, cc
   __shared__ float sbias[CO];
+  __shared__ __attribute__((aligned(16))) float sxs[2][XPRE ? CI : 4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wm = wave / GN, wn = wave % GN;
   const int range = blockIdx.x;
@@ -72,6 +75,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   const int64_t kend = kbeg + a.per < a.M ? kbeg + a.per : a.M;
   const bool do_bias = a.dbias != nullptr;
   if (tid < CO) sbias[tid] = 0.f;
+  if constexpr (XPRE) {
+    for (int c = tid; c < 2 * CI; c += 256) sxs[c / CI][c % CI] = a.x_ss[c];
+  }
 
   if constexpr (FUSE) {
     if (tid < CO) {
@@ -166,6 +172,26 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
         for (int e = 0; e < 8; ++e) bs[e] += rd[c].get(e);
       }
     }
+    if constexpr (XPRE) {                            // the producer's BatchNorm + activation on this thread's 8 input channels
+      const int xg8 = (tid % (CI / 8)) * 8;
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(&sxs[0][xg8]), sc1 = *reinterpret_cast<const f32x4*>(&sxs[0][xg8 + 4]);
+      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(&sxs[1][xg8]), sh1 = *reinterpret_cast<const f32x4*>(&sxs[1][xg8 + 4]);
+      auto apply = [&](auto ACT) {
+#pragma unroll
+        for (int c = 0; c < XV; ++c) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float z = fmaf(rx[c].get(e), e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+            o[e] = decltype(ACT)::value == 1 ? fmaxf(z, 0.f) : decltype(ACT)::value == 2 ? gelu_erf(z) : z;
+          }
+          rx[c].set_all(o);
+        }
+      };
+      if (a.x_act == 1) apply(std::integral_constant<int, 1>{});
+      else if (a.x_act == 2) apply(std::integral_constant<int, 2>{});
+      else apply(std::integral_constant<int, 0>{});
+    }
 #pragma unroll
     for (int c = 0; c < XV; ++c) {
       const int id = tid + c * 256, row = id / (CI / 8), col = (id % (CI / 8)) * 8;
@@ -252,6 +278,11 @@ int launch_shape(const PwWgradArgs& a, int ksplit, bool fuse, bool res, hipStrea
 
 namespace rssf { namespace cv {
 
+// (Cout, Cin) = (32, 128) - MlpDWBN's fc2 - has the variant with a pre-activation input operand
+bool wgrad_pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx) {
+  return Cout == 32 && Cin == 128 && wgrad_pw_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx);
+}
+
 bool wgrad_pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx) {
   if (ntaps != 1 || stride != 1 || IH != OH || IW != OW || dy[0] != 0 || dx[0] != 0) return false;
   const Shape* s = shape_of(Cout, Cin);
@@ -277,7 +308,7 @@ int wgrad_pw_ksplit(int B, int OH, int OW, int Cin, int Cout) {
 }
 
 int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbias, int B, int OH, int OW, int Cin, int Cout, int ksplit,
-                    const WgradBn* bn, hipStream_t st) {
+                    const WgradBn* bn, hipStream_t st, const float* x_ss, int x_act) {
   const Shape* s = shape_of(Cout, Cin);
   if (!s) { set_error("conv_wgrad_pw: no kernel for %d -> %d channels", Cin, Cout); return RSSF_ERR_UNSUPPORTED; }
   PwWgradArgs a;
@@ -296,6 +327,12 @@ int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbi
   }
   const bool fuse = bn != nullptr;
   const int co = Cout, ci = Cin;
+  if (x_ss) {
+    if (fuse || !(co == 32 && ci == 128)) { set_error("conv_wgrad_pw: the pre-activation input operand is a feature of the plain 32 <- 128 kernel"); return RSSF_ERR_UNSUPPORTED; }
+    a.x_ss = x_ss; a.x_act = x_act;
+    conv_wgrad_pw_kernel<1, 2, 2, 64, false, false, true><<<dim3((unsigned)ksplit), 256, 0, st>>>(a);
+    return check_launch("conv_wgrad_pw");
+  }
   if (co == 128 && ci == 32) return launch_shape<4, 2, 2, 64, 64>(a, ksplit, fuse, res, st);
   if (co == 32 && ci == 128) return launch_shape<1, 2, 2, 64, 64>(a, ksplit, fuse, res, st);
   if (co == 256 && ci == 64) return launch_shape<4, 4, 4, 32, 32>(a, ksplit, fuse, res, st);

@@ -115,11 +115,15 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const T* __restrict__
 // are folded through LDS.  Same sums in another order (fp32 accumulation of weighted bf16 values).
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) bilinear_bwd_rows_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int IH, int IW, int OH,
-                                                                int OW, int C, int ldw, float sy, float sx) {
+                                                                int OW, int C, int ldw, float sy, float sx, int xcd_per) {
   __shared__ float sred[256 * VEC];
   const int cols = C / VEC, R = 256 / cols;                  // cols divides 256 (the launcher checks)
   const int cv = threadIdx.x % cols, r = threadIdx.x / cols;
-  int64_t p = blockIdx.x;
+  // XCD-major numbering: the windows of neighbouring input pixels overlap by (window - 1 / factor) in each direction; hardware block
+  // order deals neighbours round-robin over the eight L2s, each of which then fetched its own copy of the overlap (round 4: 417 MB
+  // across the fabric for 201 MB of gradient).  An XCD takes a contiguous run of input pixels instead.
+  int64_t p = (int64_t)(blockIdx.x & 7u) * xcd_per + (blockIdx.x >> 3);
+  if (p >= (int64_t)B * IH * IW) return;
   const int ix = (int)(p % IW); p /= IW;
   const int iy = (int)(p % IH);
   const int b = (int)(p / IH);
@@ -369,7 +373,8 @@ int bilinear_launch(const void* in, void* out, int B, int IH, int IW, int OH, in
     const int cols = vec ? C / V : 0;
     // factor >= 4 (a window of >= 9 x 9 output pixels per input pixel): a block per input pixel, the window's rows over its threads
     if (vec && sy > 0.f && sx > 0.f && sy <= 0.26f && sx <= 0.26f && cols >= 4 && cols <= 256 && 256 % cols == 0 && px < ((int64_t)1 << 31))
-      bilinear_bwd_rows_kernel<T, V><<<dim3((unsigned)px), 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
+      bilinear_bwd_rows_kernel<T, V><<<dim3((unsigned)((px + 7) / 8 * 8)), 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx,
+                                                                                         (int)((px + 7) / 8));
     else if (vec) bilinear_bwd_kernel<T, V><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
     else bilinear_bwd_kernel<T, 1><<<g, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
   }

@@ -4,9 +4,13 @@ dense convs summed -> SyncBN -> GELU -> 1x1 conv -> SyncBN -> GELU.
 Three fused launches-groups on the hand-written HIP kernels: fc1 -> BN -> GELU; the three hidden convolutions as ONE
 19-tap implicit GEMM (K = 19*4C) -> BN -> GELU; fc2 -> BN -> GELU (+ the block's residual).  nn.SyncBatchNorm modules
 are kept (state_dict + "always synchronised" semantics of the reference under data parallelism)."""
+import os
+
 import torch.nn as nn
 
 from ..... import nnf
+
+_DEFER_NORM2 = os.environ.get("RSSF_DEFER_MLP_APPLY", "1") != "0"       # A/B switch: norm2 + GELU applied by fc2's kernels on load
 
 
 class MlpDWBN(nn.Module):
@@ -39,7 +43,10 @@ class MlpDWBN(nn.Module):
             # the tap sum's weight gradient reads its input TRANSPOSED (csrc/conv_wgrad_planes.hip): norm1's apply writes that copy too
             l1.want_planes = True
         t = nnf.conv_bn_act(t, self.fc1, self.norm1, nnf.ACT_GELU, stats_out=l1)
-        t = nnf.conv_bn_act(t, [self.dw, self.dw6, self.dw12], self.norm2, nnf.ACT_GELU, stats_out=l2, stats_in=l1)
+        # GELU(norm2(sum)) is consumed by fc2 alone: where fc2's kernels can apply norm2 + GELU on the raw sum while they load it, that
+        # activation is never written (nnf.can_defer_apply: one 67 MB write + read less per block and direction)
+        defer = _DEFER_NORM2 and l2 is not None and nnf.can_defer_apply(t, [self.dw, self.dw6, self.dw12], self.fc2)
+        t = nnf.conv_bn_act(t, [self.dw, self.dw6, self.dw12], self.norm2, nnf.ACT_GELU, stats_out=l2, stats_in=l1, defer_apply=defer)
         return nnf.conv_bn_act(t, self.fc2, self.norm3, nnf.ACT_GELU, res_post=residual, stats_in=l2, post_relu=post_relu)
 
     def forward(self, x, H, W, residual=None, post_relu=False):

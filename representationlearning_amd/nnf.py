@@ -696,12 +696,13 @@ _DEFER_CACHE = {}
 def can_defer_apply(x, conv_a, conv_b):
     """True when `act(bn(conv_a(x)))` - consumed by conv_b and nothing else - need not be materialised: conv_b's forward and
     weight-gradient kernels can apply the producer's BatchNorm + activation to the raw convolution output while they stage it
-    (rssf_conv_gather_preact / rssf_conv_wgrad_bnapply(in_scale_shift); bf16, 3x3 / stride 1, channels multiples of 8)."""
+    (rssf_conv_gather_preact / rssf_conv_wgrad_bnapply(in_scale_shift) / rssf_conv_wgrad_preact; bf16; 3x3 / stride 1 with channels
+    multiples of 8, or MlpDWBN's fc2 behind its tap sum - conv_a may be the list of summed convolutions)."""
     if not (_DEFER_BN_APPLY and _FUSED_BN_APPLY and _FUSED_BN_STATS and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16):
         return False
-    if current().deterministic or conv_b.bias is not None:
+    if current().deterministic:
         return False
-    sa, sb = spec_of([conv_a]), spec_of([conv_b])
+    sa, sb = spec_of(list(conv_a) if isinstance(conv_a, (list, tuple)) else [conv_a]), spec_of([conv_b])
     B, _, H, W = x.shape
     OH, OW = sa.out_hw(H, W)
     key = (id(sb), B, OH, OW)
@@ -709,9 +710,11 @@ def can_defer_apply(x, conv_a, conv_b):
         lib = L.load()
         OH2, OW2 = sb.out_hw(OH, OW)
         code = L.RSSF_BF16
-        ok = sb.parts is None and sb.cin % 8 == 0 and sb.cout % 8 == 0
+        ok = sb.parts is None and sa.parts is None and sb.cin % 8 == 0 and sb.cout % 8 == 0
         ok = ok and lib.rssf_conv_gather_preact_supported(B, OH, OW, sb.cin, OH2, OW2, sb.cout, sb.stride, 1, sb.ntaps, sb.c_dy, sb.c_dx, code) == 1
-        ok = ok and lib.rssf_conv_wgrad_preact_supported(B, OH, OW, sb.cin, OH2, OW2, sb.cout, sb.stride, sb.ntaps, 1, sb.c_dy, sb.c_dx, 0, code) == 1
+        # 1: pre-activation operand + fused apply in one launch (bias-free 3x3); 2: pre-activation operand only (MlpDWBN's fc2, biased)
+        ok = ok and lib.rssf_conv_wgrad_preact_supported(B, OH, OW, sb.cin, OH2, OW2, sb.cout, sb.stride, sb.ntaps, 1, sb.c_dy, sb.c_dx,
+                                                         int(conv_b.bias is not None), code) in (1, 2)
         _DEFER_CACHE[key] = bool(ok)
     return _DEFER_CACHE[key]
 
@@ -998,9 +1001,10 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=Non
                                             L.ptr(bdg), L.ptr(bdb), bact, bn_n, int(btr), bps, L.ptr(xh), L.ptr(xss), xact, *tail),
                 "rssf_conv_wgrad_bnapply")
     else:
-        if xpre is not None:
-            raise RuntimeError("conv_wgrad: a pre-activation input operand needs the fused apply path")
-        L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), *tail), "rssf_conv_wgrad")
+        if xpre is not None:           # xh is the producer's RAW output; this layer's own apply was a separate pass (e.g. the _post form)
+            L.check(lib.rssf_conv_wgrad_preact(L.ptr(dout), L.ptr(xh), L.ptr(xpre[0]), xpre[1], *tail), "rssf_conv_wgrad_preact")
+        else:
+            L.check(lib.rssf_conv_wgrad(L.ptr(dout), L.ptr(xh), *tail), "rssf_conv_wgrad")
     if job is not None:
         if ref is not None and bytes(job) != bytes(ref):
             raise RuntimeError("WgradPlan: a deferred weight-gradient reduction changed between steps")
@@ -1165,8 +1169,6 @@ class _ConvBNAct(torch.autograd.Function):
         # the entry point falls back to the two launches itself); channel counts the kernels would see padded keep the two calls
         vch = 8 if raw.dtype == torch.bfloat16 else 4
         fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0 and not post
-        if xpre is not None and not fuse_apply:
-            raise RuntimeError("conv_bn_act: a pre-activation input needs the fused weight-gradient path (can_defer_apply)")
         dpost = None
         if fuse_apply:
             gbs = weight_grads((dyh, raw, ss, mi, sums, rp, dres, dgamma, dbeta, act, n, training, pscale))

@@ -387,6 +387,11 @@ def test_bn_finalize_apply_planes_matches_apply(B, H, W, act, training):
     assert bool((border == 7.0).all())                 # only the interior is written
 
 
+# a convolution bias in front of a training-mode BatchNorm has a gradient of exactly zero (the mean is subtracted): what the kernels
+# return is the rounding residue of sum(draw), different in every run
+ZERO_GRAD_BIASES = ("fc1.bias", "dw.bias", "dw6.bias", "dw12.bias", "fc2.bias")
+
+
 def test_mlp_block_gradients_with_and_without_planes():
     """MlpDWBN forward + backward with the transposed-copy weight gradient on and off: the same outputs, the same gradients up to the
     summation order of the tap sum's weight gradient (and the bf16 rounding noise named below)."""
@@ -415,10 +420,12 @@ def test_mlp_block_gradients_with_and_without_planes():
     # two runs of ONE configuration already differ (the BatchNorm statistics are sums of atomics; bf16 roundings move with their last
     # bit): the run with the transposed copy must sit within a small multiple of that floor
     def floor(a, b):
-        return max(3.0 * rel_err(a.cpu(), b.cpu()), 5e-4)
+        return max(3.0 * rel_err(a.cpu(), b.cpu()), 5e-3)
     assert rel_err(runs[2][0].cpu(), runs[0][0].cpu()) < floor(runs[1][0], runs[0][0])
     assert rel_err(runs[2][1].cpu(), runs[0][1].cpu()) < floor(runs[1][1], runs[0][1])
     for k in runs[0][2]:
+        if k in ZERO_GRAD_BIASES:
+            continue
         assert rel_err(runs[2][2][k].cpu(), runs[0][2][k].cpu()) < floor(runs[1][2][k], runs[0][2][k]), k
 
 
@@ -485,3 +492,46 @@ def test_pointwise_wgrad_with_fused_bn_apply_matches_two_launches(cout, cin, act
     assert torch.equal(a[0], b[0]) and (not res or torch.equal(a[1], b[1]))
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     assert float(b[4].abs().max()) > 0 and rel_err(b[4].cpu(), a[4].cpu()) < 2e-5
+
+
+def test_mlp_block_with_norm2_applied_on_load_matches_materialised():
+    """MlpDWBN with GELU(norm2(sum)) applied by fc2's kernels on load (rssf_conv_gather_preact / rssf_conv_wgrad_preact on the point-wise
+    stream kernels) against the form that writes the activation: outputs, input gradient, every parameter gradient and the running
+    statistics, within a small multiple of the run-to-run floor of one configuration."""
+    from representationlearning_amd import nnf
+    from representationlearning_amd.module.baseline.base_hrnet.modules.ffn_block import MlpDWBN
+    torch.manual_seed(7)
+    x = torch.randn(2, 64, 64, 32, device=DEV).bfloat16()               # [B, H, W, C]: fc1 32 -> 128, fc2 128 -> 32
+    dy = torch.randn(2, 64, 64, 32, device=DEV).bfloat16()
+    res = torch.randn(2, 64, 64, 32, device=DEV).bfloat16()
+    keep = nnf._DEFER_BN_APPLY
+    runs = []
+    try:
+        for on in (False, False, True):
+            nnf._DEFER_BN_APPLY = on
+            nnf._DEFER_CACHE.clear()
+            torch.manual_seed(8)
+            m = MlpDWBN(32, 128, 32).to(DEV).train()
+            xi = x.clone().permute(0, 3, 1, 2).requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m.forward_nhwc(xi, res.permute(0, 3, 1, 2), post_relu=True)
+            y.backward(dy.permute(0, 3, 1, 2))
+            torch.cuda.synchronize()
+            deferred = nnf.can_defer_apply(xi, [m.dw, m.dw6, m.dw12], m.fc2)
+            assert deferred == on, "the path under test must be the one that ran"
+            runs.append((y.detach().float(), xi.grad.float(), {k: p.grad.float().clone() for k, p in m.named_parameters()},
+                         {k: b.float().clone() for k, b in m.named_buffers() if "running" in k}))
+    finally:
+        nnf._DEFER_BN_APPLY = keep
+        nnf._DEFER_CACHE.clear()
+
+    def floor(a, b):            # (a wrong channel map or a missing activation is an O(1) error: the bar only has to clear the bf16 noise)
+        return max(3.0 * rel_err(a.cpu(), b.cpu()), 2e-2)
+    assert rel_err(runs[2][0].cpu(), runs[0][0].cpu()) < floor(runs[1][0], runs[0][0])
+    assert rel_err(runs[2][1].cpu(), runs[0][1].cpu()) < floor(runs[1][1], runs[0][1])
+    for k in runs[0][2]:
+        if k in ZERO_GRAD_BIASES:
+            continue
+        assert rel_err(runs[2][2][k].cpu(), runs[0][2][k].cpu()) < floor(runs[1][2][k], runs[0][2][k]), k
+    for k in runs[0][3]:
+        assert rel_err(runs[2][3][k].cpu(), runs[0][3][k].cpu()) < 1e-5, k
