@@ -47,3 +47,17 @@ def test_param_struct_layout_matches_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = re.findall(r"(\w+)\s*(?=[,;])", body)
     assert [n for n, _ in _lib.WinAttnFwdParams._fields_] == names
+
+
+def test_library_reads_no_environment_variable():
+    """rssf.h: kernel selection is a function of the call's arguments.  The library neither imports getenv nor mentions it in its sources
+    (the explicit knob is RSSF_CONV_GENERIC in the dtype argument of the convolution entry points)."""
+    import glob
+    import subprocess
+    from representationlearning_amd import _lib
+    csrc = os.path.join(ROOT, "representationlearning_amd", "csrc")
+    hits = [os.path.basename(f) for pat in ("*.hip", "*.cpp", "*.h") for f in glob.glob(os.path.join(csrc, pat)) if "getenv" in open(f).read()]
+    assert not hits, hits
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    assert _lib.CONV_GENERIC == 0x100 and "#define RSSF_CONV_GENERIC 0x100" in open(os.path.join(ROOT, "include", "rssf.h")).read()
