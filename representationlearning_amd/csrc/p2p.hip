@@ -58,8 +58,17 @@ __global__ void __launch_bounds__(256) p2p_exchange_kernel(ExArgs a) {
     while (j >= a.item_n[i]) { j -= a.item_n[i]; ++i; }
     float* blk = a.stats + a.item_off[i] + j;
     const int n = a.item_n[i];
+    // the slots in slot order; all loads of a pass in flight together (as a loop the sixteen loads were sixteen round trips in a row)
     float v = 0.f;
-    for (int s = 0; s < a.nslots; ++s) v += blk[(size_t)s * n];
+    int s = 0;
+    for (; s + 8 <= a.nslots; s += 8) {
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = blk[(size_t)(s + k) * n];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += x[k];
+    }
+    for (; s < a.nslots; ++s) v += blk[(size_t)s * n];
     const u64 word = ((u64)e << 32) | (u64)__float_as_uint(v);
     for (int r = 0; r < a.world; ++r) __hip_atomic_store(a.win[r] + mine + f, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // rank-ordered sum of what the ranks sent (every rank adds in the same order: bit-identical totals)
