@@ -70,11 +70,14 @@ __global__ void __launch_bounds__(256) p2p_exchange_kernel(ExArgs a) {
     }
     for (; s < a.nslots; ++s) v += blk[(size_t)s * n];
     const u64 word = ((u64)e << 32) | (u64)__float_as_uint(v);
-    for (int r = 0; r < a.world; ++r) __hip_atomic_store(a.win[r] + mine + f, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (this rank's own contribution stays in the register: no round trip through its uncached window)
+    for (int r = 0; r < a.world; ++r)
+      if (r != a.rank) __hip_atomic_store(a.win[r] + mine + f, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // rank-ordered sum of what the ranks sent (every rank adds in the same order: bit-identical totals)
     float t = 0.f;
     const long long t0 = wall_clock64();
     for (int r = 0; r < a.world; ++r) {
+      if (r == a.rank) { t += v; continue; }
       u64 w = __hip_atomic_load(inbox + (size_t)r * MAXF + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       while ((unsigned)(w >> 32) != e) {
         if (a.timeout_ticks > 0 && wall_clock64() - t0 > a.timeout_ticks) { atomicExch(a.err, 1u + (unsigned)r); break; }
