@@ -262,6 +262,19 @@ int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, const float* 
                             const int* alias_of_tap, float* dbias, float* workspace, int B, int IH, int IW, int Cin, int OH, int OW,
                             int Cout, int stride, int ntaps, const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce,
                             int dtype, void* stream);
+/* A point-wise (1x1, stride 1, one bias) layer's WHOLE backward in one launch: rssf_conv_wgrad_bnapply (BatchNorm-backward apply on the way:
+ * draw, dgamma, dbeta; weight gradient into the split-K workspace; bias gradient) plus its data gradient dx[p][ci] = sum_co draw[p][co] * W[co][ci]
+ * (`weight`: the fp32 master weights [Cout][Cin], rounded to bf16 as rssf_conv_pack does) - the draw tile a block has formed in LDS is the
+ * data gradient's operand, so dx costs no further pass over the 4 C-channel tensors (MlpDWBN's fc1, ffn_block.py:218-224: the launch that
+ * would re-read draw to form dx disappears).  Only where rssf_conv_wgrad_bnapply_dgrad_supported() returns 1 (bf16, 128 <- 32 channels,
+ * no residual before the activation); same results as rssf_conv_wgrad_bnapply + rssf_conv_gather (transposed pack) up to the summation order. */
+int rssf_conv_wgrad_bnapply_dgrad_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy,
+                                            const int* dx, int has_res_pre, int dtype);
+int rssf_conv_wgrad_bnapply_dgrad(const void* bn_dy, const void* bn_raw, const float* bn_scale_shift, const float* bn_mean_invstd,
+                                  const float* bn_sums, void* draw, float* dgamma, float* dbeta, int bn_act, double bn_n, int bn_training,
+                                  float param_grad_scale, const void* in, const float* weight, void* dx_out, float* dw, float* dbias,
+                                  float* workspace, int B, int H, int W, int Cin, int Cout, rssf_wgrad_reduce_job* defer_reduce, int dtype,
+                                  void* stream);
 int rssf_conv_wgrad_reduce_blocks(const rssf_wgrad_reduce_job* job);
 int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, const int* block_map, int nblocks, void* stream);
 

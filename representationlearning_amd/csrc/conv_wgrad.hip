@@ -1086,7 +1086,7 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
                     int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
                     float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
                     const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, const BnApply* bn, const XPreAct* xpre, int dtype_flags,
-                    void* stream) {
+                    void* stream, const float* w_dg = nullptr, void* dx_dg = nullptr) {
   const int dtype = dtype_flags & 0xff;
   const bool generic = (dtype_flags & RSSF_CONV_GENERIC) != 0;       // the narrow point-wise kernel off (rssf.h): parity tests, A/B runs
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
@@ -1141,10 +1141,11 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
   if (dtype == RSSF_BF16 && workspace && !generic && wgrad_pw_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx)) {
     // narrow point-wise layers: one block per pixel range streams both operands once (conv_wgrad_pw.hip), the apply rides along
     a.ksplit = wgrad_pw_ksplit(B, OH, OW, Cin, Cout);
-    if (int rc = launch_wgrad_pw(dout, in, workspace, dbias, B, OH, OW, Cin, Cout, a.ksplit, bn, st)) return rc;
+    if (int rc = launch_wgrad_pw(dout, in, workspace, dbias, B, OH, OW, Cin, Cout, a.ksplit, bn, st, nullptr, 0, w_dg, dx_dg)) return rc;
     return finish_reduce(a, defer_reduce, st);
   }
 #endif
+  if (w_dg || dx_dg) { set_error("conv_wgrad: no kernel with a fused data gradient for this call (ask rssf_conv_wgrad_bnapply_dgrad_supported)"); return RSSF_ERR_UNSUPPORTED; }
   if (bn) {                    // no kernel with a fused apply for this shape: the separate pass, then the plain weight gradient
     const int rc = rssf_bn_bwd_apply(bn->dy, bn->raw, bn->ss, bn->mi, bn->sums, bn->res, bn->draw, bn->dres, bn->dgamma, bn->dbeta,
                                      (int64_t)B * OH * OW, Cout, bn->act, bn->n, bn->training, bn->pscale, dtype, stream);
@@ -1193,6 +1194,30 @@ extern "C" int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, co
   const XPreAct xp = {in_scale_shift, in_act};
   return conv_wgrad_impl(draw, in, dw0, dw1, dw2, ksizes, nsrc, src_of_tap, kpos_of_tap, alias_of_tap, dbias, workspace, B, IH, IW, Cin, OH,
                          OW, Cout, stride, ntaps, dy, dx, defer_reduce, &bn, in_scale_shift ? &xp : nullptr, dtype, stream);
+}
+
+extern "C" int rssf_conv_wgrad_bnapply_dgrad_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
+                                                       const int* dy, const int* dx, int has_res_pre, int dtype) {
+#ifdef RSSF_WGRAD_PW_DISABLE
+  return 0;
+#else
+  return dtype == RSSF_BF16 && dy && dx && !has_res_pre && wgrad_pw_dgrad_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx) ? 1 : 0;
+#endif
+}
+
+extern "C" int rssf_conv_wgrad_bnapply_dgrad(const void* bn_dy, const void* bn_raw, const float* bn_scale_shift, const float* bn_mean_invstd,
+                                             const float* bn_sums, void* draw, float* dgamma, float* dbeta, int bn_act, double bn_n,
+                                             int bn_training, float param_grad_scale, const void* in, const float* weight, void* dx_out,
+                                             float* dw, float* dbias, float* workspace, int B, int H, int W, int Cin, int Cout,
+                                             rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream) {
+  RSSF_REQUIRE(bn_dy && bn_raw && bn_scale_shift && bn_mean_invstd && bn_sums && draw && bn_act >= 0 && bn_act <= 2 && weight && dx_out && dw &&
+                   workspace, "conv_wgrad_bnapply_dgrad: bad arguments");
+  RSSF_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "conv_wgrad_bnapply_dgrad: dgamma and dbeta go together");
+  static const int ks1[1] = {1}, z1[1] = {0};
+  const BnApply bn = {bn_dy, bn_raw, bn_scale_shift, bn_mean_invstd, bn_sums, nullptr, draw, nullptr, dgamma, dbeta, bn_n, bn_act, bn_training,
+                      param_grad_scale};
+  return conv_wgrad_impl(draw, in, dw, nullptr, nullptr, ks1, 1, z1, z1, nullptr, dbias, workspace, B, H, W, Cin, H, W, Cout, 1, 1, z1, z1,
+                         defer_reduce, &bn, nullptr, dtype, stream, weight, dx_out);
 }
 
 extern "C" int rssf_conv_wgrad_reduce_blocks(const rssf_wgrad_reduce_job* job) {

@@ -42,6 +42,9 @@ struct PwWgradArgs {
   int bn_act, bn_training;
   // XPRE: `in` is the RAW output of the producing convolution, the operand contracted is act(in * scale + shift) (x_ss: [2][CI])
   const float* x_ss; int x_act;
+  // DG: the layer's DATA gradient in the same launch, dx[p][ci] = sum_co draw[p][co] * W[co][ci] - the draw chunk is in LDS anyway and a
+  // 1x1 convolution's data gradient needs nothing else (w: the fp32 master weights [CO][CI], rounded to bf16 as the weight pack does)
+  const float* w; bf16_t* dx_out;
 };
 
 // MFMA fragment of a K-step (32 pixel rows from k0) for 16 channels from column c0 of a pixel-major tile: conv_wgrad.hip's SlabFrag
@@ -56,7 +59,7 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* tile, int ld, int k0, int c
 }
 
 // GM x GN waves (GN = 4 / GM), each WM x WN tiles of 16 x 16: CO = 16 GM WM output channels, CI = 16 GN WN input channels; KPX pixels per chunk
-template <int GM, int WM, int WN, int KPX, bool FUSE, bool RES, bool XPRE = false>
+template <int GM, int WM, int WN, int KPX, bool FUSE, bool RES, bool XPRE = false, bool DG = false>
 __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   constexpr int GN = 4 / GM, CO = 16 * GM * WM, CI = 16 * GN * WN;
   constexpr int LDD = CO + 16, LDX = CI + 16;                       // +32 B per row: conflict-free transposing reads (conv_wgrad.hip)
@@ -68,6 +71,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   __shared__ __attribute__((aligned(16))) float sbn[4][FUSE ? CO : 4];      // scale, shift, cb, cc
   __shared__ float sbias[CO];
   __shared__ __attribute__((aligned(16))) float sxs[2][XPRE ? CI : 4];
+  constexpr int LDW = CO + 8;                                       // W^T [ci][co] bf16, 16-byte aligned rows
+  static_assert(!DG || (KPX == 64 && CI % 16 == 0 && CO % 32 == 0), "DG: one 16-pixel tile per wave, whole MFMA tiles");
+  __shared__ __attribute__((aligned(16))) bf16_t WT[DG ? CI * LDW : 8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wm = wave / GN, wn = wave % GN;
   const int range = blockIdx.x;
@@ -77,6 +83,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   if (tid < CO) sbias[tid] = 0.f;
   if constexpr (XPRE) {
     for (int c = tid; c < 2 * CI; c += 256) sxs[c / CI][c % CI] = a.x_ss[c];
+  }
+  if constexpr (DG) {
+    for (int i = tid; i < CO * CI; i += 256) WT[(i % CI) * LDW + i / CI].v = f2bf(a.w[i]);
   }
 
   if constexpr (FUSE) {
@@ -232,6 +241,29 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    if constexpr (DG) {
+      // dx^T[ci][px] = W^T[ci][co] * draw^T[co][px] for the wave's 16 pixels: A = rows of W^T, B = rows of the draw tile (both K = co
+      // contiguous: plain 16-byte LDS reads); the result has a lane's four values = four consecutive ci of ONE pixel: 8-byte stores
+      f32x4 dacc[CI / 16];
+#pragma unroll
+      for (int j = 0; j < CI / 16; ++j) dacc[j] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kq = 0; kq < CO / 32; ++kq) {
+        const bf16x8 fp = *reinterpret_cast<const bf16x8*>(DS + (wave * 16 + l15) * LDD + kq * 32 + grp * 8);
+#pragma unroll
+        for (int j = 0; j < CI / 16; ++j) {
+          const bf16x8 fw = *reinterpret_cast<const bf16x8*>(WT + (j * 16 + l15) * LDW + kq * 32 + grp * 8);
+          dacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fp, dacc[j], 0, 0, 0);
+        }
+      }
+      bf16_t* drow = a.dx_out + (k0 + wave * 16 + l15) * CI + grp * 4;
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+#pragma unroll
+      for (int j = 0; j < CI / 16; ++j) {
+        const u32x2 o = {f2bf2(dacc[j][0], dacc[j][1]), f2bf2(dacc[j][2], dacc[j][3])};
+        *reinterpret_cast<u32x2*>(drow + j * 16) = o;
+      }
+    }
     __syncthreads();
   }
 
@@ -283,6 +315,12 @@ bool wgrad_pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, in
   return Cout == 32 && Cin == 128 && wgrad_pw_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx);
 }
 
+// MlpDWBN's fc1 (128 <- 32): weight gradient + BatchNorm-backward apply + data gradient in one launch
+bool wgrad_pw_dgrad_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx) {
+  static const int z[1] = {0};
+  return Cout == 128 && Cin == 32 && wgrad_pw_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy ? dy : z, dx ? dx : z);
+}
+
 bool wgrad_pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx) {
   if (ntaps != 1 || stride != 1 || IH != OH || IW != OW || dy[0] != 0 || dx[0] != 0) return false;
   const Shape* s = shape_of(Cout, Cin);
@@ -308,7 +346,7 @@ int wgrad_pw_ksplit(int B, int OH, int OW, int Cin, int Cout) {
 }
 
 int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbias, int B, int OH, int OW, int Cin, int Cout, int ksplit,
-                    const WgradBn* bn, hipStream_t st, const float* x_ss, int x_act) {
+                    const WgradBn* bn, hipStream_t st, const float* x_ss, int x_act, const float* w_dg, void* dx_dg) {
   const Shape* s = shape_of(Cout, Cin);
   if (!s) { set_error("conv_wgrad_pw: no kernel for %d -> %d channels", Cin, Cout); return RSSF_ERR_UNSUPPORTED; }
   PwWgradArgs a;
@@ -327,6 +365,15 @@ int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbi
   }
   const bool fuse = bn != nullptr;
   const int co = Cout, ci = Cin;
+  if (w_dg || dx_dg) {
+    if (!w_dg || !dx_dg || !wgrad_pw_dgrad_eligible(B, OH, OW, Cin, OH, OW, Cout, 1, 1, nullptr, nullptr) || !fuse || res || x_ss) {
+      set_error("conv_wgrad_pw: the fused data gradient is a feature of the 128 <- 32 kernel with the fused apply (no residual)");
+      return RSSF_ERR_UNSUPPORTED;
+    }
+    a.w = w_dg; a.dx_out = (bf16_t*)dx_dg;
+    conv_wgrad_pw_kernel<4, 2, 2, 64, true, false, false, true><<<dim3((unsigned)ksplit), 256, 0, st>>>(a);
+    return check_launch("conv_wgrad_pw");
+  }
   if (x_ss) {
     if (fuse || !(co == 32 && ci == 128)) { set_error("conv_wgrad_pw: the pre-activation input operand is a feature of the plain 32 <- 128 kernel"); return RSSF_ERR_UNSUPPORTED; }
     a.x_ss = x_ss; a.x_act = x_act;

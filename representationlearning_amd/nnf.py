@@ -779,6 +779,7 @@ _FORK_FUSE = os.environ.get("RSSF_FORK_FUSE", "1") != "0"      # A/B switch: fus
 _DEFER_BN_APPLY = os.environ.get("RSSF_DEFER_BN_APPLY", "1") != "0"      # A/B switch: forward BatchNorm apply inside the consumer's staging
 _WGRAD_PLANES = os.environ.get("RSSF_WGRAD_PLANES", "1") != "0"          # A/B switch: transposed-input weight gradient of the MLP's tap sum
 PLANES_PAD = 12                      # zero border of the transposed copy: the largest tap offset of the MLP's dilated convolutions
+_FUSED_PW_DGRAD = os.environ.get("RSSF_FUSED_PW_DGRAD", "1") != "0"      # A/B switch: a point-wise layer's data gradient inside its weight-gradient launch
 _FUSED_BN_APPLY = os.environ.get("RSSF_FUSED_BN_APPLY", "1") != "0"      # A/B switch: BatchNorm-backward apply inside the weight-gradient launch
 _FUSED_BN_STATS = os.environ.get("RSSF_FUSED_BN_STATS", "1") != "0"      # A/B switch (tools)
 
@@ -945,7 +946,7 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, b
     return dx
 
 
-def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=None, generic=False):
+def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=None, generic=False, dgrad=None):
     """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional).  Under a WgradPlan the split-K
     reduction is deferred to the plan's one batched launch (the gradients are complete after WgradPlan.flush()).
     bn: (dy, raw, ss, mi, sums, res_pre, dres, dgamma, dbeta, act, n, training, pscale) - `dout` is then an OUTPUT: the launch
@@ -992,6 +993,13 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=Non
         L.check(lib.rssf_conv_wgrad_planes(L.ptr(dout), L.ptr(planes[0]), planes[1], L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws),
                                            spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb), L.ptr(ws), B, H, W, C, spec.ntaps, spec.c_dy, spec.c_dx,
                                            None if job is None else ctypes.byref(job), L.dtype_code(xh), L.stream()), "rssf_conv_wgrad_planes")
+    elif dgrad is not None:
+        # the layer's whole backward in one launch (rssf_conv_wgrad_bnapply_dgrad): dgrad = (fp32 weights, dx to fill)
+        bdy, braw, bss, bmi, bsums, brp, bdres, bdg, bdb, bact, bn_n, btr, bps = bn
+        L.check(lib.rssf_conv_wgrad_bnapply_dgrad(L.ptr(bdy), L.ptr(braw), L.ptr(bss), L.ptr(bmi), L.ptr(bsums), L.ptr(dout), L.ptr(bdg), L.ptr(bdb),
+                                                  bact, bn_n, int(btr), bps, L.ptr(xh), L.ptr(dgrad[0]), L.ptr(dgrad[1]), L.ptr(d[0]), L.ptr(tdb),
+                                                  L.ptr(ws), B, H, W, C, CO, None if job is None else ctypes.byref(job), L.dtype_code(xh), L.stream()),
+                "rssf_conv_wgrad_bnapply_dgrad")
     elif bn is not None:
         if padded:
             raise RuntimeError("conv_wgrad: the fused BatchNorm-backward apply needs channel counts the kernels take unpadded")
@@ -1148,11 +1156,11 @@ class _ConvBNAct(torch.autograd.Function):
 
         xpre = ctx.xpre             # xh is the producer's RAW output: the weight gradient applies its BatchNorm + activation on load
 
-        def weight_grads(bn):
+        def weight_grads(bn, dgrad=None):
             gbs = []
             if nbias == 1:          # the weight-gradient kernel accumulates straight into the bias gradient: no staging buffer, no add
                 tb, direct = grad_target(p_biases[0], rt)
-                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn, xpre=xpre, planes=ctx.xplanes)
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn, xpre=xpre, planes=ctx.xplanes, dgrad=dgrad)
                 gbs.append(grad_result(p_biases[0], tb, direct, rt))
             else:
                 db = _zeros(C, raw.device, rt) if nbias else None
@@ -1170,7 +1178,21 @@ class _ConvBNAct(torch.autograd.Function):
         vch = 8 if raw.dtype == torch.bfloat16 else 4
         fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0 and not post
         dpost = None
-        if fuse_apply:
+        # a point-wise layer whose data gradient has no rider (no skip gradient to add, no producer statistics to collect, no shared
+        # accumulator): the weight-gradient launch forms dx too (rssf_conv_wgrad_bnapply_dgrad: MlpDWBN's fc1)
+        dx_fused = None
+        si0 = ctx.stats_in
+        if (fuse_apply and _FUSED_PW_DGRAD and x_req and nbias == 1 and nw == 1 and rp is None and xpre is None and ctx.xplanes is None and
+                ctx.accum is None and ctx.links[0] is None and (si0 is None or si0.raw is None or rt.deterministic) and spec.parts is None and
+                raw.dtype == torch.bfloat16 and weights[0].dtype == torch.float32 and weights[0].is_contiguous() and
+                xh.shape[3] == spec.cin and raw.shape[3] == spec.cout):
+            Bx, Hx, Wx, _ = xh.shape
+            if lib.rssf_conv_wgrad_bnapply_dgrad_supported(Bx, Hx, Wx, spec.cin, raw.shape[1], raw.shape[2], spec.cout, spec.stride, spec.ntaps,
+                                                           spec.c_dy, spec.c_dx, 0, L.dtype_code(raw)) == 1:
+                dx_fused = torch.empty_like(xh)
+        if fuse_apply and dx_fused is not None:
+            gbs = weight_grads((dyh, raw, ss, mi, sums, rp, dres, dgamma, dbeta, act, n, training, pscale), dgrad=(weights[0], dx_fused))
+        elif fuse_apply:
             gbs = weight_grads((dyh, raw, ss, mi, sums, rp, dres, dgamma, dbeta, act, n, training, pscale))
         elif post:
             dpost = torch.empty_like(raw) if has_post else None
@@ -1193,6 +1215,8 @@ class _ConvBNAct(torch.autograd.Function):
                 raise RuntimeError("GradAccum: a convolution cannot be both the sink of a residual link and an accumulating consumer")
             _accumulate_dgrad(accum, spec, draw, weights, xh.shape, rt)
             dx = None
+        elif x_req and dx_fused is not None:
+            dx = _nchw(dx_fused)
         elif x_req:
             si, bn = ctx.stats_in, None
             if si is not None and si.raw is not None and not rt.deterministic:

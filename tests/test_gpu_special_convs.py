@@ -535,3 +535,48 @@ def test_mlp_block_with_norm2_applied_on_load_matches_materialised():
         assert rel_err(runs[2][2][k].cpu(), runs[0][2][k].cpu()) < floor(runs[1][2][k], runs[0][2][k]), k
     for k in runs[0][3]:
         assert rel_err(runs[2][3][k].cpu(), runs[0][3][k].cpu()) < 1e-5, k
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 128, 128), (3, 16, 64)])
+@pytest.mark.parametrize("act,training", [(2, True), (1, True), (0, False)])
+def test_pointwise_backward_in_one_launch_matches_three(B, H, W, act, training):
+    """rssf_conv_wgrad_bnapply_dgrad (MlpDWBN's fc1, 128 <- 32): draw / dgamma / dbeta / dW / dbias of rssf_conv_wgrad_bnapply and the data
+    gradient of rssf_conv_gather on the transposed pack, from one launch."""
+    from representationlearning_amd import nnf, _lib as L
+    lib = L.load()
+    torch.manual_seed(41)
+    cin, cout = 32, 128
+    conv = nn.Conv2d(cin, cout, 1).to(DEV)
+    spec = nnf.spec_of([conv])
+    x = torch.randn(B, H, W, cin, device=DEV).bfloat16()
+    dy = torch.randn(B, H, W, cout, device=DEV).bfloat16()
+    raw = (torch.randn(B, H, W, cout, device=DEV) * 1.3 + 0.2).bfloat16()
+    mean, var = raw.float().mean((0, 1, 2)), raw.float().var((0, 1, 2), unbiased=False)
+    istd = torch.rsqrt(var + 1e-5)
+    gamma, beta = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.2
+    ss = torch.stack([gamma * istd, beta - mean * gamma * istd]).contiguous()
+    mi = torch.stack([mean, istd]).contiguous()
+    rows, n = B * H * W, float(B * H * W)
+    assert lib.rssf_conv_wgrad_bnapply_dgrad_supported(B, H, W, cin, H, W, cout, 1, 1, spec.c_dy, spec.c_dx, 0, L.dtype_code(raw)) == 1
+    sums = torch.zeros(nnf.BN_BWD_SLOTS * 2 * cout, device=DEV)
+    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dy), L.ptr(raw), L.ptr(ss), None, L.ptr(sums), rows, cout, act, None, L.dtype_code(raw), L.stream()), "reduce")
+    w = conv.weight.detach().contiguous()
+    outs = []
+    for fused in (False, True):
+        draw = torch.empty_like(raw)
+        dg, dbt = torch.full((cout,), 0.125, device=DEV), torch.full((cout,), 0.25, device=DEV)
+        dw, db = torch.zeros_like(w), torch.zeros(cout, device=DEV)
+        bn = (dy, raw, ss, mi, sums, None, None, dg, dbt, act, n, training, 0.5)
+        if fused:
+            dx = torch.full((B, H, W, cin), 7.0, device=DEV).bfloat16()
+            nnf._conv_wgrad(spec, draw, x, [dw], db, bn=bn, dgrad=(w, dx))
+        else:
+            nnf._conv_wgrad(spec, draw, x, [dw], db, bn=bn)
+            dx = nnf._conv_dgrad(spec, draw, [w], (B, H, W, cin), None).clone()
+        outs.append((draw, dg, dbt, dw, db, dx))
+    torch.cuda.synchronize()
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert float(b[3].abs().max()) > 0 and rel_err(b[3].cpu(), a[3].cpu()) < 2e-5 and rel_err(b[4].cpu(), a[4].cpu()) < 2e-4
+    ref = torch.einsum("bhwo,oi->bhwi", a[0].float(), w.bfloat16().float().view(cout, cin))
+    assert rel_err(b[5].float().cpu(), ref.cpu()) < 4e-3 and rel_err(b[5].float().cpu(), a[5].float().cpu()) < 2e-3
