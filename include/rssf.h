@@ -275,6 +275,15 @@ int rssf_conv_wgrad_bnapply_dgrad(const void* bn_dy, const void* bn_raw, const f
                                   float param_grad_scale, const void* in, const float* weight, void* dx_out, float* dw, float* dbias,
                                   float* workspace, int B, int H, int W, int Cin, int Cout, rssf_wgrad_reduce_job* defer_reduce, int dtype,
                                   void* stream);
+/* The same for a point-wise layer whose INPUT is the raw output of the producing convolution (run forward by rssf_conv_gather_preact) and
+ * whose own BatchNorm-backward apply is a different pass: weight gradient (rssf_conv_wgrad_preact), bias gradient, the data gradient
+ * dx = dout * W AND the producer's BatchNorm-backward statistics {sum dz, sum dz * in_raw}, dz = dx * act'(in_raw * scale + shift)
+ * (rssf_conv_gather_bnbwd's epilogue) into in_bn_sums [RSSF_BN_BWD_SLOTS][2][Cin] (zeroed by the caller) - one pass over the 4 C-channel
+ * raw tensor instead of two (MlpDWBN's fc2 behind norm2, ffn_block.py:229-236).  bf16, 32 <- 128 channels. */
+int rssf_conv_wgrad_preact_dgrad_supported(int B, int H, int W, int Cin, int Cout, int dtype);
+int rssf_conv_wgrad_preact_dgrad(const void* dout, const void* in_raw, const float* in_scale_shift, int in_act, const float* weight, void* dx_out,
+                                 float* in_bn_sums, float* dw, float* dbias, float* workspace, int B, int H, int W, int Cin, int Cout,
+                                 rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream);
 int rssf_conv_wgrad_reduce_blocks(const rssf_wgrad_reduce_job* job);
 int rssf_conv_wgrad_reduce_batch(const rssf_wgrad_reduce_job* jobs, const int* block_map, int nblocks, void* stream);
 

@@ -107,6 +107,8 @@ SIGNATURES = {
                                        c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_preact": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rssf_conv_wgrad_preact_dgrad_supported": (c_int, [c_int] * 6),
+    "rssf_conv_wgrad_preact_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_bnapply_dgrad_supported": (c_int, [c_int] * 9 + [c_void_p, c_void_p, c_int, c_int]),
     "rssf_conv_wgrad_bnapply_dgrad": (c_int, [c_void_p] * 8 + [c_int, ctypes.c_double, c_int, c_float] + [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_int, c_void_p]),
     "rssf_conv_wgrad_bnapply": (c_int, [c_void_p] * 10 + [c_int, ctypes.c_double, c_int, c_float] + [c_void_p, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

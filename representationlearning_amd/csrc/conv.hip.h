@@ -113,7 +113,7 @@ bool wgrad_pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, in
 bool wgrad_pw_dgrad_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx);
 int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbias, int B, int OH, int OW, int Cin, int Cout, int ksplit,
                     const WgradBn* bn, hipStream_t st, const float* x_ss = nullptr, int x_act = 0, const float* w_dg = nullptr,
-                    void* dx_dg = nullptr);
+                    void* dx_dg = nullptr, float* st_sums = nullptr);
 
 template <typename T> struct LdsPad;
 template <> struct LdsPad<bf16_t> { static constexpr int X = 8; };   // +16 B per row: conflict-free ds_read_b128

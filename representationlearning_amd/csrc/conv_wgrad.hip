@@ -1086,7 +1086,7 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
                     int nsrc, const int* src_of_tap, const int* kpos_of_tap, const int* alias_of_tap, float* dbias,
                     float* workspace, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,
                     const int* dy, const int* dx, rssf_wgrad_reduce_job* defer_reduce, const BnApply* bn, const XPreAct* xpre, int dtype_flags,
-                    void* stream, const float* w_dg = nullptr, void* dx_dg = nullptr) {
+                    void* stream, const float* w_dg = nullptr, void* dx_dg = nullptr, float* st_sums = nullptr) {
   const int dtype = dtype_flags & 0xff;
   const bool generic = (dtype_flags & RSSF_CONV_GENERIC) != 0;       // the narrow point-wise kernel off (rssf.h): parity tests, A/B runs
   RSSF_REQUIRE(dout && in && dw0 && ksizes && src_of_tap && kpos_of_tap && dy && dx && nsrc >= 1 && nsrc <= 3 && ntaps >= 1 &&
@@ -1133,7 +1133,8 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
       if (rc) return rc;
     }
     a.ksplit = wgrad_pw_ksplit(B, OH, OW, Cin, Cout);
-    if (int rc = launch_wgrad_pw(dout, in, workspace, dbias, B, OH, OW, Cin, Cout, a.ksplit, nullptr, st, xpre->ss, xpre->act)) return rc;
+    if (int rc = launch_wgrad_pw(dout, in, workspace, dbias, B, OH, OW, Cin, Cout, a.ksplit, nullptr, st, xpre->ss, xpre->act, w_dg, dx_dg, st_sums))
+      return rc;
     return finish_reduce(a, defer_reduce, st);
   }
   if (xpre) { set_error("conv_wgrad: no kernel with a pre-activation input operand for this shape (ask rssf_conv_wgrad_preact_supported)"); return RSSF_ERR_UNSUPPORTED; }
@@ -1194,6 +1195,23 @@ extern "C" int rssf_conv_wgrad_bnapply(const void* bn_dy, const void* bn_raw, co
   const XPreAct xp = {in_scale_shift, in_act};
   return conv_wgrad_impl(draw, in, dw0, dw1, dw2, ksizes, nsrc, src_of_tap, kpos_of_tap, alias_of_tap, dbias, workspace, B, IH, IW, Cin, OH,
                          OW, Cout, stride, ntaps, dy, dx, defer_reduce, &bn, in_scale_shift ? &xp : nullptr, dtype, stream);
+}
+
+extern "C" int rssf_conv_wgrad_preact_dgrad_supported(int B, int H, int W, int Cin, int Cout, int dtype) {
+  static const int z1[1] = {0};
+  return dtype == RSSF_BF16 && wgrad_pw_preact_eligible(B, H, W, Cin, H, W, Cout, 1, 1, z1, z1) ? 1 : 0;
+}
+
+extern "C" int rssf_conv_wgrad_preact_dgrad(const void* dout, const void* in_raw, const float* in_scale_shift, int in_act, const float* weight,
+                                            void* dx_out, float* in_bn_sums, float* dw, float* dbias, float* workspace, int B, int H, int W,
+                                            int Cin, int Cout, rssf_wgrad_reduce_job* defer_reduce, int dtype, void* stream) {
+  RSSF_REQUIRE(dout && in_raw && in_scale_shift && in_act >= 0 && in_act <= 2 && weight && dx_out && in_bn_sums && dw && workspace,
+               "conv_wgrad_preact_dgrad: bad arguments");
+  RSSF_REQUIRE(rssf_conv_wgrad_preact_dgrad_supported(B, H, W, Cin, Cout, dtype) == 1, "conv_wgrad_preact_dgrad: unsupported shape (ask _supported)");
+  static const int ks1[1] = {1}, z1[1] = {0};
+  const XPreAct xp = {in_scale_shift, in_act};
+  return conv_wgrad_impl(dout, in_raw, dw, nullptr, nullptr, ks1, 1, z1, z1, nullptr, dbias, workspace, B, H, W, Cin, H, W, Cout, 1, 1, z1, z1,
+                         defer_reduce, nullptr, &xp, dtype, stream, weight, dx_out, in_bn_sums);
 }
 
 extern "C" int rssf_conv_wgrad_bnapply_dgrad_supported(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps,

@@ -45,6 +45,9 @@ struct PwWgradArgs {
   // DG: the layer's DATA gradient in the same launch, dx[p][ci] = sum_co draw[p][co] * W[co][ci] - the draw chunk is in LDS anyway and a
   // 1x1 convolution's data gradient needs nothing else (w: the fp32 master weights [CO][CI], rounded to bf16 as the weight pack does)
   const float* w; bf16_t* dx_out;
+  // DGS (with XPRE): the data gradient of a layer whose input is the producer's RAW output, plus that producer's BatchNorm-backward
+  // statistics {sum dz, sum dz * raw}, dz = dx * act'(raw * scale + shift) (rssf_conv_gather_bnbwd's epilogue), into st_sums
+  float* st_sums;            // [RSSF_BN_BWD_SLOTS][2][CI]
 };
 
 // MFMA fragment of a K-step (32 pixel rows from k0) for 16 channels from column c0 of a pixel-major tile: conv_wgrad.hip's SlabFrag
@@ -59,7 +62,7 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* tile, int ld, int k0, int c
 }
 
 // GM x GN waves (GN = 4 / GM), each WM x WN tiles of 16 x 16: CO = 16 GM WM output channels, CI = 16 GN WN input channels; KPX pixels per chunk
-template <int GM, int WM, int WN, int KPX, bool FUSE, bool RES, bool XPRE = false, bool DG = false>
+template <int GM, int WM, int WN, int KPX, bool FUSE, bool RES, bool XPRE = false, bool DG = false, bool DGS = false>
 __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   constexpr int GN = 4 / GM, CO = 16 * GM * WM, CI = 16 * GN * WN;
   constexpr int LDD = CO + 16, LDX = CI + 16;                       // +32 B per row: conflict-free transposing reads (conv_wgrad.hip)
@@ -73,7 +76,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   __shared__ __attribute__((aligned(16))) float sxs[2][XPRE ? CI : 4];
   constexpr int LDW = CO + 8;                                       // W^T [ci][co] bf16, 16-byte aligned rows
   static_assert(!DG || (KPX == 64 && CI % 16 == 0 && CO % 32 == 0), "DG: one 16-pixel tile per wave, whole MFMA tiles");
-  __shared__ __attribute__((aligned(16))) bf16_t WT[DG ? CI * LDW : 8];
+  __shared__ __attribute__((aligned(16))) bf16_t WT[(DG || DGS) ? CI * LDW : 8];
+  static_assert(!DGS || (XPRE && !FUSE && !DG && KPX == 64 && CO == 32 && CI % 16 == 0), "DGS: the 32 <- 128 kernel with a pre-activation input");
+  constexpr int LDY = CI + 8;                                       // dx tile [px][ci] bf16 (+16 B per row)
+  __shared__ __attribute__((aligned(16))) bf16_t YS[DGS ? KPX * LDY : 8];
+  static_assert(!DGS || KPX * LDY * 2 >= 2 * 16 * CI * 4, "the statistics fold reuses the dx tile");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, grp = lane >> 4;
   const int wm = wave / GN, wn = wave % GN;
   const int range = blockIdx.x;
@@ -84,7 +91,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   if constexpr (XPRE) {
     for (int c = tid; c < 2 * CI; c += 256) sxs[c / CI][c % CI] = a.x_ss[c];
   }
-  if constexpr (DG) {
+  if constexpr (DG || DGS) {
     for (int i = tid; i < CO * CI; i += 256) WT[(i % CI) * LDW + i / CI].v = f2bf(a.w[i]);
   }
 
@@ -123,7 +130,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) bs[e] = 0.f;
 
-  Vec<bf16_t> rd[DV], rx[XV], rr[FUSE ? DV : 1], rq[FUSE && RES ? DV : 1], vdz[FUSE ? DV : 1];
+  Vec<bf16_t> rd[DV], rx[XV], rr[FUSE ? DV : 1], rq[FUSE && RES ? DV : 1], vdz[FUSE ? DV : 1], rawk[DGS ? XV : 1];
+  float st1[8], st2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
   unsigned soff[DV];
   auto load_chunk = [&](int64_t k0) {
     const unsigned db = (unsigned)(k0 * CO * 2) + (unsigned)tid * 16u, xb = (unsigned)(k0 * CI * 2) + (unsigned)tid * 16u;
@@ -180,6 +190,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[e] += rd[c].get(e);
       }
+    }
+    if constexpr (DGS) {
+#pragma unroll
+      for (int c = 0; c < XV; ++c) rawk[c] = rx[c];
     }
     if constexpr (XPRE) {                            // the producer's BatchNorm + activation on this thread's 8 input channels
       const int xg8 = (tid % (CI / 8)) * 8;
@@ -264,7 +278,63 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
         *reinterpret_cast<u32x2*>(drow + j * 16) = o;
       }
     }
+    if constexpr (DGS) {
+      // dx^T[ci][px] for the wave's 16 pixels (K = the 32 output channels: one MFMA per 16 input channels) -> the dx tile in LDS
+      const bf16x8 fp = *reinterpret_cast<const bf16x8*>(DS + (wave * 16 + l15) * LDD + grp * 8);
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+#pragma unroll
+      for (int j = 0; j < CI / 16; ++j) {
+        const bf16x8 fw = *reinterpret_cast<const bf16x8*>(WT + (j * 16 + l15) * LDW + grp * 8);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fp, zero, 0, 0, 0);
+        const u32x2 o = {f2bf2(d[0], d[1]), f2bf2(d[2], d[3])};
+        *reinterpret_cast<u32x2*>(YS + (wave * 16 + l15) * LDY + j * 16 + grp * 4) = o;
+      }
+    }
     __syncthreads();
+    if constexpr (DGS) {
+      // the thread's own 16-byte pieces again (its channel group is fixed): dx out, and the producer's statistics on the bf16 values
+      // stored, with the raw input kept from staging - the arithmetic of conv_pw_kernel's BNB epilogue
+      const int xg8 = (tid % (CI / 8)) * 8;
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(&sxs[0][xg8]), sc1 = *reinterpret_cast<const f32x4*>(&sxs[0][xg8 + 4]);
+      const f32x4 sh0 = *reinterpret_cast<const f32x4*>(&sxs[1][xg8]), sh1 = *reinterpret_cast<const f32x4*>(&sxs[1][xg8 + 4]);
+      auto accumulate = [&](auto ACT) {
+#pragma unroll
+        for (int c = 0; c < XV; ++c) {
+          const int id = tid + c * 256, row = id / (CI / 8), col = (id % (CI / 8)) * 8;
+          Vec<bf16_t> g;
+          g.load(YS + row * LDY + col);
+          *reinterpret_cast<u32x4*>(a.dx_out + (k0 + row) * CI + col) = g.raw;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = rawk[c].get(e);
+            const float z = fmaf(x, e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+            const float gv = g.get(e);
+            const float dz = decltype(ACT)::value == 1 ? (z > 0.f ? gv : 0.f) : decltype(ACT)::value == 2 ? gv * gelu_erf_grad(z) : gv;
+            st1[e] += dz; st2[e] = fmaf(dz, x, st2[e]);
+          }
+        }
+      };
+      if (a.x_act == 1) accumulate(std::integral_constant<int, 1>{});
+      else if (a.x_act == 2) accumulate(std::integral_constant<int, 2>{});
+      else accumulate(std::integral_constant<int, 0>{});
+    }
+  }
+  if constexpr (DGS) {
+    // fold the 16 row groups of the block through LDS (the dx tile is dead), then one atomic per channel and sum
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(YS);                     // [2][16][CI]
+    const int rg = tid / (CI / 8), xg8 = (tid % (CI / 8)) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[(0 * 16 + rg) * CI + xg8 + e] = st1[e]; red[(1 * 16 + rg) * CI + xg8 + e] = st2[e]; }
+    __syncthreads();
+    for (int i = tid; i < 2 * CI; i += 256) {
+      const int which = i / CI, c = i % CI;
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[(which * 16 + g) * CI + c];
+      atomicAdd(a.st_sums + ((size_t)(range % RSSF_BN_BWD_SLOTS) * 2 + which) * CI + c, t);
+    }
   }
 
   // partial plane of this pixel range: rows = co (4 grp + r), columns = ci (l15)
@@ -346,7 +416,7 @@ int wgrad_pw_ksplit(int B, int OH, int OW, int Cin, int Cout) {
 }
 
 int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbias, int B, int OH, int OW, int Cin, int Cout, int ksplit,
-                    const WgradBn* bn, hipStream_t st, const float* x_ss, int x_act, const float* w_dg, void* dx_dg) {
+                    const WgradBn* bn, hipStream_t st, const float* x_ss, int x_act, const float* w_dg, void* dx_dg, float* st_sums) {
   const Shape* s = shape_of(Cout, Cin);
   if (!s) { set_error("conv_wgrad_pw: no kernel for %d -> %d channels", Cin, Cout); return RSSF_ERR_UNSUPPORTED; }
   PwWgradArgs a;
@@ -365,6 +435,15 @@ int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbi
   }
   const bool fuse = bn != nullptr;
   const int co = Cout, ci = Cin;
+  if (st_sums) {             // the 32 <- 128 layer's whole backward behind a pre-activation input: dW, dbias, dx and the producer's statistics
+    if (!w_dg || !dx_dg || !x_ss || fuse || !(co == 32 && ci == 128) || (a.M / s->kpx) * (int64_t)s->kpx != a.M) {
+      set_error("conv_wgrad_pw: data gradient + statistics are a feature of the plain 32 <- 128 kernel with a pre-activation input");
+      return RSSF_ERR_UNSUPPORTED;
+    }
+    a.x_ss = x_ss; a.x_act = x_act; a.w = w_dg; a.dx_out = (bf16_t*)dx_dg; a.st_sums = st_sums;
+    conv_wgrad_pw_kernel<1, 2, 2, 64, false, false, true, false, true><<<dim3((unsigned)ksplit), 256, 0, st>>>(a);
+    return check_launch("conv_wgrad_pw");
+  }
   if (w_dg || dx_dg) {
     if (!w_dg || !dx_dg || !wgrad_pw_dgrad_eligible(B, OH, OW, Cin, OH, OW, Cout, 1, 1, nullptr, nullptr) || !fuse || res || x_ss) {
       set_error("conv_wgrad_pw: the fused data gradient is a feature of the 128 <- 32 kernel with the fused apply (no residual)");

@@ -993,6 +993,11 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=Non
         L.check(lib.rssf_conv_wgrad_planes(L.ptr(dout), L.ptr(planes[0]), planes[1], L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws),
                                            spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb), L.ptr(ws), B, H, W, C, spec.ntaps, spec.c_dy, spec.c_dx,
                                            None if job is None else ctypes.byref(job), L.dtype_code(xh), L.stream()), "rssf_conv_wgrad_planes")
+    elif dgrad is not None and len(dgrad) == 3:
+        # a pre-activation input (xpre) and no apply of its own in the call: dgrad = (fp32 weights, dx to fill, the producer's statistics)
+        L.check(lib.rssf_conv_wgrad_preact_dgrad(L.ptr(dout), L.ptr(xh), L.ptr(xpre[0]), xpre[1], L.ptr(dgrad[0]), L.ptr(dgrad[1]), L.ptr(dgrad[2]),
+                                                 L.ptr(d[0]), L.ptr(tdb), L.ptr(ws), B, H, W, C, CO, None if job is None else ctypes.byref(job),
+                                                 L.dtype_code(xh), L.stream()), "rssf_conv_wgrad_preact_dgrad")
     elif dgrad is not None:
         # the layer's whole backward in one launch (rssf_conv_wgrad_bnapply_dgrad): dgrad = (fp32 weights, dx to fill)
         bdy, braw, bss, bmi, bsums, brp, bdres, bdg, bdb, bact, bn_n, btr, bps = bn
@@ -1181,6 +1186,7 @@ class _ConvBNAct(torch.autograd.Function):
         # a point-wise layer whose data gradient has no rider (no skip gradient to add, no producer statistics to collect, no shared
         # accumulator): the weight-gradient launch forms dx too (rssf_conv_wgrad_bnapply_dgrad: MlpDWBN's fc1)
         dx_fused = None
+        wg_done = False
         si0 = ctx.stats_in
         if (fuse_apply and _FUSED_PW_DGRAD and x_req and nbias == 1 and nw == 1 and rp is None and xpre is None and ctx.xplanes is None and
                 ctx.accum is None and ctx.links[0] is None and (si0 is None or si0.raw is None or rt.deterministic) and spec.parts is None and
@@ -1222,12 +1228,24 @@ class _ConvBNAct(torch.autograd.Function):
             if si is not None and si.raw is not None and not rt.deterministic:
                 si.sums = _zeros(BN_BWD_SLOTS * 2 * si.C, raw.device, rt)
                 bn = (si, si.sums)
-            dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape, addend, rt, bn=bn))
+            # a point-wise layer behind a deferred producer (xpre) whose own apply was a separate pass: weight gradient, data gradient and
+            # the producer's statistics in ONE pass over the producer's raw output (rssf_conv_wgrad_preact_dgrad: MlpDWBN's fc2)
+            if (bn is not None and xpre is not None and not fuse_apply and _FUSED_PW_DGRAD and addend is None and nbias == 1 and nw == 1 and
+                    si.rp is None and si.raw.data_ptr() == xh.data_ptr() and si.act == xpre[1] and spec.parts is None and
+                    weights[0].dtype == torch.float32 and weights[0].is_contiguous() and xh.shape[3] == spec.cin and
+                    lib.rssf_conv_wgrad_preact_dgrad_supported(xh.shape[0], xh.shape[1], xh.shape[2], spec.cin, spec.cout,
+                                                               L.dtype_code(xh)) == 1):
+                dxh = torch.empty_like(xh)
+                gbs = weight_grads(None, dgrad=(weights[0], dxh, si.sums))
+                wg_done = True
+                dx = _nchw(dxh)
+            else:
+                dx = _nchw(_conv_dgrad(spec, draw, weights, xh.shape, addend, rt, bn=bn))
         else:
             if addend is not None:
                 raise RuntimeError("GradLink: a skip gradient was deposited but this node computes no input gradient")
             dx = None
-        if not fuse_apply:
+        if not fuse_apply and not wg_done:
             gbs = weight_grads(None)
         gws = [grad_result(w, t[0], t[1], rt) for w, t in zip(p_weights, wt)]
         return (dx, None if dres is None else _nchw(dres), (dy if dpost is None else _nchw(dpost)) if has_post else None,

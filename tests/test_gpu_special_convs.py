@@ -580,3 +580,44 @@ def test_pointwise_backward_in_one_launch_matches_three(B, H, W, act, training):
     assert float(b[3].abs().max()) > 0 and rel_err(b[3].cpu(), a[3].cpu()) < 2e-5 and rel_err(b[4].cpu(), a[4].cpu()) < 2e-4
     ref = torch.einsum("bhwo,oi->bhwi", a[0].float(), w.bfloat16().float().view(cout, cin))
     assert rel_err(b[5].float().cpu(), ref.cpu()) < 4e-3 and rel_err(b[5].float().cpu(), a[5].float().cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 128, 128), (3, 16, 64)])
+@pytest.mark.parametrize("act", [2, 1, 0])
+def test_pointwise_backward_behind_a_preactivation_input_in_one_launch(B, H, W, act):
+    """rssf_conv_wgrad_preact_dgrad (MlpDWBN's fc2, 32 <- 128, input = the raw tap sum): dW / dbias of rssf_conv_wgrad_preact, dx and the
+    producer's BatchNorm-backward statistics of rssf_conv_gather_bnbwd - from one pass over the raw input."""
+    from representationlearning_amd import nnf, _lib as L
+    lib = L.load()
+    torch.manual_seed(43)
+    cin, cout = 128, 32
+    conv = nn.Conv2d(cin, cout, 1).to(DEV)
+    spec = nnf.spec_of([conv])
+    raw_in = (torch.randn(B, H, W, cin, device=DEV) * 1.2 + 0.1).bfloat16()
+    dout = torch.randn(B, H, W, cout, device=DEV).bfloat16()
+    ss = torch.stack([torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.3]).contiguous()
+    assert lib.rssf_conv_wgrad_preact_dgrad_supported(B, H, W, cin, cout, L.dtype_code(raw_in)) == 1
+    w = conv.weight.detach().contiguous()
+    link = nnf.BnBwdLink()
+    link.raw, link.rp, link.act, link.C, link.ss = raw_in, None, act, cin, ss
+    outs = []
+    for fused in (False, True):
+        dw, db = torch.zeros_like(w), torch.zeros(cout, device=DEV)
+        sm = torch.zeros(nnf.BN_BWD_SLOTS * 2 * cin, device=DEV)
+        if fused:
+            dx = torch.full((B, H, W, cin), 7.0, device=DEV).bfloat16()
+            nnf._conv_wgrad(spec, dout, raw_in, [dw], db, xpre=(ss, act), dgrad=(w, dx, sm))
+        else:
+            nnf._conv_wgrad(spec, dout, raw_in, [dw], db, xpre=(ss, act))
+            dx = nnf._conv_dgrad(spec, dout, [w], (B, H, W, cin), None, bn=(link, sm)).clone()
+        outs.append((dw, db, dx, sm.view(nnf.BN_BWD_SLOTS, 2, cin).sum(0)))
+    torch.cuda.synchronize()
+    a, b = outs
+    z = raw_in.float() * ss[0] + ss[1]
+    y = torch.relu(z) if act == 1 else (F.gelu(z) if act == 2 else z)
+    ref_dw = torch.einsum("bhwo,bhwi->oi", dout.float(), y.bfloat16().float()).view(cout, cin, 1, 1)
+    assert rel_err(b[0].cpu(), ref_dw.cpu()) < 3e-3 and rel_err(b[0].cpu(), a[0].cpu()) < 2e-5
+    assert rel_err(b[1].cpu(), a[1].cpu()) < 2e-5
+    ref_dx = torch.einsum("bhwo,oi->bhwi", dout.float(), w.bfloat16().float().view(cout, cin))
+    assert rel_err(b[2].float().cpu(), ref_dx.cpu()) < 4e-3 and rel_err(b[2].float().cpu(), a[2].float().cpu()) < 2e-3
+    assert rel_err(b[3].cpu(), a[3].cpu()) < 2e-3
