@@ -30,6 +30,9 @@ typedef enum { RSSF_F32 = 0, RSSF_BF16 = 1 } rssf_dtype;
  * (the point-wise stream kernels of the forward pass and of the weight gradient, the 128-channel many-tap kernel) - same results up to
  * the summation order; the parity tests hold the two against each other. */
 #define RSSF_CONV_GENERIC 0x100
+/* OR-ed into the `dtype` argument of rssf_conv_wgrad_bnapply: the caller will not read `draw` after the call (the layer needs no data
+ * gradient - the stem's first convolution): a kernel that forms draw on the fly may skip writing it.  `draw` must still be a valid buffer. */
+#define RSSF_WGRAD_NO_DRAW 0x200
 /* per-channel BatchNorm statistics are accumulated into this many interleaved copies (slot = block index mod slots) to
  * spread same-address atomics; every statistics buffer below is [RSSF_BN_SLOTS][2][C] fp32 and consumers sum the slots */
 #define RSSF_BN_SLOTS 16

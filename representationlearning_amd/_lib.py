@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RSSF_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "librssf.so")
 
 RSSF_F32, RSSF_BF16 = 0, 1
-CONV_GENERIC = 0x100          # rssf.h RSSF_CONV_GENERIC: OR-ed into the dtype argument of rssf_conv_gather* (generic kernels only)
+WGRAD_NO_DRAW = 0x200         # rssf.h RSSF_WGRAD_NO_DRAW: the caller of rssf_conv_wgrad_bnapply will not read `draw`
+CONV_GENERIC = 0x100
+          # rssf.h RSSF_CONV_GENERIC: OR-ed into the dtype argument of rssf_conv_gather* (generic kernels only)
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 

@@ -1052,6 +1052,14 @@ extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Ci
     const int pk = wgrad_pw_ksplit(B, OH, OW, Cin, Cout);
     if (pk > ks) ks = pk;
   }
+  {
+    int sdy[9], sdx[9];
+    for (int t = 0; t < 9; ++t) { sdy[t] = t / 3 - 1; sdx[t] = t % 3 - 1; }
+    if (ntaps == 9 && wgrad_stem_eligible(B, 2 * OH, 2 * OW, Cin, OH, OW, Cout, 2, 9, sdy, sdx)) {     // (a stride-2 stem layer or not: the bound holds)
+      const int sk = wgrad_stem_ksplit(B, OH, OW);
+      if (sk > ks) ks = sk;
+    }
+  }
   const int64_t generic = (int64_t)ks * ntaps * Cout * Cin, planes = wgrad_planes_workspace_elems(B, OH, OW, Cin, Cout, ntaps);
   return generic > planes ? generic : planes;       // either first stage may run (rssf_conv_wgrad_planes takes the same workspace)
 }
@@ -1138,6 +1146,15 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
     return finish_reduce(a, defer_reduce, st);
   }
   if (xpre) { set_error("conv_wgrad: no kernel with a pre-activation input operand for this shape (ask rssf_conv_wgrad_preact_supported)"); return RSSF_ERR_UNSUPPORTED; }
+#ifndef RSSF_WGRAD_STEM_DISABLE     // (A/B builds: tools/ab_lib_flags.sh)
+  if (dtype == RSSF_BF16 && workspace && !generic && !dbias && !xpre && !w_dg && (!bn || (!bn->res && !bn->dres)) &&
+      wgrad_stem_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx)) {
+    // the stem's first convolution: apply + weight gradient in one pass over dy / raw, `draw` only on request (conv_wgrad_stem.hip)
+    a.ksplit = wgrad_stem_ksplit(B, OH, OW);
+    if (int rc = launch_wgrad_stem(dout, in, workspace, B, IH, IW, OH, OW, a.ksplit, bn, (dtype_flags & RSSF_WGRAD_NO_DRAW) == 0, st)) return rc;
+    return finish_reduce(a, defer_reduce, st);
+  }
+#endif
 #ifndef RSSF_WGRAD_PW_DISABLE       // (A/B builds: tools/ab_lib_flags.sh)
   if (dtype == RSSF_BF16 && workspace && !generic && wgrad_pw_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx)) {
     // narrow point-wise layers: one block per pixel range streams both operands once (conv_wgrad_pw.hip), the apply rides along

@@ -946,7 +946,7 @@ def _conv_dgrad(spec, dout, weights, in_shape, addend=None, rt=None, out=None, b
     return dx
 
 
-def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=None, generic=False, dgrad=None):
+def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=None, generic=False, dgrad=None, no_draw=False):
     """Accumulates (+=) into the fp32 buffers dws (one per source conv) and db (optional).  Under a WgradPlan the split-K
     reduction is deferred to the plan's one batched launch (the gradients are complete after WgradPlan.flush()).
     bn: (dy, raw, ss, mi, sums, res_pre, dres, dgamma, dbeta, act, n, training, pscale) - `dout` is then an OUTPUT: the launch
@@ -978,7 +978,7 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=Non
         ws = torch.empty(nws, device=xh.device, dtype=torch.float32)
     tail = (L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), spec.c_ksizes, len(dws), spec.c_src, spec.c_kpos, spec.c_alias, L.ptr(tdb),
             L.ptr(ws), B, H, W, C, OH, OW, CO, spec.stride, spec.ntaps, spec.c_dy, spec.c_dx, None if job is None else ctypes.byref(job),
-            L.dtype_code(xh) | (L.CONV_GENERIC if generic else 0), L.stream())
+            L.dtype_code(xh) | (L.CONV_GENERIC if generic else 0) | (L.WGRAD_NO_DRAW if no_draw else 0), L.stream())
     use_planes = (planes is not None and (rt or current()).planes_current(planes[2], planes[3]) and not padded and xpre is None and
                   spec.stride == 1 and OH == H and OW == W and tuple(planes[0].shape) == (C, B, H + 2 * planes[1], W + 2 * planes[1]) and
                   lib.rssf_conv_wgrad_planes_supported(B, H, W, C, CO, 1, spec.ntaps, spec.c_dy, spec.c_dx, planes[1], L.dtype_code(xh)) == 1)
@@ -1006,8 +1006,8 @@ def _conv_wgrad(spec, dout, xh, dws, db, rt=None, bn=None, xpre=None, planes=Non
                                                   L.ptr(ws), B, H, W, C, CO, None if job is None else ctypes.byref(job), L.dtype_code(xh), L.stream()),
                 "rssf_conv_wgrad_bnapply_dgrad")
     elif bn is not None:
-        if padded:
-            raise RuntimeError("conv_wgrad: the fused BatchNorm-backward apply needs channel counts the kernels take unpadded")
+        if CO != spec.cout:
+            raise RuntimeError("conv_wgrad: the fused BatchNorm-backward apply needs an output channel count the kernels take unpadded")
         bdy, braw, bss, bmi, bsums, brp, bdres, bdg, bdb, bact, bn_n, btr, bps = bn
         xss, xact = xpre if xpre is not None else (None, 0)
         L.check(lib.rssf_conv_wgrad_bnapply(L.ptr(bdy), L.ptr(braw), L.ptr(bss), L.ptr(bmi), L.ptr(bsums), L.ptr(brp), L.ptr(dout), L.ptr(bdres),
@@ -1161,15 +1161,17 @@ class _ConvBNAct(torch.autograd.Function):
 
         xpre = ctx.xpre             # xh is the producer's RAW output: the weight gradient applies its BatchNorm + activation on load
 
+        bn_no_draw_ok = ctx.accum is None
+
         def weight_grads(bn, dgrad=None):
             gbs = []
             if nbias == 1:          # the weight-gradient kernel accumulates straight into the bias gradient: no staging buffer, no add
                 tb, direct = grad_target(p_biases[0], rt)
-                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn, xpre=xpre, planes=ctx.xplanes, dgrad=dgrad)
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], tb, rt, bn=bn, xpre=xpre, planes=ctx.xplanes, dgrad=dgrad, no_draw=no_draw)
                 gbs.append(grad_result(p_biases[0], tb, direct, rt))
             else:
                 db = _zeros(C, raw.device, rt) if nbias else None
-                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt, bn=bn, xpre=xpre, planes=ctx.xplanes)
+                _conv_wgrad(spec, draw, xh, [t[0] for t in wt], db, rt, bn=bn, xpre=xpre, planes=ctx.xplanes, no_draw=no_draw)
                 tbs = [grad_target(b, rt) for b in p_biases]      # every summed conv's bias sees the same gradient: one launch
                 if tbs:
                     d = [t[0] for t in tbs] + [None, None]
@@ -1181,7 +1183,10 @@ class _ConvBNAct(torch.autograd.Function):
         # the BatchNorm-backward apply rides in the weight-gradient launch where a kernel for that exists (rssf_conv_wgrad_bnapply:
         # the entry point falls back to the two launches itself); channel counts the kernels would see padded keep the two calls
         vch = 8 if raw.dtype == torch.bfloat16 else 4
-        fuse_apply = _FUSED_BN_APPLY and spec.cin % vch == 0 and spec.cout % vch == 0 and not post
+        # (an input whose channels were padded - the 3-channel image - is fine: the weight gradient of the padded problem is folded back
+        # by _conv_wgrad; `draw` has no reader when the layer needs no data gradient: the stem's launch then never writes it)
+        fuse_apply = _FUSED_BN_APPLY and (spec.cin % vch == 0 or xpre is None) and spec.cout % vch == 0 and not post
+        no_draw = bool(bn_no_draw_ok and not x_req)
         dpost = None
         # a point-wise layer whose data gradient has no rider (no skip gradient to add, no producer statistics to collect, no shared
         # accumulator): the weight-gradient launch forms dx too (rssf_conv_wgrad_bnapply_dgrad: MlpDWBN's fc1)

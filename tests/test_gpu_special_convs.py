@@ -621,3 +621,45 @@ def test_pointwise_backward_behind_a_preactivation_input_in_one_launch(B, H, W, 
     ref_dx = torch.einsum("bhwo,oi->bhwi", dout.float(), w.bfloat16().float().view(cout, cin))
     assert rel_err(b[2].float().cpu(), ref_dx.cpu()) < 4e-3 and rel_err(b[2].float().cpu(), a[2].float().cpu()) < 2e-3
     assert rel_err(b[3].cpu(), a[3].cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 128, 128), (1, 256, 128), (3, 64, 192)])
+@pytest.mark.parametrize("training", [True, False])
+def test_stem_backward_apply_and_weight_gradient_in_one_pass(B, H, W, training):
+    """csrc/conv_wgrad_stem.hip (the stem's Conv2d(3, 64, 3, stride 2, padding 1) behind BatchNorm + ReLU, _hrnet_rssformer.py:407-413): draw /
+    dgamma / dbeta of rssf_bn_bwd_apply bit for bit, the weight gradient of the generic kernel and of torch; with RSSF_WGRAD_NO_DRAW the
+    same gradients and `draw` left alone."""
+    from representationlearning_amd import nnf, _lib as L
+    lib = L.load()
+    torch.manual_seed(51)
+    conv = nn.Conv2d(3, 64, 3, 2, 1, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    OH, OW, C = H // 2, W // 2, 64
+    x = torch.randn(B, H, W, 3, device=DEV).bfloat16()
+    dy = torch.randn(B, OH, OW, C, device=DEV).bfloat16()
+    raw = (torch.randn(B, OH, OW, C, device=DEV) * 1.3 + 0.2).bfloat16()
+    mean, var = raw.float().mean((0, 1, 2)), raw.float().var((0, 1, 2), unbiased=False)
+    istd = torch.rsqrt(var + 1e-5)
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+    ss = torch.stack([gamma * istd, beta - mean * gamma * istd]).contiguous()
+    mi = torch.stack([mean, istd]).contiguous()
+    rows, n = B * OH * OW, float(B * OH * OW)
+    sums = torch.zeros(nnf.BN_BWD_SLOTS * 2 * C, device=DEV)
+    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dy), L.ptr(raw), L.ptr(ss), None, L.ptr(sums), rows, C, 1, None, L.dtype_code(raw), L.stream()), "reduce")
+    outs = []
+    for generic, no_draw in ((True, False), (False, False), (False, True)):
+        draw = torch.full_like(raw, 7.0)
+        dg, dbt = torch.full((C,), 0.125, device=DEV), torch.full((C,), 0.25, device=DEV)
+        dw = torch.zeros_like(conv.weight, dtype=torch.float32)
+        bn = (dy, raw, ss, mi, sums, None, None, dg, dbt, 1, n, training, 0.5)
+        nnf._conv_wgrad(spec, draw, x, [dw], None, bn=bn, generic=generic, no_draw=no_draw)
+        outs.append((draw, dg, dbt, dw))
+    torch.cuda.synchronize()
+    a, b, c = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(b[1], c[1]) and torch.equal(b[2], c[2]) and bool((c[0].float() == 7.0).all())        # draw untouched on request
+    xr = x.permute(0, 3, 1, 2).float()
+    w = conv.weight.detach().clone().float().requires_grad_(True)
+    F.conv2d(xr, w, None, 2, 1).backward(a[0].permute(0, 3, 1, 2).float())
+    assert float(b[3].abs().max()) > 0
+    assert rel_err(b[3].cpu(), w.grad.cpu()) < 2e-5 and rel_err(b[3].cpu(), a[3].cpu()) < 2e-5 and rel_err(c[3].cpu(), b[3].cpu()) < 1e-6
