@@ -755,6 +755,12 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
     if (rc || !bn || fused) return rc;
     return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
   }
+#ifndef RSSF_DGRAD_S2_DISABLE      // (A/B builds: tools/ab_lib_flags.sh)
+  if (!generic && dtype == RSSF_BF16 && !pre && !bias && !stats && !addend && (!bn || (Cout % 8) == 0) &&
+      dgrad_s2_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
+    return launch_dgrad_s2(in, wpk, out, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr, bn ? bn->sums : nullptr, bn ? bn->act : 0,
+                           B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st);
+#endif
   if (dtype == RSSF_BF16 && pre && !bn && !a.stats_ws && !addend && pw_preact_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx)) {
     // (the stream kernel is the only one with a pre-activation operand for this shape: RSSF_CONV_GENERIC does not apply)
     const PwPre pp = {pre->stats, pre->gamma, pre->beta, pre->rmean, pre->rvar, pre->mi, pre->ss, pre->n, pre->momentum, pre->eps, pre->training, pre->act};

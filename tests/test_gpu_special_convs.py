@@ -663,3 +663,32 @@ def test_stem_backward_apply_and_weight_gradient_in_one_pass(B, H, W, training):
     F.conv2d(xr, w, None, 2, 1).backward(a[0].permute(0, 3, 1, 2).float())
     assert float(b[3].abs().max()) > 0
     assert rel_err(b[3].cpu(), w.grad.cpu()) < 2e-5 and rel_err(b[3].cpu(), a[3].cpu()) < 2e-5 and rel_err(c[3].cpu(), b[3].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 128, 64), (3, 16, 48), (1, 1, 16)])        # (H, W) of the OUTPUT gradient; dx is twice that
+@pytest.mark.parametrize("act,res", [(None, False), (1, False), (1, True), (2, False)])
+def test_stride2_dgrad_stream_matches_gather_and_torch(B, H, W, act, res):
+    """csrc/conv_dgrad_s2.hip (the stem's Conv2d(64, 64, 3, stride 2, padding 1), _hrnet_rssformer.py:409-413): the data gradient by output
+    parity against the generic gather kernel (RSSF_CONV_GENERIC) and torch, plain and with the producer's BatchNorm-backward statistics."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(61)
+    conv = nn.Conv2d(64, 64, 3, 2, 1, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    dout = torch.randn(B, H, W, 64, device=DEV).bfloat16()
+    shape = (B, 2 * H, 2 * W, 64)
+    link = None
+    if act is not None:
+        link = nnf.BnBwdLink()
+        link.raw, link.act, link.C = torch.randn(*shape, device=DEV).bfloat16(), act, 64
+        link.rp = torch.randn(*shape, device=DEV).bfloat16() if res else None
+        link.ss = torch.stack([torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.3]).contiguous()
+    got = []
+    for on in (False, True):
+        sm = torch.zeros(nnf.BN_BWD_SLOTS * 2 * 64, device=DEV)
+        d = nnf._conv_dgrad(spec, dout, [conv.weight.detach()], shape, None, bn=(link, sm) if link is not None else None, generic=not on).clone()
+        got.append((d, sm.view(nnf.BN_BWD_SLOTS, 2, 64).sum(0)))
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(dout.permute(0, 3, 1, 2).float(), conv.weight.detach().bfloat16().float(), None, 2, 1, output_padding=1).permute(0, 2, 3, 1)
+    assert rel_err(got[1][0].float().cpu(), ref.cpu()) < 4e-3 and rel_err(got[1][0].float().cpu(), got[0][0].float().cpu()) < 2e-3
+    if link is not None:
+        assert rel_err(got[1][1].cpu(), got[0][1].cpu()) < 2e-3
