@@ -755,6 +755,10 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
     if (rc || !bn || fused) return rc;
     return rssf_bn_bwd_reduce(out, bn->raw, bn->ss, bn->res, bn->sums, (int64_t)B * OH * OW, Cout, bn->act, nullptr, dtype, stream);
   }
+#ifndef RSSF_STEM_FWD_DISABLE      // (A/B builds: tools/ab_lib_flags.sh)
+  if (!generic && dtype == RSSF_BF16 && !pre && !bias && !addend && !bn && !a.stats_ws && stem_fwd_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
+    return launch_stem_fwd(in, wpk, out, stats, B, IH, IW, OH, OW, a.CinP, a.CoutP, st);
+#endif
 #ifndef RSSF_DGRAD_S2_DISABLE      // (A/B builds: tools/ab_lib_flags.sh)
   if (!generic && dtype == RSSF_BF16 && !pre && !bias && !stats && !addend && (!bn || (Cout % 8) == 0) &&
       dgrad_s2_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))

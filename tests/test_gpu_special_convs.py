@@ -692,3 +692,30 @@ def test_stride2_dgrad_stream_matches_gather_and_torch(B, H, W, act, res):
     assert rel_err(got[1][0].float().cpu(), ref.cpu()) < 4e-3 and rel_err(got[1][0].float().cpu(), got[0][0].float().cpu()) < 2e-3
     if link is not None:
         assert rel_err(got[1][1].cpu(), got[0][1].cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 128, 96), (3, 32, 32), (1, 2, 32)])
+def test_stem_forward_stream_matches_gather_and_torch(B, H, W):
+    """csrc/conv_stem_fwd.hip (Conv2d(3, 64, 3, stride 2, padding 1) on the channel-padded image, _hrnet_rssformer.py:407, 441): against the
+    generic gather kernel and torch, with the fused BatchNorm statistics."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(71)
+    conv = nn.Conv2d(3, 64, 3, 2, 1, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    x = torch.randn(B, H, W, 3, device=DEV).bfloat16()
+    xp = nnf._pad_channels(x)
+    outs, stats = [], []
+    for on in (False, True):
+        st = torch.zeros(nnf.BN_SLOTS * 2 * 64, device=DEV)
+        outs.append(nnf._conv_forward(spec, xp, [conv.weight.detach()], None, st, generic=not on))
+        stats.append(st.view(nnf.BN_SLOTS, 2, 64).sum(0))
+        outs.append(nnf._conv_forward(spec, xp, [conv.weight.detach()], None, None, generic=not on))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).float(), conv.weight.detach().bfloat16().float(), None, 2, 1).permute(0, 2, 3, 1)
+    for o in (outs[2], outs[3]):
+        assert tuple(o.shape) == (B, H // 2, W // 2, 64)
+        assert rel_err(o.float().cpu(), ref.cpu()) < 6e-3
+    assert rel_err(outs[2].float().cpu(), outs[0].float().cpu()) < 3e-3 and torch.equal(outs[2], outs[3])
+    assert rel_err(stats[1].cpu(), stats[0].cpu()) < 3e-4
+    n = B * (H // 2) * (W // 2)
+    assert rel_err(stats[1][1].cpu() / n, (ref.reshape(-1, 64) ** 2).mean(0).cpu()) < 1e-3
