@@ -97,10 +97,10 @@ struct PwPre {
 // the stem's first convolution forward (8 <- 3 padded channels -> 64, 3x3 / stride 2) with the im2col row as the K axis (conv_stem_fwd.hip)
 bool stem_fwd_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_stem_fwd(const void* in, const void* wpk, void* out, float* stats, int B, int IH, int IW, int OH, int OW, int CinP, int CoutP, hipStream_t st);
-// data gradient of a 3x3 / stride-2 / padding-1 convolution (64 -> 64) by output parity, a stream over the output-gradient rows (conv_dgrad_s2.hip)
+// data gradient of a 3x3 / stride-2 / padding-1 convolution (narrow channel counts) by output parity, a stream over the output-gradient rows (conv_dgrad_s2.hip)
 bool dgrad_s2_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
-int launch_dgrad_s2(const void* dout, const void* wpk, void* dx, const void* bn_raw, const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act,
-                    int B, int IH, int IW, int Cin, int Cout, int CinP, int CoutP, hipStream_t st);
+int launch_dgrad_s2(const void* dout, const void* wpk, void* dx, const void* addend, const void* bn_raw, const void* bn_res, const float* bn_ss,
+                    float* bn_sums, int bn_act, int B, int IH, int IW, int Cin, int Cout, int CinP, int CoutP, hipStream_t st);
 bool pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
               const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st,

@@ -29,6 +29,7 @@ struct S2Args {
   const bf16_t* dout;      // [B][OH][OW][CO]   (the convolution's output gradient)
   const bf16_t* wpk;       // transposed pack [9][CiP][CoP]: slab t = kernel position (t / 3, t % 3), rows = input channels, K = output channels
   bf16_t* dx;              // [B][2 OH][2 OW][CI]
+  const bf16_t* addend;    // added before rounding (an accumulating consumer: may be dx itself), or null
   const bf16_t* bn_raw; const bf16_t* bn_res; const float* bn_ss; float* bn_sums; int bn_act;      // BNB
   int B, OH, OW, CiP, CoP;
   int64_t ntiles;          // B * OH * OW / 16
@@ -140,6 +141,14 @@ __global__ void __launch_bounds__(512) conv_dgrad_s2_kernel(S2Args a) {
       };
       (one(pairs), ...);
       const int64_t po = px00 + ((int64_t)pi * IW + pj) * CI;
+      if (a.addend) {                                           // block-uniform
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const u32x2 av = *reinterpret_cast<const u32x2*>(a.addend + po + n * 16);
+          acc[n][0] += __uint_as_float(av[0] << 16); acc[n][1] += __uint_as_float(av[0] & 0xffff0000u);
+          acc[n][2] += __uint_as_float(av[1] << 16); acc[n][3] += __uint_as_float(av[1] & 0xffff0000u);
+        }
+      }
       u32x2 rawv[BNB ? NT : 1], resv[BNB ? NT : 1];
       if constexpr (BNB) {
 #pragma unroll
@@ -200,43 +209,58 @@ __global__ void __launch_bounds__(512) conv_dgrad_s2_kernel(S2Args a) {
 }
 
 template <int KS, int NT>
-size_t s2_lds() { return (size_t)9 * (16 * NT) * (32 * KS + 8) * 2 + (size_t)(8 * 2 + 2) * (16 * NT) * 4; }
+constexpr size_t s2_lds() { return (size_t)9 * (16 * NT) * (32 * KS + 8) * 2 + (size_t)(8 * 2 + 2) * (16 * NT) * 4; }
+
+template <int KS, int NT, bool BNB>
+int s2_launch(const S2Args& a, int blocks, hipStream_t st) {
+  static hipError_t e = hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<KS, NT, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2_lds<KS, NT>());
+  if (e != hipSuccess) { set_error("conv_dgrad_s2: cannot raise the LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
+  conv_dgrad_s2_kernel<KS, NT, BNB><<<dim3((unsigned)blocks), 512, s2_lds<KS, NT>(), st>>>(a);
+  return check_launch("conv_dgrad_s2");
+}
+
+// (output-gradient channels, dx channels) with an instantiation: 9 weight slabs of [dx channels][output-gradient channels] must fit the LDS
+bool s2_shape(int cin, int cout) {
+  return (cin == 64 && cout == 64) || (cin == 64 && cout == 32) || (cin == 32 && cout == 32) || (cin == 128 && cout == 32) || (cin == 32 && cout == 64);
+}
 
 }  // namespace
 
 namespace rssf { namespace cv {
 
 // the data gradient of a 3x3 / stride-2 / padding-1 convolution in conv_gather_impl's terms: `in` = the output gradient [B, IH, IW, Cin],
-// `out` = dx [B, 2 IH, 2 IW, Cout], mul 1, div 2, the nine mirrored taps
+// `out` = dx [B, 2 IH, 2 IW, Cout], mul 1, div 2, the nine mirrored taps.  The stem's convolution (64 -> 64) and the down-sampling fuse
+// convolutions of the HighResolutionModules whose weight slabs fit (reference _hrnet_rssformer.py:380-405)
 bool dgrad_s2_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx) {
-  if (mul != 1 || div != 2 || ntaps != 9 || OH != 2 * IH || OW != 2 * IW || (IW % 16) != 0 || Cin != 64 || Cout != 64) return false;
+  if (mul != 1 || div != 2 || ntaps != 9 || OH != 2 * IH || OW != 2 * IW || (IW % 16) != 0 || !s2_shape(Cin, Cout)) return false;
   for (int t = 0; t < 9; ++t)
     if (dy[t] != 1 - t / 3 || dx[t] != 1 - t % 3) return false;
   return (int64_t)B * OH * OW * Cout < ((int64_t)1 << 30) && (int64_t)B * IH * IW * Cin * 2 < ((int64_t)1 << 31);
 }
 
-int launch_dgrad_s2(const void* dout, const void* wpk, void* dx, const void* bn_raw, const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act,
-                    int B, int IH, int IW, int Cin, int Cout, int CinP, int CoutP, hipStream_t st) {
+int launch_dgrad_s2(const void* dout, const void* wpk, void* dx, const void* addend, const void* bn_raw, const void* bn_res, const float* bn_ss,
+                    float* bn_sums, int bn_act, int B, int IH, int IW, int Cin, int Cout, int CinP, int CoutP, hipStream_t st) {
   S2Args a;
   memset(&a, 0, sizeof(a));
-  a.dout = (const bf16_t*)dout; a.wpk = (const bf16_t*)wpk; a.dx = (bf16_t*)dx;
+  a.dout = (const bf16_t*)dout; a.wpk = (const bf16_t*)wpk; a.dx = (bf16_t*)dx; a.addend = (const bf16_t*)addend;
   a.bn_raw = (const bf16_t*)bn_raw; a.bn_res = (const bf16_t*)bn_res; a.bn_ss = bn_ss; a.bn_sums = bn_sums; a.bn_act = bn_act;
   a.B = B; a.OH = IH; a.OW = IW; a.CiP = CoutP; a.CoP = CinP;       // (the pack's rows = dx channels, its K = output-gradient channels)
   a.ntiles = (int64_t)B * IH * IW / 16;
   static const int cus = [] { int d = 0, v = 256; (void)hipGetDevice(&d); if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256; return v; }();
-  int64_t blocks = (a.ntiles + 7) / 8;
-  if (blocks > cus) blocks = cus;                                   // one resident workgroup per CU (83 KB of weights in LDS), persistent
-  const size_t lds = s2_lds<2, 4>();
-  if (bn_sums) {
-    static hipError_t e1 = hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2_lds<2, 4>());
-    if (e1 != hipSuccess) { set_error("conv_dgrad_s2: cannot raise the LDS limit: %s", hipGetErrorString(e1)); return RSSF_ERR_LAUNCH; }
-    conv_dgrad_s2_kernel<2, 4, true><<<dim3((unsigned)blocks), 512, lds, st>>>(a);
-  } else {
-    static hipError_t e0 = hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2_lds<2, 4>());
-    if (e0 != hipSuccess) { set_error("conv_dgrad_s2: cannot raise the LDS limit: %s", hipGetErrorString(e0)); return RSSF_ERR_LAUNCH; }
-    conv_dgrad_s2_kernel<2, 4, false><<<dim3((unsigned)blocks), 512, lds, st>>>(a);
-  }
-  return check_launch("conv_dgrad_s2");
+  // one resident workgroup per CU (its weights live in LDS), persistent; a small map gets fewer workgroups so that a wave still walks
+  // >= 2 tiles behind its share of the weight fill
+  int64_t blocks = (a.ntiles + 15) / 16;
+  if (blocks > cus) blocks = cus;
+  if (blocks < 1) blocks = 1;
+  const bool bnb = bn_sums != nullptr;
+  const int nb = (int)blocks;
+  if (Cin == 64 && Cout == 64) return bnb ? s2_launch<2, 4, true>(a, nb, st) : s2_launch<2, 4, false>(a, nb, st);
+  if (Cin == 64 && Cout == 32) return bnb ? s2_launch<2, 2, true>(a, nb, st) : s2_launch<2, 2, false>(a, nb, st);
+  if (Cin == 32 && Cout == 32) return bnb ? s2_launch<1, 2, true>(a, nb, st) : s2_launch<1, 2, false>(a, nb, st);
+  if (Cin == 128 && Cout == 32) return bnb ? s2_launch<4, 2, true>(a, nb, st) : s2_launch<4, 2, false>(a, nb, st);
+  if (Cin == 32 && Cout == 64) return bnb ? s2_launch<1, 4, true>(a, nb, st) : s2_launch<1, 4, false>(a, nb, st);
+  set_error("conv_dgrad_s2: no kernel for %d -> %d channels", Cin, Cout);
+  return RSSF_ERR_UNSUPPORTED;
 }
 
 } }

@@ -760,9 +760,9 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
     return launch_stem_fwd(in, wpk, out, stats, B, IH, IW, OH, OW, a.CinP, a.CoutP, st);
 #endif
 #ifndef RSSF_DGRAD_S2_DISABLE      // (A/B builds: tools/ab_lib_flags.sh)
-  if (!generic && dtype == RSSF_BF16 && !pre && !bias && !stats && !addend && (!bn || (Cout % 8) == 0) &&
+  if (!generic && dtype == RSSF_BF16 && !pre && !bias && !stats && (!bn || (Cout % 8) == 0) &&
       dgrad_s2_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
-    return launch_dgrad_s2(in, wpk, out, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr, bn ? bn->sums : nullptr, bn ? bn->act : 0,
+    return launch_dgrad_s2(in, wpk, out, addend, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr, bn ? bn->sums : nullptr, bn ? bn->act : 0,
                            B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st);
 #endif
   if (dtype == RSSF_BF16 && pre && !bn && !a.stats_ws && !addend && pw_preact_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx)) {

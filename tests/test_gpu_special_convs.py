@@ -719,3 +719,41 @@ def test_stem_forward_stream_matches_gather_and_torch(B, H, W):
     assert rel_err(stats[1].cpu(), stats[0].cpu()) < 3e-4
     n = B * (H // 2) * (W // 2)
     assert rel_err(stats[1][1].cpu() / n, (ref.reshape(-1, 64) ** 2).mean(0).cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (32, 32), (32, 128), (64, 32)])        # the convolution: dx has cin channels, dout cout
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 16, 64), (3, 8, 16)])
+@pytest.mark.parametrize("mode", ["plain", "addend", "in_place", "bn"])
+def test_stride2_dgrad_stream_shapes_and_accumulation(cin, cout, B, H, W, mode):
+    """The down-sampling fuse convolutions of the HighResolutionModules (_hrnet_rssformer.py:380-405) on csrc/conv_dgrad_s2.hip: every
+    instantiated channel pair, with a skip-gradient addend, accumulating in place (nnf.GradAccum) and with the producer's statistics."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(63)
+    conv = nn.Conv2d(cin, cout, 3, 2, 1, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    dout = torch.randn(B, H, W, cout, device=DEV).bfloat16()
+    shape = (B, 2 * H, 2 * W, cin)
+    base = torch.randn(*shape, device=DEV).bfloat16()
+    link = None
+    if mode == "bn":
+        link = nnf.BnBwdLink()
+        link.raw, link.act, link.C, link.rp = torch.randn(*shape, device=DEV).bfloat16(), 1, cin, None
+        link.ss = torch.stack([torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.3]).contiguous()
+    got = []
+    for on in (False, True):
+        sm = torch.zeros(nnf.BN_BWD_SLOTS * 2 * cin, device=DEV)
+        if mode == "in_place":
+            buf = base.clone()
+            d = nnf._conv_dgrad(spec, dout, [conv.weight.detach()], shape, buf, out=buf, generic=not on).clone()
+        else:
+            d = nnf._conv_dgrad(spec, dout, [conv.weight.detach()], shape, base if mode == "addend" else None,
+                                bn=(link, sm) if link is not None else None, generic=not on).clone()
+        got.append((d, sm.view(nnf.BN_BWD_SLOTS, 2, cin).sum(0)))
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(dout.permute(0, 3, 1, 2).float(), conv.weight.detach().bfloat16().float(), None, 2, 1, output_padding=1).permute(0, 2, 3, 1)
+    if mode in ("addend", "in_place"):
+        ref = ref + base.float()
+    # (two bf16 roundings of sums formed in different orders: each within 2^-9 of the exact value, up to ~2.5e-3 of each other)
+    assert rel_err(got[1][0].float().cpu(), ref.cpu()) < 4e-3 and rel_err(got[1][0].float().cpu(), got[0][0].float().cpu()) < 3e-3
+    if link is not None:
+        assert rel_err(got[1][1].cpu(), got[0][1].cpu()) < 2e-3
