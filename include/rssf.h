@@ -604,6 +604,9 @@ int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, voi
 int rssf_debug_lane_reduce(const float* in, float* out, void* stream);
 /* probe of the LDS transpose read (ds_read_b64_tr_b16): lds[i] = i, lane l reads at element address addr[l] */
 int rssf_debug_trread(const int* addr, short* out, void* stream);
+/* fills the LDS of every CU with `pattern` (e.g. 0x7fc07fc0: bf16 / fp32 NaNs): a kernel launched next that reads LDS it never wrote sees it
+ * (scratch4: 4 bytes of device memory) */
+int rssf_debug_poison_lds(unsigned pattern, void* scratch4, void* stream);
 
 #ifdef __cplusplus
 }

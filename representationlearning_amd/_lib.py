@@ -181,6 +181,7 @@ SIGNATURES = {
     "rssf_p2p_destroy": (c_int, [c_void_p]),
     "rssf_debug_lane_reduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_trread": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "rssf_debug_poison_lds": (c_int, [ctypes.c_uint, c_void_p, c_void_p]),
     "rssf_debug_mma": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
 }
 

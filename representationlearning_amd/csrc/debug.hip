@@ -80,3 +80,24 @@ extern "C" int rssf_debug_mma(const void* a, const void* b, float* d, int K, int
   else { set_error("debug_mma: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
   return check_launch("debug_mma");
 }
+
+// Fill the LDS of every CU with a bit pattern (one 160 KB workgroup per CU at a time, four rounds): what a kernel that reads LDS it never
+// wrote would see next.  tests/test_gpu_trainer.py runs a training step before and after poisoning with NaNs: a result that depends on
+// uninitialised LDS (a pad column that enters an MFMA, a fold buffer read past what was written) turns up as a different loss or gradient.
+__global__ void __launch_bounds__(256) debug_poison_lds_kernel(unsigned pattern, unsigned* sink) {
+  extern __shared__ unsigned pl[];
+  const int n = 160 * 1024 / 4;
+  for (int i = threadIdx.x; i < n; i += 256) pl[i] = pattern;
+  __syncthreads();
+  if (sink && pl[(threadIdx.x * 37) % n] != pattern) sink[0] = 1u;       // (keeps the stores alive)
+}
+extern "C" int rssf_debug_poison_lds(unsigned pattern, void* scratch4, void* stream) {
+  static hipError_t e = hipFuncSetAttribute((const void*)debug_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) { set_error("debug_poison_lds: cannot raise the LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  debug_poison_lds_kernel<<<dim3((unsigned)cus * 4), 256, 160 * 1024, (hipStream_t)stream>>>(pattern, (unsigned*)scratch4);
+  return check_launch("debug_poison_lds");
+}
+
