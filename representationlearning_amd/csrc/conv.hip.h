@@ -116,11 +116,12 @@ struct WgradBn {
 // narrow point-wise weight gradients, one block per pixel range (conv_wgrad_pw.hip); wgrad_pw_ksplit() partial planes [Cout][Cin]
 bool wgrad_pw_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx);
 int wgrad_pw_ksplit(int B, int OH, int OW, int Cin, int Cout);
-// the stem's first convolution (8 <- 3 padded channels -> 64, 3x3 / stride 2): apply + weight gradient in one pass (conv_wgrad_stem.hip)
+// 3x3 / stride-2 convolutions with few input channels (the stem: 8 <- 3 padded -> 64; the fuse layers' 32 -> 32 / 64 / 128): a block owns
+// every (co, tap, ci) of a pixel range; apply + weight gradient in one pass (conv_wgrad_stem.hip)
 bool wgrad_stem_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx);
-int wgrad_stem_ksplit(int B, int OH, int OW);
-int launch_wgrad_stem(const void* dout, const void* in, float* partial, int B, int IH, int IW, int OH, int OW, int ksplit, const WgradBn* bn,
-                      bool write_draw, hipStream_t st);
+int wgrad_stem_ksplit(int B, int OH, int OW, int Cin, int Cout);
+int launch_wgrad_stem(const void* dout, const void* in, float* partial, int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int ksplit,
+                      const WgradBn* bn, bool write_draw, hipStream_t st);
 bool wgrad_pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx);
 bool wgrad_pw_dgrad_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int stride, int ntaps, const int* dy, const int* dx);
 int launch_wgrad_pw(const void* dout, const void* in, float* partial, float* dbias, int B, int OH, int OW, int Cin, int Cout, int ksplit,

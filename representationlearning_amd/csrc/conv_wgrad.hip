@@ -1056,7 +1056,7 @@ extern "C" int64_t rssf_conv_wgrad_workspace_elems(int B, int OH, int OW, int Ci
     int sdy[9], sdx[9];
     for (int t = 0; t < 9; ++t) { sdy[t] = t / 3 - 1; sdx[t] = t % 3 - 1; }
     if (ntaps == 9 && wgrad_stem_eligible(B, 2 * OH, 2 * OW, Cin, OH, OW, Cout, 2, 9, sdy, sdx)) {     // (a stride-2 stem layer or not: the bound holds)
-      const int sk = wgrad_stem_ksplit(B, OH, OW);
+      const int sk = wgrad_stem_ksplit(B, OH, OW, Cin, Cout);
       if (sk > ks) ks = sk;
     }
   }
@@ -1150,8 +1150,8 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
   if (dtype == RSSF_BF16 && workspace && !generic && !dbias && !xpre && !w_dg && (!bn || (!bn->res && !bn->dres)) &&
       wgrad_stem_eligible(B, IH, IW, Cin, OH, OW, Cout, stride, ntaps, dy, dx)) {
     // the stem's first convolution: apply + weight gradient in one pass over dy / raw, `draw` only on request (conv_wgrad_stem.hip)
-    a.ksplit = wgrad_stem_ksplit(B, OH, OW);
-    if (int rc = launch_wgrad_stem(dout, in, workspace, B, IH, IW, OH, OW, a.ksplit, bn, (dtype_flags & RSSF_WGRAD_NO_DRAW) == 0, st)) return rc;
+    a.ksplit = wgrad_stem_ksplit(B, OH, OW, Cin, Cout);
+    if (int rc = launch_wgrad_stem(dout, in, workspace, B, IH, IW, Cin, OH, OW, Cout, a.ksplit, bn, (dtype_flags & RSSF_WGRAD_NO_DRAW) == 0, st)) return rc;
     return finish_reduce(a, defer_reduce, st);
   }
 #endif

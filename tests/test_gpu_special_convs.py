@@ -757,3 +757,48 @@ def test_stride2_dgrad_stream_shapes_and_accumulation(cin, cout, B, H, W, mode):
     assert rel_err(got[1][0].float().cpu(), ref.cpu()) < 4e-3 and rel_err(got[1][0].float().cpu(), got[0][0].float().cpu()) < 3e-3
     if link is not None:
         assert rel_err(got[1][1].cpu(), got[0][1].cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("cout", [32, 64])
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 32, 64), (3, 16, 32)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_stride2_weight_gradient_block_owns_all_taps(cout, B, H, W, fused):
+    """The 32-input-channel instances of csrc/conv_wgrad_stem.hip (the down-sampling fuse convolutions, _hrnet_rssformer.py:380-405): weight
+    gradient against the generic one-tap-per-block kernel and torch, plain and with the BatchNorm-backward apply in the launch."""
+    from representationlearning_amd import nnf, _lib as L
+    lib = L.load()
+    torch.manual_seed(81)
+    conv = nn.Conv2d(32, cout, 3, 2, 1, bias=False).to(DEV)
+    spec = nnf.spec_of([conv])
+    OH, OW = H // 2, W // 2
+    x = torch.randn(B, H, W, 32, device=DEV).bfloat16()
+    dy = torch.randn(B, OH, OW, cout, device=DEV).bfloat16()
+    raw = (torch.randn(B, OH, OW, cout, device=DEV) * 1.3 + 0.2).bfloat16()
+    mean, var = raw.float().mean((0, 1, 2)), raw.float().var((0, 1, 2), unbiased=False)
+    istd = torch.rsqrt(var + 1e-5)
+    gamma, beta = torch.rand(cout, device=DEV) + 0.5, torch.randn(cout, device=DEV) * 0.2
+    ss = torch.stack([gamma * istd, beta - mean * gamma * istd]).contiguous()
+    mi = torch.stack([mean, istd]).contiguous()
+    rows, n = B * OH * OW, float(B * OH * OW)
+    sums = torch.zeros(nnf.BN_BWD_SLOTS * 2 * cout, device=DEV)
+    L.check(lib.rssf_bn_bwd_reduce(L.ptr(dy), L.ptr(raw), L.ptr(ss), None, L.ptr(sums), rows, cout, 1, None, L.dtype_code(raw), L.stream()), "reduce")
+    outs = []
+    for generic in (True, False):
+        dw = torch.zeros_like(conv.weight, dtype=torch.float32)
+        if fused:
+            draw = torch.empty_like(raw)
+            dg, dbt = torch.zeros(cout, device=DEV), torch.zeros(cout, device=DEV)
+            nnf._conv_wgrad(spec, draw, x, [dw], None, bn=(dy, raw, ss, mi, sums, None, None, dg, dbt, 1, n, True, 1.0), generic=generic)
+            outs.append((dw, draw, dg, dbt))
+        else:
+            nnf._conv_wgrad(spec, dy, x, [dw], None, generic=generic)
+            outs.append((dw, dy, None, None))
+    torch.cuda.synchronize()
+    a, b = outs
+    if fused:
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    xr = x.permute(0, 3, 1, 2).float()
+    w = conv.weight.detach().clone().float().requires_grad_(True)
+    F.conv2d(xr, w, None, 2, 1).backward(a[1].permute(0, 3, 1, 2).float())
+    assert float(b[0].abs().max()) > 0
+    assert rel_err(b[0].cpu(), w.grad.cpu()) < 2e-5 and rel_err(b[0].cpu(), a[0].cpu()) < 2e-5
