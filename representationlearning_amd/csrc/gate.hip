@@ -113,58 +113,102 @@ __global__ void __launch_bounds__(64 * PARTS) gate_pool_fwd_vec_kernel(const T* 
   }
 }
 
-// ---- the two 7x7 convolutions run on 16x16-pixel tiles staged (with a 3-pixel halo, zero outside the image) in LDS ---
-constexpr int GT = 16, GH = GT + 6, GLD = GH + 1;
+// ---- the two 7x7 convolutions (and their backward) run on pixel tiles staged with their halo, zero outside the image, in LDS ---
 constexpr int GATE_SLOT_ELEMS = 196 + 6;            // dk [2][2][7][7], dwl [2][2], dbl [2]
-__device__ __forceinline__ void gate_load_tile(const float* __restrict__ plane, int H, int W, int h0, int w0, float* sm) {
-  for (int i = threadIdx.x; i < GH * GH; i += blockDim.x) {
-    const int r = i / GH, c = i % GH, hh = h0 + r - 3, ww = w0 + c - 3;
-    sm[r * GLD + c] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? plane[hh * W + ww] : 0.f;
+// 32 x 32-pixel tiles with their halo (3 rows above / below, 4 columns left / right: 16-byte aligned rows) for the 7x7 kernels below
+constexpr int G2T = 32, G2H = G2T + 6, G2W = G2T + 8, G2LD = 44, G2PLANE = G2H * G2LD;
+// stages NPL planes of one tile: tile row i = image row h0 - 3 + i, tile column j = image column w0 - 4 + j, zero outside the image.
+// All of a thread's loads are in flight together (a loop of load -> LDS store round trips cost 6 of the kernel's 15 us).
+template <int NPL, typename F>
+__device__ __forceinline__ void gate2_stage(float* sp, int tid, int h0, int w0, int H, int W, F plane_of) {
+  if ((W & 3) == 0) {
+    constexpr int UNITS = NPL * G2H * (G2W / 4), NIT = (UNITS + 255) / 256;
+    f32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * 256;
+      const int pl = e / (G2H * (G2W / 4)), rem = e % (G2H * (G2W / 4)), r = rem / (G2W / 4), c = (rem % (G2W / 4)) * 4;
+      const int hh = h0 - 3 + r, ww = w0 - 4 + c;
+      v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e < UNITS && hh >= 0 && hh < H && ww >= 0 && ww < W) v[it] = *reinterpret_cast<const f32x4*>(plane_of(pl) + (int64_t)hh * W + ww);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * 256;
+      const int pl = e / (G2H * (G2W / 4)), rem = e % (G2H * (G2W / 4)), r = rem / (G2W / 4), c = (rem % (G2W / 4)) * 4;
+      if (e < UNITS) *reinterpret_cast<f32x4*>(sp + pl * G2PLANE + r * G2LD + c) = v[it];
+    }
+  } else {
+    for (int e = tid; e < NPL * G2H * G2W; e += 256) {
+      const int pl = e / (G2H * G2W), rem = e % (G2H * G2W), r = rem / G2W, c = rem % G2W;
+      const int hh = h0 - 3 + r, ww = w0 - 4 + c;
+      sp[pl * G2PLANE + r * G2LD + c] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? plane_of(pl)[(int64_t)hh * W + ww] : 0.f;
+    }
   }
 }
 
 // ---- weights: 7x7 conv (2->1, pad 3, no bias) + sigmoid per stream, 1x1 conv 2->2 + softmax over the 2 streams
+// Round 5: 32 x 32 tiles, a thread owns FOUR pixels of a row - per kernel row and map it reads the 12 values under them once (three
+// 16-byte LDS reads for 28 FMAs; a thread per pixel read LDS once per FMA) and the tile's loads are all in flight together.
 __global__ void __launch_bounds__(256) gate_weights_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ k,
                                                                const float* __restrict__ wl, const float* __restrict__ bl,
                                                                float* __restrict__ gsig, float* __restrict__ omega,
                                                                float* __restrict__ logits, int B, int H, int W) {
-  __shared__ float sk[196];
-  __shared__ float sm[4][GH * GLD];
+  __shared__ __attribute__((aligned(16))) float sp[4 * G2PLANE];
   const int N = H * W;
-  const int tw = (W + GT - 1) / GT, th = (H + GT - 1) / GT;
+  const int tw = (W + G2T - 1) / G2T, th = (H + G2T - 1) / G2T;
   const int b = blockIdx.x / (tw * th), t = blockIdx.x % (tw * th);
-  const int h0 = (t / tw) * GT, w0 = (t % tw) * GT;
-  for (int i = threadIdx.x; i < 196; i += blockDim.x) sk[i] = k[i];
-#pragma unroll
-  for (int pl = 0; pl < 4; ++pl) gate_load_tile(pooled + ((int64_t)b * 4 + pl) * N, H, W, h0, w0, sm[pl]);
+  const int h0 = (t / tw) * G2T, w0 = (t % tw) * G2T;
+  const int tid = threadIdx.x;
+  gate2_stage<4>(sp, tid, h0, w0, H, W, [&](int pl) { return pooled + ((int64_t)b * 4 + pl) * N; });
   __syncthreads();
-  const int lh = threadIdx.x / GT, lw = threadIdx.x % GT, h = h0 + lh, w = w0 + lw;
+  const int row = tid >> 3, c4 = (tid & 7) * 4;
+  const int h = h0 + row, w = w0 + c4;
   if (h >= H || w >= W) return;
-  float g[2];
+  float g[2][4];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    float acc = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      const float* m = sm[2 * s + ch] + lh * GLD + lw;
-      const float* kk = sk + (s * 2 + ch) * 49;
+    for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-      for (int u = 0; u < 7; ++u)
+      for (int u = 0; u < 7; ++u) {
+        // out[h, w] += k[u, v] * in[h + u - 3, w + v - 3]: tile row row + u, tile column c4 + j + v + 1
+        const float* m = sp + (2 * s + ch) * G2PLANE + (row + u) * G2LD + c4;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(m), x1 = *reinterpret_cast<const f32x4*>(m + 4), x2 = *reinterpret_cast<const f32x4*>(m + 8);
+        const float x[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
 #pragma unroll
-        for (int v = 0; v < 7; ++v) acc += kk[u * 7 + v] * m[u * GLD + v];
-    }
-    g[s] = sigmoidf(acc);
+        for (int v = 0; v < 7; ++v) {
+          const float kv = k[((s * 2 + ch) * 7 + u) * 7 + v];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(kv, x[j + v + 1], acc[j]);
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[s][j] = sigmoidf(acc[j]);
   }
-  const float l0 = wl[0] * g[0] + wl[1] * g[1] + bl[0];
-  const float l1 = wl[2] * g[0] + wl[3] * g[1] + bl[1];
-  const float m = fmaxf(l0, l1);
-  const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
-  const float inv = 1.f / (e0 + e1);
-  const int64_t o = (int64_t)b * 2 * N;
-  const int p = h * W + w;
-  gsig[o + p] = g[0]; gsig[o + N + p] = g[1];
-  omega[o + p] = e0 * inv; omega[o + N + p] = e1 * inv;
-  if (logits) { logits[o + p] = l0; logits[o + N + p] = l1; }
+  float o0[4], o1[4], l0[4], l1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    l0[j] = wl[0] * g[0][j] + wl[1] * g[1][j] + bl[0];
+    l1[j] = wl[2] * g[0][j] + wl[3] * g[1][j] + bl[1];
+    const float m = fmaxf(l0[j], l1[j]);
+    const float e0 = __expf(l0[j] - m), e1 = __expf(l1[j] - m);
+    const float inv = 1.f / (e0 + e1);
+    o0[j] = e0 * inv; o1[j] = e1 * inv;
+  }
+  const int64_t o = (int64_t)b * 2 * N + (int64_t)h * W + w;
+  auto put = [&](float* dst, const float (&v)[4]) {
+    if ((W & 3) == 0) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (w + j < W) dst[j] = v[j];
+    }
+  };
+  put(gsig + o, g[0]); put(gsig + o + N, g[1]);
+  put(omega + o, o0); put(omega + o + N, o1);
+  if (logits) { put(logits + o, l0); put(logits + o + N, l1); }
 }
 
 // ---- weights backward, stage 1: domega -> dpre (gradient at the 7x7 conv outputs, pre-sigmoid); dwl/dbl --------
@@ -201,63 +245,119 @@ __global__ void __launch_bounds__(256) gate_weights_bwd1_kernel(const float* __r
   if (threadIdx.x < 6) atomicAdd(&slots[(blockIdx.x % RSSF_GATE_SLOTS) * GATE_SLOT_ELEMS + 196 + threadIdx.x], red[threadIdx.x]);
 }
 
-// stage 2: dpooled = conv^T(dpre, k) ; dk += sum_pixels dpre * shifted(pooled).  Same 16x16 tiles: the dpre halo tile
-// serves the transposed convolution, the pooled halo tiles the kernel gradient; per-tap partial sums are folded over the
-// wave by shuffles and over the block through LDS, one global atomic per tap per block.
+// stage 2: dpooled = conv^T(dpre, k) ; dk += sum_pixels dpre * shifted(pooled), on 32 x 32-pixel tiles staged with their halo in LDS
+// (six planes: dpre of the two streams, the four pooled maps).
+//
+// Round 5.  The first form (16 x 16 tiles, a thread per pixel) formed the kernel gradient as 196 per-pixel products per thread, each
+// folded over a lane quad by two DPP adds, written to LDS and summed there behind a barrier per (stream, channel): 3 LDS reads + 1 LDS
+// write per tap and pixel, 34 us per launch at B = 16 x 128 x 128 for 0.1 GFLOP.  Now both halves are register-blocked and nothing
+// but the final 196 sums crosses lanes:
+//   * dpooled: a thread owns FOUR pixels of a row; per kernel row it reads the 12 dpre values under them once (three 16-byte LDS
+//     reads) for 4 x 7 taps x 2 channels of FMAs;
+//   * dk: a thread owns ONE kernel row u and one tile row: it walks the 32 pixels of the row with dpre's row and pooled's row (shifted by u - 3)
+//     in registers - 7 accumulators (the taps v of its row), 18 16-byte LDS reads per 224 FMAs; the tile's 32 rows are summed through LDS
+//     once at the end (one barrier), one global atomic per tap and block - a quarter of the blocks of the old form.
+// Row pitch 44 words: the 15 rows a wave's dk threads touch at one column lie in 15 different bank quads.
+// (gate.hip is built without SLP vectorisation: tests/test_build_isa.py.)
 __global__ void __launch_bounds__(256) gate_weights_bwd2_kernel(const float* __restrict__ dpre, const float* __restrict__ pooled,
                                                                 const float* __restrict__ k, float* __restrict__ dpooled,
                                                                 float* __restrict__ slots, int B, int H, int W) {
-  __shared__ float sk[196];
-  __shared__ float sdk[196];
-  __shared__ float sd[2][GH * GLD];
-  __shared__ float sm[4][GH * GLD];
-  __shared__ float red[49][65];                          // per-tap partial sums of the 64 lane quads of the block
+  __shared__ __attribute__((aligned(16))) float sp[6 * G2PLANE];        // [0..1] dpre s, [2..5] pooled (2 s + ch); later the row sums
   const int N = H * W;
-  const int tw = (W + GT - 1) / GT, th = (H + GT - 1) / GT;
+  const int tw = (W + G2T - 1) / G2T, th = (H + G2T - 1) / G2T;
   const int b = blockIdx.x / (tw * th), t = blockIdx.x % (tw * th);
-  const int h0 = (t / tw) * GT, w0 = (t % tw) * GT;
-  for (int i = threadIdx.x; i < 196; i += blockDim.x) { sk[i] = k[i]; sdk[i] = 0.f; }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) gate_load_tile(dpre + ((int64_t)b * 2 + s) * N, H, W, h0, w0, sd[s]);
-#pragma unroll
-  for (int pl = 0; pl < 4; ++pl) gate_load_tile(pooled + ((int64_t)b * 4 + pl) * N, H, W, h0, w0, sm[pl]);
+  const int h0 = (t / tw) * G2T, w0 = (t % tw) * G2T;
+  const int tid = threadIdx.x;
+  // ---- stage the six planes: tile row i = image row h0 - 3 + i, tile column j = image column w0 - 4 + j; zero outside the image
+  gate2_stage<6>(sp, tid, h0, w0, H, W, [&](int pl) { return pl < 2 ? dpre + ((int64_t)b * 2 + pl) * N : pooled + ((int64_t)b * 4 + (pl - 2)) * N; });
   __syncthreads();
-  const int lh = threadIdx.x / GT, lw = threadIdx.x % GT, h = h0 + lh, w = w0 + lw;
-  const bool ok = h < H && w < W;
+  // ---- dpooled: pixels (row, c4 .. c4 + 3).  forward: out[h, w] += k[u, v] * in[h + u - 3, w + v - 3]  ->  input (h, w) was read by
+  //      output (h + 3 - u, w + 3 - v): tile row row + 6 - u, tile column c4 + j + 7 - v
+  {
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const float* dp = sd[s] + lh * GLD + lw;             // dp[(3+a)*GLD + 3+c] = dpre(h+a, w+c)
-    const float mine = ok ? dp[3 * GLD + 3] : 0.f;
+    for (int s = 0; s < 2; ++s) {
+      float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      const float* m = sm[2 * s + ch] + lh * GLD + lw;
-      const float* kk = sk + (s * 2 + ch) * 49;
-      float acc = 0.f;
+      for (int u = 0; u < 7; ++u) {
+        const float* dp = sp + s * G2PLANE + (row + 6 - u) * G2LD + c4;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(dp), x1 = *reinterpret_cast<const f32x4*>(dp + 4), x2 = *reinterpret_cast<const f32x4*>(dp + 8);
+        const float x[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
 #pragma unroll
-      for (int u = 0; u < 7; ++u)
+        for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-        for (int v = 0; v < 7; ++v) {
-          // forward: out[h,w] += k[u,v] * in[h+u-3, w+v-3]  ->  this input was read by output (h-(u-3), w-(v-3))
-          acc += kk[u * 7 + v] * dp[(6 - u) * GLD + (6 - v)];
-          // kernel-gradient partial: fold the lane quad with two DPP adds (no LDS traffic), one LDS write per quad
-          float tq = mine * m[u * GLD + v];
-          tq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tq), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-          tq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tq), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-          red[u * 7 + v][threadIdx.x >> 2] = tq;           // the four lanes of a quad store the same value
-        }
-      if (ok) dpooled[((int64_t)b * 4 + 2 * s + ch) * N + h * W + w] = acc;
-      __syncthreads();
-      if (threadIdx.x < 245) {                            // 5 threads per tap, ~13 quads each
-        const int tap = threadIdx.x % 49, part = threadIdx.x / 49;
-        float sum = 0.f;
-        for (int q = part * 13; q < (part * 13 + 13 < 64 ? part * 13 + 13 : 64); ++q) sum += red[tap][q];
-        atomicAdd(&sdk[(s * 2 + ch) * 49 + tap], sum);
+          for (int v = 0; v < 7; ++v) {
+            const float kv = k[((s * 2 + ch) * 7 + u) * 7 + v];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ch][j] = fmaf(kv, x[j + 7 - v], acc[ch][j]);
+          }
       }
-      __syncthreads();
+      const int h = h0 + row, w = w0 + c4;
+      if (h < H) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          float* dst = dpooled + ((int64_t)b * 4 + 2 * s + ch) * N + (int64_t)h * W + w;
+          if ((W & 3) == 0) {
+            if (w < W) *reinterpret_cast<f32x4*>(dst) = f32x4{acc[ch][0], acc[ch][1], acc[ch][2], acc[ch][3]};
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (w + j < W) dst[j] = acc[ch][j];
+          }
+        }
+      }
     }
   }
+  // ---- dk: kernel row u, tile row `row`: dk[s][ch][u][v] += dpre_s(row, col) * pooled_{s,ch}(row + u - 3, col + v - 3); dpre is zero
+  //      outside the image, so the tile's dead pixels add nothing
+  const int ku = tid & 7, krow = tid >> 3;
+  float dkacc[4][7];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int v = 0; v < 7; ++v) dkacc[q][v] = 0.f;
+  if (ku < 7) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float dv[32];
+      const float* dr = sp + s * G2PLANE + (krow + 3) * G2LD + 4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(dr + 4 * i);
+        dv[4 * i] = q[0]; dv[4 * i + 1] = q[1]; dv[4 * i + 2] = q[2]; dv[4 * i + 3] = q[3];
+      }
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        float mv[40];
+        const float* mr = sp + (2 + 2 * s + ch) * G2PLANE + (krow + ku) * G2LD;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(mr + 4 * i);
+          mv[4 * i] = q[0]; mv[4 * i + 1] = q[1]; mv[4 * i + 2] = q[2]; mv[4 * i + 3] = q[3];
+        }
+#pragma unroll
+        for (int col = 0; col < 32; ++col)
+#pragma unroll
+          for (int v = 0; v < 7; ++v) dkacc[2 * s + ch][v] = fmaf(dv[col], mv[col + v + 1], dkacc[2 * s + ch][v]);
+      }
+    }
+  }
+  __syncthreads();                                       // every wave is done with the planes: their storage takes the row sums
+  constexpr int RLD = 197;
+  static_assert(32 * RLD <= 6 * G2PLANE, "row sums do not fit the plane storage");
+  if (ku < 7) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int v = 0; v < 7; ++v) sp[krow * RLD + q * 49 + ku * 7 + v] = dkacc[q][v];
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i < 196; i += blockDim.x) atomicAdd(&slots[(blockIdx.x % RSSF_GATE_SLOTS) * GATE_SLOT_ELEMS + i], sdk[i]);
+  if (tid < 196) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) sum += sp[r * RLD + tid];
+    atomicAdd(&slots[(blockIdx.x % RSSF_GATE_SLOTS) * GATE_SLOT_ELEMS + tid], sum);
+  }
 }
 
 // folds the slot copies into the parameter gradients: dk [196], dwl [4], dbl [2]
@@ -358,7 +458,7 @@ extern "C" int rssf_gate_pool_fwd(const void* x, const void* y, const float* sta
 extern "C" int rssf_gate_weights_fwd(const float* pooled, const float* k, const float* wl, const float* bl, float* gsig,
                                      float* omega, float* logits, int B, int H, int W, void* stream) {
   RSSF_REQUIRE(pooled && k && wl && bl && gsig && omega && B > 0 && H > 0 && W > 0, "gate_weights_fwd: bad arguments");
-  const int tiles = ((H + GT - 1) / GT) * ((W + GT - 1) / GT);
+  const int tiles = ((H + G2T - 1) / G2T) * ((W + G2T - 1) / G2T);
   gate_weights_fwd_kernel<<<dim3((unsigned)(B * tiles)), 256, 0, (hipStream_t)stream>>>(pooled, k, wl, bl, gsig, omega, logits, B, H, W);
   return check_launch("gate_weights_fwd");
 }
@@ -382,7 +482,7 @@ extern "C" int rssf_gate_weights_bwd(const float* domega, const float* pooled, c
   int rc = check_launch("gate_weights_bwd1");
   if (rc) return rc;
   // note: dpre layout is [B][2][N] contiguous after the 4N planes of ALL batches
-  const int tiles = ((H + GT - 1) / GT) * ((W + GT - 1) / GT);
+  const int tiles = ((H + G2T - 1) / G2T) * ((W + G2T - 1) / G2T);
   gate_weights_bwd2_kernel<<<dim3((unsigned)(B * tiles)), 256, 0, st>>>(dpre, pooled, k, dpooled, slots, B, H, W);
   rc = check_launch("gate_weights_bwd2");
   if (rc) return rc;
