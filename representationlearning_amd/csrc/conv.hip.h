@@ -104,7 +104,8 @@ int launch_dgrad_s2(const void* dout, const void* wpk, void* dx, const void* add
 bool pw_preact_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_pw(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* bn_raw, const void* bn_res,
               const float* bn_ss, float* bn_sums, int bn_act, int B, int H, int W, int Cin, int Cout, int CinP, int CoutP, hipStream_t st,
-              const PwPre* pre = nullptr);
+              const PwPre* pre = nullptr, const void* addend = nullptr);
+bool pw_addend_eligible(int Cin, int Cout);      // the stream kernel adds `addend` for this shape (64 -> 256: layer1's conv1 data gradients)
 int launch_stats_fold(const float* ws, int64_t tiles, int C, float* stats, hipStream_t st);
 int launch_wgrad_reduce(const rssf_wgrad_reduce_job& j, hipStream_t st);      // second stage of a split-K weight gradient (conv_wgrad.hip)
 int64_t wgrad_planes_workspace_elems(int B, int H, int W, int Cin, int Cout, int ntaps);     // 0: conv_wgrad_planes.hip does not serve the shape

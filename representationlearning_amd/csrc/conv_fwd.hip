@@ -770,9 +770,10 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
     const PwPre pp = {pre->stats, pre->gamma, pre->beta, pre->rmean, pre->rvar, pre->mi, pre->ss, pre->n, pre->momentum, pre->eps, pre->training, pre->act};
     return launch_pw(in, wpk, out, bias, stats, nullptr, nullptr, nullptr, nullptr, 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st, &pp);
   }
-  if (!generic && dtype == RSSF_BF16 && !pre && !a.stats_ws && !addend && pw_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
+  if (!generic && dtype == RSSF_BF16 && !pre && !a.stats_ws && (!addend || pw_addend_eligible(Cin, Cout)) &&
+      pw_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx))
     return launch_pw(in, wpk, out, bias, stats, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr, bn ? bn->sums : nullptr,
-                     bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st);
+                     bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, st, nullptr, addend);
   if (!generic && dtype == RSSF_BF16 && !pre && !a.stats_ws && taps128_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps))
     return launch_taps128(in, wpk, out, bias, stats, addend, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr,
                           bn ? bn->sums : nullptr, bn ? bn->act : 0, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, ntaps, dy, dx, st);

@@ -226,6 +226,42 @@ def test_pointwise_64_to_256_forward_and_dgrad(B, H, W):
     assert rel_err(sm1.cpu(), sm0.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 7, 9), (2, 64, 64), (1, 128, 128)])
+@pytest.mark.parametrize("mode", ["plain", "bn", "in_place"])
+def test_pointwise_64_to_256_dgrad_with_skip_gradient(B, H, W, mode):
+    """layer1's conv1 data gradients (the transpose of Conv2d(256, 64, 1), _hrnet_rssformer.py:249-287) ADD the residual path's
+    gradient: the stream kernel carries the addend (16-byte pieces, one tile ahead, added before rounding) - against the generic
+    kernel (which rounds the convolution first) and fp32; with the fused BatchNorm-backward statistics; accumulating in place."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(11)
+    down = nn.Conv2d(256, 64, 1, bias=False).to(DEV)
+    sd = nnf.spec_of([down])
+    dout = torch.randn(B, H, W, 64, device=DEV).bfloat16()
+    skip = torch.randn(B, H, W, 256, device=DEV).bfloat16()
+    link = nnf.BnBwdLink()
+    link.raw, link.rp, link.act, link.C = torch.randn(B, H, W, 256, device=DEV).bfloat16(), torch.randn(B, H, W, 256, device=DEV).bfloat16(), 1, 256
+    link.ss = torch.stack([torch.rand(256, device=DEV) + 0.5, torch.randn(256, device=DEV) * 0.3]).contiguous()
+    outs, sums = [], []
+    for on in (False, True):
+        sm = torch.zeros(nnf.BN_BWD_SLOTS * 2 * 256, device=DEV)
+        if mode == "in_place":
+            buf = skip.clone()
+            d = nnf._conv_dgrad(sd, dout, [down.weight.detach()], (B, H, W, 256), buf, out=buf, generic=not on)
+            assert d.data_ptr() == buf.data_ptr()
+        else:
+            d = nnf._conv_dgrad(sd, dout, [down.weight.detach()], (B, H, W, 256), skip, bn=(link, sm) if mode == "bn" else None, generic=not on)
+        outs.append(d.clone())
+        sums.append(sm.view(nnf.BN_BWD_SLOTS, 2, 256).sum(0))
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(dout.permute(0, 3, 1, 2).float(), down.weight.detach().bfloat16().float()).permute(0, 2, 3, 1) + skip.float()
+    assert rel_err(outs[1].float().cpu(), ref.cpu()) < 4e-3
+    assert rel_err(outs[1].float().cpu(), outs[0].float().cpu()) < 4e-3
+    # (one rounding instead of two: not further from fp32 than the generic kernel)
+    assert rel_err(outs[1].float().cpu(), ref.cpu()) <= rel_err(outs[0].float().cpu(), ref.cpu()) * 1.05
+    if mode == "bn":
+        assert rel_err(sums[1].cpu(), sums[0].cpu()) < 3e-3
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,taps", [
     (2, 16, 64, 480, 480, [(0, 0)]),                                   # the neck's point-wise convolution (hrnet_aux.py:45-49), small map
     (1, 8, 64, 160, 224, [(0, 0), (-1, 2), (3, -5)]),                 # a ragged last input chunk (32 of 128) and output tile (96 of 128)
