@@ -15,7 +15,9 @@
 // so a wave takes 16 consecutive (i, j..j+15): the four shifted dout tiles are coalesced-enough 16-byte loads that ARE the MFMA operands
 // (lane = pixel x 8-channel group, as in conv_pw.hip; out-of-range rows / columns load zeros), the nine weight slabs sit in LDS as bf16
 // (shared by the block's eight waves, read as fragments), and the MFMAs form the TRANSPOSED results: a lane holds four consecutive
-// input channels of one dx pixel per fragment - 8-byte stores, and the producer's raw values in the same layout for the statistics.
+// input channels of one dx pixel per fragment, and the rows of a fragment PAIR are a permutation of 32 channels (the slabs are staged in
+// that row order) that makes a lane's 4 + 4 values eight consecutive channels (conv_pw.hip): 16-byte stores, and the addend and the
+// producer's raw values in 16-byte pieces of the same layout.
 // The next tile's loads are in flight under the current tile's 72 MFMAs.  No masks, no staging, no barrier in the loop.
 #include <cstring>
 #include <type_traits>
@@ -34,6 +36,10 @@ struct S2Args {
   int B, OH, OW, CiP, CoP;
   int64_t ntiles;          // B * OH * OW / 16
 };
+
+// channel (less 8 grp) of value r of result fragment n; LDS row of input channel ci inside a slab (conv_pw.hip's pairing)
+__device__ __forceinline__ constexpr int s2_co(int n, int r) { return 32 * (n >> 1) + 4 * (n & 1) + r; }
+__device__ __forceinline__ int s2_row(int ci) { return ((ci >> 5) * 2 + ((ci >> 2) & 1)) * 16 + ((ci >> 3) & 3) * 4 + (ci & 3); }
 
 __device__ __forceinline__ float row16_sum_s2(float v) {
   v += dpp_mov<0xB1>(v);
@@ -56,7 +62,7 @@ __global__ void __launch_bounds__(512) conv_dgrad_s2_kernel(S2Args a) {
   // the nine slabs: 16-byte pieces, (tap, ci) rows of CO channels
   for (int i = tid; i < 9 * CI * (CO / 8); i += 512) {
     const int row = i / (CO / 8), c8 = (i % (CO / 8)) * 8, t = row / CI, ci = row % CI;
-    *reinterpret_cast<u32x4*>(WS + (size_t)row * LDW + c8) = *reinterpret_cast<const u32x4*>(a.wpk + ((size_t)t * a.CiP + ci) * a.CoP + c8);
+    *reinterpret_cast<u32x4*>(WS + (size_t)(t * CI + s2_row(ci)) * LDW + c8) = *reinterpret_cast<const u32x4*>(a.wpk + ((size_t)t * a.CiP + ci) * a.CoP + c8);
   }
   if constexpr (BNB) {
     if (tid < 2 * CI) sss[tid] = a.bn_ss[tid];
@@ -96,7 +102,6 @@ __global__ void __launch_bounds__(512) conv_dgrad_s2_kernel(S2Args a) {
   float s1[NT * 4], s2[NT * 4];
 #pragma unroll
   for (int e = 0; e < NT * 4; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
   for (; t < a.ntiles; t += stride) {
     u32x4 xc[4][KS];
@@ -120,8 +125,8 @@ __global__ void __launch_bounds__(512) conv_dgrad_s2_kernel(S2Args a) {
     const int64_t r = t / tpr;
     const int i = (int)(r % a.OH), b = (int)(r / a.OH);
     const int j = jt * 16 + l15;
-    // dx pixel (2 i + pi, 2 j + pj): element offset of this lane's 4 channels of fragment 0
-    const int64_t px00 = (((int64_t)b * 2 * a.OH + 2 * i) * IW + 2 * j) * CI + grp * 4;
+    // dx pixel (2 i + pi, 2 j + pj): element offset of this lane's 8 channels of fragment pair 0
+    const int64_t px00 = (((int64_t)b * 2 * a.OH + 2 * i) * IW + 2 * j) * CI + grp * 8;
     // one parity class: acc = sum over its (tap, shifted tile) pairs; store; statistics
     auto cls = [&](int pi, int pj, auto... pairs) {            // pairs: std::integral_constant<int, 4 * tap + shifted tile>: compile-time indices
       f32x4 acc[NT];
@@ -143,41 +148,50 @@ __global__ void __launch_bounds__(512) conv_dgrad_s2_kernel(S2Args a) {
       const int64_t po = px00 + ((int64_t)pi * IW + pj) * CI;
       if (a.addend) {                                           // block-uniform
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const u32x2 av = *reinterpret_cast<const u32x2*>(a.addend + po + n * 16);
-          acc[n][0] += __uint_as_float(av[0] << 16); acc[n][1] += __uint_as_float(av[0] & 0xffff0000u);
-          acc[n][2] += __uint_as_float(av[1] << 16); acc[n][3] += __uint_as_float(av[1] & 0xffff0000u);
+        for (int q = 0; q < NT / 2; ++q) {
+          const u32x4 av = *reinterpret_cast<const u32x4*>(a.addend + po + q * 32);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4& c = acc[2 * q + h];
+            c[0] += __uint_as_float(av[2 * h] << 16); c[1] += __uint_as_float(av[2 * h] & 0xffff0000u);
+            c[2] += __uint_as_float(av[2 * h + 1] << 16); c[3] += __uint_as_float(av[2 * h + 1] & 0xffff0000u);
+          }
         }
       }
-      u32x2 rawv[BNB ? NT : 1], resv[BNB ? NT : 1];
+      u32x4 rawv[BNB ? NT / 2 : 1], resv[BNB ? NT / 2 : 1];
       if constexpr (BNB) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          rawv[n] = *reinterpret_cast<const u32x2*>(a.bn_raw + po + n * 16);
-          if (a.bn_res) resv[n] = *reinterpret_cast<const u32x2*>(a.bn_res + po + n * 16);
+        for (int q = 0; q < NT / 2; ++q) {
+          rawv[q] = *reinterpret_cast<const u32x4*>(a.bn_raw + po + q * 32);
+          if (a.bn_res) resv[q] = *reinterpret_cast<const u32x4*>(a.bn_res + po + q * 32);
         }
       }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const u32x2 o = {f2bf2(acc[n][0], acc[n][1]), f2bf2(acc[n][2], acc[n][3])};
-        *reinterpret_cast<u32x2*>(a.dx + po + n * 16) = o;
+      for (int q = 0; q < NT / 2; ++q) {
+        const u32x4 o = {f2bf2(acc[2 * q][0], acc[2 * q][1]), f2bf2(acc[2 * q][2], acc[2 * q][3]),
+                         f2bf2(acc[2 * q + 1][0], acc[2 * q + 1][1]), f2bf2(acc[2 * q + 1][2], acc[2 * q + 1][3])};
+        *reinterpret_cast<u32x4*>(a.dx + po + q * 32) = o;
         if constexpr (BNB) {
-          const f32x4 bsc4 = *reinterpret_cast<const f32x4*>(sss + n * 16 + grp * 4), bsh4 = *reinterpret_cast<const f32x4*>(sss + CI + n * 16 + grp * 4);
-          auto accumulate = [&](auto ACT) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const unsigned ow = o[q >> 1], rw = rawv[n][q >> 1];
-              const float g = (q & 1) ? __uint_as_float(ow & 0xffff0000u) : __uint_as_float(ow << 16);
-              const float x = (q & 1) ? __uint_as_float(rw & 0xffff0000u) : __uint_as_float(rw << 16);
-              float z = fmaf(x, bsc4[q], bsh4[q]);
-              if (a.bn_res) { const unsigned pw = resv[n][q >> 1]; z += (q & 1) ? __uint_as_float(pw & 0xffff0000u) : __uint_as_float(pw << 16); }
-              const float dz = decltype(ACT)::value == 1 ? (z > 0.f ? g : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
-              s1[n * 4 + q] += dz; s2[n * 4 + q] = fmaf(dz, x, s2[n * 4 + q]);
-            }
-          };
-          if (a.bn_act == 1) accumulate(std::integral_constant<int, 1>{});
-          else if (a.bn_act == 2) accumulate(std::integral_constant<int, 2>{});
-          else accumulate(std::integral_constant<int, 0>{});
+          for (int h = 0; h < 2; ++h) {
+            const int n = 2 * q + h;
+            const f32x4 bsc4 = *reinterpret_cast<const f32x4*>(sss + s2_co(n, 0) + grp * 8), bsh4 = *reinterpret_cast<const f32x4*>(sss + CI + s2_co(n, 0) + grp * 8);
+            auto accumulate = [&](auto ACT) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const unsigned ow = o[2 * h + (e >> 1)], rw = rawv[q][2 * h + (e >> 1)];
+                const float g = (e & 1) ? __uint_as_float(ow & 0xffff0000u) : __uint_as_float(ow << 16);
+                const float x = (e & 1) ? __uint_as_float(rw & 0xffff0000u) : __uint_as_float(rw << 16);
+                float z = fmaf(x, bsc4[e], bsh4[e]);
+                if (a.bn_res) { const unsigned pw = resv[q][2 * h + (e >> 1)]; z += (e & 1) ? __uint_as_float(pw & 0xffff0000u) : __uint_as_float(pw << 16); }
+                const float dz = decltype(ACT)::value == 1 ? (z > 0.f ? g : 0.f) : decltype(ACT)::value == 2 ? g * gelu_erf_grad(z) : g;
+                s1[n * 4 + e] += dz; s2[n * 4 + e] = fmaf(dz, x, s2[n * 4 + e]);
+              }
+            };
+            if (a.bn_act == 1) accumulate(std::integral_constant<int, 1>{});
+            else if (a.bn_act == 2) accumulate(std::integral_constant<int, 2>{});
+            else accumulate(std::integral_constant<int, 0>{});
+          }
         }
       }
     };
@@ -196,7 +210,7 @@ __global__ void __launch_bounds__(512) conv_dgrad_s2_kernel(S2Args a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { sred[(wave * 2 + 0) * CI + n * 16 + grp * 4 + q] = s1[n * 4 + q]; sred[(wave * 2 + 1) * CI + n * 16 + grp * 4 + q] = s2[n * 4 + q]; }
+      for (int q = 0; q < 4; ++q) { sred[(wave * 2 + 0) * CI + s2_co(n, q) + grp * 8] = s1[n * 4 + q]; sred[(wave * 2 + 1) * CI + s2_co(n, q) + grp * 8] = s2[n * 4 + q]; }
   }
   __syncthreads();
   if (tid < 2 * CI) {

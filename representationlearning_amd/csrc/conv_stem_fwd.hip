@@ -7,7 +7,8 @@
 // im2col row of an output pixel - 9 taps x 8 channels = 72 values - is the K axis directly: three K-steps of four taps; lane
 // (pixel, tap-in-step) loads ITS tap's 16-byte pixel straight into the MFMA operand register (out of the image, or tap 9..11: the
 // sentinel offset -> zeros), the [64][72] weights live in registers as twelve fragments per wave, and the MFMAs form the transposed
-// result - a lane holds four consecutive output channels of one pixel: 8-byte stores (conv_pw.hip).  Nothing is staged; the next
+// result - a lane holds four consecutive output channels of one pixel per fragment, eight per fragment pair (the weight rows of a pair
+// are fetched as conv_pw.hip's 32-channel permutation): 16-byte stores.  Nothing is staged; the next
 // tile's three loads are in flight under the current tile's twelve MFMAs and its stores.
 #include <cstring>
 #include "conv.hip.h"
@@ -21,6 +22,9 @@ struct StemFwdArgs {
   int B, IH, IW, OH, OW, CoutP, CinP;
   int64_t ntiles;          // B * OH * OW / 16
 };
+
+// channel (less 8 grp) of value r of result fragment j (conv_pw.hip's pairing)
+__device__ __forceinline__ constexpr int sf_co(int j, int r) { return 32 * (j >> 1) + 4 * (j & 1) + r; }
 
 __device__ __forceinline__ float row16_sum_sf(float v) {
   v += dpp_mov<0xB1>(v);
@@ -49,7 +53,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       u32x4 w = {0u, 0u, 0u, 0u};
-      if (tapok[ks]) w = *reinterpret_cast<const u32x4*>(a.wpk + ((size_t)tap * a.CoutP + j * 16 + l15) * a.CinP);
+      if (tapok[ks]) w = *reinterpret_cast<const u32x4*>(a.wpk + ((size_t)tap * a.CoutP + sf_co(j, l15 & 3) + 8 * (l15 >> 2)) * a.CinP);
       fw[j][ks] = __builtin_bit_cast(bf16x8, w);
     }
   }
@@ -80,7 +84,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xa[ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, off[ks], 0, 0));
   }
-  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
   for (; t < a.ntiles; t += stride) {
     u32x4 xc[KS];
     {
@@ -99,15 +102,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][ks], __builtin_bit_cast(bf16x8, xc[ks]), acc[j], 0, 0, 0);
     }
-    bf16_t* orow = a.out + (t * 16 + l15) * CO + grp * 4;
+    bf16_t* orow = a.out + (t * 16 + l15) * CO + grp * 8;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const u32x2 o = {f2bf2(acc[j][0], acc[j][1]), f2bf2(acc[j][2], acc[j][3])};
-      *reinterpret_cast<u32x2*>(orow + j * 16) = o;
-      if (want) {
+    for (int q = 0; q < NT / 2; ++q) {
+      const u32x4 o = {f2bf2(acc[2 * q][0], acc[2 * q][1]), f2bf2(acc[2 * q][2], acc[2 * q][3]),
+                       f2bf2(acc[2 * q + 1][0], acc[2 * q + 1][1]), f2bf2(acc[2 * q + 1][2], acc[2 * q + 1][3])};
+      *reinterpret_cast<u32x4*>(orow + q * 32) = o;
+    }
+    if (want) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float v = acc[j][r]; s1[j * 4 + r] += v; s2[j * 4 + r] = fmaf(v, v, s2[j * 4 + r]); }
-      }
     }
   }
   if (!want) return;
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { sred[wave][0][j * 16 + grp * 4 + r] = s1[j * 4 + r]; sred[wave][1][j * 16 + grp * 4 + r] = s2[j * 4 + r]; }
+      for (int r = 0; r < 4; ++r) { sred[wave][0][sf_co(j, r) + grp * 8] = s1[j * 4 + r]; sred[wave][1][sf_co(j, r) + grp * 8] = s2[j * 4 + r]; }
   }
   __syncthreads();
   if (tid < CO) {
