@@ -282,6 +282,88 @@ __global__ void __launch_bounds__(256) bilinear_bwd_px_kernel(const T* __restric
   }
 }
 
+// The same gather for a TILE of input pixels per block, separable and out of LDS (round 5).  With a thread per input pixel every lane
+// walks its own ~9 x 9 window of 12-byte pixels: a wave's load touches 64 different cache lines for 4 bytes each, every output pixel is
+// fetched by up to four input pixels, and the 16 x 512 x 512 x 6 gradient of the head's x 4 up-sampling (50 MB) took 81 us.  Here a
+// block owns TY x TX input pixels: the output rows / columns their windows cover are staged ONCE as flat dword runs (lanes on
+// consecutive dwords), summed along x into [window row][input column] partials (weights cx) and then along y (weights cy).  NU = 4-byte
+// units per pixel (PxUnit), pixel pitch of both tensors = NU units.
+constexpr int PXT_TY = 8, PXT_TX = 16, PXT_NYM = 40, PXT_NXM = 72;
+template <typename T, int NU>
+__global__ void __launch_bounds__(256) bilinear_bwd_px_tile_kernel(const T* __restrict__ dout, T* __restrict__ din, int B, int IH, int IW, int OH, int OW,
+                                                                   float sy, float sx, int tiles_y, int tiles_x) {
+  using U = PxUnit<T>;
+  typedef typename U::raw raw;
+  constexpr int CH = U::CH, NF = NU * CH;
+  __shared__ raw hi[PXT_NYM][PXT_NXM * NU];
+  __shared__ float part[PXT_NYM][PXT_TX][NF];
+  const int tid = threadIdx.x;
+  const int tx = (int)(blockIdx.x % (unsigned)tiles_x), t1 = (int)(blockIdx.x / (unsigned)tiles_x);
+  const int ty = t1 % tiles_y, b = t1 / tiles_y;
+  const int iy0 = ty * PXT_TY, ix0 = tx * PXT_TX;
+  // output rows / columns read by the tile's pixels: o with |o * s - i| < 1 for some i of the tile
+  int oyA = (int)floorf((iy0 - 1) / sy), oyB = (int)ceilf((iy0 + PXT_TY) / sy);
+  int oxA = (int)floorf((ix0 - 1) / sx), oxB = (int)ceilf((ix0 + PXT_TX) / sx);
+  oyA = oyA < 0 ? 0 : oyA; oyB = oyB > OH - 1 ? OH - 1 : oyB;
+  oxA = oxA < 0 ? 0 : oxA; oxB = oxB > OW - 1 ? OW - 1 : oxB;
+  const int NY = oyB - oyA + 1, NX = oxB - oxA + 1;          // <= PXT_NYM, PXT_NXM: the launcher checked the scale factors
+  const raw* src = reinterpret_cast<const raw*>(dout);
+  const int run = NX * NU;
+  for (int e = tid; e < NY * run; e += 256) {
+    const int r = e / run, c = e - r * run;
+    hi[r][c] = src[(((int64_t)b * OH + oyA + r) * OW + oxA) * NU + c];
+  }
+  __syncthreads();
+  // along x: part[r][ixl] = sum over ox of cx(ox, ix) * dout[oyA + r][ox]
+  for (int e = tid; e < NY * PXT_TX; e += 256) {
+    const int r = e / PXT_TX, ixl = e % PXT_TX, ix = ix0 + ixl;
+    float acc[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) acc[k] = 0.f;
+    if (ix < IW) {
+      int lo = (int)floorf((ix - 1) / sx), hi_ = (int)ceilf((ix + 1) / sx);
+      lo = lo < oxA ? oxA : lo; hi_ = hi_ > oxB ? oxB : hi_;
+      for (int ox = lo; ox <= hi_; ++ox) {
+        const float fx = src_coord(ox, sx);
+        const int x0 = (int)fx, x1 = x0 + 1 < IW ? x0 + 1 : IW - 1;
+        const float wx = fx - x0;
+        const float cx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          float v[CH];
+          U::get(hi[r][(ox - oxA) * NU + u], v);
+#pragma unroll
+          for (int k = 0; k < CH; ++k) acc[u * CH + k] += cx * v[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NF; ++k) part[r][ixl][k] = acc[k];
+  }
+  __syncthreads();
+  // along y
+  for (int e = tid; e < PXT_TY * PXT_TX; e += 256) {
+    const int iyl = e / PXT_TX, ixl = e % PXT_TX, iy = iy0 + iyl, ix = ix0 + ixl;
+    if (iy >= IH || ix >= IW) continue;
+    int lo = (int)floorf((iy - 1) / sy), hi_ = (int)ceilf((iy + 1) / sy);
+    lo = lo < oyA ? oyA : lo; hi_ = hi_ > oyB ? oyB : hi_;
+    float acc[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) acc[k] = 0.f;
+    for (int oy = lo; oy <= hi_; ++oy) {
+      const float fy = src_coord(oy, sy);
+      const int y0 = (int)fy, y1 = y0 + 1 < IH ? y0 + 1 : IH - 1;
+      const float wy = fy - y0;
+      const float cy = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+#pragma unroll
+      for (int k = 0; k < NF; ++k) acc[k] += cy * part[oy - oyA][ixl][k];
+    }
+    raw* dst = reinterpret_cast<raw*>(din) + (((int64_t)b * IH + iy) * IW + ix) * NU;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) dst[u] = U::put(acc + u * CH);
+  }
+}
+
 // out = (acc ? acc : 0) + nearest_up(in, s)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) nearest_add_fwd_kernel(const T* __restrict__ acc, const T* __restrict__ in, T* __restrict__ out, int B,
@@ -362,7 +444,12 @@ int bilinear_launch(const void* in, void* out, int B, int IH, int IW, int OH, in
   if (!vec && C % UCH == 0 && ldw % UCH == 0 && C / UCH <= PX_MAXU) {        // few channels: one thread per pixel
     const int gp = grid_for(px);
     if (!backward) bilinear_fwd_px_kernel<T><<<gp, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
-    else bilinear_bwd_px_kernel<T><<<gp, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
+    else if (C == 3 * UCH && ldw == C && sy > 0.f && sx > 0.f && (PXT_TY + 1) / sy + 3.f <= (float)PXT_NYM && (PXT_TX + 1) / sx + 3.f <= (float)PXT_NXM &&
+             (int64_t)B * OH * OW * C < ((int64_t)1 << 31)) {
+      // (the 6-class logits of the head in bf16, factor <= 4: a tile of input pixels per block, separable, out of LDS)
+      const int tiles_y = (IH + PXT_TY - 1) / PXT_TY, tiles_x = (IW + PXT_TX - 1) / PXT_TX;
+      bilinear_bwd_px_tile_kernel<T, 3><<<dim3((unsigned)(B * tiles_y * tiles_x)), 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, sy, sx, tiles_y, tiles_x);
+    } else bilinear_bwd_px_kernel<T><<<gp, 256, 0, st>>>((const T*)in, (T*)out, B, IH, IW, OH, OW, C, ldw, sy, sx);
     return check_launch(backward ? "upsample_bilinear_bwd" : "upsample_bilinear_fwd");
   }
   const int g = grid_for(px * (vec ? C / V : C));

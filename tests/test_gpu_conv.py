@@ -373,7 +373,8 @@ def test_conv_base_shape_linearity_bf16():
 
 @pytest.mark.parametrize("B,C,IH,IW,OH,OW", [(2, 64, 6, 5, 12, 10), (1, 256, 2, 1, 16, 8), (2, 6, 8, 8, 32, 32), (1, 18, 5, 7, 20, 28),
                                                     (2, 2, 5, 5, 17, 13), (1, 7, 4, 6, 9, 11), (1, 6, 64, 64, 256, 256), (3, 16, 3, 3, 3, 3),
-                                                    (1, 256, 4, 4, 32, 32), (2, 128, 8, 6, 32, 24), (1, 64, 5, 5, 40, 40)])      # factors >= 4: the row-parallel backward
+                                                    (1, 256, 4, 4, 32, 32), (2, 128, 8, 6, 32, 24), (1, 64, 5, 5, 40, 40),      # factors >= 4: the row-parallel backward
+                                                    (2, 6, 128, 128, 512, 512), (1, 6, 37, 53, 148, 212)])      # the head's logits: the tiled few-channel backward (full and ragged tiles)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upsample_bilinear(B, C, IH, IW, OH, OW, dtype):
     from representationlearning_amd import nnf
