@@ -468,10 +468,12 @@ int rssf_maxpool3x3s2(const void* in, void* out, int B, int IH, int IW, int C, i
 
 /* ---- CGFL loss: SegmentationLossaux.forward (module/CGFL.py:201-227) -> MCTransAuxLoss (losses/auxloss.py:257-305)
  *      -> softmax_focalloss (module/CGFL.py:72-101), on channels-last logits [B, HW, K] and int64 labels [B, HW] ---- */
-/* acc: fp32 scratch [B][6] (zeroed inside); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);
+/* acc: fp32 scratch of RSSF_LOSS_ACC_ELEMS floats per sample (zeroed inside; the six partial values of a sample lie on six cache
+ * lines of their own - atomics from many workgroups to one line serialise); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);
  * out[0] = loss, out[1] = backward coefficient (detached modulating bracket / n_valid).  A label outside [0, K) that is not
  * ignore_index (F.cross_entropy asserts on it) makes both NaN: the failure is loud, no out-of-range read happens. */
-/* deterministic != 0: one block per sample instead of up to 128 (no cross-block float atomics): bit-identical loss */
+/* deterministic != 0: one block per sample instead of up to 64 (no cross-block float atomics): bit-identical loss */
+#define RSSF_LOSS_ACC_ELEMS 192
 int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* aux, float* acc, float* out, int B, int HW, int K,
                        int KA, int ignore_index, int deterministic, int dtype, void* stream);
 /* dlogits = dloss * out[1] * (softmax(logits) - onehot(label)) on valid pixels, 0 on ignored ones; dloss may be NULL (=1) */

@@ -46,6 +46,15 @@ __device__ __forceinline__ void store_logits(T* dg, int K, const float* v) {
   }
 }
 
+// acc layout: RSSF_LOSS_ACC_ELEMS floats per sample, each of the six values at the head of a 128-byte line of its own.  Atomics of many
+// workgroups to ONE cache line serialise (~14 ns per wave-level request, whatever the address inside the line): with the packed
+// [B][6] layout the launch time grew linearly with the block count (32 blocks per sample 31 us, 64: 42, 128: 91, 256: 171 at
+// 16 x 512 x 512 x 6); spread over lines 64 blocks per sample take 22.5 us (128: 23.4, 256: 27.2) - DESIGN.md lesson 54.
+#define RSSF_LOSS_SS RSSF_LOSS_ACC_ELEMS
+#define RSSF_LOSS_VS 32
+#define RSSF_LOSS_BX 64
+#define RSSF_LOSS_UNR 4
+static_assert(RSSF_LOSS_ACC_ELEMS >= 6 * RSSF_LOSS_VS, "six lines per sample");
 template <typename T, int KC = 0>
 __global__ void __launch_bounds__(256) loss_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ acc,
                                                        int HW, int K_, int ignore_index) {
@@ -55,7 +64,7 @@ __global__ void __launch_bounds__(256) loss_fwd_kernel(const T* __restrict__ log
   float ce = 0.f, nv = 0.f, sm = 0.f, fg = 0.f, bg = 0.f, bad = 0.f;
   // UNR pixels of a thread in flight (compile-time class counts: the loop is a chain of memory round trips otherwise); the pixels
   // are consumed in the order of the plain loop, so the per-thread sums are the same numbers
-  constexpr int UNR = KC ? 4 : 1;
+  constexpr int UNR = KC ? RSSF_LOSS_UNR : 1;
   const int S = gridDim.x * blockDim.x;
   for (int p0 = blockIdx.x * blockDim.x + threadIdx.x; p0 < HW; p0 += UNR * S) {
     float vv[UNR][NV];
@@ -100,13 +109,15 @@ __global__ void __launch_bounds__(256) loss_fwd_kernel(const T* __restrict__ log
   if ((threadIdx.x & 63) == 0) { red[w][0] = ce; red[w][1] = nv; red[w][2] = sm; red[w][3] = fg; red[w][4] = bg; red[w][5] = bad; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float* a = acc + b * 6;
+    float* a = acc + b * RSSF_LOSS_SS;
     atomicAdd(a + 0, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    atomicAdd(a + 1, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
-    atomicAdd(a + 2, red[0][2] + red[1][2] + red[2][2] + red[3][2]);
-    if (fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])) > 0.f) atomicMax((int*)(a + 3), __float_as_int(1.f));
-    if (fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])) > 0.f) atomicMax((int*)(a + 4), __float_as_int(1.f));
-    if (fmaxf(fmaxf(red[0][5], red[1][5]), fmaxf(red[2][5], red[3][5])) > 0.f) atomicMax((int*)(a + 5), __float_as_int(1.f));
+    atomicAdd(a + 1 * RSSF_LOSS_VS, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    atomicAdd(a + 2 * RSSF_LOSS_VS, red[0][2] + red[1][2] + red[2][2] + red[3][2]);
+    // flags: 0 (the zeroed buffer) or 1 - every block that sets one stores the same bits, so a plain store does (returning atomics on
+    // one address from every block of a sample were the tail of this kernel: 32 us -> see DESIGN.md lesson 54)
+    if (fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3])) > 0.f) a[3 * RSSF_LOSS_VS] = 1.f;
+    if (fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4])) > 0.f) a[4 * RSSF_LOSS_VS] = 1.f;
+    if (fmaxf(fmaxf(red[0][5], red[1][5]), fmaxf(red[2][5], red[3][5])) > 0.f) a[5 * RSSF_LOSS_VS] = 1.f;
   }
 }
 
@@ -117,16 +128,16 @@ __global__ void __launch_bounds__(64) loss_finalize_kernel(const float* __restri
   // the end of every forward pass)
   float ce = 0.f, nv = 0.f, mf = 0.f, bad = 0.f;
   for (int b = threadIdx.x; b < B; b += 64) {
-    const float* a = acc + b * 6;
-    bad += a[5];
+    const float* a = acc + b * RSSF_LOSS_SS;
+    bad += a[5 * RSSF_LOSS_VS];
     float l1 = 0.f;
     for (int c = 0; c < KA; ++c) {
-      const float lab = c == 0 ? a[4] : (c == 1 ? a[3] : 0.f);
+      const float lab = c == 0 ? a[4 * RSSF_LOSS_VS] : (c == 1 ? a[3 * RSSF_LOSS_VS] : 0.f);
       l1 += 1.f / (1.f + expf(fabsf(aux[b * KA + c] - lab)));
     }
     l1 /= (2.f * B);
-    ce += a[0]; nv += a[1];
-    mf += a[2] * (1.f - l1 / 7.f);
+    ce += a[0]; nv += a[1 * RSSF_LOSS_VS];
+    mf += a[2 * RSSF_LOSS_VS] * (1.f - l1 / 7.f);
   }
   ce = wave_sum(ce); nv = wave_sum(nv); mf = wave_sum(mf); bad = wave_sum(bad);
   if (threadIdx.x != 0) return;
@@ -142,7 +153,7 @@ __global__ void __launch_bounds__(256) loss_bwd_kernel(const T* __restrict__ log
   constexpr int NV = KC ? KC : MAXK;
   const int K = KC ? KC : K_;
   const float g = coef[1] * (dloss ? dloss[0] : 1.f);
-  constexpr int UNR = KC ? 4 : 1;
+  constexpr int UNR = KC ? RSSF_LOSS_UNR : 1;
   const int64_t S = (int64_t)gridDim.x * blockDim.x;
   for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += UNR * S) {
     float vv[UNR][NV];
@@ -206,6 +217,45 @@ __global__ void __launch_bounds__(256) aux_pool_kernel(const T* __restrict__ f, 
     partial[((int64_t)b * AUX_CHUNKS + chunk) * C + threadIdx.x] = t;
   }
 }
+// Vector form (C a multiple of the 16-byte vector): a thread owns V channels, 256 / (C / V) pixel lanes per block, four loads in flight.
+// (The scalar form loads one 2-byte element per thread and iteration in a chain of 64 round trips: 29 us for the 16.8 MB of the
+// benchmark's feature map.)
+template <typename T>
+__global__ void __launch_bounds__(256) aux_pool_vec_kernel(const T* __restrict__ f, float* __restrict__ partial, int HW, int C) {
+  constexpr int V = Vec<T>::N;
+  __shared__ float red[256][V + 1];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int cpr = C / V, groups = 256 / cpr, cv = threadIdx.x % cpr, g = threadIdx.x / cpr;
+  const int per = (HW + AUX_CHUNKS - 1) / AUX_CHUNKS;
+  const int p0 = chunk * per, p1 = p0 + per < HW ? p0 + per : HW;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  if (g < groups) {
+    const T* base = f + (int64_t)b * HW * C + cv * V;
+    constexpr int RF = 4;
+    for (int p = p0 + g; p < p1; p += RF * groups) {
+      Vec<T> v[RF];
+#pragma unroll
+      for (int u = 0; u < RF; ++u) { const int q = p + u * groups < p1 ? p + u * groups : p; v[u].load(base + (int64_t)q * C); }
+#pragma unroll
+      for (int u = 0; u < RF; ++u)
+        if (p + u * groups < p1) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[e] += v[u].get(e);
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x, cvv = c / V, e = c % V;
+    float t = 0.f;
+    for (int k = 0; k < groups; ++k) t += red[k * cpr + cvv][e];
+    partial[((int64_t)b * AUX_CHUNKS + chunk) * C + c] = t;
+  }
+}
 __global__ void aux_linear_kernel(const float* __restrict__ partial, const float* __restrict__ w, const float* __restrict__ bias,
                                   float* __restrict__ out, int HW, int C, int K) {
   __shared__ float mean[AUX_MAXC];
@@ -232,8 +282,13 @@ extern "C" int rssf_aux_head_fwd(const void* feat, const float* weight, const fl
                "aux_head_fwd: bad arguments (C <= %d, K <= %d)", AUX_MAXC, AUX_MAXK);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(AUX_CHUNKS, (unsigned)B);
-  if (dtype == RSSF_F32) aux_pool_kernel<float><<<grid, 256, 0, st>>>((const float*)feat, workspace, HW, C);
-  else if (dtype == RSSF_BF16) aux_pool_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)feat, workspace, HW, C);
+  if (dtype == RSSF_F32) {
+    if (C % 4 == 0) aux_pool_vec_kernel<float><<<grid, 256, 0, st>>>((const float*)feat, workspace, HW, C);
+    else aux_pool_kernel<float><<<grid, 256, 0, st>>>((const float*)feat, workspace, HW, C);
+  } else if (dtype == RSSF_BF16) {
+    if (C % 8 == 0) aux_pool_vec_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)feat, workspace, HW, C);
+    else aux_pool_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)feat, workspace, HW, C);
+  }
   else { set_error("aux_head_fwd: unsupported dtype %d", dtype); return RSSF_ERR_UNSUPPORTED; }
   int rc = check_launch("aux_head_pool");
   if (rc) return rc;
@@ -245,9 +300,9 @@ extern "C" int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, con
                                   int KA, int ignore_index, int deterministic, int dtype, void* stream) {
   RSSF_REQUIRE(logits && labels && aux && acc && out && B > 0 && HW > 0 && K > 0 && K <= MAXK && KA >= 2, "cgfl_loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (int rcz = zero_floats(acc, (int64_t)6 * B, st)) return rcz;      // a kernel, not a memset node (common.hip.h)
+  if (int rcz = zero_floats(acc, (int64_t)RSSF_LOSS_SS * B, st)) return rcz;      // a kernel, not a memset node (common.hip.h)
   int bx = (HW + 255) / 256;
-  if (bx > 32) bx = 32;                // blocks per sample: every block ends in six same-address atomics (128: 57 us, 32: 27 us, 16: 35 us at 16 x 512 x 512 x 6)
+  if (bx > RSSF_LOSS_BX) bx = RSSF_LOSS_BX;                // blocks per sample (see RSSF_LOSS_SS above)
   if (deterministic) bx = 1;           // one block per sample: wave shuffles + an ordered 4-way sum, a single add into the zeroed acc
   dim3 grid((unsigned)bx, (unsigned)B);
 #define RSSF_LOSS_FWD(Tt, KCv) loss_fwd_kernel<Tt, KCv><<<grid, 256, 0, st>>>((const Tt*)logits, labels, acc, HW, K, ignore_index)

@@ -1884,7 +1884,7 @@ class _CGFLLoss(torch.autograd.Function):
         if labels.dtype != torch.int64 or labels.shape != (B, H, W):
             raise RuntimeError("cgfl_loss: labels must be int64 [B,H,W]")
         auxf = aux.detach().float().contiguous()
-        acc = torch.empty(B, 6, device=lh.device, dtype=torch.float32)
+        acc = torch.empty(B, 192, device=lh.device, dtype=torch.float32)      # RSSF_LOSS_ACC_ELEMS (include/rssf.h) per sample
         out = torch.empty(2, device=lh.device, dtype=torch.float32)
         L.check(L.load().rssf_cgfl_loss_fwd(L.ptr(lh), L.ptr(labels), L.ptr(auxf), L.ptr(acc), L.ptr(out), B, H * W, K, auxf.shape[1],
                                             ignore_index, int(current().deterministic), L.dtype_code(lh), L.stream()), "rssf_cgfl_loss_fwd")

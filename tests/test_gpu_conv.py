@@ -392,6 +392,20 @@ def test_upsample_bilinear(B, C, IH, IW, OH, OW, dtype):
     assert rel_err(xd.grad.float().cpu(), xr.grad) < tol
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 12, 8), (16, 32, 128, 128), (3, 24, 7, 5), (2, 20, 9, 9), (1, 64, 33, 31)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_aux_head_matches_torch(B, C, H, W, dtype):
+    """nnf.aux_head = Linear(AdaptiveAvgPool2d(1)(f).flatten(1)) (hrnet_aux.py:86-87, 99-100): the vector pooling kernel (C a multiple of
+    the 16-byte vector) and the scalar one, pixel counts that are not multiples of the 32 chunks."""
+    from representationlearning_amd import nnf
+    torch.manual_seed(5)
+    lin = nn.Linear(C, 7).to(DEV)
+    f = torch.randn(B, C, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    out = nnf.aux_head(f, lin)
+    ref = F.linear(f.float().mean((2, 3)), lin.weight.detach().float(), lin.bias.detach().float())
+    assert rel_err(out.cpu(), ref.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upsample_bilinear_concat(dtype):
     """SimpleFusion8's resize + cat (hrnet_aux.py:61-64) written slice by slice into one buffer, gradient read in place."""
