@@ -470,6 +470,7 @@ int rssf_maxpool3x3s2(const void* in, void* out, int B, int IH, int IW, int C, i
  *      -> softmax_focalloss (module/CGFL.py:72-101), on channels-last logits [B, HW, K] and int64 labels [B, HW] ---- */
 /* acc: fp32 scratch of RSSF_LOSS_ACC_ELEMS floats per sample (zeroed inside; the six partial values of a sample lie on six cache
  * lines of their own - atomics from many workgroups to one line serialise); aux [B][KA] fp32 image-level scores (KA = 7 in the reference);
+ * KA == 1: aux [B] IS the per-sample gamma (the l1 vector MCTransAuxLoss returns) - the call shape of softmax_focalloss(.., gamma=l1), CGFL.py:72, 221;
  * out[0] = loss, out[1] = backward coefficient (detached modulating bracket / n_valid).  A label outside [0, K) that is not
  * ignore_index (F.cross_entropy asserts on it) makes both NaN: the failure is loud, no out-of-range read happens. */
 /* deterministic != 0: one block per sample instead of up to 64 (no cross-block float atomics): bit-identical loss */

@@ -46,6 +46,7 @@ class WgradReduceJob(ctypes.Structure):       # rssf_wgrad_reduce_job
 
 
 GROUP_MAX = 4      # RSSF_GROUP_MAX
+LOSS_ACC_ELEMS = 192      # RSSF_LOSS_ACC_ELEMS: fp32 scratch per sample of rssf_cgfl_loss_fwd (tests/test_abi.py holds it against rssf.h)
 c_double = ctypes.c_double
 
 

@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(256) bn_finapply_planes_kernel(const bf16_t* _
 }  // namespace
 
 extern "C" int rssf_bn_finalize_apply_planes_supported(int B, int H, int W, int C, int pad, int dtype) {
-  return dtype == RSSF_BF16 && C == PL_C && B > 0 && H > 0 && W > 0 && (W % PL_PX) == 0 && pad >= 0 && (pad % 2) == 0 && ((W + 2 * pad) % 4) == 0 &&
+  return dtype == RSSF_BF16 && C == PL_C && B > 0 && H > 0 && W > 0 && (W % PL_PX) == 0 && pad >= 0 && (pad % 4) == 0 && ((W + 2 * pad) % 4) == 0 &&      /* pad % 4: the 8-byte stores start pad elements into a 16-byte-aligned plane row */
                  (int64_t)PL_C * B * (H + 2 * pad) * (W + 2 * pad) < ((int64_t)1 << 30)
              ? 1 : 0;
 }

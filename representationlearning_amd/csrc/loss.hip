@@ -131,11 +131,15 @@ __global__ void __launch_bounds__(64) loss_finalize_kernel(const float* __restri
     const float* a = acc + b * RSSF_LOSS_SS;
     bad += a[5 * RSSF_LOSS_VS];
     float l1 = 0.f;
-    for (int c = 0; c < KA; ++c) {
-      const float lab = c == 0 ? a[4 * RSSF_LOSS_VS] : (c == 1 ? a[3 * RSSF_LOSS_VS] : 0.f);
-      l1 += 1.f / (1.f + expf(fabsf(aux[b * KA + c] - lab)));
+    if (KA == 1) {
+      l1 = aux[b];                                           // the caller's own per-sample gamma (softmax_focalloss(.., gamma=l1), CGFL.py:72, 221)
+    } else {
+      for (int c = 0; c < KA; ++c) {
+        const float lab = c == 0 ? a[4 * RSSF_LOSS_VS] : (c == 1 ? a[3 * RSSF_LOSS_VS] : 0.f);
+        l1 += 1.f / (1.f + expf(fabsf(aux[b * KA + c] - lab)));
+      }
+      l1 /= (2.f * B);
     }
-    l1 /= (2.f * B);
     ce += a[0]; nv += a[1 * RSSF_LOSS_VS];
     mf += a[2 * RSSF_LOSS_VS] * (1.f - l1 / 7.f);
   }
@@ -298,7 +302,7 @@ extern "C" int rssf_aux_head_fwd(const void* feat, const float* weight, const fl
 
 extern "C" int rssf_cgfl_loss_fwd(const void* logits, const int64_t* labels, const float* aux, float* acc, float* out, int B, int HW, int K,
                                   int KA, int ignore_index, int deterministic, int dtype, void* stream) {
-  RSSF_REQUIRE(logits && labels && aux && acc && out && B > 0 && HW > 0 && K > 0 && K <= MAXK && KA >= 2, "cgfl_loss_fwd: bad arguments");
+  RSSF_REQUIRE(logits && labels && aux && acc && out && B > 0 && HW > 0 && K > 0 && K <= MAXK && KA >= 1, "cgfl_loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (int rcz = zero_floats(acc, (int64_t)RSSF_LOSS_SS * B, st)) return rcz;      // a kernel, not a memset node (common.hip.h)
   int bx = (HW + 255) / 256;

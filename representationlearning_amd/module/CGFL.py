@@ -2,6 +2,7 @@
 
 loss = CE_mean(valid) * [ sum_{all pixels} (1 - p_y)(1 - l1_b/7) / (n_valid + B) ]   — the bracket is detached, so the
 aux head gets no gradient.  Evaluated by the one-pass HIP loss kernels (csrc/loss.hip) through nnf.cgfl_loss."""
+import torch
 import torch.nn as nn
 
 from .. import nnf
@@ -9,13 +10,16 @@ from ..losses.auxloss import MCTransAuxLoss
 
 
 def softmax_focalloss(y_pred, y_true, ignore_index=-1, gamma=None, normalize=False, aux=None):
-    """Same call shape as the reference; `gamma` (the per-sample l1 vector) is recomputed inside the fused kernel from
-    `aux`, so callers on the HIP path pass the aux scores instead."""
+    """The reference's call shape (CGFL.py:72, 221: `softmax_focalloss(y_pred, y_true, gamma=l1)`): `gamma` is the per-sample l1
+    vector [B] that MCTransAuxLoss returns.  SegmentationLossaux passes the aux scores instead (`aux=`) and the fused kernel derives
+    l1 from them in its finalize launch."""
     if normalize:
         raise NotImplementedError("softmax_focalloss: normalize=True is not on the RSSFormer path")
-    if aux is None:
-        raise NotImplementedError("softmax_focalloss (HIP): pass the aux scores (aux=...); gamma is derived in-kernel")
-    return nnf.cgfl_loss(y_pred, y_true, aux, ignore_index)
+    if aux is not None:
+        return nnf.cgfl_loss(y_pred, y_true, aux, ignore_index)
+    if not torch.is_tensor(gamma):
+        raise TypeError("softmax_focalloss: gamma must be the per-sample tensor [B] (the reference unsqueezes it: CGFL.py:84), or pass aux=")
+    return nnf.cgfl_loss(y_pred, y_true, gamma.reshape(-1, 1), ignore_index)
 
 
 class SegmentationLossaux(nn.Module):

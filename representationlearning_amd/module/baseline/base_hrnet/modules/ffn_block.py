@@ -40,8 +40,9 @@ class MlpDWBN(nn.Module):
         # each hidden activation has ONE consumer: its BatchNorm-backward statistics ride on that consumer's data-gradient launch
         l1, l2 = nnf.bwd_stats_link(), nnf.bwd_stats_link()
         if l1 is not None:
-            # the tap sum's weight gradient reads its input TRANSPOSED (csrc/conv_wgrad_planes.hip): norm1's apply writes that copy too
-            l1.want_planes = True
+            # the tap sum's weight gradient reads its input TRANSPOSED (csrc/conv_wgrad_planes.hip): norm1's apply writes that copy too -
+            # where that kernel takes the shape (the apply's own shape test is wider: a copy nobody reads would be written)
+            l1.want_planes = nnf.wgrad_planes_ok(t, self.fc1.out_channels, [self.dw, self.dw6, self.dw12])
         t = nnf.conv_bn_act(t, self.fc1, self.norm1, nnf.ACT_GELU, stats_out=l1)
         # GELU(norm2(sum)) is consumed by fc2 alone: where fc2's kernels can apply norm2 + GELU on the raw sum while they load it, that
         # activation is never written (nnf.can_defer_apply: one 67 MB write + read less per block and direction)

@@ -102,6 +102,13 @@ class Runtime:
         k = (key, tuple(shape), dtype, str(device))
         buf = self.planes.get(k)
         if buf is None:
+            # born in the eager warm-up steps (Trainer runs three before it captures): inside a capture the zero-fill would become a
+            # node of the graph - a 94 MB fill replayed every step - and the buffer would live in the capture's private pool
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("planes_buffer: first use of %r inside a stream capture (run an eager step of this shape first)" % (k[1],))
+            # Memory: C * B * (H + 24) * (W + 24) bf16 per MlpDWBN block and input shape (94 MB at 16 x 128 x 128 x 128), kept for the
+            # life of the Runtime - a captured step replays against these addresses, so a set is never freed behind a graph's back;
+            # a run that trains on many crop shapes pays one set per shape (RSSF_WGRAD_PLANES=0 turns the path off)
             buf = self.planes[k] = torch.zeros(shape, device=device, dtype=dtype)
         self.planes_gen[k] = gen = self.planes_gen.get(k, 0) + 1
         return buf, k, gen
@@ -782,6 +789,17 @@ PLANES_PAD = 12                      # zero border of the transposed copy: the l
 _FUSED_PW_DGRAD = os.environ.get("RSSF_FUSED_PW_DGRAD", "1") != "0"      # A/B switch: a point-wise layer's data gradient inside its weight-gradient launch
 _FUSED_BN_APPLY = os.environ.get("RSSF_FUSED_BN_APPLY", "1") != "0"      # A/B switch: BatchNorm-backward apply inside the weight-gradient launch
 _FUSED_BN_STATS = os.environ.get("RSSF_FUSED_BN_STATS", "1") != "0"      # A/B switch (tools)
+
+
+def wgrad_planes_ok(x, C, convs):
+    """True when the weight gradient of `convs` (summed, stride 1, C -> C channels) on an input of x's batch / size takes the
+    transposed-planes operand (rssf_conv_wgrad_planes_supported with the pad the apply pass writes)."""
+    if not (_WGRAD_PLANES and x.is_cuda and x.dtype == torch.bfloat16):
+        return False
+    sp = spec_of(list(convs))
+    B, _, H, W = x.shape
+    return bool(sp.parts is None and sp.stride == 1 and sp.cin == C and
+                L.load().rssf_conv_wgrad_planes_supported(B, H, W, C, sp.cout, 1, sp.ntaps, sp.c_dy, sp.c_dx, PLANES_PAD, L.RSSF_BF16) == 1)
 
 
 def bwd_stats_link():
@@ -1884,7 +1902,7 @@ class _CGFLLoss(torch.autograd.Function):
         if labels.dtype != torch.int64 or labels.shape != (B, H, W):
             raise RuntimeError("cgfl_loss: labels must be int64 [B,H,W]")
         auxf = aux.detach().float().contiguous()
-        acc = torch.empty(B, 192, device=lh.device, dtype=torch.float32)      # RSSF_LOSS_ACC_ELEMS (include/rssf.h) per sample
+        acc = torch.empty(B, L.LOSS_ACC_ELEMS, device=lh.device, dtype=torch.float32)      # RSSF_LOSS_ACC_ELEMS (include/rssf.h) per sample
         out = torch.empty(2, device=lh.device, dtype=torch.float32)
         L.check(L.load().rssf_cgfl_loss_fwd(L.ptr(lh), L.ptr(labels), L.ptr(auxf), L.ptr(acc), L.ptr(out), B, H * W, K, auxf.shape[1],
                                             ignore_index, int(current().deterministic), L.dtype_code(lh), L.stream()), "rssf_cgfl_loss_fwd")

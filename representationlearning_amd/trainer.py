@@ -62,7 +62,8 @@ class FlatParams:
         keep = set(keep)
         for i in self.pairs:                 # a tightly packed pair goes in or out as a whole: every range starts 16-byte aligned
             if (i in keep) != (i + 1 in keep):
-                keep |= {i, i + 1}
+                # (widening the range silently would hand a gradient-free parameter weight decay and momentum, which torch.optim.SGD skips)
+                raise RuntimeError("FlatParams.ranges_of: parameters %d / %d are packed as one aligned pair but only one of them is live" % (i, i + 1))
         out = []
         for i in sorted(keep):
             s, e = self.offsets[i], self.offsets[i + 1]

@@ -61,3 +61,5 @@ def test_library_reads_no_environment_variable():
     und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in und
     assert _lib.CONV_GENERIC == 0x100 and "#define RSSF_CONV_GENERIC 0x100" in open(os.path.join(ROOT, "include", "rssf.h")).read()
+    # the loss scratch the Python side allocates is the header's (the ABI had changed from 6 to 192 floats per sample silently)
+    assert "#define RSSF_LOSS_ACC_ELEMS %d\n" % _lib.LOSS_ACC_ELEMS in open(os.path.join(ROOT, "include", "rssf.h")).read()

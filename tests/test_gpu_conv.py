@@ -509,6 +509,33 @@ def test_cgfl_loss_class_counts_vs_oracle(K, dtype):
     assert rel_err(ld.grad.float().cpu(), lr.grad) < (1e-5 if f32 else 1e-2)
 
 
+def test_softmax_focalloss_takes_the_reference_gamma_vector():
+    """`softmax_focalloss(y_pred, y_true, gamma=l1)` - the reference's own call (CGFL.py:221) with the per-sample l1 vector of
+    MCTransAuxLoss - equals the `aux=` form whose finalize launch derives l1 itself, and the oracle."""
+    from oracle import rssformer_cpu as O
+    from representationlearning_amd.module.CGFL import softmax_focalloss
+    torch.manual_seed(3)
+    B, K = 3, 6
+    lg = torch.randn(B, K, 10, 11) * 2.0
+    y = torch.randint(-1, K, (B, 10, 11))
+    aux = torch.randn(B, 7)
+    fg = (y > 0) & (y != -1)
+    lab = torch.zeros_like(aux)
+    lab[:, 0] = (~fg).flatten(1).any(1).float()
+    lab[:, 1] = fg.flatten(1).any(1).float()
+    l1 = (1.0 / (1.0 + torch.exp((aux - lab).abs()))).sum(1) / (2 * B)
+    want = O.cgfl_loss(lg.clone(), y, aux)
+    a = lg.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    b = lg.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    la = softmax_focalloss(a, y.to(DEV), gamma=l1.to(DEV))
+    lb = softmax_focalloss(b, y.to(DEV), aux=aux.to(DEV))
+    la.backward(); lb.backward()
+    assert abs(float(la) - float(want)) < 2e-6 * max(1.0, abs(float(want))) and abs(float(la) - float(lb)) < 1e-6
+    assert rel_err(a.grad.float().cpu(), b.grad.float().cpu()) < 1e-6
+    with pytest.raises(TypeError):
+        softmax_focalloss(a, y.to(DEV), gamma=2)
+
+
 def test_cgfl_loss_full_size_properties():
     """BASELINE config-2 size (16 x 6 x 512 x 512): finite, gradient sums to zero over classes, zero on ignored pixels."""
     from representationlearning_amd import nnf

@@ -140,10 +140,14 @@ def test_train_py_runs_saves_and_resumes(tmp_path):
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "train.py"), "--model_dir", str(tmp_path), "--batch", "2", "--size", "64", "--synthetic_tiles", "4",
-           "--config_path", "baseline.hrnetw18", "train.log_interval_step", "1", "train.eval_interval_epoch", "1"]
+           "--config_path", "baseline.hrnetw18", "train.log_interval_step", "1", "train.eval_interval_epoch", "1",
+           "train.save_ckpt_interval_epoch", "2"]
     r = subprocess.run(cmd + ["--iters", "5"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "iter 5" in r.stdout and "mIoU" in r.stdout and os.path.exists(tmp_path / "model-5.pth")
+    # 4 tiles / batch 2 = 2 iterations per epoch: the interval of 2 epochs saves after iteration 4 and not after iteration 2 (ADVICE r5:
+    # the save had slipped out of its rank-0 / interval guard)
+    assert os.path.exists(tmp_path / "model-4.pth") and not os.path.exists(tmp_path / "model-2.pth"), sorted(os.listdir(tmp_path))
     sd = torch.load(tmp_path / "model-5.pth")
     assert "backbone.hrnet.stage2.0.transformer.attn.attn.q_proj.weight" in sd
     ts = torch.load(tmp_path / "trainer-5.pth")

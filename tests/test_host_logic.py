@@ -267,3 +267,30 @@ def test_train_checkpoint_discovery(tmp_path):
     (tmp_path / "trainer-40.pth").write_bytes(b"x")
     step, mp, tp = train.latest_checkpoint(str(tmp_path))
     assert step == 40 and mp.endswith("model-40.pth") and tp.endswith("trainer-40.pth")
+
+
+def test_train_py_saves_checkpoints_on_rank_zero_only():
+    """Every save_checkpoint call of train.main sits under an `if` that tests `rank == 0` (the per-epoch save had been
+    dedented out of its guard - every rank of a data-parallel run then wrote and renamed the same files)."""
+    import ast, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = ast.parse(open(os.path.join(root, "train.py")).read())
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    parents = {}
+    for node in ast.walk(main):
+        for ch in ast.iter_child_nodes(node):
+            parents[ch] = node
+    calls = [n for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, "id", None) == "save_checkpoint"]
+    assert len(calls) >= 2
+    for c in calls:
+        node, guarded = c, False
+        while node in parents:
+            prev, node = node, parents[node]
+            if isinstance(node, ast.If) and prev in node.body and "rank == 0" in ast.unparse(node.test):
+                guarded = True
+        assert guarded, "save_checkpoint at line %d is not under a rank-0 guard" % c.lineno
+    # the per-epoch save also honours its interval
+    src = open(os.path.join(root, "train.py")).read()
+    assert src.count("trainer.check_exchange()          # never a checkpoint") == 1
+    guard = [n for n in ast.walk(main) if isinstance(n, ast.If) and "save_ckpt_interval_epoch" in ast.unparse(n.test)]
+    assert guard and any(isinstance(x, ast.Call) and getattr(x.func, "id", None) == "save_checkpoint" for g in guard for x in ast.walk(g))

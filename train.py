@@ -233,8 +233,7 @@ def main():
             evaluate()
         if rank == 0 and tr.save_ckpt_interval_epoch and ep_done % tr.save_ckpt_interval_epoch == 0:
             trainer.check_exchange()          # never a checkpoint of replicas that may have diverged
-            trainer.check_exchange()
-        log("saved", save_checkpoint(args.model_dir, model, trainer))
+            log("saved", save_checkpoint(args.model_dir, model, trainer))
     if n_timed:
         log("host time per logged iteration: loader (draw + decode-if-new + one rssf_input_pipeline launch) %.2f ms, step enqueue+sync %.2f ms; "
             "resident tiles %.0f %%" % (1e3 * t_load / n_timed, 1e3 * t_step / n_timed, 100 * loader.resident_fraction()))
