@@ -81,6 +81,12 @@ struct HaloArgs {
 bool halo_eligible(int IH, int IW, int Cin, int OH, int OW, int mul, int div, int ntaps, const int* dy, const int* dx);
 int launch_halo(HaloArgs a, hipStream_t st);
 int launch_halo_group(HaloArgs* items, int n, hipStream_t st);      // n <= RSSF_GROUP_MAX problems as one grid
+// the same convolution at 32 -> 32 channels as a row stream: weights in registers, no LDS staging (conv_rows32.hip); identity / ReLU only
+struct PwPre;
+bool rows32_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps, const int* dy, const int* dx);
+int launch_rows32(const void* in, const void* wpk, void* out, const float* bias, float* stats, const void* addend, const void* bn_raw,
+                  const void* bn_res, const float* bn_ss, float* bn_sums, int bn_act, const PwPre* pre, int B, int H, int W, bool mirror,
+                  hipStream_t st);
 // many-tap 128 -> 128 channel convolutions with the pixel operand in registers (conv_taps128.hip): MlpDWBN's fused 17-tap sum, forward
 // and data gradient (bf16)
 bool taps128_eligible(int B, int IH, int IW, int Cin, int OH, int OW, int Cout, int mul, int div, int ntaps);

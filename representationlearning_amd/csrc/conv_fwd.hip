@@ -748,6 +748,19 @@ int conv_gather_impl(const void* in, const void* wpk, void* out, const float* bi
   a.CoutP = (Cout + bnt - 1) / bnt * bnt;
   a.CinP = (Cin + bk - 1) / bk * bk;
   hipStream_t st = (hipStream_t)stream;
+#ifndef RSSF_ROWS32_DISABLE        // (A/B builds: tools/ab_lib_flags.sh)
+  // 32 -> 32 channels (the full-resolution branch's BasicBlocks): the row stream with the weights in registers (conv_rows32.hip)
+  if (!generic && dtype == RSSF_BF16 && !a.stats_ws && (!pre || pre->act <= 1) && (!bn || bn->act <= 1) &&
+      rows32_eligible(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx)) {
+    const bool mirror = dy[0] > 0;
+    if (mirror ? (!pre && !stats && !bias) : (!addend && !bn)) {
+      PwPre pp;
+      if (pre) pp = PwPre{pre->stats, pre->gamma, pre->beta, pre->rmean, pre->rvar, pre->mi, pre->ss, pre->n, pre->momentum, pre->eps, pre->training, pre->act};
+      return launch_rows32(in, wpk, out, bias, stats, addend, bn ? bn->raw : nullptr, bn ? bn->res : nullptr, bn ? bn->ss : nullptr,
+                           bn ? bn->sums : nullptr, bn ? bn->act : 0, pre ? &pp : nullptr, B, IH, IW, mirror, st);
+    }
+  }
+#endif
   if (halo_path(B, IH, IW, Cin, OH, OW, Cout, mul, div, ntaps, dy, dx, dtype)) {
     const bool fused = bn && (Cout % 8) == 0;               // the 16-byte-row epilogue carries the statistics
     const HaloArgs h = make_halo(in, wpk, out, bias, stats, addend, a.stats_ws, fused ? bn : nullptr, pre, B, IH, IW, Cin, Cout, a.CinP, a.CoutP, dy, dx);
@@ -849,16 +862,29 @@ extern "C" int rssf_conv3x3_group(const rssf_conv3x3_item* items, int n, int mir
   }
   if (grouped) {
     HaloArgs hs[RSSF_GROUP_MAX];
+    int nh = 0;
     for (int i = 0; i < n; ++i) {
       const rssf_conv3x3_item& it = items[i];
       const BnBwdStats bn = {it.bn_raw, it.bn_res, it.bn_ss, it.bn_sums, it.bn_act};
       const PreAct pre = {it.pre_stats, it.pre_gamma, it.pre_beta, it.pre_running_mean, it.pre_running_var, it.pre_mean_invstd, it.pre_ss,
                           (float)it.pre_n, it.pre_momentum, it.pre_eps, it.pre_training, it.pre_act};
+#ifndef RSSF_ROWS32_DISABLE
+      // a 32 -> 32 channel member runs on the row-stream kernel, in a launch of its own (conv_gather_impl picks it), ahead of the group
+      if (rows32_eligible(it.B, it.H, it.W, it.Cin, it.H, it.W, it.Cout, 1, 1, 9, dy, dx) && (!it.pre_ss || it.pre_act <= 1) && (!it.bn_sums || it.bn_act <= 1) &&
+          (mirrored ? !it.stats : (!it.addend && !it.bn_sums))) {
+        const int rc = conv_gather_impl(it.in, it.wpk, it.out, nullptr, it.stats, it.addend, nullptr, it.bn_sums ? &bn : nullptr,
+                                        it.pre_ss ? &pre : nullptr, it.B, it.H, it.W, it.Cin, it.H, it.W, it.Cout, 1, 1, 9, dy, dx, dtype, stream);
+        if (rc) return rc;
+        continue;
+      }
+#endif
       const int bnt = pick_bn(it.Cout);
-      hs[i] = make_halo(it.in, it.wpk, it.out, nullptr, it.stats, it.addend, nullptr, it.bn_sums ? &bn : nullptr, it.pre_ss ? &pre : nullptr, it.B,
-                        it.H, it.W, it.Cin, it.Cout, (it.Cin + 31) / 32 * 32, (it.Cout + bnt - 1) / bnt * bnt, dy, dx);
+      hs[nh++] = make_halo(it.in, it.wpk, it.out, nullptr, it.stats, it.addend, nullptr, it.bn_sums ? &bn : nullptr, it.pre_ss ? &pre : nullptr, it.B,
+                           it.H, it.W, it.Cin, it.Cout, (it.Cin + 31) / 32 * 32, (it.Cout + bnt - 1) / bnt * bnt, dy, dx);
     }
-    return launch_halo_group(hs, n, (hipStream_t)stream);
+    if (nh == 0) return RSSF_OK;
+    if (nh == 1) return launch_halo(hs[0], (hipStream_t)stream);
+    return launch_halo_group(hs, nh, (hipStream_t)stream);
   }
   for (int i = 0; i < n; ++i) {
     const rssf_conv3x3_item& it = items[i];

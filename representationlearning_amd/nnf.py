@@ -688,8 +688,8 @@ def _conv_forward(spec, xh, weights, bias, stats, rt=None, addend=None, preact=N
         (pst, pga, pbe, prm, prv, pmi, pss, pn, pmom, peps, ptr), pact = preact
         L.check(lib.rssf_conv_gather_preact(L.ptr(xh), L.ptr(pst), L.ptr(pga), L.ptr(pbe), L.ptr(prm), L.ptr(prv), L.ptr(pmi), L.ptr(pss), pn, pmom,
                                             peps, int(ptr), pact, L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), L.ptr(ws), B, H, W, C, OH, OW,
-                                            spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh), L.stream()),
-                "rssf_conv_gather_preact")
+                                            spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh) | (L.CONV_GENERIC if generic else 0),
+                                            L.stream()), "rssf_conv_gather_preact")
         return out
     L.check(lib.rssf_conv_gather_add(L.ptr(xh), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(stats), L.ptr(addend), L.ptr(ws), B, H, W, C, OH, OW,
                                      spec.cout, spec.stride, 1, spec.ntaps, spec.c_dy, spec.c_dx, L.dtype_code(xh) | (L.CONV_GENERIC if generic else 0),
