@@ -188,3 +188,4 @@ def test_rows32_member_of_a_grouped_launch():
         assert torch.equal(a, b)
         C = a.shape[-1]
         assert rel_err(t.view(-1, 2, C).sum(0).cpu(), s.view(-1, 2, C).sum(0).cpu()) < 1e-5
+

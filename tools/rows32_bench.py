@@ -1,4 +1,5 @@
-"""The 32 -> 32 channel 3x3 convolution at branch 0's geometry (B x 128 x 128 x 32): the row-stream kernel (csrc/conv_rows32.hip)
+"""(The weight-gradient cases time the halo kernel in both columns: the row-stream weight gradient was measured and dropped, DESIGN lesson 55.)
+The 32 -> 32 channel 3x3 convolution at branch 0's geometry (B x 128 x 128 x 32): the row-stream kernel (csrc/conv_rows32.hip)
 against the halo kernel (RSSF_CONV_GENERIC in the call), forward / pre-activation forward / data gradient with the fused
 BatchNorm-backward statistics and a skip gradient, launch times by HIP events - back to back on one operand set (cache-resident, what
 a step's producer -> consumer chain sees) and cycling through a ring of operand sets larger than the 256 MB Infinity Cache.
@@ -60,13 +61,45 @@ def dgrad(flag, res=True, add=True, bn=True):
                                          spec.c_ndy, spec.c_ndx, L.RSSF_BF16 | flag, L.stream()), "dgrad")
 
 
-cases = [("forward + statistics", fwd, 2), ("pre-activation forward + statistics", pre, 2),
+nws = lib.rssf_conv_wgrad_workspace_elems(B, H, W, C, C, 9)
+wsb = torch.empty(nws, device=dev)
+dwb = torch.zeros(C, C, 3, 3, device=dev)
+dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+mi2 = torch.cat([torch.randn(C, device=dev) * 0.2, torch.rand(C, device=dev) + 0.5]).contiguous()
+xss = torch.cat([torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.3]).contiguous()
+sums2 = torch.randn(nnf.BN_BWD_SLOTS * 2 * C, device=dev)
+
+
+import ctypes
+job = L.WgradReduceJob()
+DEFER = os.environ.get("DEFER", "1") != "0"      # first stage only (the step defers every reduction to one batched launch)
+
+
+def wgrad(flag, fuse=True, res=True, xpre=True):
+    s = cur()
+    tail = (L.ptr(dwb), None, None, spec.c_ksizes, 1, spec.c_src, spec.c_kpos, spec.c_alias, None, L.ptr(wsb), B, H, W, C, H, W, C, 1, 9, spec.c_dy, spec.c_dx,
+            ctypes.byref(job) if DEFER else None, L.RSSF_BF16 | flag, L.stream())
+    if fuse:
+        L.check(lib.rssf_conv_wgrad_bnapply(L.ptr(s["x"]), L.ptr(s["raw"]), L.ptr(ss), L.ptr(mi2), L.ptr(sums2), L.ptr(s["res"]) if res else None, L.ptr(s["out"]),
+                                            L.ptr(s["add"]) if res else None, L.ptr(dgm), L.ptr(dbt), 1, n, 1, 1.0, L.ptr(s["raw"]), L.ptr(xss) if xpre else None, 1,
+                                            *tail), "wgrad fused")
+    else:
+        L.check(lib.rssf_conv_wgrad(L.ptr(s["x"]), L.ptr(s["raw"]), *tail), "wgrad")
+
+
+cases = [("weight gradient plain", lambda f: wgrad(f, False, False, False), 2),
+         ("weight gradient + BN-backward apply", lambda f: wgrad(f, True, False, False), 4),
+         ("weight gradient + apply + residual + pre-activation input", lambda f: wgrad(f, True, True, True), 6),
+         ("forward + statistics", fwd, 2), ("pre-activation forward + statistics", pre, 2),
          ("data gradient plain", lambda f: dgrad(f, False, False, False), 2),
          ("data gradient + BN-backward statistics", lambda f: dgrad(f, False, False, True), 3),
          ("data gradient + statistics + residual + skip gradient", lambda f: dgrad(f, True, True, True), 5)]
 tb = B * H * W * C * 2 / 1e6
 print("B=%d %dx%d C=%d: one tensor = %.1f MB, 4.8 GFLOP at B = 16" % (B, H, W, C, tb))
+ONLY = os.environ.get("CASES")
 for name, fn, ntens in cases:
+    if ONLY and not any(k in name for k in ONLY.split(",")):
+        continue
     row = []
     for ring in (False, True):
         state["ring"] = ring
