@@ -124,11 +124,32 @@ def measure_dominant_kernels(B, S, iters=30, C=32):
     x = torch.relu(torch.randn(B, H, W, C, device=dev)).bfloat16()
     cstats = torch.zeros(nnf.BN_SLOTS * 2 * C, device=dev)
     flops = 2.0 * rows * C * C * 9
-    us = _time_us(lambda: nnf._conv_forward(spec, x, [conv.weight], None, cstats), iters)
-    entry("conv3x3_halo_kernel<8,%d> (+ 4 us weight pack)" % C, us, 2 * tensor_bytes, "3x3 conv %d->%d with fused BN statistics: read in, write out" % (C, C), flops)
+    # the launches alone, as in the step: the weights are packed once per step for all layers (nnf.PackPlan), the split-K second stage of
+    # every weight gradient is the step's ONE batched reduction
+    import ctypes
+    wpk = nnf._pack(spec, [conv.weight], False, x.dtype, x.device)
+    wpk_t = nnf._pack(spec, [conv.weight], True, x.dtype, x.device)
+    cout = torch.empty_like(x)
+    dims = (B, H, W, C, H, W, C, 1, 1, 9)
+    us = _time_us(lambda: L.check(lib.rssf_conv_gather_add(L.ptr(x), L.ptr(wpk), L.ptr(cout), None, L.ptr(cstats), None, None, *dims, spec.c_dy, spec.c_dx,
+                                                           code, st()), "conv"), iters)
+    entry("conv3x3_rows32_kernel<forward>", us, 2 * tensor_bytes, "3x3 conv %d->%d with fused BN statistics: read in, write out" % (C, C), flops)
+    us = _time_us(lambda: L.check(lib.rssf_conv_gather_add(L.ptr(x), L.ptr(wpk), L.ptr(cout), None, L.ptr(cstats), None, None, *dims, spec.c_dy, spec.c_dx,
+                                                           code | L.CONV_GENERIC, st()), "conv"), iters)
+    entry("conv3x3_halo_kernel<8,%d> (the generic kernel on the same call: RSSF_CONV_GENERIC)" % C, us, 2 * tensor_bytes,
+          "3x3 conv %d->%d with fused BN statistics: read in, write out" % (C, C), flops)
+    us = _time_us(lambda: L.check(lib.rssf_conv_gather_bnbwd(L.ptr(dy), L.ptr(wpk_t), L.ptr(cout), L.ptr(draw), L.ptr(raw), L.ptr(x), L.ptr(ss), 1, L.ptr(sums),
+                                                             *dims, spec.c_ndy, spec.c_ndx, code, st()), "dgrad"), iters)
+    entry("conv3x3_rows32_kernel<data gradient, BN-backward statistics, residual, skip gradient>", us, 5 * tensor_bytes,
+          "3x3 data gradient %d->%d: read dout, raw, residual, skip gradient; write dx" % (C, C), flops)
     dw = torch.zeros_like(conv.weight)
-    us = _time_us(lambda: nnf._conv_wgrad(spec, dy, x, [dw], None), iters)
-    entry("conv3x3_wgrad_halo_kernel + wgrad_reduce_kernel", us, 2 * tensor_bytes, "3x3 weight gradient %dx%d: read dout, in" % (C, C), flops)
+    nws = lib.rssf_conv_wgrad_workspace_elems(B, H, W, C, C, 9)
+    wws = torch.empty(nws, device=dev)
+    wjob = L.WgradReduceJob()
+    us = _time_us(lambda: L.check(lib.rssf_conv_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), None, None, spec.c_ksizes, 1, spec.c_src, spec.c_kpos, spec.c_alias, None,
+                                                      L.ptr(wws), B, H, W, C, H, W, C, 1, 9, spec.c_dy, spec.c_dx, ctypes.byref(wjob), code, st()), "wgrad"), iters)
+    entry("conv3x3_wgrad_halo_kernel (first stage; %d partial planes)" % int(wjob.ksplit), us, 2 * tensor_bytes,
+          "3x3 weight gradient %dx%d: read dout, in" % (C, C), flops)
     # MlpDWBN's fc1 backward at the same map: 4C <- C point-wise weight gradient with the BatchNorm-backward apply fused in
     # (conv_wgrad_pw.hip): reads dy, raw [4C] and the input [C], writes draw [4C]
     C4 = 4 * C

@@ -1119,7 +1119,13 @@ int conv_wgrad_impl(const void* dout, const void* in, float* dw0, float* dw1, fl
   a.ksplit = pick_ksplit(Cout, Cin, ntaps, (int64_t)B * OH * OW);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RSSF_BF16 && workspace && !dbias && halo_wgrad_eligible(IH, IW, Cin, OH, OW, Cout, stride, ntaps, nsrc, dy, dx)) {
-    constexpr int stpb = 8, smin = 256;          // tiles per block / fewest blocks (swept in round 4: tools/wgrad_bench.py)
+#ifndef RSSF_HALO_WG_TPB
+#define RSSF_HALO_WG_TPB 8
+#endif
+#ifndef RSSF_HALO_WG_MIN
+#define RSSF_HALO_WG_MIN 256
+#endif
+    constexpr int stpb = RSSF_HALO_WG_TPB, smin = RSSF_HALO_WG_MIN;          // tiles per block / fewest blocks (swept in round 4: tools/wgrad_bench.py)
     const WgradHaloArgs h = make_wgrad_halo(dout, in, workspace, B, IH, IW, Cin, Cout, bn, xpre, a.ksplit, stpb, smin);
     const dim3 hgrid((unsigned)h.xcd_per * 8);
     if (xpre) {

@@ -10,6 +10,25 @@ namespace {
 // G lanes (a power of two) serve one row, the first C / VEC of them hold VEC channels each - C = 48 bf16 is six live lanes of
 // eight (Large: the one-thread-per-row fallback took 117 us forward / 868 us backward per launch at 4 x 1024 x 1024);
 // fallback (C not a multiple of VEC, or more than 16 lanes): one thread per row, scalar loop.
+// sum over the G lanes of a row's lane group (G = 1, 2, 4, 8, 16 consecutive lanes inside one 16-lane DPP row), result in every lane
+// of the group: pure VALU (the __shfl_xor form is ds_bpermute - an LDS instruction with ~100 cycles of latency - twice per row sum
+// on the dependency chain of every row)
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+  if (G >= 2) v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+  if (G >= 4) v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_mov<0x141>(v);       // row_half_mirror
+  if (G >= 16) v += dpp_mov<0x140>(v);      // row_mirror
+  return v;
+}
+// sum over the lanes of a wave that own the same channels (same lane % G), result in every such lane
+template <int G> __device__ __forceinline__ float same_sub_sum(float v) {
+  if (G <= 8) v += dpp_mov<0x128>(v);       // row_ror:8
+  if (G <= 4) v += dpp_mov<0x124>(v);       // row_ror:4
+  if (G <= 2) v += dpp_mov<0x122>(v);       // row_ror:2
+  if (G <= 1) v += dpp_mov<0x121>(v);       // row_ror:1
+  return rows_reduce<OpSum>(v);             // the four 16-lane rows
+}
+
 template <typename T, int G>
 __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, T* __restrict__ y,
@@ -26,16 +45,14 @@ __global__ void __launch_bounds__(256) ln_fwd_vec(const T* __restrict__ x, const
 #pragma unroll
     for (int i = 0; i < VEC; ++i) s += v.get(i);
   }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  s = group_sum<G>(s);
   const float mean = s / C;
   float q = 0.f;
   if (ok) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { float d = v.get(i) - mean; q += d * d; }
   }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  q = group_sum<G>(q);
   const float rstd = rsqrtf(q / C + eps);
   if (!ok) return;
   if (stats && sub == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
@@ -148,8 +165,7 @@ __global__ void __launch_bounds__(RSSF_LN_BWD_THREADS) ln_bwd_vec(const T* __res
       s1 += g[i]; s2 += g[i] * xh[i];
       ag[i] += d * xh[i]; ab[i] += d;
     }
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 = group_sum<G>(s1); s2 = group_sum<G>(s2);
     s1 /= C; s2 /= C;
     float o[VEC];
 #pragma unroll
@@ -186,9 +202,7 @@ __global__ void __launch_bounds__(RSSF_LN_BWD_THREADS) ln_bwd_vec(const T* __res
   }
   // lanes that own the same channels (same `sub`) inside a wave are folded by shuffles before the LDS atomics
 #pragma unroll
-  for (int o = 32; o >= G; o >>= 1)
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { ag[i] += __shfl_xor(ag[i], o, 64); ab[i] += __shfl_xor(ab[i], o, 64); }
+  for (int i = 0; i < VEC; ++i) { ag[i] = same_sub_sum<G>(ag[i]); ab[i] = same_sub_sum<G>(ab[i]); }
   if ((threadIdx.x & 63) < G && live) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { atomicAdd(&sg[sub * VEC + i], ag[i]); atomicAdd(&sb[sub * VEC + i], ab[i]); }

@@ -27,6 +27,9 @@ using namespace rssf::wa;
 #ifndef RSSF_FWD_OCC
 #define RSSF_FWD_OCC 2             // waves per SIMD the register allocator makes room for (bf16)
 #endif
+#ifndef RSSF_FWD_DBG
+#define RSSF_FWD_DBG 0             // timing builds only (tools/ab_lib_flags.sh): 1 no softmax arithmetic, 2 no attention core (S / softmax / PV),
+#endif                             // 4 no LayerNorm / gate arithmetic in the tile staging, 8 no projections either (tiles -> out-projection)
 #ifndef RSSF_FWD_PREFETCH_STATS
 #define RSSF_FWD_PREFETCH_STATS 1  // LayerNorm statistics travel with the prefetched tiles (1) or are fetched at use (0)
 #endif
@@ -238,6 +241,7 @@ __device__ __forceinline__ void tiles_finish(const TileRegs<T, DM>& R, const rss
 #else
       const float2 sx = sxv[it], sy = syv[it];
 #endif
+      if (RSSF_FWD_DBG & 4) { fx[i] = R.vx[it].get(i) + sx.x + w0[i] + ga; fy[i] = R.vy[it].get(i) + sy.y + w1[i] + be; continue; }
       fx[i] = ((R.vx[it].get(i) - sx.x) * sx.y * ga + be) * w0[i];
       fy[i] = ((R.vy[it].get(i) - sy.x) * sy.y * ga + be) * w1[i];
     }
@@ -459,6 +463,11 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
         // Of key tile 3 (keys 48..63) only key 48 is live - element r = 0 of lane group 0: the other three rows of that tile are
         // constants (-inf / 0) and cost no arithmetic.
         static_assert(LW == 3 * 16 + 1 && NT == 4, "softmax: 49 live keys in four 16-key tiles");
+        if (RSSF_FWD_DBG & 2) {
+#pragma unroll
+          for (int mi = 0; mi < TPH; ++mi) o[h * TPH + mi][qt] = PK::pack(s[mi]);
+          continue;
+        }
         s[3][0] = grp == 0 ? s[3][0] : -INFINITY;
         float mx = s[3][0];
 #pragma unroll
@@ -469,6 +478,7 @@ __global__ void __launch_bounds__((FwdLayout<T, DM>::WAVES * 64), (FwdOcc<T, DM>
         const f32x2 mx2 = {mx, mx};
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
+          if (RSSF_FWD_DBG & 1) continue;
           const f32x2 lo = pk_sub_lo(f32x2{s[kt][0], s[kt][1]}, mx2), hi = pk_sub_lo(f32x2{s[kt][2], s[kt][3]}, mx2);
           s[kt][0] = __builtin_amdgcn_exp2f(lo[0]); s[kt][1] = __builtin_amdgcn_exp2f(lo[1]);
           s[kt][2] = __builtin_amdgcn_exp2f(hi[0]); s[kt][3] = __builtin_amdgcn_exp2f(hi[1]);

@@ -35,7 +35,19 @@ def _oracle_step(variant, x, y, dtype=torch.float32, backward=True):
     return loss.detach(), taps, P
 
 
-def _gpu_step(variant, x, y, backward=True):
+def _gpu_step(variant, x, y, backward=True, deterministic=False):
+    """deterministic: fixed-order BatchNorm statistics and loss sums (nnf.Runtime.deterministic) - the comparison with the
+    oracle then carries no run-to-run noise of the statistics' atomics."""
+    from representationlearning_amd import nnf
+    rt = nnf.current()
+    was, rt.deterministic = rt.deterministic, bool(deterministic)
+    try:
+        return _gpu_step_inner(variant, x, y, backward)
+    finally:
+        rt.deterministic = was
+
+
+def _gpu_step_inner(variant, x, y, backward):
     m = _build(variant).train()
     hr = m.backbone.hrnet
     taps, handles = {}, []
@@ -59,7 +71,7 @@ def test_base_full_step_2x512_fp32_vs_oracle():
     module does not route its gradient through a max."""
     B, S = 2, 512
     x, y = seeded_input((B, 3, S, S), 7), proc_labels(B, S, S, 6, 8)
-    loss_g, taps_g, m = _gpu_step("base", x, y)
+    loss_g, taps_g, m = _gpu_step("base", x, y, deterministic=True)       # (VERDICT r5: no atomics noise in the oracle comparison)
     loss_o, taps_o, P = _oracle_step("base", x, y)
     assert abs(float(loss_g) - float(loss_o)) < 1e-3 * abs(float(loss_o)), (float(loss_g), float(loss_o))
     assert rel_err(taps_g["logits"][:, :, ::16, ::16].cpu(), taps_o["logits"][:, :, ::16, ::16].detach()) < 1e-3
@@ -81,15 +93,16 @@ def test_base_full_step_2x512_fp32_vs_oracle():
     assert np.median(dev) < max(3e-3, 3 * np.median(self_dev)), (np.median(dev), np.median(self_dev))
     assert np.percentile(dev, 95) < max(3e-2, 3 * np.percentile(self_dev, 95)), (np.percentile(dev, 95), np.percentile(self_dev, 95))
     # element-wise (norm of the difference over the norm), parameter by parameter, outside the max-routed modules
-    # (bar: 3e-2; a parameter whose gradient is a cancelling sum - a BatchNorm bias deep in the net - gets 5x the distance between
+    # (bar: 2e-2; a parameter whose gradient is a cancelling sum - a BatchNorm bias deep in the net - gets 4x the distance between
     # the oracle's OWN fp32 and fp64 gradients when that is larger: the reference cannot pin it tighter than it pins itself)
     plain = [k for k in live if not any(s in k for s in ROUTED)]
     assert len(plain) > 0.8 * len(live)
     errs = {k: rel_err(got[k].cpu(), P[k].grad) for k in plain}
     spread = {k: rel_err(P64[k].grad.float(), P[k].grad) for k in plain}
-    # (round 5: one run in three of the suite saw a BatchNorm weight of stage4's fuse layers at 2.6e-2 against 4 x 0.64e-2 - the run-to-run
-    # noise of the statistics' atomics on a cancelling sum; the bar is 3e-2 / 5 x now, still far below a wrong kernel's O(1))
-    bad = [(k, errs[k], spread[k]) for k in plain if errs[k] > max(3e-2, 5 * spread[k])]
+    # (round 5 had loosened this to 3e-2 / 5 x for the run-to-run noise of the statistics' atomics on a cancelling sum - one run in
+    # three saw a BatchNorm weight of stage4's fuse layers at 2.6e-2; round 6 runs the step in deterministic-statistics mode instead
+    # and holds the round-4 bar)
+    bad = [(k, errs[k], spread[k]) for k in plain if errs[k] > max(2e-2, 4 * spread[k])]
     assert not bad, bad[:5]
     # in distribution the HIP path sits as close to the fp32 oracle as the oracle's fp64 run does (measured, MI355X: median element-wise
     # distance 3.0e-2 vs 2.1e-2, p95 3.8e-2 vs 2.7e-2 - a 300-layer BatchNorm network at random initialisation amplifies rounding differences of ANY two
