@@ -27,8 +27,10 @@ typedef enum { RSSF_F32 = 0, RSSF_BF16 = 1 } rssf_dtype;
 /* Kernel selection is a function of the call's arguments only (shape, dtype, which optional operands are present): no environment
  * variable or other process state steers it.  The one explicit knob: OR RSSF_CONV_GENERIC into the `dtype` argument of the
  * rssf_conv_gather* / rssf_conv_wgrad* entry points to run the generic gather / halo / tiled kernels instead of a shape-specialised one
- * (the point-wise stream kernels of the forward pass and of the weight gradient, the 128-channel many-tap kernel) - same results up to
- * the summation order; the parity tests hold the two against each other. */
+ * (the point-wise stream kernels of the forward pass and of the weight gradient, the 128-channel many-tap kernel, the 32 -> 32 channel
+ * 3x3 row-stream kernel of rssf_conv_gather* / rssf_conv_gather_preact / rssf_conv_gather_bnbwd / rssf_conv3x3_group: conv_rows32.hip)
+ * - same results up to the summation order (bit-identical for the 3x3 forward without a bias); the parity tests hold the two against
+ * each other. */
 #define RSSF_CONV_GENERIC 0x100
 /* OR-ed into the `dtype` argument of rssf_conv_wgrad_bnapply: the caller will not read `draw` after the call (the layer needs no data
  * gradient - the stem's first convolution): a kernel that forms draw on the fly may skip writing it.  `draw` must still be a valid buffer. */
@@ -607,8 +609,9 @@ int rssf_debug_mma(const void* a, const void* b, float* d, int K, int dtype, voi
 int rssf_debug_lane_reduce(const float* in, float* out, void* stream);
 /* probe of the LDS transpose read (ds_read_b64_tr_b16): lds[i] = i, lane l reads at element address addr[l] */
 int rssf_debug_trread(const int* addr, short* out, void* stream);
-/* fills the LDS of every CU with `pattern` (e.g. 0x7fc07fc0: bf16 / fp32 NaNs): a kernel launched next that reads LDS it never wrote sees it
- * (scratch4: 4 bytes of device memory) */
+/* TEST HOOK, not part of any training / inference path (tests/test_gpu_trainer.py::test_step_does_not_read_uninitialised_lds is its one
+ * caller): fills the LDS of every CU with `pattern` (e.g. 0x7fc07fc0: bf16 / fp32 NaNs), so that a kernel launched next that reads LDS it
+ * never wrote sees it (scratch4: 4 bytes of device memory) */
 int rssf_debug_poison_lds(unsigned pattern, void* scratch4, void* stream);
 
 #ifdef __cplusplus

@@ -53,8 +53,12 @@ template <typename T, typename DM, bool ACC_LDS> struct BwdLayout {
   static constexpr int PAIR_ELEMS = 3 * REGX + 3 * REGV + 2 * SCRATCH;
   static constexpr size_t WAVE_BYTES = sizeof(T) * PAIR_ELEMS;            // per pair
   static constexpr size_t LIM = 160 * 1024 - 64;     // 64 B: the statically allocated pair-barrier counters
-  static constexpr int PAIRS = (SHARED_OFF + 4 * WAVE_BYTES <= LIM) ? 4 : (SHARED_OFF + 3 * WAVE_BYTES <= LIM) ? 3
-                             : (SHARED_OFF + 2 * WAVE_BYTES <= LIM) ? 2 : 1;
+#ifndef RSSF_BWD_MAX_PAIRS
+#define RSSF_BWD_MAX_PAIRS 4       // timing builds only: fewer window pairs per workgroup (= waves per SIMD halved at 2)
+#endif
+  static constexpr int PAIRS_FIT = (SHARED_OFF + 4 * WAVE_BYTES <= LIM) ? 4 : (SHARED_OFF + 3 * WAVE_BYTES <= LIM) ? 3
+                                 : (SHARED_OFF + 2 * WAVE_BYTES <= LIM) ? 2 : 1;
+  static constexpr int PAIRS = PAIRS_FIT < RSSF_BWD_MAX_PAIRS ? PAIRS_FIT : RSSF_BWD_MAX_PAIRS;
   static constexpr int WAVES = 2 * PAIRS;
   static constexpr size_t BYTES = SHARED_OFF + WAVE_BYTES * PAIRS;
   static constexpr bool FITS = BYTES <= LIM;

@@ -84,6 +84,9 @@ template <typename U> __device__ __forceinline__ U* at_bytes(void* base, unsigne
 // {a.x - b.x, a.y - b.x} as ONE packed instruction (the compiler emits two v_sub_f32 for scores that come out of an MFMA)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk_sub_lo(f32x2 a, f32x2 b) {
+#ifdef RSSF_FWD_NO_PK
+  return f32x2{a[0] - b[0], a[1] - b[0]};
+#endif
   f32x2 d;
   asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
   return d;
@@ -611,6 +614,9 @@ int launch_fwd(const rssf_winattn_fwd_params* p, const Geom& g, hipStream_t st) 
   });
   if (e != hipSuccess) { set_error("winattn_fwd: cannot raise LDS limit: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
   if (blocks > resident[dev]) blocks = resident[dev];
+#ifdef RSSF_FWD_GRID_DIV           // timing builds only: a 1 / n grid (one workgroup per CU at n = 2: the window chain of a wave ALONE on its SIMD)
+  if (blocks > resident[dev] / RSSF_FWD_GRID_DIV) blocks = resident[dev] / RSSF_FWD_GRID_DIV;
+#endif
   Geom gx = g;
   gx.xcd_major = (blocks % 8 == 0 && blocks >= 8) ? 1 : 0;
   kern<<<blocks, LY::WAVES * 64, LY::BYTES, st>>>(*p, gx);
