@@ -881,9 +881,16 @@ __device__ __forceinline__ void wgrad_halo_block(const WgradHaloArgs& a, const i
 #pragma unroll
     for (int kk = 0; kk < HNPX / 64; ++kk) {                  // 32 pixels = image rows 2ks, 2ks+1 of the tile
       const bf16x8 fa = tr8(dbase + kk * 32 * HLD, HTW);
+#ifdef RSSF_HALO_WG_DBG_ONEREAD      // timing builds only: ONE input fragment read per K-step instead of nine (what the transposing reads cost)
+      const bf16x8 fb0 = tr8(xbase + ((2 * kk) * (HTW + 2)) * HLD, HTW + 2);
+#endif
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
+#ifdef RSSF_HALO_WG_DBG_ONEREAD
+        const bf16x8 fb = fb0;
+#else
         const bf16x8 fb = tr8(xbase + ((2 * kk + tap / 3 - 1) * (HTW + 2) + tap % 3 - 1) * HLD, HTW + 2);
+#endif
         acc[tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[tap], 0, 0, 0);
       }
     }
@@ -1313,7 +1320,13 @@ extern "C" int rssf_conv3x3_wgrad_group(const rssf_wgrad3x3_item* items, int n, 
       int ksplit = 1;
       // the problems of a group fill the chip TOGETHER: each may run longer tile runs per block (fewer split-K partial planes for
       // the second stage to fold: 3.5 GB per step with runs of 8) as long as it keeps >= gmin blocks
-      constexpr int gtpb = 16, gmin = 128;
+#ifndef RSSF_HALO_WG_GTPB
+#define RSSF_HALO_WG_GTPB 16
+#endif
+#ifndef RSSF_HALO_WG_GMIN
+#define RSSF_HALO_WG_GMIN 128
+#endif
+      constexpr int gtpb = RSSF_HALO_WG_GTPB, gmin = RSSF_HALO_WG_GMIN;
       g.it[i] = make_wgrad_halo(it.bn_dy ? it.draw : it.dout, it.in, it.workspace, it.B, it.H, it.W, it.Cin, it.Cout, it.bn_dy ? &bn : nullptr,
                                 it.in_ss ? &xp : nullptr, ksplit, n >= 2 ? gtpb : 8, n >= 2 ? gmin : 256);
       g.start[i] = idx;
