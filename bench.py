@@ -387,6 +387,9 @@ def main():
         trainer.step(img, target)
     for _ in range(args.warmup):
         loss = trainer.step(img, target)
+    nch = (1 + len(trainer.side_comms)) if trainer.p2p is not None else 0
+    for k in range(nch):                              # (the exchange kernels count what they wait for their peers: start the count here)
+        trainer.p2p.wait_us(k, reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -403,6 +406,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss)
+    # per rank and exchange channel (the step's stream, then the side streams): exchanges per step and the ms per step they spent waiting
+    # for their peers' words - rank skew + xGMI write / poll latency, the part of a data-parallel step that is not this rank's own work
+    exch = None
+    if nch:
+        mine = [trainer.p2p.wait_us(k) for k in range(nch)]
+        t = torch.tensor([[us / 1e3 / args.steps, n / args.steps] for us, n in mine], device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(t) for _ in range(world)] if world > 1 else [t]
+        if world > 1:
+            dist.all_gather(allr, t)
+        exch = [{"rank": r, "wait_ms_per_step": [round(float(v[0]), 3) for v in a], "exchanges_per_step": [int(round(float(v[1]))) for v in a]}
+                for r, a in enumerate(allr)]
 
     if rank == 0:
         f0, s0, c0 = VARIANTS[args.variant]
@@ -421,6 +435,7 @@ def main():
                        "step_launch": "hipGraph replay" if trainer.graph is not None else "eager", "graph_init_steps": init_steps,
                        "rccl_nranks": (trainer.grad_comm.nranks() if hasattr(trainer.grad_comm, "nranks") else None) if world > 1 else None,
                        "p2p_self_test": None if world == 1 else ("passed" if trainer.p2p is not None else "not run / failed: RCCL exchanges"),
+                       "p2p_exchange_wait": exch,
                        "collectives": None if world == 1 else (
                            "SyncBN: %s, one channel / communicator per stream (main + %d side); gradients: %s" % (
                                "peer-to-peer kernel over hipIpc windows" if trainer.p2p is not None else "RCCL all-reduce", len(trainer.side_comms),

@@ -569,6 +569,11 @@ int rssf_p2p_exchange(rssf_p2p* p2p, int channel, float* stats, const int* item_
  * with 10 000 ms. */
 int rssf_p2p_set_timeout_ms(rssf_p2p* p2p, int ms);
 int rssf_p2p_status(rssf_p2p* p2p, int* timed_out);
+/* diagnosis of a multi-GPU run: the time the exchanges of `channel` have spent WAITING for their peers' words since the object was
+ * created (or since the last call with reset != 0), in microseconds, and how many exchanges that was - counted on the device by the
+ * exchange kernel itself (it rides in the captured step), read here with a synchronising copy.  What a rank waits is the skew of the
+ * slowest peer plus the xGMI write / poll latency: `bench.py --gpus N` prints it per rank. */
+int rssf_p2p_wait_us(rssf_p2p* p2p, int channel, double* wait_us, int64_t* exchanges, int reset);
 int rssf_p2p_destroy(rssf_p2p* p2p);
 
 /* ---- Mix-Transformer (SegFormer MiT) inference operators of the SCD class-activation-map path: BASELINE config 5 as worded

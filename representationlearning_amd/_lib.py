@@ -179,6 +179,7 @@ SIGNATURES = {
     "rssf_p2p_connect_local": (c_int, [c_void_p, c_int, c_void_p]),
     "rssf_p2p_set_timeout_ms": (c_int, [c_void_p, c_int]),
     "rssf_p2p_status": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "rssf_p2p_wait_us": (c_int, [c_void_p, c_int, ctypes.POINTER(c_double), ctypes.POINTER(ctypes.c_int64), c_int]),
     "rssf_p2p_destroy": (c_int, [c_void_p]),
     "rssf_debug_lane_reduce": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rssf_debug_trread": (c_int, [c_void_p, c_void_p, c_void_p]),

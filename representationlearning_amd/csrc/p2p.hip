@@ -36,6 +36,7 @@ struct ExArgs {
   u64* win[MAX_WORLD];          // base of every rank's window (this process's mapping), already offset to the channel
   unsigned* epoch;              // this rank's epoch counter of the channel (device memory)
   unsigned* err;                // this rank's error word: != 0 after a timed-out wait
+  u64* wait;                    // this rank's {ticks spent waiting for peers, exchanges} of the channel (rssf_p2p_wait_us)
   float* stats;
   int item_off[RSSF_P2P_MAX_ITEMS], item_n[RSSF_P2P_MAX_ITEMS];   // per layer: offset of its [nslots][n] block in `stats`, n = 2C
   int nitems, nslots, rank, world;
@@ -88,6 +89,9 @@ __global__ void __launch_bounds__(256) p2p_exchange_kernel(ExArgs a) {
     }
     blk[0] = t;
     for (int s = 1; s < a.nslots; ++s) blk[(size_t)s * n] = 0.f;
+    // what this exchange WAITED for its peers (value 0 of the exchange: the words of one sender arrive together), for the per-rank
+    // diagnosis of a multi-GPU run (bench.py --gpus N): kernels of one channel run in stream order, so a plain read-modify-write is enough
+    if (f == 0) { a.wait[0] += (u64)(wall_clock64() - t0); a.wait[1] += 1; }
   }
   __syncthreads();
   if (tid == 0) __hip_atomic_store(a.epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -101,6 +105,7 @@ struct rssf_p2p {
   u64* peer[MAX_WORLD];        // mapped windows (peer[rank] == window)
   bool opened[MAX_WORLD];
   unsigned* counters;            // [channels] epochs + [1] error word (ordinary device memory: only this rank's kernels touch it)
+  u64* waits;                    // [channels][2] {wall_clock64 ticks waited for peers, exchanges}
   long long timeout_ticks;
 };
 
@@ -118,6 +123,8 @@ extern "C" int rssf_p2p_create(rssf_p2p** out, int rank, int world, int channels
   if (e == hipSuccess) e = hipMemset(h->window, 0, bytes);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->counters), (channels + 1) * sizeof(unsigned));
   if (e == hipSuccess) e = hipMemset(h->counters, 0, (channels + 1) * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->waits), (size_t)channels * 2 * sizeof(u64));
+  if (e == hipSuccess) e = hipMemset(h->waits, 0, (size_t)channels * 2 * sizeof(u64));
   hipIpcMemHandle_t ih;
   if (e == hipSuccess) e = hipIpcGetMemHandle(&ih, h->window);
   if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -126,6 +133,7 @@ extern "C" int rssf_p2p_create(rssf_p2p** out, int rank, int world, int channels
     (void)hipGetLastError();
     if (h->window) (void)hipFree(h->window);
     if (h->counters) (void)hipFree(h->counters);
+    if (h->waits) (void)hipFree(h->waits);
     delete h;
     return RSSF_ERR_LAUNCH;
   }
@@ -182,6 +190,7 @@ extern "C" int rssf_p2p_exchange(rssf_p2p* h, int channel, float* stats, const i
   }
   a.epoch = h->counters + channel;
   a.err = h->counters + h->channels;
+  a.wait = h->waits + (size_t)channel * 2;
   a.stats = stats; a.nitems = nitems; a.nslots = nslots; a.rank = h->rank; a.world = h->world;
   a.timeout_ticks = h->timeout_ticks;
   p2p_exchange_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a);
@@ -203,12 +212,24 @@ extern "C" int rssf_p2p_status(rssf_p2p* h, int* timed_out) {
   return RSSF_OK;
 }
 
+extern "C" int rssf_p2p_wait_us(rssf_p2p* h, int channel, double* wait_us, int64_t* exchanges, int reset) {
+  RSSF_REQUIRE(h && channel >= 0 && channel < h->channels && wait_us && exchanges, "p2p_wait_us: bad arguments");
+  u64 v[2] = {0, 0};
+  hipError_t e = hipMemcpy(v, h->waits + (size_t)channel * 2, sizeof(v), hipMemcpyDeviceToHost);      // synchronises
+  if (e == hipSuccess && reset) e = hipMemset(h->waits + (size_t)channel * 2, 0, sizeof(v));
+  if (e != hipSuccess) { set_error("p2p_wait_us: %s", hipGetErrorString(e)); return RSSF_ERR_LAUNCH; }
+  *wait_us = (double)v[0] * 0.01;          // wall_clock64: 100 MHz
+  *exchanges = (int64_t)v[1];
+  return RSSF_OK;
+}
+
 extern "C" int rssf_p2p_destroy(rssf_p2p* h) {
   if (!h) return RSSF_OK;
   for (int r = 0; r < h->world; ++r)
     if (h->opened[r] && h->peer[r]) (void)hipIpcCloseMemHandle(h->peer[r]);
   if (h->window) (void)hipFree(h->window);
   if (h->counters) (void)hipFree(h->counters);
+  if (h->waits) (void)hipFree(h->waits);
   (void)hipGetLastError();
   delete h;
   return RSSF_OK;

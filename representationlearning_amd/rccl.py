@@ -137,6 +137,13 @@ class P2PExchange:
         L.check(self._lib.rssf_p2p_status(self._h, ctypes.byref(v)), "rssf_p2p_status")
         return v.value
 
+    def wait_us(self, channel, reset=False):
+        """(microseconds the exchanges of `channel` waited for their peers, exchanges) since creation / the last reset - counted on the
+        device by the exchange kernel (rssf_p2p_wait_us; synchronises)."""
+        us, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+        L.check(self._lib.rssf_p2p_wait_us(self._h, int(channel), ctypes.byref(us), ctypes.byref(n), int(bool(reset))), "rssf_p2p_wait_us")
+        return us.value, n.value
+
     def destroy(self):
         if self._h:
             self._lib.rssf_p2p_destroy(self._h)

@@ -368,6 +368,13 @@ def _local8_worker():
                 for r in range(world):
                     tot, rest = totals(bufs[k][r])
                     assert torch.equal(tot, tot0) and float(rest.abs().sum()) == 0.0, (it, k, r)
+        # the exchange kernels count what they waited for their peers and how often (rssf_p2p_wait_us: what bench.py --gpus N prints per
+        # rank): 12 exchanges per rank and channel so far, a finite non-negative wait; a read with reset starts the count again
+        for r in range(world):
+            for k in range(2):
+                us, n = group[r].wait_us(k, reset=(k == 1))
+                assert n == 12 and 0.0 <= us < 60e6, (r, k, us, n)
+            assert group[r].wait_us(1) == (0.0, 0) and group[r].wait_us(0)[1] == 12
         # chunked: 24 layers of 2 * 256 values = 12 288 floats, three window runs per exchange
         nl, nv = 24, 512
         big = [torch.randn(4 * nl * nv, generator=g).cuda() for _ in range(world)]
