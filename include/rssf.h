@@ -65,6 +65,13 @@ int rssf_layernorm_bwd(const void* dy, const void* x, const float* stats, const 
 int rssf_gate_pool_fwd(const void* x, const void* y, const float* stats_x, const float* stats_y,
                        const float* gamma, const float* beta, float* pooled, int32_t* argmax,
                        int B, int N, int C, int dtype, void* stream);
+/* the same launch FORMING the LayerNorm statistics of x and y instead of reading them (norm1 of both streams, MTFM.py:104-105: the two
+ * statistics-only rssf_layernorm_fwd passes are not needed): stats_x / stats_y [B*N][2] = {mean, rstd} are OUTPUTS, rssf_layernorm_fwd(eps)'s
+ * arithmetic (equal to the last bit or one ulp).  Shapes: N % C == 0, C a multiple of the 16-byte vector, a power of two of <= 16 vectors per row
+ * (rssf_ln_gate_pool_fwd_supported == 1; Base C = 32 in both dtypes). */
+int rssf_ln_gate_pool_fwd_supported(int B, int N, int C, int dtype);
+int rssf_ln_gate_pool_fwd(const void* x, const void* y, const float* gamma, const float* beta, float eps, float* stats_x, float* stats_y,
+                          float* pooled, int32_t* argmax, int B, int N, int C, int dtype, void* stream);
 /* weights: g_s = sigmoid(conv7x7(pooled_s; k_s)); omega = softmax_2(Wl [g0;g1] + bl).
  * k [2][2][7][7], wl [2][2], bl [2]; gsig [B][2][N] (saved for bwd), omega [B][2][N], logits [B][2][N] (optional). */
 int rssf_gate_weights_fwd(const float* pooled, const float* k, const float* wl, const float* bl, float* gsig,

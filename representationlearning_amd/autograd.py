@@ -5,7 +5,11 @@ the allocator / stream / autograd-graph plumbing.
 """
 import torch
 
+import os
+
 from . import nnf, ops
+
+_FUSED_LN_POOL = os.environ.get("RSSF_FUSED_LN_POOL", "1") != "0"      # A/B switch (tools/round.sh ab): the three-launch form
 
 
 def _gate_kernels(k1, k2):
@@ -30,9 +34,13 @@ class GatedWindowCrossAttention(torch.autograd.Function):
     def forward(ctx, x, y, ln_g, ln_b, k1, k2, wl, bl, wq, bq, wk, bk, wv, bv, wo, bo, H, W, heads):
         x = x.contiguous()
         y = y.contiguous()
-        _, sx = ops.layernorm_fwd(x, ln_g, ln_b, want_y=False)
-        _, sy = ops.layernorm_fwd(y, ln_g, ln_b, want_y=False)
-        pooled, argmax = ops.gate_pool_fwd(x, y, sx, sy, ln_g, ln_b)
+        fused = ops.ln_gate_pool_fwd(x, y, ln_g, ln_b) if _FUSED_LN_POOL else None      # norm1's statistics of both streams + the gate's pooling: one pass
+        if fused is not None:
+            sx, sy, pooled, argmax = fused
+        else:
+            _, sx = ops.layernorm_fwd(x, ln_g, ln_b, want_y=False)
+            _, sy = ops.layernorm_fwd(y, ln_g, ln_b, want_y=False)
+            pooled, argmax = ops.gate_pool_fwd(x, y, sx, sy, ln_g, ln_b)
         kk = _gate_kernels(k1, k2)                                   # [2(stream), 2(mean,max), 7, 7]
         wl2 = wl.reshape(2, 2).contiguous()
         gsig, omega, _ = ops.gate_weights_fwd(pooled, kk, wl2, bl, H, W)

@@ -45,12 +45,24 @@ __global__ void __launch_bounds__(256) gate_pool_fwd_kernel(const T* __restrict_
 // argmax} are folded through LDS in channel order (strictly greater wins: the FIRST maximum, as the one-thread walk - and
 // torch.max - picks it).  With one thread per pixel group the launch was 256 blocks of 32 dependent 16-byte loads each: 23 us for
 // 33 MB at B = 16 (1.5 TB/s).
-template <typename T, int PARTS>
+// STATS = G > 0 (rssf_ln_gate_pool_fwd): the LayerNorm statistics are FORMED here instead of read.  With N % C == 0 a token row is the
+// V-element pieces of G = C / V consecutive, G-aligned lanes at EVERY view-channel (the element offset cp * N + p0 keeps p0 mod C),
+// every (view-channel, lane group) is a different token and every token occurs exactly once in the grid: the row sums are quad /
+// half-row DPP folds (norm.hip::ln_fwd_vec's arithmetic, statement by statement), lane 0 of a group writes {mean, rstd}
+// for the attention kernels - the two statistics-only LayerNorm passes over x and y (2 x 7.3 us per block) are not launched.
+template <int G> __device__ __forceinline__ float gate_group_sum(float v) {
+  if (G >= 2) v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+  if (G >= 4) v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_mov<0x141>(v);       // row_half_mirror
+  if (G >= 16) v += dpp_mov<0x140>(v);      // row_mirror
+  return v;
+}
+template <typename T, int PARTS, int G = 0>
 __global__ void __launch_bounds__(64 * PARTS) gate_pool_fwd_vec_kernel(const T* __restrict__ x, const T* __restrict__ y,
-                                                                       const float* __restrict__ stx, const float* __restrict__ sty,
+                                                                       float* __restrict__ stx, float* __restrict__ sty,
                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                        float* __restrict__ pooled, int32_t* __restrict__ argmax,
-                                                                       int B, int N, int C) {
+                                                                       int B, int N, int C, float eps) {
   constexpr int V = Vec<T>::N;
   __shared__ float ssum[PARTS > 1 ? PARTS - 1 : 1][64][V], smax[PARTS > 1 ? PARTS - 1 : 1][64][V];
   __shared__ int sarg[PARTS > 1 ? PARTS - 1 : 1][64][V];
@@ -63,7 +75,7 @@ __global__ void __launch_bounds__(64 * PARTS) gate_pool_fwd_vec_kernel(const T* 
   const int s = (int)((g / nv) % 2);
   const int b = (int)(g / (2 * (int64_t)nv));
   const T* src = (s == 0 ? x : y) + (int64_t)b * N * C;
-  const float2* st = reinterpret_cast<const float2*>((s == 0 ? stx : sty) + (int64_t)b * N * 2);
+  float2* st = reinterpret_cast<float2*>((s == 0 ? stx : sty) + (int64_t)b * N * 2);
   const int qn = N / C, rn = N % C;
   const int cper = C / PARTS, cp0 = part * cper;
   // (token, channel) of view-channel cp0 at view-pixel p0: flat index cp0 * N + p0 of the [N][C] token tensor
@@ -77,7 +89,22 @@ __global__ void __launch_bounds__(64 * PARTS) gate_pool_fwd_vec_kernel(const T* 
   for (int cp = cp0; cp < cp0 + cper; ++cp) {
     Vec<T> v;
     v.load(src + (int64_t)cp * N + p0);
-    const float2 ms = st[n];
+    float2 ms;
+    if constexpr (G > 0) {
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) sm += v.get(i);
+      sm = gate_group_sum<G>(sm);
+      const float mean = sm / C;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) { const float d = v.get(i) - mean; q += d * d; }
+      q = gate_group_sum<G>(q);
+      ms = float2{mean, rsqrtf(q / C + eps)};
+      if (live && (lane & (G - 1)) == 0) st[n] = ms;
+    } else {
+      ms = st[n];
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float t = (v.get(i) - ms.x) * ms.y * gamma[c + i] + beta[c + i];
@@ -426,6 +453,32 @@ __global__ void __launch_bounds__(64 * PARTS) gate_pool_bwd_vec_kernel(const flo
 
 }  // namespace
 
+// lanes per token row of the fused statistics + pooling launch, or 0: N % C == 0 (a row keeps its lanes at every view-channel), whole
+// 16-byte vectors, a power of two of at most 16 lanes per row, four waves over the view-channels
+static int ln_gate_pool_group(int N, int C, int dtype) {
+  const int V = dtype == RSSF_BF16 ? 8 : dtype == RSSF_F32 ? 4 : 0;
+  if (!V || C % V || N % C || C % 4) return 0;
+  const int g = C / V;
+  return (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) ? g : 0;
+}
+extern "C" int rssf_ln_gate_pool_fwd_supported(int B, int N, int C, int dtype) { return (B > 0 && N > 0 && C > 0 && ln_gate_pool_group(N, C, dtype)) ? 1 : 0; }
+
+extern "C" int rssf_ln_gate_pool_fwd(const void* x, const void* y, const float* gamma, const float* beta, float eps, float* stats_x,
+                                     float* stats_y, float* pooled, int32_t* argmax, int B, int N, int C, int dtype, void* stream) {
+  RSSF_REQUIRE(x && y && stats_x && stats_y && gamma && beta && pooled && argmax && B > 0 && N > 0 && C > 0, "ln_gate_pool_fwd: bad arguments");
+  const int G = ln_gate_pool_group(N, C, dtype);
+  RSSF_REQUIRE(G, "ln_gate_pool_fwd: unsupported shape (ask rssf_ln_gate_pool_fwd_supported)");
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  const int64_t total = (int64_t)B * 2 * N;
+  const dim3 gv((unsigned)((total / V + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+#define RSSF_LGP(Tt, Gv) gate_pool_fwd_vec_kernel<Tt, 4, Gv><<<gv, 256, 0, st>>>((const Tt*)x, (const Tt*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C, eps)
+  if (dtype == RSSF_BF16) { if (G == 1) RSSF_LGP(bf16_t, 1); else if (G == 2) RSSF_LGP(bf16_t, 2); else if (G == 4) RSSF_LGP(bf16_t, 4); else if (G == 8) RSSF_LGP(bf16_t, 8); else RSSF_LGP(bf16_t, 16); }
+  else { if (G == 1) RSSF_LGP(float, 1); else if (G == 2) RSSF_LGP(float, 2); else if (G == 4) RSSF_LGP(float, 4); else if (G == 8) RSSF_LGP(float, 8); else RSSF_LGP(float, 16); }
+#undef RSSF_LGP
+  return check_launch("ln_gate_pool_fwd");
+}
+
 extern "C" int rssf_gate_pool_fwd(const void* x, const void* y, const float* stats_x, const float* stats_y,
                                   const float* gamma, const float* beta, float* pooled, int32_t* argmax, int B, int N,
                                   int C, int dtype, void* stream) {
@@ -439,11 +492,11 @@ extern "C" int rssf_gate_pool_fwd(const void* x, const void* y, const float* sta
     dim3 gv((unsigned)((total / V + 63) / 64));                // 64 pixel groups per block
     const bool split = C % 4 == 0;                               // four waves, a quarter of the view-channels each
     if (dtype == RSSF_F32) {
-      if (split) gate_pool_fwd_vec_kernel<float, 4><<<gv, 256, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C);
-      else gate_pool_fwd_vec_kernel<float, 1><<<gv, 64, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C);
+      if (split) gate_pool_fwd_vec_kernel<float, 4><<<gv, 256, 0, st>>>((const float*)x, (const float*)y, const_cast<float*>(stats_x), const_cast<float*>(stats_y), gamma, beta, pooled, argmax, B, N, C, 0.f);
+      else gate_pool_fwd_vec_kernel<float, 1><<<gv, 64, 0, st>>>((const float*)x, (const float*)y, const_cast<float*>(stats_x), const_cast<float*>(stats_y), gamma, beta, pooled, argmax, B, N, C, 0.f);
     } else {
-      if (split) gate_pool_fwd_vec_kernel<bf16_t, 4><<<gv, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C);
-      else gate_pool_fwd_vec_kernel<bf16_t, 1><<<gv, 64, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, stats_x, stats_y, gamma, beta, pooled, argmax, B, N, C);
+      if (split) gate_pool_fwd_vec_kernel<bf16_t, 4><<<gv, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, const_cast<float*>(stats_x), const_cast<float*>(stats_y), gamma, beta, pooled, argmax, B, N, C, 0.f);
+      else gate_pool_fwd_vec_kernel<bf16_t, 1><<<gv, 64, 0, st>>>((const bf16_t*)x, (const bf16_t*)y, const_cast<float*>(stats_x), const_cast<float*>(stats_y), gamma, beta, pooled, argmax, B, N, C, 0.f);
     }
   } else if (dtype == RSSF_F32)
     gate_pool_fwd_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)y, stats_x, stats_y, gamma, beta,

@@ -70,6 +70,23 @@ def gate_pool_fwd(x, y, stats_x, stats_y, gamma, beta):
     return pooled, argmax
 
 
+def ln_gate_pool_fwd(x, y, gamma, beta, eps=LN_EPS):
+    """(stats_x, stats_y, pooled, argmax): the LayerNorm statistics of both token streams and the gate's pooled maps in ONE pass over x
+    and y (rssf_ln_gate_pool_fwd), or None where the fused launch does not take the shape (the caller then runs the three launches)."""
+    _same(x, y)
+    B, N, C = x.shape
+    lib = L.load()
+    if lib.rssf_ln_gate_pool_fwd_supported(B, N, C, L.dtype_code(x)) != 1:
+        return None
+    sx = torch.empty(B * N, 2, device=x.device, dtype=torch.float32)
+    sy = torch.empty_like(sx)
+    pooled = torch.empty(B, 4, N, device=x.device, dtype=torch.float32)
+    argmax = torch.empty(B, 2, N, device=x.device, dtype=torch.int32)
+    L.check(lib.rssf_ln_gate_pool_fwd(L.ptr(_tok(x)), L.ptr(_tok(y)), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), eps, L.ptr(sx), L.ptr(sy), L.ptr(pooled),
+                                      L.ptr(argmax), B, N, C, L.dtype_code(x), L.stream()), "rssf_ln_gate_pool_fwd")
+    return sx, sy, pooled, argmax
+
+
 def gate_weights_fwd(pooled, k, wl, bl, H, W, want_logits=False):
     """k: [2,2,7,7] (stream, {mean,max}, 7, 7); wl [2,2]; bl [2] -> gsig, omega (, logits) each [B,2,N]."""
     B = pooled.shape[0]

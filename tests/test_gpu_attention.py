@@ -267,3 +267,31 @@ def test_gate_weights_backward_repeats_under_load(B, H, W):
     p.start()
     p.join(300)
     assert p.exitcode == 0, "worker failed (exit code %s)" % p.exitcode
+
+
+@pytest.mark.parametrize("B,H,W,C,dtype", [(2, 16, 16, 32, torch.bfloat16), (1, 24, 32, 32, torch.float32), (3, 8, 8, 16, torch.bfloat16), (16, 128, 128, 32, torch.bfloat16),
+                                            (1, 8, 8, 64, torch.bfloat16)])
+def test_fused_ln_statistics_and_gate_pooling_equal_the_three_launches(B, H, W, C, dtype):
+    """rssf_ln_gate_pool_fwd (norm1's statistics of both token streams formed inside the gate's pooling pass: one read of x and y
+    instead of two) against rssf_layernorm_fwd x 2 + rssf_gate_pool_fwd: the statistics and the pooled maps agree to the last bit or
+    one ulp, the arg-max indices agree; shapes the fused launch does not take say so."""
+    from representationlearning_amd import ops, _lib as L
+    torch.manual_seed(5)
+    N = H * W
+    x = (torch.randn(B, N, C, device=DEV) * 1.3 + 0.2).to(dtype)
+    y = (torch.randn(B, N, C, device=DEV) * 0.7 - 0.1).to(dtype)
+    g, b = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+    fused = ops.ln_gate_pool_fwd(x, y, g, b)
+    assert fused is not None
+    _, sx = ops.layernorm_fwd(x, g, b, want_y=False)
+    _, sy = ops.layernorm_fwd(y, g, b, want_y=False)
+    pooled, argmax = ops.gate_pool_fwd(x, y, sx, sy, g, b)
+    # the same arithmetic in the same order; the two translation units differ in the last bit here and there (1 ulp in ~8 % of the
+    # statistics: fused multiply-add choices), an arg-max may only move between view-channels that tie to that precision
+    for got, want, name in zip(fused[:3], (sx, sy, pooled), ("stats_x", "stats_y", "pooled")):
+        assert torch.allclose(got, want, rtol=3e-7, atol=1e-6), (name, float((got - want).abs().max()))
+    assert float((fused[3] == argmax).float().mean()) > 0.999
+    lib = L.load()
+    assert lib.rssf_ln_gate_pool_fwd_supported(2, 100, 48, L.RSSF_BF16) == 0          # N % C != 0
+    assert lib.rssf_ln_gate_pool_fwd_supported(2, 48 * 16, 48, L.RSSF_BF16) == 0      # six vectors per row: not a DPP group
+    assert lib.rssf_ln_gate_pool_fwd_supported(2, 18 * 8, 18, L.RSSF_F32) == 0

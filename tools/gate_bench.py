@@ -24,6 +24,7 @@ print("ln_bwd             %.1f us" % ev(lambda: ops.layernorm_bwd(dy, x, sx, g, 
 print("ln_bwd(+add)       %.1f us" % ev(lambda: ops.layernorm_bwd(dy, x, sx, g, dg, db, dx_add=y)))
 pooled, argmax = ops.gate_pool_fwd(x, y, sx, sy, g, b)
 print("gate_pool_fwd      %.1f us" % ev(lambda: ops.gate_pool_fwd(x, y, sx, sy, g, b)))
+print("ln statistics x 2 + gate pooling as ONE launch (rssf_ln_gate_pool_fwd)  %.1f us" % ev(lambda: ops.ln_gate_pool_fwd(x, y, g, b)))
 k = torch.randn(2, 2, 7, 7, device=dev) * 0.1; wl = torch.randn(2, 2, device=dev); bl = torch.zeros(2, device=dev)
 gsig, omega, _ = ops.gate_weights_fwd(pooled, k, wl, bl, H, W)
 print("gate_weights_fwd   %.1f us" % ev(lambda: ops.gate_weights_fwd(pooled, k, wl, bl, H, W)))
