@@ -90,6 +90,15 @@ int rssf_gate_weights_bwd(const float* domega, const float* pooled, const float*
  * dxhat/dyhat hold the attention-path gradient w.r.t. LN1 outputs on entry and the total on exit. */
 int rssf_gate_pool_bwd(const float* dpooled, const int32_t* argmax, void* dxhat, void* dyhat, int B, int N, int C,
                        int dtype, void* stream);
+/* the same merge AND the LayerNorm backward of both token streams (norm1, MTFM.py:104-105) in one pass: what rssf_gate_pool_bwd followed
+ * by rssf_layernorm_bwd(dxhat, x, stats_x, gamma, dx_add, dx, ..) and rssf_layernorm_bwd(dyhat, y, stats_y, gamma, NULL, dy, ..) compute
+ * (the merged gradient is rounded to the activation dtype as the three launches round it; dgamma / dbeta accumulate, both streams share
+ * the LayerNorm).  dxhat / dyhat are NOT modified.  dx_add (optional): the residual-path gradient added to dx.  Shapes as
+ * rssf_ln_gate_pool_fwd's, C <= 128 (rssf_gate_pool_ln_bwd_supported == 1). */
+int rssf_gate_pool_ln_bwd_supported(int B, int N, int C, int dtype);
+int rssf_gate_pool_ln_bwd(const float* dpooled, const int32_t* argmax, const void* dxhat, const void* dyhat, const void* x, const void* y,
+                          const float* stats_x, const float* stats_y, const float* gamma, const void* dx_add, void* dx, void* dy,
+                          float* dgamma, float* dbeta, int B, int N, int C, int dtype, void* stream);
 
 /* ---- Fused 7x7-window cross attention: InterlacedPoolAttention2.forward :168-188, PadBlock /
  *      LocalPermuteModule (multihead_isa_attention.py:364-426), Mhca (DAL.py:785-1030) and the

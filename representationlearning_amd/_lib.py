@@ -87,6 +87,8 @@ SIGNATURES = {
     "rssf_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_void_p]),
     "rssf_gate_pool_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_ln_gate_pool_fwd_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "rssf_gate_pool_ln_bwd_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "rssf_gate_pool_ln_bwd": (c_int, [c_void_p] * 14 + [c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_ln_gate_pool_fwd": (c_int, [c_void_p] * 4 + [c_float] + [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
     "rssf_gate_weights_fwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "rssf_gate_weights_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_void_p]),

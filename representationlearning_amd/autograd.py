@@ -80,10 +80,15 @@ class GatedWindowCrossAttention(torch.autograd.Function):
             gp = zb[:nk + 6].clone()                           # the pool slice is recycled next step: hand autograd a copy
             h = nk // 2
             ggate = (gp[:h].view_as(kk[0:1]), gp[h:nk].view_as(kk[1:2]), gp[nk:nk + 4].view(2, 2, 1, 1), gp[nk + 4:nk + 6])
-        ops.gate_pool_bwd_(dpooled, argmax, dxhat, dyhat)
         dg, db = tg["ln_g"][0], tg["ln_b"][0]
-        dx = ops.layernorm_bwd(dxhat, x, sx, ln_g, dg, db, dx_add=dout)      # + residual path
-        dy = ops.layernorm_bwd(dyhat, y, sy, ln_g, dg, db)
+        # gate-path gradient merged into d(LN1 output) + norm1's backward on both streams (+ the residual path on x): one pass
+        fused = ops.gate_pool_ln_bwd(dpooled, argmax, dxhat, dyhat, x, y, sx, sy, ln_g, dg, db, dx_add=dout) if _FUSED_LN_POOL else None
+        if fused is not None:
+            dx, dy = fused
+        else:
+            ops.gate_pool_bwd_(dpooled, argmax, dxhat, dyhat)
+            dx = ops.layernorm_bwd(dxhat, x, sx, ln_g, dg, db, dx_add=dout)      # + residual path
+            dy = ops.layernorm_bwd(dyhat, y, sy, ln_g, dg, db)
         r = {n: nnf.grad_result(P[n], tg[n][0], tg[n][1], rt) for n in P}
         return (dx, dy, r["ln_g"], r["ln_b"], *ggate,
                 r["wq"], r["bq"], r["wk"], r["bk"], r["wv"], r["bv"], r["wo"], r["bo"], None, None, None)

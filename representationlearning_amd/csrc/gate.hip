@@ -451,6 +451,103 @@ __global__ void __launch_bounds__(64 * PARTS) gate_pool_bwd_vec_kernel(const flo
   }
 }
 
+// Pool backward AND the LayerNorm backward of both token streams in one walk (rssf_gate_pool_ln_bwd): the same thread -> (view pixels,
+// view-channel range) map as the pooling kernels, so a thread's {d mean, d max, argmax} and its eight LayerNorm weights (the channel of
+// a view pixel does not depend on the view-channel when N % C == 0) live in registers, a token row is the pieces of G aligned lanes, and
+// what rssf_gate_pool_bwd wrote back to d(xhat) only for rssf_layernorm_bwd to read it again never leaves the registers (it is rounded
+// to the activation dtype as the three-launch form rounds it).  LayerNorm backward: norm.hip::ln_bwd_vec's arithmetic.  Persistent
+// grid (<= RSSF_GLB_BLOCKS blocks: every block ends in 2C same-address atomics).
+template <typename T, int G>
+__global__ void __launch_bounds__(256) gate_pool_ln_bwd_kernel(const float* __restrict__ dpooled, const int32_t* __restrict__ argmax,
+                                                               const T* __restrict__ dxhat, const T* __restrict__ dyhat, const T* __restrict__ x,
+                                                               const T* __restrict__ y, const float* __restrict__ stx, const float* __restrict__ sty,
+                                                               const float* __restrict__ gamma, const T* __restrict__ dx_add, T* __restrict__ dx,
+                                                               T* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int N,
+                                                               int C) {
+  constexpr int V = Vec<T>::N, PARTS = 4;
+  __shared__ float sg[PARTS][2][64 * 2];            // per wave: dgamma / dbeta partials of its lanes' channel pieces [G][V] (G * V = C <= 128)
+  const int nv = N / V;
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int sub = lane & (G - 1);                   // this lane's piece of a token row: channels sub * V .. + V - 1
+  const int qn = N / C;
+  const int cper = C / PARTS, cp0 = part * cper;
+  float gam[V], ag[V], ab[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { gam[i] = gamma[sub * V + i]; ag[i] = 0.f; ab[i] = 0.f; }
+  const int64_t total = (int64_t)B * 2 * nv;
+  for (int64_t g0 = (int64_t)blockIdx.x * 64; g0 < total; g0 += (int64_t)gridDim.x * 64) {
+    const int64_t gid = g0 + lane;
+    const bool live = gid < total;                  // (total is a multiple of G: a lane group is live or dead as a whole)
+    const int64_t gq = live ? gid : 0;
+    const int p0 = (int)(gq % nv) * V;
+    const int s = (int)((gq / nv) % 2);
+    const int b = (int)(gq / (2 * (int64_t)nv));
+    const float* dm = dpooled + ((int64_t)b * 4 + 2 * s) * N + p0;
+    const int32_t* am = argmax + ((int64_t)b * 2 + s) * N + p0;
+    float gmean[V], gmax[V];
+    int a[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { gmean[i] = dm[i] / C; gmax[i] = dm[N + i]; a[i] = am[i]; }
+    const int64_t img = (int64_t)b * N * C;
+    const T* src = (s == 0 ? x : y) + img + p0;
+    const T* dsrc = (s == 0 ? dxhat : dyhat) + img + p0;
+    const T* asrc = (s == 0 && dx_add) ? dx_add + img + p0 : nullptr;
+    T* dst = (s == 0 ? dx : dy) + img + p0;
+    const float2* st = reinterpret_cast<const float2*>((s == 0 ? stx : sty) + (int64_t)b * N * 2);
+    int n = (int)(((int64_t)cp0 * N + p0) / C);
+    for (int cp = cp0; cp < cp0 + cper; ++cp) {
+      Vec<T> vx, vd, va;
+      vx.load(src + (int64_t)cp * N); vd.load(dsrc + (int64_t)cp * N);
+      if (asrc) va.load(asrc + (int64_t)cp * N);
+      const float2 ms = st[n];
+      float s1 = 0.f, s2 = 0.f, xh[V], gg[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float d = vd.get(i) + gmean[i] + (a[i] == cp ? gmax[i] : 0.f);
+        if constexpr (sizeof(T) == 2) d = bf2f(f2bf(d));          // what rssf_gate_pool_bwd stores and rssf_layernorm_bwd reads back
+        xh[i] = (vx.get(i) - ms.x) * ms.y;
+        gg[i] = d * gam[i];
+        s1 += gg[i]; s2 += gg[i] * xh[i];
+        if (live) { ag[i] += d * xh[i]; ab[i] += d; }
+      }
+      s1 = gate_group_sum<G>(s1); s2 = gate_group_sum<G>(s2);
+      s1 /= C; s2 /= C;
+      float o[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        o[i] = ms.y * (gg[i] - s1 - xh[i] * s2);
+        if (asrc) o[i] += va.get(i);
+      }
+      if (live) {
+        Vec<T> w;
+        w.set_all(o);
+        w.store(dst + (int64_t)cp * N);
+      }
+      n += qn;
+    }
+  }
+  // lanes of a wave that own the same channel piece (same lane % G): rotations inside the 16-lane rows, then the four rows
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float u = ag[i], w = ab[i];
+    if (G <= 8) { u += dpp_mov<0x128>(u); w += dpp_mov<0x128>(w); }
+    if (G <= 4) { u += dpp_mov<0x124>(u); w += dpp_mov<0x124>(w); }
+    if (G <= 2) { u += dpp_mov<0x122>(u); w += dpp_mov<0x122>(w); }
+    if (G <= 1) { u += dpp_mov<0x121>(u); w += dpp_mov<0x121>(w); }
+    ag[i] = rows_reduce<OpSum>(u); ab[i] = rows_reduce<OpSum>(w);
+  }
+  if (lane < G) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) { sg[part][0][lane * V + i] = ag[i]; sg[part][1][lane * V + i] = ab[i]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int w = i / C, c = i % C;
+    const float t = (sg[0][w][c] + sg[1][w][c]) + (sg[2][w][c] + sg[3][w][c]);
+    atomicAdd((w == 0 ? dgamma : dbeta) + c, t);
+  }
+}
+
 }  // namespace
 
 // lanes per token row of the fused statistics + pooling launch, or 0: N % C == 0 (a row keeps its lanes at every view-channel), whole
@@ -477,6 +574,30 @@ extern "C" int rssf_ln_gate_pool_fwd(const void* x, const void* y, const float* 
   else { if (G == 1) RSSF_LGP(float, 1); else if (G == 2) RSSF_LGP(float, 2); else if (G == 4) RSSF_LGP(float, 4); else if (G == 8) RSSF_LGP(float, 8); else RSSF_LGP(float, 16); }
 #undef RSSF_LGP
   return check_launch("ln_gate_pool_fwd");
+}
+
+extern "C" int rssf_gate_pool_ln_bwd_supported(int B, int N, int C, int dtype) { return (B > 0 && N > 0 && C > 0 && C <= 128 && ln_gate_pool_group(N, C, dtype)) ? 1 : 0; }
+
+extern "C" int rssf_gate_pool_ln_bwd(const float* dpooled, const int32_t* argmax, const void* dxhat, const void* dyhat, const void* x, const void* y,
+                                     const float* stats_x, const float* stats_y, const float* gamma, const void* dx_add, void* dx, void* dy,
+                                     float* dgamma, float* dbeta, int B, int N, int C, int dtype, void* stream) {
+  RSSF_REQUIRE(dpooled && argmax && dxhat && dyhat && x && y && stats_x && stats_y && gamma && dx && dy && dgamma && dbeta,
+               "gate_pool_ln_bwd: bad arguments");
+  RSSF_REQUIRE(rssf_gate_pool_ln_bwd_supported(B, N, C, dtype) == 1, "gate_pool_ln_bwd: unsupported shape (ask rssf_gate_pool_ln_bwd_supported)");
+  const int G = ln_gate_pool_group(N, C, dtype);
+  const int V = dtype == RSSF_BF16 ? 8 : 4;
+  int64_t blocks = ((int64_t)B * 2 * (N / V) + 63) / 64;
+#ifndef RSSF_GLB_BLOCKS
+#define RSSF_GLB_BLOCKS 512      // (16 x 128 x 128 x 32 bf16: 256 blocks 33.4 us, 512: 25.8, 1 024: 29.8 - every block ends in 2C same-address atomics)
+#endif
+  if (blocks > RSSF_GLB_BLOCKS) blocks = RSSF_GLB_BLOCKS;
+  hipStream_t st = (hipStream_t)stream;
+#define RSSF_GLB(Tt, Gv) gate_pool_ln_bwd_kernel<Tt, Gv><<<(unsigned)blocks, 256, 0, st>>>(dpooled, argmax, (const Tt*)dxhat, (const Tt*)dyhat, (const Tt*)x, \
+    (const Tt*)y, stats_x, stats_y, gamma, (const Tt*)dx_add, (Tt*)dx, (Tt*)dy, dgamma, dbeta, B, N, C)
+  if (dtype == RSSF_BF16) { if (G == 1) RSSF_GLB(bf16_t, 1); else if (G == 2) RSSF_GLB(bf16_t, 2); else if (G == 4) RSSF_GLB(bf16_t, 4); else if (G == 8) RSSF_GLB(bf16_t, 8); else RSSF_GLB(bf16_t, 16); }
+  else { if (G == 1) RSSF_GLB(float, 1); else if (G == 2) RSSF_GLB(float, 2); else if (G == 4) RSSF_GLB(float, 4); else if (G == 8) RSSF_GLB(float, 8); else RSSF_GLB(float, 16); }
+#undef RSSF_GLB
+  return check_launch("gate_pool_ln_bwd");
 }
 
 extern "C" int rssf_gate_pool_fwd(const void* x, const void* y, const float* stats_x, const float* stats_y,

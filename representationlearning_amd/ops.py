@@ -118,6 +118,23 @@ def gate_pool_bwd_(dpooled, argmax, dxhat, dyhat):
                                         L.dtype_code(dxhat), L.stream()), "rssf_gate_pool_bwd")
 
 
+def gate_pool_ln_bwd(dpooled, argmax, dxhat, dyhat, x, y, stats_x, stats_y, gamma, dgamma, dbeta, dx_add=None):
+    """(dx, dy): the gate-path gradient merged into d(LN1 output) and the LayerNorm backward of both token streams in ONE pass
+    (rssf_gate_pool_ln_bwd; dgamma / dbeta accumulate), or None where the fused launch does not take the shape."""
+    _same(dxhat, dyhat); _same(x, y); _same(x, dxhat, dx_add)
+    B, N, C = x.shape
+    lib = L.load()
+    if lib.rssf_gate_pool_ln_bwd_supported(B, N, C, L.dtype_code(x)) != 1:
+        return None
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    if dx_add is not None:
+        _tok(dx_add)
+    L.check(lib.rssf_gate_pool_ln_bwd(L.ptr(dpooled), L.ptr(argmax), L.ptr(_tok(dxhat)), L.ptr(_tok(dyhat)), L.ptr(_tok(x)), L.ptr(_tok(y)),
+                                      L.ptr(stats_x), L.ptr(stats_y), L.ptr(_f32(gamma)), L.ptr(dx_add), L.ptr(dx), L.ptr(dy), L.ptr(_f32(dgamma)),
+                                      L.ptr(_f32(dbeta)), B, N, C, L.dtype_code(x), L.stream()), "rssf_gate_pool_ln_bwd")
+    return dx, dy
+
+
 def _winattn_params(x, y, stats_x, stats_y, omega, ln_g, ln_b, w, H, W, heads, out):
     B, N, C = x.shape
     p = L.WinAttnFwdParams()

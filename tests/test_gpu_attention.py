@@ -295,3 +295,34 @@ def test_fused_ln_statistics_and_gate_pooling_equal_the_three_launches(B, H, W, 
     assert lib.rssf_ln_gate_pool_fwd_supported(2, 100, 48, L.RSSF_BF16) == 0          # N % C != 0
     assert lib.rssf_ln_gate_pool_fwd_supported(2, 48 * 16, 48, L.RSSF_BF16) == 0      # six vectors per row: not a DPP group
     assert lib.rssf_ln_gate_pool_fwd_supported(2, 18 * 8, 18, L.RSSF_F32) == 0
+
+
+@pytest.mark.parametrize("B,H,W,C,dtype", [(2, 16, 16, 32, torch.bfloat16), (1, 24, 32, 32, torch.float32), (3, 8, 8, 16, torch.bfloat16), (16, 128, 128, 32, torch.bfloat16),
+                                            (1, 8, 8, 64, torch.bfloat16)])
+@pytest.mark.parametrize("add", [True, False])
+def test_fused_gate_pool_and_layernorm_backward_equal_the_three_launches(B, H, W, C, dtype, add):
+    """rssf_gate_pool_ln_bwd (the gate-path gradient merged into d(LN1 output) and norm1's backward on both token streams in one
+    walk) against rssf_gate_pool_bwd + rssf_layernorm_bwd x 2: dx, dy to the output rounding, dgamma / dbeta to the summation order."""
+    from representationlearning_amd import ops
+    torch.manual_seed(9)
+    N = H * W
+    x = (torch.randn(B, N, C, device=DEV) * 1.3 + 0.2).to(dtype)
+    y = (torch.randn(B, N, C, device=DEV) * 0.7 - 0.1).to(dtype)
+    dxh, dyh = torch.randn(B, N, C, device=DEV).to(dtype), torch.randn(B, N, C, device=DEV).to(dtype)
+    dout = torch.randn(B, N, C, device=DEV).to(dtype) if add else None
+    g, b = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+    _, sx = ops.layernorm_fwd(x, g, b, want_y=False)
+    _, sy = ops.layernorm_fwd(y, g, b, want_y=False)
+    _, argmax = ops.gate_pool_fwd(x, y, sx, sy, g, b)
+    dpooled = torch.randn(B, 4, N, device=DEV)
+    dg1, db1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    fused = ops.gate_pool_ln_bwd(dpooled, argmax, dxh, dyh, x, y, sx, sy, g, dg1, db1, dx_add=dout)
+    assert fused is not None
+    a, c = dxh.clone(), dyh.clone()
+    ops.gate_pool_bwd_(dpooled, argmax, a, c)
+    dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.layernorm_bwd(a, x, sx, g, dg2, db2, dx_add=dout)
+    dy = ops.layernorm_bwd(c, y, sy, g, dg2, db2)
+    tol = 1e-5 if dtype == torch.float32 else 4e-3            # (bf16: one output rounding)
+    assert rel_err(fused[0].float().cpu(), dx.float().cpu()) < tol and rel_err(fused[1].float().cpu(), dy.float().cpu()) < tol
+    assert rel_err(dg1.cpu(), dg2.cpu()) < 2e-5 and rel_err(db1.cpu(), db2.cpu()) < 2e-5

@@ -34,3 +34,5 @@ dpooled = ops.gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl,
 print("gate_weights_bwd   %.1f us" % ev(lambda: ops.gate_weights_bwd(domega, pooled, gsig, omega, k, wl, dk, dwl, dbl, H, W)))
 dxh, dyh = x.clone(), y.clone()
 print("gate_pool_bwd      %.1f us" % ev(lambda: ops.gate_pool_bwd_(dpooled, argmax, dxh, dyh)))
+print("gate pool backward + ln_bwd(+add) + ln_bwd as ONE launch (rssf_gate_pool_ln_bwd)  %.1f us"
+      % ev(lambda: ops.gate_pool_ln_bwd(dpooled, argmax, dxh, dyh, x, y, sx, sy, g, dg, db, dx_add=dy)))
