@@ -257,6 +257,9 @@ int lane_group(int n) {            // the smallest power of two >= n lanes (0: m
   return g <= 16 ? g : 0;
 }
 
+#ifndef RSSF_LN_BWD_BLOCKS
+#define RSSF_LN_BWD_BLOCKS 256
+#endif
 template <typename T>
 int ln_bwd_launch(const void* dy, const void* x, const float* stats, const float* gamma, const void* dx_add, void* dx,
                   float* dgamma, float* dbeta, int64_t rows, int C, hipStream_t st) {
@@ -265,7 +268,7 @@ int ln_bwd_launch(const void* dy, const void* x, const float* stats, const float
   const size_t sh = 2 * C * sizeof(float);
   const T* a = (const T*)dy; const T* b = (const T*)x; const T* c = (const T*)dx_add; T* d = (T*)dx;
   // 256 blocks: every block ends with 2C same-address global atomics (~40 ns each, serialised per address)
-  auto grid = [&](int g) { int64_t n = (rows * g + RSSF_LN_BWD_THREADS - 1) / RSSF_LN_BWD_THREADS; return dim3((unsigned)(n > 256 ? 256 : n)); };
+  auto grid = [&](int g) { int64_t n = (rows * g + RSSF_LN_BWD_THREADS - 1) / RSSF_LN_BWD_THREADS; return dim3((unsigned)(n > RSSF_LN_BWD_BLOCKS ? RSSF_LN_BWD_BLOCKS : n)); };
   switch (G) {
     case 1: ln_bwd_vec<T, 1><<<grid(1), RSSF_LN_BWD_THREADS, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
     case 2: ln_bwd_vec<T, 2><<<grid(2), RSSF_LN_BWD_THREADS, sh, st>>>(a, b, stats, gamma, c, d, dgamma, dbeta, rows, C); break;
