@@ -126,9 +126,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
-  float bs[8];
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 bs2[4];                                    // dbias of the thread's 8 output channels: (e0, e1) .. (e6, e7)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+  for (int j = 0; j < 4; ++j) bs2[j] = f32x2{0.f, 0.f};
 
   Vec<bf16_t> rd[DV], rx[XV], rr[FUSE ? DV : 1], rq[FUSE && RES ? DV : 1], vdz[FUSE ? DV : 1], rawk[DGS ? XV : 1];
   float st1[8], st2[8];
@@ -187,8 +188,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
       rd[c].store(DS + row * LDD + col);
       soff[c] = (unsigned)(k0 * CO * 2) + (unsigned)id * 16u;
       if (do_bias) {
+        // the two halves of each 32-bit word as ONE float pair, added as a pair: left to itself the SLP vectoriser paired (e1, e2) of
+        // two words into a `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` - the crossed-halves form whose LOW half comes back wrong
+        // in a few percent of the launches once other queues of a replayed graph keep the CU busy (DESIGN.md lesson 59)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bs[e] += rd[c].get(e);
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = rd[c].raw[j];
+          bs2[j] += f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+        }
       }
     }
     if constexpr (DGS) {
@@ -349,7 +356,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
       }
   if (do_bias) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&sbias[cg8 + e], bs[e]);
+    for (int e = 0; e < 8; ++e) atomicAdd(&sbias[cg8 + e], bs2[e >> 1][e & 1]);
     __syncthreads();
     if (tid < CO) atomicAdd(a.dbias + tid, sbias[tid]);
   }

@@ -9,35 +9,57 @@ import pytest
 CSRC = os.path.join(os.path.dirname(__file__), "..", "representationlearning_amd", "csrc")
 
 
+def _isa_scan():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import isa_scan
+    return isa_scan
+
+
+def test_crossed_operand_detector():
+    """What tools/isa_scan.py calls crossed: a source whose op_sel bit is 1 and op_sel_hi bit 0 (omitted: op_sel 0, op_sel_hi 1)."""
+    crossed = _isa_scan().crossed
+    assert crossed("v_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[0,1] op_sel_hi:[1,0]")          # lesson 23 (gate_weights_bwd2_kernel)
+    assert crossed("v_pk_add_f32 v[92:93], v[92:93], v[18:19] op_sel:[0,1] op_sel_hi:[1,0]")    # lesson 59 (conv_wgrad_pw_kernel)
+    assert crossed("v_pk_mul_f32 v[26:27], v[20:21], v[26:27] op_sel:[1,0] op_sel_hi:[0,1]")    # crossed first source
+    assert crossed("v_pk_fma_f32 v[12:13], v[14:15], v[16:17], v[12:13] op_sel:[0,0,1] op_sel_hi:[1,1,0]")
+    assert not crossed("v_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel_hi:[1,0]")                   # broadcasts of one half: not crossed
+    assert not crossed("v_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[1,0]")
+    assert not crossed("v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9]")
+    assert not crossed("v_pk_add_u16 v2, v4, v6 op_sel:[0,1] op_sel_hi:[1,0]")
+
+
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
-def test_gate_kernels_have_no_cross_lane_packed_multiply(tmp_path):
+@pytest.mark.parametrize("unit", ["gate", "upsample"])
+def test_units_built_without_slp_have_no_crossed_packed_arithmetic(tmp_path, unit):
     """`v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (the SLP vectoriser's pairing of the 7x7 taps in gate_weights_bwd2_kernel)
     returned 0 in its low half for lanes 48..63 of a wave once other streams kept the CUs busy: one tap of the transposed
     convolution missing in a 16-pixel row of dpooled, in 5-15 % of the replays of a captured step (DESIGN.md lesson 23;
-    tools/replay_race.py).  gate.hip is therefore built without SLP vectorisation: this test compiles it with the Makefile's own
-    command line and looks at the ISA."""
-    out = subprocess.run(["make", "-n", "-B", "build/gate.o"], cwd=CSRC, capture_output=True, text=True, check=True).stdout
-    cmd = [l for l in out.splitlines() if "gate.hip" in l and "hipcc" in l.split()[0]]
+    tools/replay_race.py).  Round 6 found the second instance: `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` in conv_wgrad_pw_kernel's
+    bias sums (the vectoriser's pairing of bf16 element 1 of one word with element 0 of the next), again the low half, again only inside
+    a replayed multi-queue graph, 3-5 % of the replays (lesson 59; tools/replay_param_noise.py).  The units where the vectoriser
+    produces the form are built without it: this test compiles them with the Makefile's own command line and looks at the ISA."""
+    crossed = _isa_scan().crossed
+    out = subprocess.run(["make", "-n", "-B", "build/%s.o" % unit], cwd=CSRC, capture_output=True, text=True, check=True).stdout
+    cmd = [l for l in out.splitlines() if unit + ".hip" in l and "hipcc" in l.split()[0]]
     assert cmd, out
     args = cmd[0].split()
     assert "-fno-slp-vectorize" in args, cmd[0]
     i = args.index("-c")
-    asm = str(tmp_path / "gate.s")
-    args = args[:i] + ["-S", "--cuda-device-only", "gate.hip", "-o", asm]
+    asm = str(tmp_path / (unit + ".s"))
+    args = args[:i] + ["-S", "--cuda-device-only", unit + ".hip", "-o", asm]
     subprocess.run(args, cwd=CSRC, check=True, capture_output=True)
     text = open(asm).read()
-    assert "gate_weights_bwd2_kernel" in text
-    bad = [l for l in text.splitlines() if re.search(r"v_pk_mul_f32.*op_sel:\[0,1\].*op_sel_hi:\[1,0\]", l)]
+    assert ("gate_weights_bwd2_kernel" if unit == "gate" else "bilinear_fwd_kernel") in text
+    bad = [l for l in text.splitlines() if crossed(l)]
     assert not bad, bad[:3]
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="no ROCm LLVM tools")
-def test_built_library_has_no_cross_lane_packed_multiply():
-    """The same instruction form anywhere in the built librssf.so (every embedded gfx950 code object is disassembled:
-    tools/isa_scan.py): a kernel that grows it through a compiler choice is caught here, not by a drifting training run."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
-    import isa_scan
+def test_built_library_has_no_crossed_packed_arithmetic():
+    """The same instruction forms anywhere in the built librssf.so (every embedded gfx950 code object is disassembled:
+    tools/isa_scan.py): a kernel that grows one through a compiler choice is caught here, not by a drifting training run."""
+    isa_scan = _isa_scan()
     if not os.path.exists(isa_scan.LIB):
         pytest.skip("librssf.so not built")
     hits, n = isa_scan.scan()

@@ -1,11 +1,24 @@
-"""Disassembles every gfx950 code object inside librssf.so and counts instruction patterns (default: the packed multiply with
-crossed operand selects of DESIGN.md lesson 23).  No GPU needed.
+"""Disassembles every gfx950 code object inside librssf.so and counts instruction patterns (default: packed fp32 arithmetic with
+CROSSED operand selects - DESIGN.md lessons 23 and 59).  No GPU needed.
   python tools/isa_scan.py [regex]"""
 import os, re, subprocess, sys, tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "representationlearning_amd", "lib", "librssf.so")
-CROSSED_PK_MUL = r"v_pk_mul_f32.*op_sel:\[0,1\].*op_sel_hi:\[1,0\]"
+
+
+def crossed(line):
+    """True for a packed fp32 instruction with a CROSSED operand: for some source i, op_sel[i] = 1 and op_sel_hi[i] = 0 - the low
+    result reads the pair's HIGH register and the high result its LOW register (omitted fields default to op_sel 0, op_sel_hi 1).
+    Broadcasts (op_sel[i] = op_sel_hi[i]) are not crossed."""
+    if not re.search(r"\bv_pk_(mul|add|fma)_f32\b", line):
+        return False
+    lo = re.search(r"op_sel:\[([01,]+)\]", line)
+    hi = re.search(r"op_sel_hi:\[([01,]+)\]", line)
+    lo = [int(c) for c in lo.group(1).split(",")] if lo else [0, 0, 0]
+    hi = [int(c) for c in hi.group(1).split(",")] if hi else [1, 1, 1]
+    return any(a == 1 and b == 0 for a, b in zip(lo, hi))
+
 
 
 def code_objects(lib=LIB):
@@ -27,9 +40,11 @@ def code_objects(lib=LIB):
             yield subprocess.run([LLVM + "/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
 
 
-def scan(pattern=CROSSED_PK_MUL, lib=LIB):
-    """[(kernel symbol, matching line)] over the whole library, and the number of code objects looked at."""
-    rx, hits, n = re.compile(pattern), [], 0
+def scan(pattern=None, lib=LIB):
+    """[(kernel symbol, matching line)] over the whole library, and the number of code objects looked at.  pattern: a regular
+    expression, or None for the crossed packed fp32 forms."""
+    match = crossed if pattern is None else re.compile(pattern).search
+    hits, n = [], 0
     for text in code_objects(lib):
         n += 1
         sym = "?"
@@ -37,13 +52,13 @@ def scan(pattern=CROSSED_PK_MUL, lib=LIB):
             m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
             if m:
                 sym = m.group(1)
-            elif rx.search(line):
+            elif match(line):
                 hits.append((sym, line.strip()))
     return hits, n
 
 
 if __name__ == "__main__":
-    hits, n = scan(sys.argv[1] if len(sys.argv) > 1 else CROSSED_PK_MUL)
+    hits, n = scan(sys.argv[1] if len(sys.argv) > 1 else None)
     print("%d code objects, %d matching instructions" % (n, len(hits)))
     per = {}
     for s, _ in hits:
