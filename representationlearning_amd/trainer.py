@@ -381,7 +381,10 @@ class Trainer:
                 if self._seed is None or self._seed.dtype != loss.dtype or self._seed.device != loss.device:
                     self._seed = torch.ones((), device=loss.device, dtype=loss.dtype)
                 loss.backward(self._seed)                 # the seed gradient is a constant of the trainer, not a fill per step
-                if self.rt.branch_streams and os.environ.get("RSSF_JOIN_AFTER_BACKWARD", "1") != "0":
+                if self.rt.branch_streams:
+                    # the kernels add parameter gradients straight into the flat buffer (no AccumulateGrad node, so autograd's
+                    # end-of-backward join of "leaf streams" knows nothing of the side streams): join them here, before the
+                    # deferred reductions, the norm and the update read that buffer.  Inside a capture these are graph edges.
                     cur = torch.cuda.current_stream()
                     for st in self.rt.side_streams.get(self.flat.flat.device, []):
                         cur.wait_stream(st)
