@@ -24,7 +24,8 @@ nnf._conv_forward, nnf._conv_dgrad, nnf._conv_wgrad = fwd, dgr, wgr
 registry.register_all()
 model = registry.MODEL["RSSFormer"](rssformer_config("base")).cuda()
 tr = Trainer(model, bf16=True, sync_bn=False, use_graph=False)
-x = torch.randn(16, 3, 512, 512, device="cuda"); y = torch.randint(0, 6, (16, 512, 512), device="cuda")
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+x = torch.randn(BATCH, 3, 512, 512, device="cuda"); y = torch.randint(0, 6, (BATCH, 512, 512), device="cuda")
 tr.step(x, dict(cls=y)); log.clear()
 tr.step(x, dict(cls=y)); torch.cuda.synchronize()
 for k, v in sorted(log.items(), key=lambda kv: (kv[0][0], -kv[0][1][1] * kv[0][1][2] * kv[0][1][3] * kv[0][2] * kv[0][3])):
