@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_pw_kernel(PwWgradArgs a) {
       if (do_bias) {
         // the two halves of each 32-bit word as ONE float pair, added as a pair: left to itself the SLP vectoriser paired (e1, e2) of
         // two words into a `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` - the crossed-halves form whose LOW half comes back wrong
-        // in a few percent of the launches once other queues of a replayed graph keep the CU busy (DESIGN.md lesson 59)
+        // on gfx950 when another wave of the SIMD issues MFMAs (DESIGN.md lesson 59; tools/pk_crossed_repro.hip)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const uint32_t w = rd[c].raw[j];

@@ -36,8 +36,9 @@ def test_units_built_without_slp_have_no_crossed_packed_arithmetic(tmp_path, uni
     returned 0 in its low half for lanes 48..63 of a wave once other streams kept the CUs busy: one tap of the transposed
     convolution missing in a 16-pixel row of dpooled, in 5-15 % of the replays of a captured step (DESIGN.md lesson 23;
     tools/replay_race.py).  Round 6 found the second instance: `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` in conv_wgrad_pw_kernel's
-    bias sums (the vectoriser's pairing of bf16 element 1 of one word with element 0 of the next), again the low half, again only inside
-    a replayed multi-queue graph, 3-5 % of the replays (lesson 59; tools/replay_param_noise.py).  The units where the vectoriser
+    bias sums (the vectoriser's pairing of bf16 element 1 of one word with element 0 of the next), again the low half, 3-5 % of the
+    replays at the test geometry, a fifth of the eager launches at the benchmark's (lesson 59; tools/replay_param_noise.py, tools/pw_race.py; the
+    instruction alone beside MFMAs of another wave: tools/pk_crossed_repro.hip).  The units where the vectoriser
     produces the form are built without it: this test compiles them with the Makefile's own command line and looks at the ISA."""
     crossed = _isa_scan().crossed
     out = subprocess.run(["make", "-n", "-B", "build/%s.o" % unit], cwd=CSRC, capture_output=True, text=True, check=True).stdout
