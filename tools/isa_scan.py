@@ -1,10 +1,18 @@
-"""Disassembles every gfx950 code object inside librssf.so and counts instruction patterns (default: packed fp32 arithmetic with
-CROSSED operand selects - DESIGN.md lessons 23 and 59).  No GPU needed.
+"""Disassembles every gfx950 code object inside librssf.so and counts instruction patterns (default: the packed fp32 operand
+selects of DESIGN.md lessons 23 and 59 - see `unsafe`).  No GPU needed.
   python tools/isa_scan.py [regex]"""
 import os, re, subprocess, sys, tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "representationlearning_amd", "lib", "librssf.so")
+
+
+def _selects(line):
+    lo = re.search(r"op_sel:\[([01,]+)\]", line)
+    hi = re.search(r"op_sel_hi:\[([01,]+)\]", line)
+    lo = [int(c) for c in lo.group(1).split(",")] if lo else [0, 0, 0]
+    hi = [int(c) for c in hi.group(1).split(",")] if hi else [1, 1, 1]
+    return lo, hi
 
 
 def crossed(line):
@@ -13,12 +21,18 @@ def crossed(line):
     Broadcasts (op_sel[i] = op_sel_hi[i]) are not crossed."""
     if not re.search(r"\bv_pk_(mul|add|fma)_f32\b", line):
         return False
-    lo = re.search(r"op_sel:\[([01,]+)\]", line)
-    hi = re.search(r"op_sel_hi:\[([01,]+)\]", line)
-    lo = [int(c) for c in lo.group(1).split(",")] if lo else [0, 0, 0]
-    hi = [int(c) for c in hi.group(1).split(",")] if hi else [1, 1, 1]
+    lo, hi = _selects(line)
     return any(a == 1 and b == 0 for a, b in zip(lo, hi))
 
+
+def unsafe(line):
+    """True for the packed fp32 forms this library does not ship: the SECOND source's op_sel bit set (the low result reads src1's high
+    register - crossed or broadcast: wrong low results beside MFMAs of another wave on gfx950, tools/pk_crossed_repro.hip), and - for
+    good measure - any crossed source (the first / third source crossed measured clean, but only the vectoriser ever produces them)."""
+    if not re.search(r"\bv_pk_(mul|add|fma)_f32\b", line):
+        return False
+    lo, _ = _selects(line)
+    return (len(lo) > 1 and lo[1] == 1) or crossed(line)
 
 
 def code_objects(lib=LIB):
@@ -42,8 +56,8 @@ def code_objects(lib=LIB):
 
 def scan(pattern=None, lib=LIB):
     """[(kernel symbol, matching line)] over the whole library, and the number of code objects looked at.  pattern: a regular
-    expression, or None for the crossed packed fp32 forms."""
-    match = crossed if pattern is None else re.compile(pattern).search
+    expression, or None for the packed fp32 forms the library does not ship (`unsafe`)."""
+    match = unsafe if pattern is None else re.compile(pattern).search
     hits, n = [], 0
     for text in code_objects(lib):
         n += 1

@@ -11,7 +11,7 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f4;
-enum { SRC1 = 0, SRC0 = 1, SWAPPED = 2 };                 // form of the checked add
+enum { SRC1 = 0, SRC0 = 1, SWAPPED = 2, ADD_HI = 3, ADD_LO = 4, FMA_S1X = 5, FMA_S1HI = 6, FMA_S1LO = 7, FMA_S0X = 8, MUL_S1X = 9, NIP_ADD_HI = 10, NIP_MUL_X = 11, MUL_S0HI = 12, FMA_S2X = 13, FMA_S2HI = 14, MUL_S1HI = 15 };   // form of the checked in-place instruction
 enum { MF_NONE = 0, MF_SAME = 1, MF_OTHER_WAVES = 2 };    // where the MFMAs run
 
 template <int FORM, int MF, int NOPS, bool NAT, int PAD = 0>
@@ -30,8 +30,31 @@ __global__ void __launch_bounds__(256) probe(unsigned* bad, unsigned* first, int
       f2 x = {(float)((t * 3 + i * 5) & 127), (float)((t * 7 + i) & 127)};
       if (FORM == SRC1) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(accA) : "v"(x));
       else if (FORM == SRC0) asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[1,0] op_sel_hi:[0,1]" : "+v"(accA) : "v"(x));
-      else { f2 y = {x.y, x.x}; asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(accA) : "v"(y)); }
-      rA0 += x.y; rA1 += x.x;
+      else if (FORM == SWAPPED) { f2 y = {x.y, x.x}; asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(accA) : "v"(y)); }
+      const f2 a = {(float)((t + i) & 3), (float)((t * 5 + i * 3) & 3)};
+      if (FORM <= SWAPPED) { rA0 += x.y; rA1 += x.x; }
+      else if (FORM == ADD_HI) { asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(accA) : "v"(x)); rA0 += x.y; rA1 += x.y; }
+      else if (FORM == ADD_LO) { asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(accA) : "v"(x)); rA0 += x.x; rA1 += x.x; }
+      else if (FORM == FMA_S1X) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(accA) : "v"(a), "v"(x)); rA0 += a.x * x.y; rA1 += a.y * x.x; }
+      else if (FORM == FMA_S1HI) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(accA) : "v"(a), "v"(x)); rA0 += a.x * x.y; rA1 += a.y * x.y; }
+      else if (FORM == FMA_S1LO) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(accA) : "v"(a), "v"(x)); rA0 += a.x * x.x; rA1 += a.y * x.x; }
+      else if (FORM == FMA_S0X) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(accA) : "v"(x), "v"(a)); rA0 += x.y * a.x; rA1 += x.x * a.y; }
+      else if (FORM == NIP_ADD_HI) { f2 y; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(y) : "v"(a), "v"(x)); accA.x += y.x; accA.y += y.y; rA0 += a.x + x.y; rA1 += a.y + x.y; }
+      else if (FORM == NIP_MUL_X) { f2 y; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(y) : "v"(a), "v"(x)); accA.x += y.x; accA.y += y.y; rA0 += a.x * x.y; rA1 += a.y * x.x; }
+      else if (FORM == FMA_S2X) { const f2 one = {1.f, 1.f}; asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "+v"(accA) : "v"(one), "v"(x)); rA0 += x.y; rA1 += x.x; }
+      else if (FORM == FMA_S2HI) { const f2 one = {1.f, 1.f}; asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1]" : "+v"(accA) : "v"(one), "v"(x)); rA0 += x.y; rA1 += x.y; }
+      else if (FORM == MUL_S0HI || FORM == MUL_S1HI) {
+        const f2 p = {(i & 1) ? 0.5f : 2.0f, ((i + (t & 1)) & 1) ? 2.0f : 0.5f};
+        if (i == 0) { accA = f2{1.f, 1.f}; rA0 = rA1 = 1.f; }
+        if (FORM == MUL_S0HI) asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel:[1,0]" : "+v"(accA) : "v"(p));
+        else asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(accA) : "v"(p));
+        rA0 *= p.y; rA1 *= p.y;
+      }
+      else if (FORM == MUL_S1X) {            // products of powers of two that cancel over two iterations: exact, bounded
+        const f2 p = {(i & 1) ? 0.5f : 2.0f, ((i + (t & 1)) & 1) ? 2.0f : 0.5f};
+        if (i == 0) { accA = f2{1.f, 1.f}; rA0 = rA1 = 1.f; }
+        asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(accA) : "v"(p)); rA0 *= p.y; rA1 *= p.x;
+      }
       if (NAT) { asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(accB) : "v"(x)); rB0 += x.x; rB1 += x.y; }
       for (int k = 0; k < PAD; ++k) asm volatile("v_nop");       // VALU issue slots between the packed add and the loop's next MFMA
     }
@@ -115,7 +138,22 @@ int main(int argc, char** argv) {
   row<SRC0, MF_OTHER_WAVES, 0, false>("first source crossed in the even waves, MFMAs only in the odd waves");
   row<SWAPPED, MF_SAME, 0, false>("natural selects on swapped data, an MFMA per add in the same wave");
   row<SWAPPED, MF_OTHER_WAVES, 0, false>("natural selects on swapped data in the even waves, MFMAs only in the odd waves");
-  printf("other instructions and selects, an MFMA per packed instruction in the same wave:\n");
+  printf("other IN-PLACE forms, even waves; MFMAs only in the odd waves of the block:\n");
+  row<ADD_HI, MF_OTHER_WAVES, 0, false>("v_pk_add_f32 acc, acc, x op_sel:[0,1]                      (second source: high half to both)");
+  row<ADD_LO, MF_OTHER_WAVES, 0, false>("v_pk_add_f32 acc, acc, x op_sel_hi:[1,0]                   (second source: low half to both)");
+  row<MUL_S1X, MF_OTHER_WAVES, 0, false>("v_pk_mul_f32 acc, acc, x op_sel:[0,1] op_sel_hi:[1,0]      (second source crossed)");
+  row<FMA_S1X, MF_OTHER_WAVES, 0, false>("v_pk_fma_f32 acc, a, x, acc op_sel:[0,1,0] op_sel_hi:[1,0,1] (second source crossed)");
+  row<FMA_S0X, MF_OTHER_WAVES, 0, false>("v_pk_fma_f32 acc, x, a, acc op_sel:[1,0,0] op_sel_hi:[0,1,1] (first source crossed)");
+  row<FMA_S1HI, MF_OTHER_WAVES, 0, false>("v_pk_fma_f32 acc, a, x, acc op_sel:[0,1,0]                (second source: high half to both)");
+  row<FMA_S1LO, MF_OTHER_WAVES, 0, false>("v_pk_fma_f32 acc, a, x, acc op_sel_hi:[1,0,1]             (second source: low half to both)");
+  row<MUL_S1HI, MF_OTHER_WAVES, 0, false>("v_pk_mul_f32 acc, acc, x op_sel:[0,1]                      (second source: high half to both)");
+  row<MUL_S0HI, MF_OTHER_WAVES, 0, false>("v_pk_mul_f32 acc, x, acc op_sel:[1,0]                      (FIRST source: high half to both)");
+  row<FMA_S2X, MF_OTHER_WAVES, 0, false>("v_pk_fma_f32 acc, acc, 1, x op_sel:[0,0,1] op_sel_hi:[1,1,0] (THIRD source crossed)");
+  row<FMA_S2HI, MF_OTHER_WAVES, 0, false>("v_pk_fma_f32 acc, acc, 1, x op_sel:[0,0,1]                 (third source: high half to both)");
+  printf("NOT in place (fresh destination, summed by scalar adds), even waves; MFMAs only in the odd waves:\n");
+  row<NIP_ADD_HI, MF_OTHER_WAVES, 0, false>("v_pk_add_f32 y, a, x op_sel:[0,1]                          (second source: high half to both)");
+  row<NIP_MUL_X, MF_OTHER_WAVES, 0, false>("v_pk_mul_f32 y, a, x op_sel:[0,1] op_sel_hi:[1,0]          (second source crossed: lesson 23's instruction)");
+  printf("other instructions and selects (not in place), an MFMA per packed instruction in the same wave:\n");
   row2<MUL_X1>("v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]     (second source crossed: lesson 23's instruction)");
   row2<MUL_X0>("v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1]     (first source crossed)");
   row2<FMA_X1>("v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1] (second source crossed)");
