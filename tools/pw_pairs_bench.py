@@ -20,9 +20,11 @@ def t_us(fn, n=40):
         for _ in range(5): g.replay()
         e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (5 * n)
-pairs = [(64, 32), (128, 64), (256, 128), (128, 32), (256, 64), (256, 32), (32, 64), (64, 128), (128, 256), (32, 128), (64, 256), (32, 256), (64, 64)]
-for cin, cout in pairs:
+pairs = [(256, 64, 128), (64, 256, 128), (64, 32), (128, 64), (256, 128), (128, 32), (256, 64), (256, 32), (32, 64), (64, 128), (128, 256), (32, 128), (64, 256), (32, 256), (64, 64)]
+for pr in pairs:
+    cin, cout = pr[0], pr[1]
     side = 4096 // max(cin, 32) if cin >= cout else 4096 // max(cout, 32)      # the LOW-resolution map of the pair (the larger channel count)
+    if len(pr) > 2: side = pr[2]                                               # (layer1: 256 / 64 channels on the 128 x 128 map)
     B, H, W = 16, side, side
     conv = torch.nn.Conv2d(cin, cout, 1, bias=False).to(dev)
     spec = nnf.spec_of([conv])
